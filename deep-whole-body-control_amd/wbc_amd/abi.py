@@ -1,0 +1,257 @@
+"""ctypes mirrors of the structs in include/wbc_sim.h and the host-side fillers that turn a
+`RobotModel` + config objects into them. This is the Python end of the C-ABI; it contains no
+torch types (tensors cross the boundary as raw device pointers)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional
+
+import numpy as np
+
+from .urdf_model import RobotModel, merge_piece
+
+NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 10
+NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 21, 10
+
+f32, i32 = C.c_float, C.c_int32
+
+REWARD_TERMS = [
+    "energy_square", "survive", "tracking_lin_vel_x_l1", "tracking_ang_vel_yaw_exp", "hip_action_l2",
+    "foot_contacts_z", "tracking_ee_sphere", "arm_energy_abs_sum", "tracking_ee_cart", "tracking_ee_orn",
+    "tracking_ee_orn_ry", "leg_energy_abs_sum", "leg_energy_sum_abs", "leg_action_l2", "leg_energy",
+    "tracking_lin_vel", "tracking_lin_vel_x_exp", "tracking_ang_vel_yaw_l1", "tracking_lin_vel_y_l2",
+    "tracking_lin_vel_z_l2", "torques"]
+METRIC_NAMES = ["leg_energy_abs_sum", "tracking_lin_vel_x_l1", "tracking_ang_vel_yaw_exp", "tracking_ee_cart",
+                "tracking_ee_sphere", "tracking_ee_orn", "leg_action_l2", "torque", "energy_square",
+                "foot_contacts_z"]   # WG:165
+
+
+class WbcModel(C.Structure):
+    _fields_ = [
+        ("parent", i32 * NB), ("axis", i32 * NB), ("dof", i32 * NB),
+        ("joint_xyz", (f32 * 3) * NB), ("mass", f32 * NB), ("com", (f32 * 3) * NB), ("inertia", (f32 * 6) * NB),
+        ("q_lower", f32 * NDOF), ("q_upper", f32 * NDOF), ("qd_limit", f32 * NDOF), ("effort", f32 * NDOF),
+        ("rb_body", i32 * NRB), ("rb_offset", (f32 * 3) * NRB), ("feet_rb", i32 * NFEET), ("gripper_rb", i32),
+        ("ncp", i32), ("cp_body", i32 * NCP), ("cp_pos", (f32 * 3) * NCP), ("cp_radius", f32 * NCP),
+        ("cp_rb", i32 * NCP),
+        ("base_piece_mass", f32), ("base_piece_com", f32 * 3), ("base_piece_inertia", f32 * 6),
+        ("base_rest_mass", f32), ("base_rest_com", f32 * 3), ("base_rest_inertia", f32 * 6),
+        ("gripper_body", i32),
+        ("grip_piece_mass", f32), ("grip_piece_com", f32 * 3), ("grip_piece_inertia", f32 * 6),
+        ("grip_rest_mass", f32), ("grip_rest_com", f32 * 3), ("grip_rest_inertia", f32 * 6),
+    ]
+
+
+class WbcTaskCfg(C.Structure):
+    _fields_ = [
+        ("sim_dt", f32), ("decimation", i32), ("gravity", f32 * 3),
+        ("contact_margin", f32), ("contact_erp", f32), ("max_depenetration_vel", f32), ("terrain_friction", f32),
+        ("limit_kappa", f32), ("limit_delta", f32), ("contact_iters", i32), ("joint_armature", f32 * NACT),
+        ("clip_actions", f32), ("action_scale", f32 * NACT), ("p_gains", f32 * NACT), ("d_gains", f32 * NACT),
+        ("default_dof_pos", f32 * NDOF), ("torque_limits", f32 * NDOF), ("action_delay", i32),
+        ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32), ("obs_scale_dof_vel", f32), ("clip_obs", f32),
+        ("commands_scale", f32 * 3),
+        ("max_episode_length", i32), ("term_rp_threshold", f32), ("term_z_threshold", f32),
+        ("resample_interval", i32), ("push_interval", i32), ("max_push_vel", f32),
+        ("lin_vel_x_clip", f32), ("ang_vel_yaw_clip", f32),
+        ("goal_collision_lower", f32 * 3), ("goal_collision_upper", f32 * 3), ("goal_underground_limit", f32),
+        ("goal_collision_samples", i32), ("goal_delta_orn_range", (f32 * 2) * 3),
+        ("sphere_error_scale", f32 * 3), ("orn_error_scale", f32 * 3), ("z_invariant_offset", f32),
+        ("tracking_sigma", f32), ("tracking_ee_sigma", f32), ("only_positive_rewards", i32),
+        ("base_init_state", f32 * 13), ("origin_perturb_range", f32), ("init_vel_perturb_range", f32),
+        ("dof_reset_lo", f32), ("dof_reset_hi", f32), ("box_origin_x", f32), ("box_origin_z", f32),
+        ("ground_z", f32),
+    ]
+
+
+class WbcCurriculum(C.Structure):
+    _fields_ = [
+        ("lin_vel_x_range", f32 * 2), ("ang_vel_yaw_range", f32 * 2),
+        ("goal_l_range", f32 * 2), ("goal_p_range", f32 * 2), ("goal_y_range", f32 * 2),
+        ("leg_reward_scale", f32 * NREW), ("arm_reward_scale", f32 * NREW),
+    ]
+
+
+# enum wbc_tensor_id, same order as the header
+TENSOR_IDS = [
+    "ROOT_STATES", "DOF_STATE", "NET_CONTACT_FORCE", "RIGID_BODY_STATE", "FORCE_SENSOR", "TORQUES", "OBS_BUF",
+    "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_ROOT_VEL", "COMMANDS",
+    "GOAL_STATE", "REW_BUF", "ARM_REW_BUF", "RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH", "EPISODE_SUMS",
+    "METRIC_SUMS", "EPISODE_SUMS_DONE", "METRIC_SUMS_DONE", "BASE_LIN_VEL", "BASE_ANG_VEL", "MASS_PARAMS",
+    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS"]
+T = {name: i for i, name in enumerate(TENSOR_IDS)}
+# per-env shapes (without the leading N) and dtypes, as the header documents them
+TENSOR_SHAPES = {
+    "ROOT_STATES": (2, 13), "DOF_STATE": (20, 2), "NET_CONTACT_FORCE": (28, 3), "RIGID_BODY_STATE": (28, 13),
+    "FORCE_SENSOR": (4, 6), "TORQUES": (20,), "OBS_BUF": (860,), "OBS_HISTORY": (10, 76),
+    "ACTION_HISTORY": (4, 18), "ACTIONS": (18,), "LAST_ACTIONS": (18,), "LAST_DOF_VEL": (20,),
+    "LAST_ROOT_VEL": (6,), "COMMANDS": (3,), "GOAL_STATE": (24,), "REW_BUF": (), "ARM_REW_BUF": (),
+    "RESET_BUF": (), "TIME_OUT_BUF": (), "EPISODE_LENGTH": (), "EPISODE_SUMS": (21,), "METRIC_SUMS": (10,),
+    "EPISODE_SUMS_DONE": (21,), "METRIC_SUMS_DONE": (10,), "BASE_LIN_VEL": (3,), "BASE_ANG_VEL": (3,),
+    "MASS_PARAMS": (5,), "FRICTION": (), "MOTOR_STRENGTH": (18,), "ENV_ORIGINS": (3,), "BOX_DELTA_Y": (),
+    "BODY_PARAMS": (20,)}
+TENSOR_DTYPES = {name: "f32" for name in TENSOR_IDS}
+TENSOR_DTYPES.update(RESET_BUF="i64", EPISODE_LENGTH="i64", TIME_OUT_BUF="u8")
+
+DEFAULT_MODEL_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "widowgo1_model.json")
+
+
+def load_default_model() -> RobotModel:
+    with open(DEFAULT_MODEL_JSON) as f:
+        return RobotModel.from_json(f.read())
+
+
+def _set(arr, values):
+    """Copy `values` into a (possibly nested) ctypes array of floats."""
+    view = np.ctypeslib.as_array(arr)
+    view[...] = np.asarray(values, dtype=np.float64).reshape(view.shape)
+
+
+def _seti(arr, values):
+    view = np.ctypeslib.as_array(arr)
+    view[...] = np.asarray(values, dtype=np.int64).reshape(view.shape)
+
+
+def fill_model(m: RobotModel, foot_name: str = "foot",
+               gripper_name: str = "wx250s/ee_gripper_link") -> WbcModel:
+    """RobotModel -> wbc_model, adding the contact spheres of this framework's physics spec:
+    4 feet (URDF collision spheres r=0.02 at the foot links), 4 knees (calf origins), the gripper
+    tip and the elbow. Mesh collision of the arm links and self-collision are not modelled."""
+    assert m.nb == NB and m.num_dofs == NDOF and m.num_rigid_bodies == NRB
+    out = WbcModel()
+    _seti(out.parent, m.parent)
+    _seti(out.axis, m.axis)
+    _seti(out.dof, m.body_dof)
+    _set(out.joint_xyz, m.joint_xyz)
+    _set(out.mass, m.mass)
+    _set(out.com, m.com)
+    _set(out.inertia, m.inertia)
+    lo, hi = m.dof_lower.copy(), m.dof_upper.copy()
+    _set(out.q_lower, lo)
+    _set(out.q_upper, hi)
+    _set(out.qd_limit, m.dof_velocity)
+    _set(out.effort, m.dof_effort)
+    _seti(out.rb_body, m.rb_body)
+    _set(out.rb_offset, m.rb_offset)
+    feet = [i for i, n in enumerate(m.rb_names) if foot_name in n]          # WG:297
+    assert len(feet) == NFEET
+    _seti(out.feet_rb, feet)
+    out.gripper_rb = m.rb_names.index(gripper_name)                         # WG:318
+    cps = []
+    for rb in feet:                                                         # foot spheres
+        cps.append((m.rb_body[rb], m.rb_offset[rb], 0.02, rb))
+    for rb in feet:                                                         # knees = calf origins
+        calf_rb = rb - 1
+        cps.append((m.rb_body[calf_rb], np.zeros(3), 0.02, calf_rb))
+    cps.append((m.rb_body[out.gripper_rb], m.rb_offset[out.gripper_rb], 0.012, out.gripper_rb))
+    elbow_rb = m.rb_names.index("wx250s/upper_forearm_link")
+    cps.append((m.rb_body[elbow_rb], np.zeros(3), 0.025, elbow_rb))
+    assert len(cps) == NCP
+    out.ncp = NCP
+    for k, (b, pos, rad, rb) in enumerate(cps):
+        out.cp_body[k] = int(b)
+        for j in range(3):
+            out.cp_pos[k][j] = float(pos[j])
+        out.cp_radius[k] = rad
+        out.cp_rb[k] = int(rb)
+    bp, gp = m.base_piece, m.gripper_piece
+    out.base_piece_mass = bp["mass"]
+    _set(out.base_piece_com, bp["com"])
+    _set(out.base_piece_inertia, bp["inertia"])
+    out.base_rest_mass = bp["rest_mass"]
+    _set(out.base_rest_com, bp["rest_com"])
+    _set(out.base_rest_inertia, bp["rest_inertia"])
+    out.gripper_body = int(gp["body"])
+    out.grip_piece_mass = gp["mass"]
+    _set(out.grip_piece_com, gp["com"])
+    _set(out.grip_piece_inertia, gp["inertia"])
+    out.grip_rest_mass = gp["rest_mass"]
+    _set(out.grip_rest_com, gp["rest_com"])
+    _set(out.grip_rest_inertia, gp["rest_inertia"])
+    return out
+
+
+def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None) -> WbcTaskCfg:
+    """WidowGo1RoughCfg (+ LeggedRobotCfg.sim) -> wbc_task_cfg, resolving names to numbers the way
+    WidowGo1._parse_cfg / _init_buffers do (WG:78-121, 498-672)."""
+    out = WbcTaskCfg()
+    dt = float(cfg.sim.dt if sim_dt is None else sim_dt)
+    out.sim_dt = dt
+    out.decimation = int(cfg.control.decimation)
+    _set(out.gravity, cfg.sim.gravity)
+    px = cfg.sim.physx
+    out.contact_margin = float(px.contact_offset)
+    out.contact_erp = 0.2
+    out.max_depenetration_vel = float(px.max_depenetration_velocity)
+    out.terrain_friction = float(cfg.terrain.static_friction)
+    out.limit_kappa, out.limit_delta = 0.25, 0.5
+    out.contact_iters = 2
+    out.clip_actions = float(cfg.normalization.clip_actions)
+    _set(out.action_scale, cfg.control.action_scale)
+    names = m.dof_names
+    for i in range(NACT):                                                    # WG:648-660
+        kp = kd = 0.0
+        for key in cfg.control.stiffness.keys():
+            if key in names[i]:
+                kp, kd = cfg.control.stiffness[key], cfg.control.damping[key]
+        out.p_gains[i], out.d_gains[i] = kp, kd
+        out.joint_armature[i] = dt * kd + dt * dt * kp
+    for i in range(NDOF):                                                    # WG:642-646
+        out.default_dof_pos[i] = float(cfg.init_state.default_joint_angles[names[i]])
+        out.torque_limits[i] = float(m.dof_effort[i])                        # LR:294-299
+    out.action_delay = int(cfg.env.action_delay)
+    sc = cfg.normalization.obs_scales
+    out.obs_scale_ang_vel, out.obs_scale_dof_pos, out.obs_scale_dof_vel = sc.ang_vel, sc.dof_pos, sc.dof_vel
+    out.clip_obs = float(cfg.normalization.clip_observations)
+    _set(out.commands_scale, [sc.lin_vel, sc.lin_vel, sc.ang_vel])           # WG:628
+    policy_dt = out.decimation * dt                                          # WG:80
+    out.max_episode_length = int(math.ceil(cfg.env.episode_length_s / policy_dt))   # WG:117-118
+    out.term_rp_threshold = 0.2                                              # WG:945-946 (hard-coded)
+    out.term_z_threshold = float(cfg.termination.z_threshold)
+    out.resample_interval = int(cfg.commands.resampling_time / policy_dt)    # WG:922
+    out.push_interval = int(math.ceil(cfg.domain_rand.push_interval_s / policy_dt)) if cfg.domain_rand.push_robots else 0
+    out.max_push_vel = float(cfg.domain_rand.max_push_vel_xy)
+    out.lin_vel_x_clip = float(cfg.commands.lin_vel_x_clip)
+    out.ang_vel_yaw_clip = float(cfg.commands.ang_vel_yaw_clip)
+    g = cfg.goal_ee
+    _set(out.goal_collision_lower, g.collision_lower_limits)
+    _set(out.goal_collision_upper, g.collision_upper_limits)
+    out.goal_underground_limit = float(g.underground_limit)
+    out.goal_collision_samples = int(g.num_collision_check_samples)
+    _set(out.goal_delta_orn_range, g.ranges.final_delta_orn)
+    _set(out.sphere_error_scale, g.sphere_error_scale)
+    _set(out.orn_error_scale, g.orn_error_scale)
+    out.z_invariant_offset = 0.53                                            # WG:597
+    out.tracking_sigma = float(cfg.rewards.tracking_sigma)
+    out.tracking_ee_sigma = float(cfg.rewards.tracking_ee_sigma)
+    out.only_positive_rewards = int(bool(cfg.rewards.only_positive_rewards))
+    st = cfg.init_state
+    _set(out.base_init_state, list(st.pos) + list(st.rot) + list(st.lin_vel) + list(st.ang_vel))   # WG:341
+    out.origin_perturb_range = float(cfg.terrain.origin_perturb_range)
+    out.init_vel_perturb_range = float(cfg.terrain.init_vel_perturb_range)
+    out.dof_reset_lo, out.dof_reset_hi = 0.8, 1.2                            # WG:824
+    out.box_origin_x = float(cfg.box.box_env_origins_x)
+    out.box_origin_z = float(cfg.box.box_env_origins_z)
+    out.ground_z = 0.0
+    return out
+
+
+def body_params_from_randomisation(m: RobotModel, base_dmass, base_dcom, gripper_dmass) -> np.ndarray:
+    """Per-env composite (mass, com3, inertia6) of moving body 0 and of the gripper body after the
+    mass randomisation of WG:431-456. Spec decision (Isaac Gym's recomputeInertia semantics are not
+    observable here): the added mass is a point mass at the piece's (shifted) centre of mass and the
+    piece's rotational inertia about its centre of mass is unchanged."""
+    base_dmass = np.asarray(base_dmass, dtype=np.float64)
+    n = base_dmass.shape[0]
+    bp, gp = m.base_piece, m.gripper_piece
+    M0, C0, I0 = merge_piece(bp["rest_mass"], bp["rest_com"], bp["rest_inertia"],
+                             bp["mass"] + base_dmass, bp["com"][None, :] + np.asarray(base_dcom, dtype=np.float64),
+                             np.broadcast_to(bp["inertia"], (n, 6)))
+    gd = np.asarray(gripper_dmass, dtype=np.float64)
+    M1, C1, I1 = merge_piece(gp["rest_mass"], gp["rest_com"], gp["rest_inertia"],
+                             gp["mass"] + gd, np.broadcast_to(gp["com"], (n, 3)),
+                             np.broadcast_to(gp["inertia"], (n, 6)))
+    out = np.concatenate([M0[:, None], C0, I0, M1[:, None], C1, I1], axis=1)
+    return out.astype(np.float32)

@@ -1,0 +1,277 @@
+/*
+ * wbc_sim.h -- C-ABI of libwbc_amd.so: the MI355X-native replacement for the part of
+ * the widowGo1 hot path that the reference delegates to Isaac Gym (closed source) and
+ * to ~150 eager PyTorch ops per policy step.
+ *
+ * Every entry point names the reference interface it stands in for (paths relative to
+ * the reference root; WG = legged_gym/legged_gym/envs/widowGo1/widowGo1.py,
+ * BT = legged_gym/legged_gym/envs/base/base_task.py,
+ * LR = legged_gym/legged_gym/envs/base/legged_robot.py,
+ * RS = rsl_rl/rsl_rl/storage/rollout_storage.py).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative error code (text via wbc_last_error()); no exceptions cross the boundary; device
+ * pointers are HIP device pointers on the device given at creation; `stream` is a
+ * hipStream_t passed as void* (NULL = the legacy default stream) and all work is
+ * asynchronous on that stream; the library creates no hidden streams or threads.
+ * Quaternions are xyzw, float tensors are fp32, reset/episode-length buffers are int64,
+ * as in the reference (BT:71-80).
+ */
+#ifndef WBC_SIM_H
+#define WBC_SIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- fixed sizes of the widowGo1 articulation ---- */
+#define WBC_NB 19        /* moving bodies: floating root + 18 revolute joints */
+#define WBC_NJ 18        /* revolute joints */
+#define WBC_NDOF 20      /* simulator DoFs: 18 revolute + 2 locked prismatic fingers */
+#define WBC_NACT 18      /* num_actions = num_torques (widowGo1_config.py:118-119) */
+#define WBC_NRB 27       /* robot rigid bodies as the importer lists them */
+#define WBC_NRB_ENV 28   /* + the free box actor (WG:384,542,546) */
+#define WBC_NFEET 4
+#define WBC_NCP 10       /* contact points per robot */
+#define WBC_NPROP 76     /* num_proprio (widowGo1_config.py:122) */
+#define WBC_NPRIV 24     /* num_priv */
+#define WBC_HIST 10      /* history_len */
+#define WBC_NOBS 860     /* num_observations */
+#define WBC_ADELAY_LEN 4 /* action_delay + 2 (WG:540) */
+#define WBC_NREW 21      /* reward terms implemented (enum wbc_reward_term) */
+#define WBC_NMETRIC 10   /* episode_metric_sums (WG:165) */
+#define WBC_MAX_DEPTH 6
+
+/* Articulated-body model, produced on the host from the URDF (replaces gym.load_asset +
+ * get_asset_* getters, WG:285-294). All joint frames are unrotated (URDF rpy = 0). */
+typedef struct {
+  int32_t parent[WBC_NB];       /* parent moving body, -1 for the root */
+  int32_t axis[WBC_NB];         /* 0/1/2 = x/y/z, -1 root */
+  int32_t dof[WBC_NB];          /* simulator DoF index of joint i, -1 root */
+  float joint_xyz[WBC_NB][3];   /* joint origin in the parent body frame */
+  float mass[WBC_NB];
+  float com[WBC_NB][3];
+  float inertia[WBC_NB][6];     /* xx,yy,zz,xy,xz,yz about the com, body axes */
+  float q_lower[WBC_NDOF], q_upper[WBC_NDOF];   /* URDF limits; lower==upper==0: unlimited */
+  float qd_limit[WBC_NDOF];     /* URDF velocity limit */
+  float effort[WBC_NDOF];       /* URDF effort limit -> torque_limits (LR:294-299) */
+  int32_t rb_body[WBC_NRB];     /* moving body each importer rigid body rides on */
+  float rb_offset[WBC_NRB][3];
+  int32_t feet_rb[WBC_NFEET];   /* rigid-body indices of the feet, importer order FL,FR,RL,RR */
+  int32_t gripper_rb;           /* wx250s/ee_gripper_link (WG:318) */
+  int32_t ncp;
+  int32_t cp_body[WBC_NCP];     /* contact spheres: body, centre (body frame), radius */
+  float cp_pos[WBC_NCP][3];
+  float cp_radius[WBC_NCP];
+  int32_t cp_rb[WBC_NCP];       /* rigid body whose net_contact_force row receives the force */
+  /* pieces for per-env mass randomisation (WG:431-456) */
+  float base_piece_mass, base_piece_com[3], base_piece_inertia[6];
+  float base_rest_mass, base_rest_com[3], base_rest_inertia[6];
+  int32_t gripper_body;
+  float grip_piece_mass, grip_piece_com[3], grip_piece_inertia[6];
+  float grip_rest_mass, grip_rest_com[3], grip_rest_inertia[6];
+} wbc_model;
+
+enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) */
+  WBC_REW_ENERGY_SQUARE = 0, WBC_REW_SURVIVE, WBC_REW_TRACKING_LIN_VEL_X_L1,
+  WBC_REW_TRACKING_ANG_VEL_YAW_EXP, WBC_REW_HIP_ACTION_L2, WBC_REW_FOOT_CONTACTS_Z,
+  WBC_REW_TRACKING_EE_SPHERE, WBC_REW_ARM_ENERGY_ABS_SUM,
+  WBC_REW_TRACKING_EE_CART, WBC_REW_TRACKING_EE_ORN, WBC_REW_TRACKING_EE_ORN_RY,
+  WBC_REW_LEG_ENERGY_ABS_SUM, WBC_REW_LEG_ENERGY_SUM_ABS, WBC_REW_LEG_ACTION_L2,
+  WBC_REW_LEG_ENERGY, WBC_REW_TRACKING_LIN_VEL, WBC_REW_TRACKING_LIN_VEL_X_EXP,
+  WBC_REW_TRACKING_ANG_VEL_YAW_L1, WBC_REW_TRACKING_LIN_VEL_Y_L2,
+  WBC_REW_TRACKING_LIN_VEL_Z_L2, WBC_REW_TORQUES
+};
+
+enum wbc_metric {        /* WG:165 order */
+  WBC_MET_LEG_ENERGY_ABS_SUM = 0, WBC_MET_TRACKING_LIN_VEL_X_L1, WBC_MET_TRACKING_ANG_VEL_YAW_EXP,
+  WBC_MET_TRACKING_EE_CART, WBC_MET_TRACKING_EE_SPHERE, WBC_MET_TRACKING_EE_ORN,
+  WBC_MET_LEG_ACTION_L2, WBC_MET_TORQUE, WBC_MET_ENERGY_SQUARE, WBC_MET_FOOT_CONTACTS_Z
+};
+
+/* Task constants: WidowGo1RoughCfg + LeggedRobotCfg.sim resolved to numbers. */
+typedef struct {
+  /* sim (legged_robot_config.py:182-199) */
+  float sim_dt;                 /* 0.005 */
+  int32_t decimation;           /* 4 */
+  float gravity[3];
+  /* contact / limit model of THIS framework's physics spec */
+  float contact_margin;         /* physx.contact_offset 0.01 */
+  float contact_erp;            /* fraction of penetration removed per step */
+  float max_depenetration_vel;  /* physx.max_depenetration_velocity 1.0 */
+  float terrain_friction;       /* terrain.static_friction 1.0 */
+  float limit_kappa, limit_delta; /* joint-limit stop gains, in units of D/dt^2 and D/dt */
+  int32_t contact_iters;
+  float joint_armature[WBC_NACT]; /* added to each joint's articulated inertia D: dt*Kd + dt^2*Kp makes
+                                     the task's PD law (WG:1281) linearly implicit */
+  /* control (WG:1262-1295, widowGo1_config.py:163-173) */
+  float clip_actions;
+  float action_scale[WBC_NACT];
+  float p_gains[WBC_NACT], d_gains[WBC_NACT];
+  float default_dof_pos[WBC_NDOF];
+  float torque_limits[WBC_NDOF];
+  int32_t action_delay;         /* 2; -1 disables the FIFO */
+  /* observations (WG:966-1001) */
+  float obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, clip_obs;
+  float commands_scale[3];
+  /* episode, termination (WG:937-963) */
+  int32_t max_episode_length;   /* 500 */
+  float term_rp_threshold;      /* 0.2, hard-coded at WG:945-946 */
+  float term_z_threshold;       /* 0.325 */
+  int32_t resample_interval;    /* int(3.0/0.02)=150 (WG:922) */
+  int32_t push_interval;        /* 150 (WG:119); <=0 disables */
+  float max_push_vel;
+  float lin_vel_x_clip, ang_vel_yaw_clip;
+  /* EE goal sampler (WG:1297-1350, widowGo1_config.py:46-85) */
+  float goal_collision_lower[3], goal_collision_upper[3];
+  float goal_underground_limit;
+  int32_t goal_collision_samples;     /* 10 */
+  float goal_delta_orn_range[3][2];
+  float sphere_error_scale[3], orn_error_scale[3];
+  float z_invariant_offset;           /* 0.53 (WG:597) */
+  /* rewards */
+  float tracking_sigma, tracking_ee_sigma;
+  int32_t only_positive_rewards;
+  /* resets (WG:757-828) */
+  float base_init_state[13];
+  float origin_perturb_range, init_vel_perturb_range;
+  float dof_reset_lo, dof_reset_hi;   /* 0.8, 1.2 */
+  float box_origin_x, box_origin_z;
+  /* flat ground height unless a heightfield is attached */
+  float ground_z;
+} wbc_task_cfg;
+
+/* Host scalars the reference recomputes in update_command_curriculum (WG:678-692). */
+typedef struct {
+  float lin_vel_x_range[2], ang_vel_yaw_range[2];
+  float goal_l_range[2], goal_p_range[2], goal_y_range[2];
+  float leg_reward_scale[WBC_NREW];   /* rewards.scales, 0 = inactive (WG:128-131) */
+  float arm_reward_scale[WBC_NREW];   /* rewards.arm_scales */
+} wbc_curriculum;
+
+/* Device tensors owned by the sim; ids for wbc_sim_get_tensor. Shapes at N envs. */
+enum wbc_tensor_id {
+  WBC_T_ROOT_STATES = 0,   /* f32 [N,2,13]  acquire_actor_root_state_tensor  (WG:505,523) */
+  WBC_T_DOF_STATE,         /* f32 [N,20,2]  acquire_dof_state_tensor         (WG:506,526) */
+  WBC_T_NET_CONTACT_FORCE, /* f32 [N,28,3]  acquire_net_contact_force_tensor (WG:507,542) */
+  WBC_T_RIGID_BODY_STATE,  /* f32 [N,28,13] acquire_rigid_body_state_tensor  (WG:508,546) */
+  WBC_T_FORCE_SENSOR,      /* f32 [N,4,6]   acquire_force_sensor_tensor      (WG:511,522) */
+  WBC_T_TORQUES,           /* f32 [N,20]    self.torques                     (WG:619,1176) */
+  WBC_T_OBS_BUF,           /* f32 [N,860]   obs_buf                          (WG:992,1196) */
+  WBC_T_OBS_HISTORY,       /* f32 [N,10,76] obs_history_buf                  (WG:539,994) */
+  WBC_T_ACTION_HISTORY,    /* f32 [N,4,18]  action_history_buf               (WG:540,1167) */
+  WBC_T_ACTIONS,           /* f32 [N,18]    self.actions (delayed, sim order)(WG:1173) */
+  WBC_T_LAST_ACTIONS,      /* f32 [N,18]                                     (WG:623,908) */
+  WBC_T_LAST_DOF_VEL,      /* f32 [N,20]                                     (WG:624,909) */
+  WBC_T_LAST_ROOT_VEL,     /* f32 [N,6]                                      (WG:625,910) */
+  WBC_T_COMMANDS,          /* f32 [N,3]                                      (WG:627) */
+  WBC_T_GOAL_STATE,        /* f32 [N,24]  ee_start_sphere,ee_goal_sphere,ee_goal_cart,
+                              curr_ee_goal_sphere,curr_ee_goal_cart,ee_goal_delta_orn_euler,
+                              ee_goal_orn_euler (3 each), goal_timer, traj_timesteps,
+                              traj_total_timesteps                           (WG:574-583) */
+  WBC_T_REW_BUF,           /* f32 [N]                                        (BT:72) */
+  WBC_T_ARM_REW_BUF,       /* f32 [N] */
+  WBC_T_RESET_BUF,         /* i64 [N]                                        (BT:74) */
+  WBC_T_TIME_OUT_BUF,      /* u8  [N]  (bool)                                (BT:76) */
+  WBC_T_EPISODE_LENGTH,    /* i64 [N]                                        (BT:75) */
+  WBC_T_EPISODE_SUMS,      /* f32 [N,21] per-term sums, zeroed on reset      (WG:162) */
+  WBC_T_METRIC_SUMS,       /* f32 [N,10]                                     (WG:166) */
+  WBC_T_EPISODE_SUMS_DONE, /* f32 [N,21] sums at the moment of reset (for extras) (WG:743-746) */
+  WBC_T_METRIC_SUMS_DONE,  /* f32 [N,10]                                     (WG:748-750) */
+  WBC_T_BASE_LIN_VEL,      /* f32 [N,3]                                      (WG:880) */
+  WBC_T_BASE_ANG_VEL,      /* f32 [N,3]                                      (WG:881) */
+  WBC_T_MASS_PARAMS,       /* f32 [N,5]  mass_params_tensor                  (WG:354,455) */
+  WBC_T_FRICTION,          /* f32 [N]    friction_coeffs_tensor              (WG:400) */
+  WBC_T_MOTOR_STRENGTH,    /* f32 [N,18]                                     (WG:403) */
+  WBC_T_ENV_ORIGINS,       /* f32 [N,3]                                      (WG:212) */
+  WBC_T_BOX_DELTA_Y,       /* f32 [N]                                        (WG:226) */
+  WBC_T_BODY_PARAMS,       /* f32 [N,20] per-env composite root + gripper (mass, com, inertia6) */
+  WBC_T_COUNT
+};
+enum wbc_dtype { WBC_F32 = 0, WBC_I64 = 1, WBC_U8 = 2 };
+
+typedef struct wbc_sim wbc_sim;
+
+const char* wbc_last_error(void);
+
+/* Bytes of device memory a sim of `num_envs` needs. */
+size_t wbc_sim_arena_bytes(int num_envs);
+
+/* gymapi.acquire_gym + create_sim + load_asset + the create_env/create_actor loop +
+ * prepare_sim (BT:42,86-87; WG:234,285,355-392). `arena` is caller-provided device memory
+ * of >= wbc_sim_arena_bytes(num_envs) bytes (e.g. a torch allocation, so that the tensors
+ * below are zero-copy views of it); NULL lets the library hipMalloc its own. */
+int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, int num_envs, int hip_device,
+                   uint64_t seed, void* arena, size_t arena_bytes, wbc_sim** out);
+int wbc_sim_destroy(wbc_sim* sim);
+
+/* acquire_*_tensor + gymtorch.wrap_tensor (WG:505-551): device pointer, shape, dtype. */
+int wbc_sim_get_tensor(wbc_sim* sim, int id, void** dev_ptr, int64_t shape[4], int* ndim, int* dtype);
+
+/* Batched replacement for the O(N) per-env Python loop that sets shape friction and
+ * randomised rigid-body properties (WG:365-389, 431-496) and motor strengths (WG:402-408).
+ * Host pointers, N entries each (motor_strength N*18, base_dcom N*3, env_origins N*3). */
+int wbc_sim_set_env_params(wbc_sim* sim, const float* friction, const float* base_dmass,
+                           const float* base_dcom, const float* gripper_dmass,
+                           const float* motor_strength, const float* env_origins,
+                           const float* box_delta_y, const float* traj_timesteps,
+                           const float* traj_total_timesteps);
+
+/* gym.add_triangle_mesh for the regular-grid terrain (WG:242-252): the int16 height samples
+ * the trimesh is built from, host pointer, rows*cols; NULL restores the flat plane. */
+int wbc_sim_set_heightfield(wbc_sim* sim, const int16_t* heights, int rows, int cols,
+                            float horizontal_scale, float vertical_scale,
+                            float tx, float ty, float tz);
+
+/* update_command_curriculum results (WG:678-692). */
+int wbc_sim_set_curriculum(wbc_sim* sim, const wbc_curriculum* cur);
+
+/* WidowGo1.step (WG:1156-1199) as ONE launch: action reorder/clip/delay FIFO, 4x
+ * {_compute_torques, simulate}, post_physics_step (EE goal, commands, pushes, termination,
+ * rewards, resets, observations), obs clipping. actions: device f32 [N,18], policy order. */
+int wbc_sim_step(wbc_sim* sim, const float* actions_dev, void* stream);
+
+/* BaseTask.reset() first half: reset_idx(all envs, start=True) (BT:127-131, WG:695-754). */
+int wbc_sim_reset_all(wbc_sim* sim, void* stream);
+
+/* gym.set_dof_actuation_force_tensor (WG:1183): device f32 [N,20]. */
+int wbc_sim_set_dof_forces(wbc_sim* sim, const float* torques_dev, void* stream);
+/* gym.simulate (WG:1184): one physics substep with the torques currently set. */
+int wbc_sim_simulate(wbc_sim* sim, void* stream);
+/* gym.set_actor_root_state_tensor / set_dof_state_tensor (WG:787,814,827): device pointers
+ * with the layouts of WBC_T_ROOT_STATES / WBC_T_DOF_STATE; passing the sim's own tensor is a
+ * no-op copy. The _indexed forms (LR:389-391,410-412) take int32 env ids on the device. */
+int wbc_sim_set_root_state(wbc_sim* sim, const float* root_dev, void* stream);
+int wbc_sim_set_dof_state(wbc_sim* sim, const float* dof_dev, void* stream);
+int wbc_sim_set_root_state_indexed(wbc_sim* sim, const float* root_dev, const int32_t* env_ids_dev, int n, void* stream);
+int wbc_sim_set_dof_state_indexed(wbc_sim* sim, const float* dof_dev, const int32_t* env_ids_dev, int n, void* stream);
+/* gym.refresh_*_tensor (WG:513-519,870-873,1187-1191): state is resident, these return 0;
+ * refresh_rigid_body_state recomputes forward kinematics after a state write. */
+int wbc_sim_refresh_dof_state(wbc_sim* sim);
+int wbc_sim_refresh_root_state(wbc_sim* sim);
+int wbc_sim_refresh_net_contact_force(wbc_sim* sim);
+int wbc_sim_refresh_force_sensor(wbc_sim* sim);
+int wbc_sim_refresh_rigid_body_state(wbc_sim* sim, void* stream);
+
+/* Step counter (common_step_counter, WG:613,876) get/set, for checkpoint/resume and tests. */
+int wbc_sim_get_step_counter(wbc_sim* sim, int64_t* out);
+int wbc_sim_set_step_counter(wbc_sim* sim, int64_t value);
+
+/* RolloutStorage.compute_returns (RS:136-150) as one launch: reverse-time GAE over both
+ * reward channels with shared dones, then advantages = returns - values. Device pointers:
+ * rewards, values, returns, advantages f32 [T,N,2]; dones u8 [T,N]; last_values f32 [N,2].
+ * stats_dev (f64 [3]: count, sum, sum of squares of the raw advantages) is filled for the
+ * joint normalisation (RS:150), which wbc_gae_normalize applies with the (optionally
+ * all-reduced) statistics. */
+int wbc_gae_compute(const float* rewards, const float* values, const uint8_t* dones,
+                    const float* last_values, float* returns, float* advantages, double* stats_dev,
+                    int T, int N, float gamma, float lam, void* stream);
+int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WBC_SIM_H */

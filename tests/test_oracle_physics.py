@@ -1,0 +1,216 @@
+"""Pins the physics half of the oracle (oracle/wbc_oracle.c), for which no reference output
+exists (Isaac Gym is closed source and absent: SURVEY.md section 8c), against formulations that
+share no code or algebra with it:
+
+  * Kane's equations evaluated with world-frame kinematics and finite-difference partial
+    velocities (no spatial vectors, no recursion) must be satisfied by the accelerations the
+    articulated-body algorithm returns;
+  * momentum / free-fall / static-equilibrium identities.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import OracleSim, default_curriculum
+from wbc_amd import abi
+
+G = np.array([0.0, 0.0, -9.81])
+
+
+def quat_to_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def rot_axis(ax, a):
+    c, s = np.cos(a), np.sin(a)
+    R = np.eye(3)
+    i, j = (ax + 1) % 3, (ax + 2) % 3
+    R[i, i], R[i, j], R[j, i], R[j, j] = c, -s, s, c
+    return R
+
+
+def body_twists(model, body_params, pos, quat, q, v, w, qd):
+    """World-frame kinematics of every moving body: rotation, com position, com velocity, omega."""
+    nb = model.nb
+    Rb = quat_to_mat(quat / np.linalg.norm(quat))
+    R, p, om, vo = [None] * nb, [None] * nb, [None] * nb, [None] * nb
+    R[0], p[0], om[0], vo[0] = Rb, pos.copy(), w.copy(), v.copy()
+    for i in range(1, nb):
+        pa, ax, d = model.parent[i], model.axis[i], model.body_dof[i]
+        p[i] = p[pa] + R[pa] @ model.joint_xyz[i]
+        R[i] = R[pa] @ rot_axis(ax, q[d])
+        om[i] = om[pa] + R[pa][:, ax] * qd[d]
+        vo[i] = vo[pa] + np.cross(om[pa], p[i] - p[pa])
+    out = []
+    for i in range(nb):
+        m, com, I6 = body_params[i]
+        c = p[i] + R[i] @ com
+        vc = vo[i] + np.cross(om[i], c - p[i])
+        Ib = np.array([[I6[0], I6[3], I6[4]], [I6[3], I6[1], I6[5]], [I6[4], I6[5], I6[2]]])
+        out.append((m, R[i] @ Ib @ R[i].T, c, vc, om[i]))
+    return out
+
+
+def kane_residual(model, body_params, state, acc, tau):
+    """Generalised active + inertia forces for each of the 6 + 18 generalised speeds."""
+    pos, quat, q, v, w, qd = state
+    a_lin, a_ang, qdd = acc
+    nb = model.nb
+
+    def twists(pos_, quat_, q_, v_, w_, qd_):
+        return body_twists(model, body_params, pos_, quat_, q_, v_, w_, qd_)
+
+    eps = 1e-6
+    # time derivative of each body's (vc, omega) along the motion, by central differences
+    def advance(h):
+        wq = np.array([w[0], w[1], w[2], 0.0])
+        x, y, z, ww = quat
+        dq = 0.5 * np.array([wq[3] * x + wq[0] * ww + wq[1] * z - wq[2] * y,
+                             wq[3] * y - wq[0] * z + wq[1] * ww + wq[2] * x,
+                             wq[3] * z + wq[0] * y - wq[1] * x + wq[2] * ww,
+                             wq[3] * ww - wq[0] * x - wq[1] * y - wq[2] * z])
+        return twists(pos + h * v, quat + h * dq, q + h * qd, v + h * a_lin, w + h * a_ang, qd + h * qdd)
+    tp, tm, t0 = advance(eps), advance(-eps), twists(pos, quat, q, v, w, qd)
+    res = np.zeros(6 + model.num_dofs)
+    gen_tau = np.zeros(6 + model.num_dofs)
+    gen_tau[6:] = tau
+    for k in range(6 + model.num_dofs):
+        dv, dw, dqd = np.zeros(3), np.zeros(3), np.zeros(model.num_dofs)
+        if k < 3:
+            dv[k] = 1
+        elif k < 6:
+            dw[k - 3] = 1
+        else:
+            dqd[k - 6] = 1
+        up = twists(pos, quat, q, v + eps * dv, w + eps * dw, qd + eps * dqd)
+        um = twists(pos, quat, q, v - eps * dv, w - eps * dw, qd - eps * dqd)
+        tot = 0.0
+        for i in range(nb):
+            m, I, c, vc, om = t0[i]
+            acc_c = (tp[i][3] - tm[i][3]) / (2 * eps)
+            alpha = (tp[i][4] - tm[i][4]) / (2 * eps)
+            pv = (up[i][3] - um[i][3]) / (2 * eps)      # partial velocity of the com
+            pw = (up[i][4] - um[i][4]) / (2 * eps)      # partial angular velocity
+            Fstar = m * (acc_c - G)
+            Tstar = I @ alpha + np.cross(om, I @ om)
+            tot += Fstar @ pv + Tstar @ pw
+        res[k] = tot - gen_tau[k]
+    return res
+
+
+def make_params(model, body_params_env):
+    bp = []
+    for i in range(model.nb):
+        bp.append((model.mass[i], model.com[i], model.inertia[i]))
+    bp[0] = (body_params_env[0], body_params_env[1:4], body_params_env[4:10])
+    g = model.gripper_piece["body"]
+    bp[g] = (body_params_env[10], body_params_env[11:14], body_params_env[14:20])
+    return bp
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_aba_satisfies_kanes_equations(robot, seed):
+    rng = np.random.default_rng(seed)
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    for j in range(18):
+        tc.joint_armature[j] = 0.0      # the implicit-PD armature is a modelling term, not rigid-body dynamics
+    o = OracleSim(robot["wmodel"], tc, 1)
+    lo = np.where(model.dof_lower < model.dof_upper, model.dof_lower, -2.0)
+    hi = np.where(model.dof_lower < model.dof_upper, model.dof_upper, 2.0)
+    locked = np.array(model.dof_locked)
+    lo, hi = np.where(locked, -1.0, lo), np.where(locked, 1.0, hi)
+    q = rng.uniform(lo + 0.05, hi - 0.05)
+    qd = rng.uniform(-3, 3, size=20)
+    q[locked], qd[locked] = 0.0, 0.0
+    tau = rng.uniform(-10, 10, size=20)
+    tau[locked] = 0
+    quat = rng.normal(size=4)
+    quat /= np.linalg.norm(quat)
+    pos = np.array([3.0, -2.0, 5.0])          # far above ground: no contacts
+    v, w = rng.uniform(-1, 1, 3), rng.uniform(-2, 2, 3)
+    root = np.zeros((1, 2, 13))
+    root[0, 0] = np.concatenate([pos, quat, v, w])
+    root[0, 1, 6] = 1
+    o.set("ROOT_STATES", root)
+    o.set("DOF_STATE", np.stack([q, qd], -1)[None])
+    o.set("TORQUES", tau[None])
+    qdd, a0 = o.debug_aba(0)
+    bp = make_params(model, o.get("BODY_PARAMS")[0])
+    res = kane_residual(model, bp, (pos, quat, q, v, w, qd), (a0[:3], a0[3:], qdd), tau)
+    scale = max(1.0, np.abs(tau).max())
+    assert np.abs(res[~np.concatenate([np.zeros(6, bool), locked])]).max() < 2e-4 * scale, res
+
+
+def test_free_fall_and_momentum(robot):
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    for j in range(18):
+        tc.joint_armature[j] = 0.0
+    o = OracleSim(robot["wmodel"], tc, 1)
+    rng = np.random.default_rng(5)
+    q = np.array(tc.default_dof_pos) + rng.uniform(-0.1, 0.1, 20)
+    q[18:] = 0
+    qd = rng.uniform(-0.5, 0.5, 20)      # below the URDF velocity limits: the (non-physical) clamp stays off
+    qd[18:] = 0
+    for j in range(20):
+        model_lo, model_hi = model.dof_lower[j], model.dof_upper[j]
+        assert not (model_lo < model_hi) or model_lo + 0.15 < q[j] < model_hi - 0.15 or j >= 18
+    root = np.zeros((1, 2, 13))
+    root[0, 0] = [0, 0, 50.0, 0, 0, 0, 1, 0.3, -0.2, 0.1, 0.5, -0.4, 0.3]
+    root[0, 1, 6] = 1
+    o.set("ROOT_STATES", root)
+    o.set("DOF_STATE", np.stack([q, qd], -1)[None])
+    o.set("TORQUES", np.zeros((1, 20)))
+    bp = make_params(model, o.get("BODY_PARAMS")[0])
+    mtot = sum(b[0] for b in bp)
+
+    def momentum():
+        r = o.get("ROOT_STATES")[0, 0]
+        d = o.get("DOF_STATE")[0]
+        tw = body_twists(model, bp, r[:3], r[3:7], d[:, 0], r[7:10], r[10:13], d[:, 1])
+        P = sum(m * vc for m, I, c, vc, om in tw)
+        cm = sum(m * c for m, I, c, vc, om in tw) / mtot
+        L = sum(I @ om + m * np.cross(c - cm, vc) for m, I, c, vc, om in tw)
+        return P, L
+    P0, L0 = momentum()
+    steps = 40
+    for _ in range(steps):
+        o.simulate()
+    assert np.abs(o.get("DOF_STATE")[0, :, 1]).max() < 3.0
+    P1, L1 = momentum()
+    t = steps * tc.sim_dt
+    np.testing.assert_allclose(P1 - P0, mtot * G * t, atol=1e-3 * mtot)       # impulse of gravity only
+    np.testing.assert_allclose(L1, L0, atol=2e-3 * max(1.0, np.abs(L0).max()))  # no external torque about the com
+
+
+def test_static_stance_supports_weight(robot):
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    tc.push_interval = 0
+    o = OracleSim(robot["wmodel"], tc, 1)
+    o.set_curriculum(default_curriculum(robot["cfg"]))
+    root = np.zeros((1, 2, 13))
+    root[0, 0, 2], root[0, 0, 6], root[0, 1, 6] = 0.34, 1, 1
+    o.set("ROOT_STATES", root)
+    dof = np.zeros((1, 20, 2))
+    dof[0, :, 0] = np.array(tc.default_dof_pos)
+    o.set("DOF_STATE", dof)
+    o.set("ACTIONS", np.zeros((1, 18)))
+    for _ in range(3000):
+        o.compute_torques()
+        o.simulate()
+    r = o.get("ROOT_STATES")[0, 0]
+    f = o.get("NET_CONTACT_FORCE")[0]
+    mtot = sum(b[0] for b in make_params(model, o.get("BODY_PARAMS")[0]))
+    assert np.abs(r[7:13]).max() < 5e-3                       # at rest
+    assert 0.28 < r[2] < 0.34                                 # standing on its feet
+    np.testing.assert_allclose(f[:, 2].sum(), mtot * 9.81, rtol=2e-3)
+    np.testing.assert_allclose(f[:, :2].sum(0), 0, atol=0.5)
+    feet = list(robot["wmodel"].feet_rb)
+    assert (f[feet, 2] > 5).all()                             # every foot carries load
+    # penetration stays within the contact margin
+    o.refresh_rigid_body_state()
+    rb = o.get("RIGID_BODY_STATE")[0]
+    assert (rb[feet, 2] - 0.02 > -0.004).all()
