@@ -1,0 +1,151 @@
+// wbc_device.h -- device-side constants and small math shared by the HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wbc_sim.h"
+
+#define WBC_NCHAIN 5
+
+// Everything the kernels read that is constant over a launch, resident in HBM and read through
+// the scalar/constant path (uniform indices) or L1 (lane-dependent indices).
+struct DevConst {
+  wbc_model model;
+  wbc_task_cfg cfg;
+  wbc_curriculum cur;
+  int32_t chain_body[WBC_NCHAIN][WBC_MAX_DEPTH];   // moving body at (chain, depth-1), -1 if none
+  int32_t chain_len[WBC_NCHAIN];
+  int32_t body_chain[WBC_NB];                      // chain of each body (-1 root)
+  int32_t body_depth[WBC_NB];                      // 0 root, 1.. along the chain
+  int32_t cp_foot[WBC_NCP];                        // force-sensor index fed by contact k, -1 none
+  // heightfield (optional)
+  const int16_t* hf;
+  int32_t hf_rows, hf_cols;
+  float hf_hs, hf_vs, hf_t[3];
+};
+
+// Per-env device tensors (AoS per env: one wave reads an env's block with consecutive lanes).
+struct DevTensors {
+  float* root;        // [N,2,13]
+  float* dof;         // [N,20,2]
+  float* contact;     // [N,28,3]
+  float* rb;          // [N,28,13]
+  float* sensor;      // [N,4,6]
+  float* torques;     // [N,20]
+  float* obs;         // [N,860]
+  float* obs_hist;    // [N,10,76]
+  float* act_hist;    // [N,4,18]
+  float* actions;     // [N,18]
+  float* last_actions;
+  float* last_dof_vel;
+  float* last_root_vel;
+  float* commands;    // [N,3]
+  float* goal;        // [N,24]
+  float* rew;
+  float* arm_rew;
+  int64_t* reset_buf;
+  uint8_t* time_out;
+  int64_t* ep_len;
+  float* ep_sums;     // [N,21]
+  float* met_sums;    // [N,10]
+  float* ep_sums_done;
+  float* met_sums_done;
+  float* base_lin_vel;
+  float* base_ang_vel;
+  float* mass_params; // [N,5]
+  float* friction;    // [N]
+  float* motor;       // [N,18]
+  float* origins;     // [N,3]
+  float* box_dy;      // [N]
+  float* body_params; // [N,20]
+};
+
+#define WBC_PI 3.14159265358979323846f
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+// counter-based uniform in [0,1): bit-identical to oracle/wbc_oracle.c rng_u01
+__device__ __forceinline__ float rng_u01(uint64_t seed, uint64_t env, uint64_t step, uint64_t slot) {
+  uint64_t h = mix64(seed + env * 0x9E3779B97F4A7C15ULL);
+  h = mix64(h + step * 0xD1B54A32D192ED03ULL + slot * 0x8CB92BA72F3D8DD7ULL);
+  return (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float rng_range(float lo, float hi, uint64_t seed, uint64_t env, uint64_t step, uint64_t slot) {
+  return (hi - lo) * rng_u01(seed, env, step, slot) + lo;
+}
+enum {
+  SLOT_GOAL_ORN = 0, SLOT_GOAL_SPHERE = 3, SLOT_CMD = 33, SLOT_PUSH = 35, SLOT_RESET_DOF = 37,
+  SLOT_RESET_XY = 57, SLOT_RESET_VEL = 59, SLOT_RESET_CMD = 65, SLOT_RESET_GOAL_ORN = 67,
+  SLOT_RESET_GOAL_SPHERE = 70
+};
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// row-major 3x3 in memory
+__device__ __forceinline__ f3 mat_mul(const float* M, f3 v) {
+  return mk3(M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z, M[6] * v.x + M[7] * v.y + M[8] * v.z);
+}
+__device__ __forceinline__ f3 matT_mul(const float* M, f3 v) {
+  return mk3(M[0] * v.x + M[3] * v.y + M[6] * v.z, M[1] * v.x + M[4] * v.y + M[7] * v.z, M[2] * v.x + M[5] * v.y + M[8] * v.z);
+}
+__device__ __forceinline__ float dot6(const float* a, const float* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+__device__ __forceinline__ void quat_to_mat(const float* q, float* R) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+__device__ __forceinline__ void quat_mul(const float* a, const float* b, float* o) {
+  float x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  float y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  float z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  float w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+__device__ __forceinline__ f3 quat_rotate_inverse(const float* q, f3 v) {
+  float w = q[3];
+  f3 qv = mk3(q[0], q[1], q[2]);
+  f3 a = v * (2 * w * w - 1);
+  f3 b = cross(qv, v) * (w * 2);
+  f3 c = qv * (2 * dot(qv, v));
+  return a - b + c;
+}
+__device__ __forceinline__ f3 euler_from_quat(const float* q) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float sp = 2 * (w * y - z * x);
+  sp = fminf(fmaxf(sp, -1.f), 1.f);
+  return mk3(atan2f(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)), asinf(sp), atan2f(2 * (w * z + x * y), 1 - 2 * (y * y + z * z)));
+}
+__device__ __forceinline__ f3 sphere2cart(f3 s) {
+  float cp = cosf(s.y);
+  return mk3(s.x * cp * cosf(s.z), s.x * cp * sinf(s.z), s.x * sinf(s.y));
+}
+__device__ __forceinline__ f3 cart2sphere(f3 c) {
+  float l = sqrtf(dot(c, c));
+  return mk3(l, asinf(c.z / l), atan2f(c.y, c.x));
+}
+__device__ __forceinline__ float wrap_to_pi(float a) {
+  const float two_pi = 2 * WBC_PI;
+  float t = a + WBC_PI;
+  t = t - two_pi * floorf(t / two_pi);
+  return t - WBC_PI;
+}
+__device__ __forceinline__ float lerp_torch(float a, float b, float w) {
+  return (w < 0.5f) ? a + w * (b - a) : b - (b - a) * (1 - w);
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

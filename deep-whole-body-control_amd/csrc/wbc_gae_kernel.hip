@@ -1,0 +1,85 @@
+// wbc_gae_kernel.hip -- RolloutStorage.compute_returns (reference rsl_rl/storage/rollout_storage.py:136-150)
+// as two launches instead of T sequential eager steps: (1) reverse-time GAE scan, one lane per
+// (env, reward channel), coalesced over the [N,2] minor dimensions, with per-block double-precision
+// partial statistics; (2) a fixed-order reduction of the partials to (count, sum, sum of squares).
+// The joint normalisation over both channels (RS:150, unbiased std) is a third, elementwise launch so
+// that a multi-GPU learner can all-reduce the three statistics in between.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#define GAE_BLOCK 256
+
+__global__ void __launch_bounds__(GAE_BLOCK) gae_scan_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                            const uint8_t* __restrict__ dones, const float* __restrict__ last_values,
+                                                            float* __restrict__ returns, float* __restrict__ advantages,
+                                                            double* __restrict__ partials, int T, int N, float gamma, float lam) {
+  const int tid = blockIdx.x * GAE_BLOCK + threadIdx.x;   // (env, channel)
+  const int M = 2 * N;
+  double sum = 0.0, sq = 0.0;
+  if (tid < M) {
+    const int n = tid >> 1;
+    float adv = 0.f;
+    float next_v = last_values[tid];
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t idx = (size_t)t * M + tid;
+      const float v = values[idx];
+      const float nt = 1.0f - (float)dones[(size_t)t * N + n];            // RS:143
+      const float delta = rewards[idx] + nt * gamma * next_v - v;         // RS:144
+      adv = delta + nt * gamma * lam * adv;                               // RS:145
+      const float ret = adv + v;                                          // RS:146
+      returns[idx] = ret;
+      const float a = ret - v;                                            // RS:149
+      advantages[idx] = a;
+      sum += (double)a; sq += (double)a * (double)a;
+      next_v = v;
+    }
+  }
+  // block reduction in a fixed tree order
+  __shared__ double ssum[GAE_BLOCK], ssq[GAE_BLOCK];
+  ssum[threadIdx.x] = sum; ssq[threadIdx.x] = sq;
+  __syncthreads();
+  for (int off = GAE_BLOCK / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { ssum[threadIdx.x] += ssum[threadIdx.x + off]; ssq[threadIdx.x] += ssq[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ssum[0]; partials[2 * blockIdx.x + 1] = ssq[0]; }
+}
+
+__global__ void gae_stats_kernel(const double* __restrict__ partials, int nblocks, double count, double* __restrict__ stats) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s += partials[2 * b]; q += partials[2 * b + 1]; }
+    stats[0] = count; stats[1] = s; stats[2] = q;
+  }
+}
+
+__global__ void __launch_bounds__(GAE_BLOCK) gae_normalize_kernel(float* __restrict__ adv, const double* __restrict__ stats, int64_t total) {
+  const double cnt = stats[0], s = stats[1], q = stats[2];
+  const double mean = s / cnt;
+  double var = (q - s * s / cnt) / (cnt - 1.0);          // unbiased, torch.std default (RS:150)
+  var = var < 0.0 ? 0.0 : var;
+  const float fmean = (float)mean, inv = (float)(1.0 / (sqrt(var) + 1e-8));
+  for (int64_t i = (int64_t)blockIdx.x * GAE_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GAE_BLOCK) adv[i] = (adv[i] - fmean) * inv;
+}
+
+extern "C" int wbc_gae_workspace_doubles(int N) { return 3 + 2 * ((2 * N + GAE_BLOCK - 1) / GAE_BLOCK); }
+
+extern "C" int wbc_gae_compute(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, float* returns,
+                               float* advantages, double* stats_dev, int T, int N, float gamma, float lam, void* stream) {
+  if (!rewards || !values || !dones || !last_values || !returns || !advantages || !stats_dev || T <= 0 || N <= 0) return -1;
+  const int nblocks = (2 * N + GAE_BLOCK - 1) / GAE_BLOCK;
+  hipLaunchKernelGGL(gae_scan_kernel, dim3(nblocks), dim3(GAE_BLOCK), 0, (hipStream_t)stream, rewards, values, dones, last_values, returns,
+                     advantages, stats_dev + 3, T, N, gamma, lam);
+  hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats_dev + 3, nblocks, (double)T * (double)N * 2.0, stats_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t total, void* stream) {
+  if (!advantages || !stats_dev || total <= 0) return -1;
+  int64_t blocks = (total + GAE_BLOCK - 1) / GAE_BLOCK;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)blocks), dim3(GAE_BLOCK), 0, (hipStream_t)stream, advantages, stats_dev, total);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

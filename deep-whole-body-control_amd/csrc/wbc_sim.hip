@@ -1,0 +1,347 @@
+// wbc_sim.hip -- host side of the C-ABI declared in include/wbc_sim.h (libwbc_amd.so).
+// Owns the device tensors of one sim (one per GPU / process rank), carves them out of a single
+// arena (caller-provided, e.g. a torch allocation, or hipMalloc'ed here) and launches the
+// kernels of wbc_step_kernel.hip / wbc_gae_kernel.hip on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "wbc_device.h"
+
+extern "C" __global__ void wbc_step_kernel(DevTensors T, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
+                                           uint64_t seed, uint64_t step);
+extern "C" __global__ void wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step);
+extern "C" __global__ void wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
+extern "C" __global__ void wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+struct TensorSpec { int dims[3]; int ndim; int dtype; };
+static const TensorSpec kSpecs[WBC_T_COUNT] = {
+    {{2, 13, 0}, 2, WBC_F32}, {{20, 2, 0}, 2, WBC_F32}, {{28, 3, 0}, 2, WBC_F32}, {{28, 13, 0}, 2, WBC_F32},
+    {{4, 6, 0}, 2, WBC_F32},  {{20, 0, 0}, 1, WBC_F32}, {{860, 0, 0}, 1, WBC_F32}, {{10, 76, 0}, 2, WBC_F32},
+    {{4, 18, 0}, 2, WBC_F32}, {{18, 0, 0}, 1, WBC_F32}, {{18, 0, 0}, 1, WBC_F32},  {{20, 0, 0}, 1, WBC_F32},
+    {{6, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{24, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},
+    {{0, 0, 0}, 0, WBC_F32},  {{0, 0, 0}, 0, WBC_I64},  {{0, 0, 0}, 0, WBC_U8},    {{0, 0, 0}, 0, WBC_I64},
+    {{21, 0, 0}, 1, WBC_F32}, {{10, 0, 0}, 1, WBC_F32}, {{21, 0, 0}, 1, WBC_F32},  {{10, 0, 0}, 1, WBC_F32},
+    {{3, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{5, 0, 0}, 1, WBC_F32},   {{0, 0, 0}, 0, WBC_F32},
+    {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32}};
+
+static size_t spec_elems(const TensorSpec& s) {
+  size_t n = 1;
+  for (int i = 0; i < s.ndim; ++i) n *= (size_t)s.dims[i];
+  return n;
+}
+static size_t dtype_bytes(int dt) { return dt == WBC_F32 ? 4 : (dt == WBC_I64 ? 8 : 1); }
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct wbc_sim {
+  int n = 0, device = 0;
+  uint64_t seed = 0;
+  int64_t step_counter = 0;
+  DevConst hc;
+  DevConst* dc = nullptr;
+  DevTensors T;
+  void* ptr[WBC_T_COUNT];
+  char* arena = nullptr;
+  bool own_arena = false;
+  size_t arena_bytes = 0;
+  int16_t* hf_dev = nullptr;
+};
+
+extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
+
+extern "C" size_t wbc_sim_arena_bytes(int num_envs) {
+  size_t off = 0;
+  for (int t = 0; t < WBC_T_COUNT; ++t) off = align_up(off + spec_elems(kSpecs[t]) * dtype_bytes(kSpecs[t].dtype) * (size_t)num_envs, 256);
+  return off + 256;
+}
+
+static int upload_const(wbc_sim* s, hipStream_t st) {
+  HIP_OK(hipMemcpyAsync(s->dc, &s->hc, sizeof(DevConst), hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+static int build_chains(DevConst& hc) {
+  const wbc_model& m = hc.model;
+  for (int c = 0; c < WBC_NCHAIN; ++c) { hc.chain_len[c] = 0; for (int d = 0; d < WBC_MAX_DEPTH; ++d) hc.chain_body[c][d] = -1; }
+  hc.body_chain[0] = -1; hc.body_depth[0] = 0;
+  int nchain = 0;
+  for (int i = 1; i < WBC_NB; ++i) {
+    const int p = m.parent[i];
+    if (p < 0 || p >= i) return -1;
+    if (p == 0) {
+      if (nchain >= WBC_NCHAIN) return -1;
+      hc.body_chain[i] = nchain++; hc.body_depth[i] = 1;
+    } else {
+      hc.body_chain[i] = hc.body_chain[p]; hc.body_depth[i] = hc.body_depth[p] + 1;
+      // serial chain: the parent must be the current tip of its chain
+      if (hc.chain_body[hc.body_chain[p]][hc.body_depth[p] - 1] != p || hc.chain_len[hc.body_chain[p]] != hc.body_depth[p]) return -1;
+    }
+    if (hc.body_depth[i] > WBC_MAX_DEPTH) return -1;
+    hc.chain_body[hc.body_chain[i]][hc.body_depth[i] - 1] = i;
+    hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
+  }
+  if (nchain != WBC_NCHAIN) return -1;
+  for (int k = 0; k < WBC_NCP; ++k) {
+    hc.cp_foot[k] = -1;
+    for (int f = 0; f < WBC_NFEET; ++f) if (k < m.ncp && m.feet_rb[f] == m.cp_rb[k]) hc.cp_foot[k] = f;
+  }
+  return 0;
+}
+
+extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, int num_envs, int hip_device, uint64_t seed, void* arena,
+                              size_t arena_bytes, wbc_sim** out) {
+  if (!model || !cfg || !out || num_envs <= 0) return fail(-1, "wbc_sim_create: bad arguments");
+  if (model->ncp != WBC_NCP) return fail(-1, "wbc_sim_create: model.ncp must equal WBC_NCP");
+  HIP_OK(hipSetDevice(hip_device));
+  wbc_sim* s = new wbc_sim();
+  s->n = num_envs; s->device = hip_device; s->seed = seed;
+  memset(&s->hc, 0, sizeof(DevConst));
+  s->hc.model = *model; s->hc.cfg = *cfg;
+  if (build_chains(s->hc) != 0) { delete s; return fail(-1, "wbc_sim_create: topology must be a root with 5 serial chains of depth <= 6"); }
+  const size_t need = wbc_sim_arena_bytes(num_envs);
+  if (arena) {
+    if (arena_bytes < need) { delete s; return fail(-1, "wbc_sim_create: arena too small"); }
+    s->arena = (char*)arena;
+  } else {
+    hipError_t e = hipMalloc((void**)&s->arena, need);
+    if (e != hipSuccess) { delete s; return fail(-2, std::string("hipMalloc arena: ") + hipGetErrorString(e)); }
+    s->own_arena = true;
+  }
+  s->arena_bytes = need;
+  size_t off = (256 - ((uintptr_t)s->arena & 255)) & 255;
+  for (int t = 0; t < WBC_T_COUNT; ++t) {
+    s->ptr[t] = s->arena + off;
+    off = align_up(off + spec_elems(kSpecs[t]) * dtype_bytes(kSpecs[t].dtype) * (size_t)num_envs, 256);
+  }
+  HIP_OK(hipMemset(s->arena, 0, need));
+  DevTensors& T = s->T;
+  T.root = (float*)s->ptr[WBC_T_ROOT_STATES]; T.dof = (float*)s->ptr[WBC_T_DOF_STATE]; T.contact = (float*)s->ptr[WBC_T_NET_CONTACT_FORCE];
+  T.rb = (float*)s->ptr[WBC_T_RIGID_BODY_STATE]; T.sensor = (float*)s->ptr[WBC_T_FORCE_SENSOR]; T.torques = (float*)s->ptr[WBC_T_TORQUES];
+  T.obs = (float*)s->ptr[WBC_T_OBS_BUF]; T.obs_hist = (float*)s->ptr[WBC_T_OBS_HISTORY]; T.act_hist = (float*)s->ptr[WBC_T_ACTION_HISTORY];
+  T.actions = (float*)s->ptr[WBC_T_ACTIONS]; T.last_actions = (float*)s->ptr[WBC_T_LAST_ACTIONS]; T.last_dof_vel = (float*)s->ptr[WBC_T_LAST_DOF_VEL];
+  T.last_root_vel = (float*)s->ptr[WBC_T_LAST_ROOT_VEL]; T.commands = (float*)s->ptr[WBC_T_COMMANDS]; T.goal = (float*)s->ptr[WBC_T_GOAL_STATE];
+  T.rew = (float*)s->ptr[WBC_T_REW_BUF]; T.arm_rew = (float*)s->ptr[WBC_T_ARM_REW_BUF]; T.reset_buf = (int64_t*)s->ptr[WBC_T_RESET_BUF];
+  T.time_out = (uint8_t*)s->ptr[WBC_T_TIME_OUT_BUF]; T.ep_len = (int64_t*)s->ptr[WBC_T_EPISODE_LENGTH]; T.ep_sums = (float*)s->ptr[WBC_T_EPISODE_SUMS];
+  T.met_sums = (float*)s->ptr[WBC_T_METRIC_SUMS]; T.ep_sums_done = (float*)s->ptr[WBC_T_EPISODE_SUMS_DONE];
+  T.met_sums_done = (float*)s->ptr[WBC_T_METRIC_SUMS_DONE]; T.base_lin_vel = (float*)s->ptr[WBC_T_BASE_LIN_VEL];
+  T.base_ang_vel = (float*)s->ptr[WBC_T_BASE_ANG_VEL]; T.mass_params = (float*)s->ptr[WBC_T_MASS_PARAMS]; T.friction = (float*)s->ptr[WBC_T_FRICTION];
+  T.motor = (float*)s->ptr[WBC_T_MOTOR_STRENGTH]; T.origins = (float*)s->ptr[WBC_T_ENV_ORIGINS]; T.box_dy = (float*)s->ptr[WBC_T_BOX_DELTA_Y];
+  T.body_params = (float*)s->ptr[WBC_T_BODY_PARAMS];
+  // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
+  {
+    const int n = num_envs;
+    std::vector<float> root((size_t)n * 26, 0.f), fr(n, 1.f), ms((size_t)n * WBC_NACT, 1.f), bp((size_t)n * 20), goal((size_t)n * 24, 0.f);
+    const int g = model->gripper_body;
+    for (int i = 0; i < n; ++i) {
+      root[(size_t)i * 26 + 6] = 1.f; root[(size_t)i * 26 + 19] = 1.f;
+      float* b = &bp[(size_t)i * 20];
+      b[0] = model->mass[0];
+      for (int k = 0; k < 3; ++k) b[1 + k] = model->com[0][k];
+      for (int k = 0; k < 6; ++k) b[4 + k] = model->inertia[0][k];
+      b[10] = model->mass[g];
+      for (int k = 0; k < 3; ++k) b[11 + k] = model->com[g][k];
+      for (int k = 0; k < 6; ++k) b[14 + k] = model->inertia[g][k];
+      goal[(size_t)i * 24 + 22] = 100.f; goal[(size_t)i * 24 + 23] = 150.f;
+    }
+    HIP_OK(hipMemcpy(T.root, root.data(), root.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(T.friction, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(T.motor, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(T.body_params, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(T.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipMalloc((void**)&s->dc, sizeof(DevConst)));
+  HIP_OK(hipMemcpy(s->dc, &s->hc, sizeof(DevConst), hipMemcpyHostToDevice));
+  *out = s;
+  return 0;
+}
+
+extern "C" int wbc_sim_destroy(wbc_sim* s) {
+  if (!s) return 0;
+  hipSetDevice(s->device);
+  if (s->own_arena && s->arena) hipFree(s->arena);
+  if (s->dc) hipFree(s->dc);
+  if (s->hf_dev) hipFree(s->hf_dev);
+  delete s;
+  return 0;
+}
+
+extern "C" int wbc_sim_get_tensor(wbc_sim* s, int id, void** dev_ptr, int64_t shape[4], int* ndim, int* dtype) {
+  if (!s || id < 0 || id >= WBC_T_COUNT) return fail(-1, "wbc_sim_get_tensor: bad id");
+  *dev_ptr = s->ptr[id];
+  shape[0] = s->n;
+  for (int i = 0; i < kSpecs[id].ndim; ++i) shape[1 + i] = kSpecs[id].dims[i];
+  *ndim = 1 + kSpecs[id].ndim;
+  *dtype = kSpecs[id].dtype;
+  return 0;
+}
+
+// composite of two rigid bodies, all about their own coms (host, double)
+static void merge2(double m1, const double* c1, const double* I1, double m2, const double* c2, const double* I2, double* m, double* c, double* I) {
+  *m = m1 + m2;
+  for (int k = 0; k < 3; ++k) c[k] = (m1 * c1[k] + m2 * c2[k]) / *m;
+  auto shift = [&](double mm, const double* cc, const double* Ii, double* out) {
+    const double d[3] = {cc[0] - c[0], cc[1] - c[1], cc[2] - c[2]};
+    const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    out[0] += Ii[0] + mm * (dd - d[0] * d[0]); out[1] += Ii[1] + mm * (dd - d[1] * d[1]); out[2] += Ii[2] + mm * (dd - d[2] * d[2]);
+    out[3] += Ii[3] - mm * d[0] * d[1]; out[4] += Ii[4] - mm * d[0] * d[2]; out[5] += Ii[5] - mm * d[1] * d[2];
+  };
+  for (int k = 0; k < 6; ++k) I[k] = 0;
+  shift(m1, c1, I1, I);
+  shift(m2, c2, I2, I);
+}
+
+extern "C" int wbc_sim_set_env_params(wbc_sim* s, const float* friction, const float* base_dmass, const float* base_dcom,
+                                      const float* gripper_dmass, const float* motor_strength, const float* env_origins,
+                                      const float* box_delta_y, const float* traj_timesteps, const float* traj_total_timesteps) {
+  if (!s) return fail(-1, "wbc_sim_set_env_params: null sim");
+  HIP_OK(hipSetDevice(s->device));
+  const int n = s->n;
+  const wbc_model& m = s->hc.model;
+  if (friction) HIP_OK(hipMemcpy(s->T.friction, friction, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (motor_strength) HIP_OK(hipMemcpy(s->T.motor, motor_strength, (size_t)n * WBC_NACT * 4, hipMemcpyHostToDevice));
+  if (env_origins) HIP_OK(hipMemcpy(s->T.origins, env_origins, (size_t)n * 3 * 4, hipMemcpyHostToDevice));
+  if (box_delta_y) HIP_OK(hipMemcpy(s->T.box_dy, box_delta_y, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (base_dmass || base_dcom || gripper_dmass) {
+    std::vector<float> bp((size_t)n * 20), mp((size_t)n * 5);
+    for (int i = 0; i < n; ++i) {
+      const double dm = base_dmass ? base_dmass[i] : 0.0, gm = gripper_dmass ? gripper_dmass[i] : 0.0;
+      double dc[3] = {0, 0, 0};
+      if (base_dcom) for (int k = 0; k < 3; ++k) dc[k] = base_dcom[(size_t)i * 3 + k];
+      mp[(size_t)i * 5] = (float)dm; for (int k = 0; k < 3; ++k) mp[(size_t)i * 5 + 1 + k] = (float)dc[k]; mp[(size_t)i * 5 + 4] = (float)gm;
+      double rc[3], rI[6], pc[3], pI[6], M, Cc[3], I[6];
+      for (int k = 0; k < 3; ++k) { rc[k] = m.base_rest_com[k]; pc[k] = m.base_piece_com[k] + dc[k]; }
+      for (int k = 0; k < 6; ++k) { rI[k] = m.base_rest_inertia[k]; pI[k] = m.base_piece_inertia[k]; }
+      merge2(m.base_rest_mass, rc, rI, m.base_piece_mass + dm, pc, pI, &M, Cc, I);
+      float* b = &bp[(size_t)i * 20];
+      b[0] = (float)M; for (int k = 0; k < 3; ++k) b[1 + k] = (float)Cc[k]; for (int k = 0; k < 6; ++k) b[4 + k] = (float)I[k];
+      for (int k = 0; k < 3; ++k) { rc[k] = m.grip_rest_com[k]; pc[k] = m.grip_piece_com[k]; }
+      for (int k = 0; k < 6; ++k) { rI[k] = m.grip_rest_inertia[k]; pI[k] = m.grip_piece_inertia[k]; }
+      merge2(m.grip_rest_mass, rc, rI, m.grip_piece_mass + gm, pc, pI, &M, Cc, I);
+      b[10] = (float)M; for (int k = 0; k < 3; ++k) b[11 + k] = (float)Cc[k]; for (int k = 0; k < 6; ++k) b[14 + k] = (float)I[k];
+    }
+    HIP_OK(hipMemcpy(s->T.body_params, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(s->T.mass_params, mp.data(), mp.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (traj_timesteps && traj_total_timesteps) {
+    std::vector<float> goal((size_t)n * 24);
+    HIP_OK(hipMemcpy(goal.data(), s->T.goal, goal.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { goal[(size_t)i * 24 + 22] = traj_timesteps[i]; goal[(size_t)i * 24 + 23] = traj_total_timesteps[i]; }
+    HIP_OK(hipMemcpy(s->T.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+extern "C" int wbc_sim_set_heightfield(wbc_sim* s, const int16_t* heights, int rows, int cols, float hs, float vs, float tx, float ty, float tz) {
+  if (!s) return fail(-1, "wbc_sim_set_heightfield: null sim");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipDeviceSynchronize());
+  if (s->hf_dev) { hipFree(s->hf_dev); s->hf_dev = nullptr; }
+  s->hc.hf = nullptr;
+  if (heights) {
+    if (rows < 2 || cols < 2) return fail(-1, "wbc_sim_set_heightfield: need at least a 2x2 grid");
+    HIP_OK(hipMalloc((void**)&s->hf_dev, (size_t)rows * cols * sizeof(int16_t)));
+    HIP_OK(hipMemcpy(s->hf_dev, heights, (size_t)rows * cols * sizeof(int16_t), hipMemcpyHostToDevice));
+    s->hc.hf = s->hf_dev; s->hc.hf_rows = rows; s->hc.hf_cols = cols; s->hc.hf_hs = hs; s->hc.hf_vs = vs;
+    s->hc.hf_t[0] = tx; s->hc.hf_t[1] = ty; s->hc.hf_t[2] = tz;
+  }
+  HIP_OK(hipMemcpy(s->dc, &s->hc, sizeof(DevConst), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
+  if (!s || !cur) return fail(-1, "wbc_sim_set_curriculum: bad arguments");
+  HIP_OK(hipSetDevice(s->device));
+  s->hc.cur = *cur;
+  // plain (synchronising) copy: the previous step's kernel must not see a half-written table
+  HIP_OK(hipMemcpy((char*)s->dc + offsetof(DevConst, cur), &s->hc.cur, sizeof(wbc_curriculum), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int wbc_sim_step(wbc_sim* s, const float* actions_dev, void* stream) {
+  if (!s || !actions_dev) return fail(-1, "wbc_sim_step: bad arguments");
+  s->step_counter += 1;
+  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int wbc_sim_reset_all(wbc_sim* s, void* stream) {
+  if (!s) return fail(-1, "wbc_sim_reset_all: null sim");
+  hipLaunchKernelGGL(wbc_reset_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n, s->seed, (uint64_t)s->step_counter);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int wbc_sim_set_dof_forces(wbc_sim* s, const float* torques_dev, void* stream) {
+  if (!s || !torques_dev) return fail(-1, "wbc_sim_set_dof_forces: bad arguments");
+  if (torques_dev != s->T.torques)
+    HIP_OK(hipMemcpyAsync(s->T.torques, torques_dev, (size_t)s->n * WBC_NDOF * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int wbc_sim_simulate(wbc_sim* s, void* stream) {
+  if (!s) return fail(-1, "wbc_sim_simulate: null sim");
+  hipLaunchKernelGGL(wbc_simulate_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int wbc_sim_set_root_state(wbc_sim* s, const float* root_dev, void* stream) {
+  if (!s || !root_dev) return fail(-1, "wbc_sim_set_root_state: bad arguments");
+  if (root_dev != s->T.root) HIP_OK(hipMemcpyAsync(s->T.root, root_dev, (size_t)s->n * 26 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int wbc_sim_set_dof_state(wbc_sim* s, const float* dof_dev, void* stream) {
+  if (!s || !dof_dev) return fail(-1, "wbc_sim_set_dof_state: bad arguments");
+  if (dof_dev != s->T.dof) HIP_OK(hipMemcpyAsync(s->T.dof, dof_dev, (size_t)s->n * 40 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+__global__ void copy_rows_indexed(float* dst, const float* src, const int32_t* ids, int n_ids, int row, int num_envs) {
+  const int i = blockIdx.x;
+  if (i >= n_ids) return;
+  const int e = ids[i];
+  if (e < 0 || e >= num_envs) return;
+  for (int k = threadIdx.x; k < row; k += blockDim.x) dst[(size_t)e * row + k] = src[(size_t)e * row + k];
+}
+extern "C" int wbc_sim_set_root_state_indexed(wbc_sim* s, const float* root_dev, const int32_t* env_ids_dev, int n, void* stream) {
+  if (!s || !root_dev || !env_ids_dev) return fail(-1, "wbc_sim_set_root_state_indexed: bad arguments");
+  if (n > 0 && root_dev != s->T.root) hipLaunchKernelGGL(copy_rows_indexed, dim3(n), dim3(64), 0, (hipStream_t)stream, s->T.root, root_dev, env_ids_dev, n, 26, s->n);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+extern "C" int wbc_sim_set_dof_state_indexed(wbc_sim* s, const float* dof_dev, const int32_t* env_ids_dev, int n, void* stream) {
+  if (!s || !dof_dev || !env_ids_dev) return fail(-1, "wbc_sim_set_dof_state_indexed: bad arguments");
+  if (n > 0 && dof_dev != s->T.dof) hipLaunchKernelGGL(copy_rows_indexed, dim3(n), dim3(64), 0, (hipStream_t)stream, s->T.dof, dof_dev, env_ids_dev, n, 40, s->n);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int wbc_sim_refresh_dof_state(wbc_sim*) { return 0; }
+extern "C" int wbc_sim_refresh_root_state(wbc_sim*) { return 0; }
+extern "C" int wbc_sim_refresh_net_contact_force(wbc_sim*) { return 0; }
+extern "C" int wbc_sim_refresh_force_sensor(wbc_sim*) { return 0; }
+extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
+  if (!s) return fail(-1, "wbc_sim_refresh_rigid_body_state: null sim");
+  hipLaunchKernelGGL(wbc_fk_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int wbc_sim_get_step_counter(wbc_sim* s, int64_t* out) { if (!s || !out) return fail(-1, "null"); *out = s->step_counter; return 0; }
+extern "C" int wbc_sim_set_step_counter(wbc_sim* s, int64_t v) { if (!s) return fail(-1, "null"); s->step_counter = v; return 0; }
+
+// sizes of the ABI structs, checked against the ctypes mirrors by the CPU tests
+extern "C" void wbc_abi_sizes(int* out) { out[0] = (int)sizeof(wbc_model); out[1] = (int)sizeof(wbc_task_cfg); out[2] = (int)sizeof(wbc_curriculum); }

@@ -1,0 +1,1000 @@
+// wbc_step_kernel.hip -- the fused widowGo1 rollout step for gfx950 (MI355X).
+//
+// One 64-lane wavefront per robot (blockDim = 64, gridDim = num_envs). All per-robot link
+// state (frames, joint screws, articulated inertias, inverse inertias, contact rows) lives in
+// LDS for the whole policy step; HBM is touched once on entry (state in) and once on exit
+// (state, observations, rewards out). Lanes are organised as 5 kinematic chains x 12 lanes
+// (4 legs of depth 3, the arm of depth 6): the three ABA passes walk the chains level by
+// level with the 6x6 algebra spread over a chain's 12 lanes (3 matrix entries per lane).
+//
+// What it replaces: WidowGo1.step (reference legged_gym/envs/widowGo1/widowGo1.py:1156-1199)
+// including the 4x {_compute_torques WG:1262-1295, gym.simulate WG:1184} decimation loop and
+// post_physics_step WG:865-915. The arithmetic mirrors oracle/wbc_oracle.c statement by
+// statement (that file is the spec and cites the reference line for every step); comments here
+// only describe the lane mapping.
+#include "wbc_device.h"
+
+#define LANES 64
+#define CH_LANES 12
+
+struct PostBuf {                  // post-physics staging; shares LDS with IA (dead once the substeps are done)
+  float out_rb[WBC_NRB_ENV][13];
+  float quatB[WBC_NB][4], omB[WBC_NB][3], voB[WBC_NB][3];
+  float o76[WBC_NPROP];
+};
+
+struct __align__(16) Smem {
+  union {
+    float IA[WBC_NB][36];        // articulated inertia; reused as K (inverse articulated inertia)
+    PostBuf post;
+  };
+  float E[WBC_NB][9];
+  float pos[WBC_NB][3];
+  float S[WBC_NB][6], v[WBC_NB][6], c[WBC_NB][6], pA[WBC_NB][6], U[WBC_NB][6], a[WBC_NB][6], g[WBC_NB][6];
+  float D[WBC_NB], u[WBC_NB], uD[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];
+  float pa1[WBC_NCHAIN][6];      // depth-1 contributions to the root, summed in fixed order
+  float q[WBC_NDOF], qd[WBC_NDOF], tau[WBC_NDOF], act[WBC_NACT];
+  float root[13], box[13], R[9], wb[3], vb[3], gF[3];
+  float bp[20], motor[WBC_NACT];
+  float cxc[WBC_NCP][3], cn[WBC_NCP][3], cW[WBC_NCP][9], cvfree[WBC_NCP][3], clam[WBC_NCP][3], cdv[WBC_NCP][3];
+  float cvtgt[WBC_NCP];
+  int cactive[WBC_NCP];
+  float out_contact[WBC_NRB_ENV][3];
+  float out_sensor[WBC_NFEET][6];
+  float goal[24], cmd[3], blv[3], bav[3];
+  float act_last[WBC_NACT];      // newest (undelayed) action, sim order
+  float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
+  float rew, arm_rew, base_yaw, mu, friction;
+  int reset_flag, time_out, ep_len;
+};
+
+// aliases: pD lives in pA, aD in c (both dead once pass 3 has run)
+#define PD(s) (s).pA
+#define AD(s) (s).c
+
+struct ChainRegs {   // per-lane constants of this lane's chain, kept in registers (static indexing only)
+  int body[WBC_MAX_DEPTH], par[WBC_MAX_DEPTH], ax[WBC_MAX_DEPTH], dof[WBC_MAX_DEPTH];
+  float arm[WBC_MAX_DEPTH];
+};
+
+__device__ __forceinline__ void fk_pass(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, int chain, int k) {
+  const int lane = threadIdx.x;
+  if (lane < 9) s.E[0][lane] = (lane % 4 == 0) ? 1.f : 0.f;
+  if (lane < 3) s.pos[0][lane] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+    const int i = cr.body[d];
+    if (chain < WBC_NCHAIN && i >= 0) {
+      const int p = cr.par[d], ax = cr.ax[d];
+      if (k < 9) {
+        const int row = k / 3, col = k % 3;
+        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        float sq, cq;
+        sincosf(s.q[cr.dof[d]], &sq, &cq);
+        const float e0 = s.E[p][row * 3 + ax], e1 = s.E[p][row * 3 + a1], e2 = s.E[p][row * 3 + a2];
+        float val = (col == ax) ? e0 : ((col == a1) ? (cq * e1 + sq * e2) : (-sq * e1 + cq * e2));
+        s.E[i][k] = val;
+      } else {
+        const int comp = k - 9;
+        const float* Ep = &s.E[p][comp * 3];
+        const float* r = C->model.joint_xyz[i];
+        s.pos[i][comp] = s.pos[p][comp] + Ep[0] * r[0] + Ep[1] * r[1] + Ep[2] * r[2];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// contact_solve of the oracle, one contact per lane
+__device__ __forceinline__ void contact_solve(const float* W, f3 n, float vn_tgt, float mu, f3 vref, float* lam) {
+  const float vn = dot(n, vref);
+  lam[0] = lam[1] = lam[2] = 0.f;
+  if (vn >= vn_tgt) return;
+  const f3 Wn = mat_mul(W, n);
+  const float nWn = dot(n, Wn);
+  const float lam_fl = (vn_tgt - vn) / nWn;
+  const f3 rhs = n * vn_tgt - vref;
+  // symmetric 3x3 solve by cofactors
+  const float a = W[0], b = W[1], c = W[2], d = W[4], e = W[5], f = W[8];
+  const float c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const float det = a * c00 + b * c01 + c * c02;
+  const float c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
+  const float id = 1.f / det;
+  const f3 st = mk3((c00 * rhs.x + c01 * rhs.y + c02 * rhs.z) * id, (c01 * rhs.x + c11 * rhs.y + c12 * rhs.z) * id,
+                    (c02 * rhs.x + c12 * rhs.y + c22 * rhs.z) * id);
+  const float ln = dot(n, st);
+  const f3 lt = st - n * ln;
+  const float ltn = sqrtf(dot(lt, lt));
+  if (ln > 0.f && ltn <= mu * ln) { lam[0] = st.x; lam[1] = st.y; lam[2] = st.z; return; }
+  if (ln <= 0.f || ltn <= 1e-12f) { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
+  const f3 dir = n + lt * (mu / ltn);
+  const f3 Wd = mat_mul(W, dir);
+  const float den = dot(n, Wd);
+  if (den <= 0.05f * nWn) { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
+  float l = (vn_tgt - vn) / den;
+  l = fmaxf(l, 0.f);
+  lam[0] = dir.x * l; lam[1] = dir.y * l; lam[2] = dir.z * l;
+}
+
+__device__ __forceinline__ void terrain_query(const DevConst* __restrict__ C, float x, float y, float* h, f3* n) {
+  if (!C->hf) { *h = C->cfg.ground_z; *n = mk3(0.f, 0.f, 1.f); return; }
+  const float fx = (x - C->hf_t[0]) / C->hf_hs, fy = (y - C->hf_t[1]) / C->hf_hs;
+  long long ix = (long long)fx, iy = (long long)fy;
+  ix = ix < 0 ? 0 : ix; iy = iy < 0 ? 0 : iy;
+  ix = ix > C->hf_rows - 2 ? C->hf_rows - 2 : ix;
+  iy = iy > C->hf_cols - 2 ? C->hf_cols - 2 : iy;
+  const float u = clampf(fx - (float)ix, 0.f, 1.f), v = clampf(fy - (float)iy, 0.f, 1.f);
+  const int16_t* H = C->hf;
+  const int cols = C->hf_cols;
+  const float h00 = H[ix * cols + iy] * C->hf_vs, h10 = H[(ix + 1) * cols + iy] * C->hf_vs;
+  const float h01 = H[ix * cols + iy + 1] * C->hf_vs, h11 = H[(ix + 1) * cols + iy + 1] * C->hf_vs;
+  float dhdx, dhdy;
+  if (u >= v) { dhdx = h10 - h00; dhdy = h11 - h10; } else { dhdy = h01 - h00; dhdx = h11 - h01; }
+  *h = h00 + u * dhdx + v * dhdy + C->hf_t[2];
+  const float gx = dhdx / C->hf_hs, gy = dhdy / C->hf_hs;
+  const float inv = 1.f / sqrtf(gx * gx + gy * gy + 1.f);
+  *n = mk3(-gx * inv, -gy * inv, inv);
+}
+
+// One physics substep on the LDS-resident state (oracle: physics_substep).
+__device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, const int chain, const int k,
+                                const bool want_outputs) {
+  const int lane = threadIdx.x;
+  const float dt = C->cfg.sim_dt;
+  const bool in_chain = chain < WBC_NCHAIN;
+  // root-frame quantities
+  if (lane == 0) {
+    quat_to_mat(&s.root[3], s.R);
+    st3(s.wb, matT_mul(s.R, ld3(&s.root[10])));
+    st3(s.vb, matT_mul(s.R, ld3(&s.root[7])));
+    st3(s.gF, matT_mul(s.R, ld3(C->cfg.gravity)));
+  }
+  fk_pass(s, C, cr, chain, k);   // begins with a barrier after the identity write, ends with one
+  // joint screws S for all 18 joints: 108 entries
+  for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
+    const int i = 1 + t / 6, kk = t % 6;
+    const int ax = C->model.axis[i];
+    const f3 sv = mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax]);
+    float val;
+    if (kk < 3) val = (kk == 0) ? sv.x : ((kk == 1) ? sv.y : sv.z);
+    else { const f3 l = cross(ld3(s.pos[i]), sv); val = (kk == 3) ? l.x : ((kk == 4) ? l.y : l.z); }
+    s.S[i][kk] = val;
+  }
+  if (lane < 6) { s.v[0][lane] = (lane < 3) ? s.wb[lane] : s.vb[lane - 3]; s.S[0][lane] = 0.f; s.c[0][lane] = 0.f; }
+  __syncthreads();
+  // velocities: each (chain, k<6) lane carries component k down its chain in a register
+  if (in_chain && k < 6) {
+    float vr = s.v[0][k];
+#pragma unroll
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+      const int i = cr.body[d];
+      if (i >= 0) { vr += s.S[i][k] * s.qd[cr.dof[d]]; s.v[i][k] = vr; }
+    }
+  }
+  __syncthreads();
+  // velocity-product accelerations c: 108 entries
+  for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
+    const int i = 1 + t / 6, kk = t % 6;
+    const float qd = s.qd[C->model.dof[i]];
+    const f3 w = ld3(&s.v[i][0]), vl = ld3(&s.v[i][3]);
+    const f3 ja = ld3(&s.S[i][0]) * qd, jl = ld3(&s.S[i][3]) * qd;
+    float val;
+    if (kk < 3) { const f3 t1 = cross(w, ja); val = (kk == 0) ? t1.x : ((kk == 1) ? t1.y : t1.z); }
+    else { const f3 t2 = cross(w, jl) + cross(vl, ja); val = (kk == 3) ? t2.x : ((kk == 4) ? t2.y : t2.z); }
+    s.c[i][kk] = val;
+  }
+  // spatial inertias in frame F and bias forces: one body per lane
+  if (lane < WBC_NB) {
+    const int i = lane;
+    float m, com[3], I6[6];
+    if (i == 0) { m = s.bp[0]; for (int j = 0; j < 3; ++j) com[j] = s.bp[1 + j]; for (int j = 0; j < 6; ++j) I6[j] = s.bp[4 + j]; }
+    else if (i == C->model.gripper_body) { m = s.bp[10]; for (int j = 0; j < 3; ++j) com[j] = s.bp[11 + j]; for (int j = 0; j < 6; ++j) I6[j] = s.bp[14 + j]; }
+    else { m = C->model.mass[i]; for (int j = 0; j < 3; ++j) com[j] = C->model.com[i][j]; for (int j = 0; j < 6; ++j) I6[j] = C->model.inertia[i][j]; }
+    const float* E = s.E[i];
+    const f3 Cc = ld3(s.pos[i]) + mat_mul(E, mk3(com[0], com[1], com[2]));
+    const float Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+    float EI[9], Ibar[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) EI[r * 3 + cc] = E[r * 3] * Ib[cc] + E[r * 3 + 1] * Ib[3 + cc] + E[r * 3 + 2] * Ib[6 + cc];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) Ibar[r * 3 + cc] = EI[r * 3] * E[cc * 3] + EI[r * 3 + 1] * E[cc * 3 + 1] + EI[r * 3 + 2] * E[cc * 3 + 2];
+    const float CC = dot(Cc, Cc);
+    const float Cv[3] = {Cc.x, Cc.y, Cc.z};
+    const float Cx[9] = {0.f, -Cc.z, Cc.y, Cc.z, 0.f, -Cc.x, -Cc.y, Cc.x, 0.f};
+    float* I = s.IA[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        I[r * 6 + cc] = Ibar[r * 3 + cc] + m * ((r == cc ? CC : 0.f) - Cv[r] * Cv[cc]);
+        I[r * 6 + 3 + cc] = m * Cx[r * 3 + cc];
+        I[(3 + r) * 6 + cc] = m * Cx[cc * 3 + r];
+        I[(3 + r) * 6 + 3 + cc] = (r == cc) ? m : 0.f;
+      }
+    float Iv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) Iv[r] = dot6(&I[r * 6], s.v[i]);
+    const f3 w = ld3(&s.v[i][0]), vl = ld3(&s.v[i][3]);
+    const f3 nn = ld3(&Iv[0]), ff = ld3(&Iv[3]);
+    st3(&s.pA[i][0], cross(w, nn) + cross(vl, ff));
+    st3(&s.pA[i][3], cross(w, ff));
+  }
+  __syncthreads();
+  // pass 2, inward: level d+1 of every chain in parallel
+#pragma unroll
+  for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
+    const int i = cr.body[d];
+    const bool act = in_chain && i >= 0;
+    if (act && k < 6) s.U[i][k] = dot6(&s.IA[i][k * 6], s.S[i]);
+    __syncthreads();
+    float Ia3[3] = {0.f, 0.f, 0.f}, pa = 0.f;
+    if (act) {
+      const int dj = cr.dof[d];
+      const float D = dot6(s.S[i], s.U[i]) + cr.arm[d];
+      float tau = s.tau[dj];
+      const float lo = C->model.q_lower[dj], hi = C->model.q_upper[dj];
+      if (lo < hi) {
+        const float qq = s.q[dj], qdv = s.qd[dj];
+        float viol = 0.f;
+        if (qq > hi) viol = qq - hi; else if (qq < lo) viol = qq - lo;
+        if (viol != 0.f) {
+          float tl = -C->cfg.limit_kappa * D / (dt * dt) * viol;
+          if (qdv * viol > 0.f) tl -= C->cfg.limit_delta * D / dt * qdv;
+          tau += tl;
+        }
+      }
+      const float u = tau - dot6(s.S[i], s.pA[i]);
+      const float invD = 1.f / D;
+      if (k == 0) { s.D[i] = D; s.u[i] = u; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int e = 3 * k + j, r = e / 6, cc = e % 6;
+        Ia3[j] = s.IA[i][e] - s.U[i][r] * s.U[i][cc] * invD;
+      }
+      if (k < 6) {
+        // row k of Ia times c = row of IA times c - U_k (U.c)/D
+        const float Uc = dot6(s.U[i], s.c[i]);
+        pa = s.pA[i][k] + (dot6(&s.IA[i][k * 6], s.c[i]) - s.U[i][k] * Uc * invD) + s.U[i][k] * u * invD;
+      }
+    }
+    __syncthreads();
+    if (act) {
+      const int p = cr.par[d];
+      if (d > 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.IA[p][3 * k + j] += Ia3[j];
+        if (k < 6) s.pA[p][k] += pa;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.IA[i][3 * k + j] = Ia3[j];
+        if (k < 6) s.pa1[chain][k] = pa;
+      }
+    }
+    __syncthreads();
+  }
+  // root: sum the five depth-1 contributions in fixed chain order
+  if (lane < 36) {
+    float acc = s.IA[0][lane];
+#pragma unroll
+    for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.IA[C->chain_body[ch][0]][lane];
+    s.IA[0][lane] = acc;
+  } else if (lane < 42) {
+    const int r = lane - 36;
+    float acc = s.pA[0][r];
+#pragma unroll
+    for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][r];
+    s.pA[0][r] = acc;
+  }
+  __syncthreads();
+  // K0 = IA0^-1 by six Gauss-Jordan sweeps, one matrix entry per lane
+  {
+    const int r = lane / 6, cc = lane % 6;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+      float val = 0.f;
+      if (lane < 36) {
+        const float id = 1.f / s.IA[0][kk * 6 + kk];
+        if (r == kk && cc == kk) val = id;
+        else if (r == kk) val = s.IA[0][kk * 6 + cc] * id;
+        else if (cc == kk) val = -s.IA[0][r * 6 + kk] * id;
+        else val = s.IA[0][r * 6 + cc] - s.IA[0][r * 6 + kk] * s.IA[0][kk * 6 + cc] * id;
+      }
+      __syncthreads();
+      if (lane < 36) s.IA[0][lane] = val;
+      __syncthreads();
+    }
+  }
+  if (lane < 6) s.a[0][lane] = -dot6(&s.IA[0][lane * 6], s.pA[0]);
+  __syncthreads();
+  // pass 3 and inverse articulated inertias, outward
+#pragma unroll
+  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+    const int i = cr.body[d];
+    const bool act = in_chain && i >= 0;
+    float invD = 0.f;
+    if (act) {
+      const int p = cr.par[d];
+      float ap[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ap[j] = s.a[p][j] + s.c[i][j];
+      invD = 1.f / s.D[i];
+      const float qdd = (s.u[i] - dot6(s.U[i], ap)) * invD;
+      if (k < 6) {
+        float apk = ap[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) apk = (k == j) ? ap[j] : apk;
+        s.a[i][k] = apk + s.S[i][k] * qdd;
+        s.g[i][k] = dot6(&s.IA[p][k * 6], s.U[i]) * invD;
+      }
+      if (k == 0) s.qdd[i] = qdd;
+    }
+    __syncthreads();
+    if (act) {
+      const int p = cr.par[d];
+      const float gam = dot6(s.U[i], s.g[i]) * invD + invD;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int e = 3 * k + j, r = e / 6, cc = e % 6;
+        s.IA[i][e] = s.IA[p][e] - s.g[i][r] * s.S[i][cc] - s.S[i][r] * s.g[i][cc] + gam * s.S[i][r] * s.S[i][cc];
+      }
+    }
+    __syncthreads();
+  }
+  // contacts: one contact sphere per lane
+  if (lane < WBC_NCP) {
+    const int kc = lane;
+    const int b = C->model.cp_body[kc];
+    const f3 xk = ld3(s.pos[b]) + mat_mul(s.E[b], ld3(C->model.cp_pos[kc]));
+    const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
+    float h; f3 nw;
+    terrain_query(C, Xw.x, Xw.y, &h, &nw);
+    const float rad = C->model.cp_radius[kc];
+    const float gap = (Xw.z - h) * nw.z - rad;
+    const int active = gap < C->cfg.contact_margin;
+    s.cactive[kc] = active;
+    s.clam[kc][0] = s.clam[kc][1] = s.clam[kc][2] = 0.f;
+    s.cdv[kc][0] = s.cdv[kc][1] = s.cdv[kc][2] = 0.f;
+    if (active) {
+      const f3 n = matT_mul(s.R, nw);
+      const f3 xc = xk - n * rad;
+      st3(s.cn[kc], n); st3(s.cxc[kc], xc);
+      s.cvtgt[kc] = (gap >= 0.f) ? -gap / dt : fminf(C->cfg.contact_erp * (-gap) / dt, C->cfg.max_depenetration_vel);
+      const float* K = s.IA[b];
+      const float X[9] = {0.f, -xc.z, xc.y, xc.z, 0.f, -xc.x, -xc.y, xc.x, 0.f};
+      float J[18];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) { J[r * 6 + cc] = -X[r * 3 + cc]; J[r * 6 + 3 + cc] = (r == cc) ? 1.f : 0.f; }
+      float KJt[18];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) KJt[r * 3 + cc] = dot6(&K[r * 6], &J[cc * 6]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc += J[r * 6 + j] * KJt[j * 3 + cc];
+          s.cW[kc][r * 3 + cc] = acc + ((r == cc) ? 1e-6f : 0.f);
+        }
+      const f3 w = ld3(&s.v[b][0]);
+      const f3 vp = ld3(&s.v[b][3]) + cross(w, xc);
+      const f3 ab_a = ld3(&s.a[b][0]);
+      const f3 ab_l = ld3(&s.a[b][3]) + ld3(s.gF);
+      const f3 apnt = ab_l + cross(ab_a, xc) + cross(w, vp);
+      st3(s.cvfree[kc], vp + apnt * dt);
+    }
+  }
+  if (lane < WBC_NB) s.qddD[lane] = 0.f;
+  if (lane < 6) AD(s)[0][lane] = 0.f;
+  __syncthreads();
+  int any = 0;
+#pragma unroll
+  for (int kc = 0; kc < WBC_NCP; ++kc) any |= s.cactive[kc];
+  if (any) {
+    for (int it = 0; it < C->cfg.contact_iters; ++it) {
+      if (lane < WBC_NCP && s.cactive[lane]) {
+        const int kc = lane;
+        const f3 own = mat_mul(s.cW[kc], ld3(s.clam[kc]));
+        const f3 vref = ld3(s.cvfree[kc]) + ld3(s.cdv[kc]) - own;
+        float lam[3];
+        contact_solve(s.cW[kc], ld3(s.cn[kc]), s.cvtgt[kc], s.mu, vref, lam);
+        s.clam[kc][0] = lam[0]; s.clam[kc][1] = lam[1]; s.clam[kc][2] = lam[2];
+      }
+      __syncthreads();
+      // gather contact wrenches per body (fixed order), pD = -f_ext
+      if (lane < WBC_NB) {
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < WBC_NCP; ++kc) {
+          if (s.cactive[kc] && C->model.cp_body[kc] == lane) {
+            const f3 f = ld3(s.clam[kc]) * (1.f / dt);
+            const f3 mom = cross(ld3(s.cxc[kc]), f);
+            acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
+        const int i = cr.body[d];
+        if (in_chain && i >= 0 && k < 6) {
+          const float uD = -dot6(s.S[i], PD(s)[i]);
+          const float val = PD(s)[i][k] + s.U[i][k] * (uD / s.D[i]);
+          if (k == 0) s.uD[i] = uD;
+          if (d > 0) PD(s)[cr.par[d]][k] += val; else s.pa1[chain][k] = val;
+        }
+        __syncthreads();
+      }
+      if (lane < 6) {
+        float acc = PD(s)[0][lane];
+#pragma unroll
+        for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][lane];
+        PD(s)[0][lane] = acc;
+      }
+      __syncthreads();
+      if (lane < 6) AD(s)[0][lane] = -dot6(&s.IA[0][lane * 6], PD(s)[0]);
+      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+        const int i = cr.body[d];
+        if (in_chain && i >= 0 && k < 6) {
+          const int p = cr.par[d];
+          const float qdd = (s.uD[i] - dot6(s.U[i], AD(s)[p])) / s.D[i];
+          AD(s)[i][k] = AD(s)[p][k] + s.S[i][k] * qdd;
+          if (k == 0) s.qddD[i] = qdd;
+        }
+        __syncthreads();
+      }
+      if (lane < WBC_NCP && s.cactive[lane]) {
+        const int kc = lane, b = C->model.cp_body[kc];
+        const f3 t = cross(ld3(&AD(s)[b][0]), ld3(s.cxc[kc]));
+        st3(s.cdv[kc], (ld3(&AD(s)[b][3]) + t) * dt);
+      }
+      __syncthreads();
+    }
+  }
+  // contact force outputs (world-frame net force per rigid body, foot-frame sensor wrench)
+  if (want_outputs) {
+    if (lane < WBC_NRB_ENV) {
+      f3 acc = mk3(0.f, 0.f, 0.f);
+      for (int kc = 0; kc < WBC_NCP; ++kc)
+        if (s.cactive[kc] && C->model.cp_rb[kc] == lane) acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * (1.f / dt));
+      st3(s.out_contact[lane], acc);
+    } else if (lane >= 32 && lane < 32 + WBC_NFEET) {
+      const int ft = lane - 32;
+      f3 fa = mk3(0.f, 0.f, 0.f), ta = mk3(0.f, 0.f, 0.f);
+      for (int kc = 0; kc < WBC_NCP; ++kc)
+        if (s.cactive[kc] && C->cp_foot[kc] == ft) {
+          const int b = C->model.cp_body[kc];
+          const f3 f = ld3(s.clam[kc]) * (1.f / dt);
+          const f3 arm = ld3(s.cn[kc]) * (-C->model.cp_radius[kc]);
+          fa = fa + matT_mul(s.E[b], f);
+          ta = ta + matT_mul(s.E[b], cross(arm, f));
+        }
+      st3(&s.out_sensor[ft][0], fa); st3(&s.out_sensor[ft][3], ta);
+    }
+  }
+  // integrate (semi-implicit Euler)
+  float a0[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) a0[j] = s.a[0][j] + AD(s)[0][j];
+  __syncthreads();
+  if (lane >= 1 && lane < WBC_NB) {
+    const int dj = C->model.dof[lane];
+    float qd = s.qd[dj] + dt * (s.qdd[lane] + s.qddD[lane]);
+    const float lim = C->model.qd_limit[dj];
+    if (lim > 0.f) qd = fminf(fmaxf(qd, -lim), lim);
+    s.qd[dj] = qd;
+    s.q[dj] += dt * qd;
+  } else if (lane == 0) {
+    const f3 wb = ld3(s.wb), vb = ld3(s.vb);
+    const f3 accF = mk3(a0[3], a0[4], a0[5]) + ld3(s.gF) + cross(wb, vb);
+    const f3 vw = ld3(&s.root[7]) + mat_mul(s.R, accF) * dt;
+    const f3 ww = ld3(&s.root[10]) + mat_mul(s.R, mk3(a0[0], a0[1], a0[2])) * dt;
+    st3(&s.root[7], vw); st3(&s.root[10], ww);
+    st3(&s.root[0], ld3(&s.root[0]) + vw * dt);
+    const float om[4] = {ww.x, ww.y, ww.z, 0.f};
+    float dq[4], nq[4], nn = 0.f;
+    quat_mul(om, &s.root[3], dq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { nq[j] = s.root[3 + j] + 0.5f * dt * dq[j]; nn += nq[j] * nq[j]; }
+    nn = 1.f / sqrtf(nn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.root[3 + j] = nq[j] * nn;
+  }
+  __syncthreads();
+}
+
+// rigid_body_state of the 27 robot bodies + box from the LDS state (oracle: update_rigid_body_state).
+// Needs E/pos of the CURRENT q (fk_pass) and s.R.
+__device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, const int chain, const int k) {
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    quat_to_mat(&s.root[3], s.R);
+    for (int j = 0; j < 3; ++j) { s.post.omB[0][j] = s.root[10 + j]; s.post.voB[0][j] = s.root[7 + j]; }
+    for (int j = 0; j < 4; ++j) s.post.quatB[0][j] = s.root[3 + j];
+  }
+  fk_pass(s, C, cr, chain, k);
+  // one lane per chain walks it: world angular velocity, origin velocity, orientation
+  if (chain < WBC_NCHAIN && k == 0) {
+#pragma unroll
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+      const int i = cr.body[d];
+      if (i >= 0) {
+        const int p = cr.par[d], ax = cr.ax[d], dj = cr.dof[d];
+        const f3 relw = mat_mul(s.R, ld3(s.pos[i]) - ld3(s.pos[p]));
+        st3(s.post.voB[i], ld3(s.post.voB[p]) + cross(ld3(s.post.omB[p]), relw));
+        const f3 sw = mat_mul(s.R, mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax]));
+        st3(s.post.omB[i], ld3(s.post.omB[p]) + sw * s.qd[dj]);
+        float sh, ch;
+        sincosf(0.5f * s.q[dj], &sh, &ch);
+        float qa[4] = {0.f, 0.f, 0.f, ch};
+        qa[0] = (ax == 0) ? sh : 0.f; qa[1] = (ax == 1) ? sh : 0.f; qa[2] = (ax == 2) ? sh : 0.f;
+        quat_mul(s.post.quatB[p], qa, s.post.quatB[i]);
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < WBC_NRB) {
+    const int r = lane, b = C->model.rb_body[r];
+    const f3 t = mat_mul(s.E[b], ld3(C->model.rb_offset[r]));
+    const f3 pw = mat_mul(s.R, ld3(s.pos[b]) + t);
+    const f3 offw = mat_mul(s.R, t);
+    st3(&s.post.out_rb[r][0], ld3(&s.root[0]) + pw);
+    for (int j = 0; j < 4; ++j) s.post.out_rb[r][3 + j] = s.post.quatB[b][j];
+    st3(&s.post.out_rb[r][7], ld3(s.post.voB[b]) + cross(ld3(s.post.omB[b]), offw));
+    st3(&s.post.out_rb[r][10], ld3(s.post.omB[b]));
+  } else if (lane == WBC_NRB) {
+    for (int j = 0; j < 13; ++j) s.post.out_rb[WBC_NRB][j] = s.box[j];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void resample_commands(Smem& s, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int slot) {
+  const float cx = rng_range(C->cur.lin_vel_x_range[0], C->cur.lin_vel_x_range[1], seed, env, step, slot);
+  const float cy = rng_range(C->cur.ang_vel_yaw_range[0], C->cur.ang_vel_yaw_range[1], seed, env, step, slot + 1);
+  const bool keep = (cx > C->cfg.lin_vel_x_clip) || (fabsf(cy) > C->cfg.ang_vel_yaw_clip);
+  s.cmd[0] = keep ? cx : 0.f; s.cmd[1] = 0.f; s.cmd[2] = keep ? cy : 0.f;
+}
+
+enum { G_START = 0, G_GOAL = 3, G_GOAL_CART = 6, G_CURR = 9, G_CURR_CART = 12, G_DORN = 15, G_ORN = 18,
+       G_TIMER = 21, G_TRAJ = 22, G_TOTAL = 23 };
+
+__device__ int goal_collision(const Smem& s, const DevConst* __restrict__ C) {
+  const int ns = C->cfg.goal_collision_samples;
+  int hit = 0;
+  for (int kk = 0; kk < ns; ++kk) {
+    const float t = (ns > 1) ? (float)kk / (float)(ns - 1) : 0.f;
+    const f3 sp = mk3(lerp_torch(s.goal[G_START], s.goal[G_GOAL], t), lerp_torch(s.goal[G_START + 1], s.goal[G_GOAL + 1], t),
+                      lerp_torch(s.goal[G_START + 2], s.goal[G_GOAL + 2], t));
+    const f3 c = sphere2cart(sp);
+    const float cv[3] = {c.x, c.y, c.z};
+    int inside = 1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) inside &= (cv[j] < C->cfg.goal_collision_upper[j]) && (cv[j] > C->cfg.goal_collision_lower[j]);
+    hit |= inside;
+    hit |= c.z < C->cfg.goal_underground_limit;
+  }
+  return hit;
+}
+
+__device__ void resample_ee_goal(Smem& s, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int slot_orn, int slot_sph, float base_yaw) {
+  for (int j = 0; j < 3; ++j) {
+    const float d = rng_range(C->cfg.goal_delta_orn_range[j][0], C->cfg.goal_delta_orn_range[j][1], seed, env, step, slot_orn + j);
+    s.goal[G_DORN + j] = d;
+    s.goal[G_ORN + j] = wrap_to_pi(d + (j == 2 ? base_yaw : 0.f));
+  }
+  for (int j = 0; j < 3; ++j) s.goal[G_START + j] = s.goal[G_GOAL + j];
+  for (int r = 0; r < 10; ++r) {
+    s.goal[G_GOAL + 0] = rng_range(C->cur.goal_l_range[0], C->cur.goal_l_range[1], seed, env, step, slot_sph + 3 * r);
+    s.goal[G_GOAL + 1] = rng_range(C->cur.goal_p_range[0], C->cur.goal_p_range[1], seed, env, step, slot_sph + 3 * r + 1);
+    s.goal[G_GOAL + 2] = rng_range(C->cur.goal_y_range[0], C->cur.goal_y_range[1], seed, env, step, slot_sph + 3 * r + 2);
+    if (!goal_collision(s, C)) break;
+  }
+  st3(&s.goal[G_GOAL_CART], sphere2cart(ld3(&s.goal[G_GOAL])));
+  s.goal[G_TIMER] = 0.f;
+}
+
+__device__ const int8_t POLICY_PERM[WBC_NDOF] = {3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19};
+__device__ const int8_t MET_OF[WBC_NREW] = {
+    WBC_MET_ENERGY_SQUARE, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, WBC_MET_TRACKING_ANG_VEL_YAW_EXP, WBC_MET_LEG_ACTION_L2,
+    WBC_MET_FOOT_CONTACTS_Z, WBC_MET_TRACKING_EE_SPHERE, -1, WBC_MET_TRACKING_EE_CART, -1, WBC_MET_TRACKING_EE_ORN,
+    WBC_MET_LEG_ENERGY_ABS_SUM, -1, WBC_MET_LEG_ACTION_L2, -1, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, -1, -1, -1, WBC_MET_TORQUE};
+
+// compute_reward of the oracle, executed by lane 0 on LDS state
+__device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq) {
+  const wbc_task_cfg& cf = C->cfg;
+  float term[WBC_NREW], met_src[WBC_NREW];
+#pragma unroll
+  for (int t = 0; t < WBC_NREW; ++t) met_src[t] = 0.f;
+  const float* ee_pos = s.post.out_rb[C->model.gripper_rb];
+  const float* ee_orn = ee_pos + 3;
+  float sq = 0.f, abs_sum = 0.f, sum = 0.f, arm_abs = 0.f, tq2 = 0.f, act_leg = 0.f;
+  for (int j = 0; j < 12; ++j) {
+    const float p = s.tau[j] * s.qd[j];
+    sq += p * p; abs_sum += fabsf(p); sum += p; act_leg += s.act[j] * s.act[j];
+  }
+  for (int j = 12; j < WBC_NDOF - 2; ++j) arm_abs += fabsf(s.tau[j] * s.qd[j]);
+  for (int j = 0; j < WBC_NDOF; ++j) tq2 += s.tau[j] * s.tau[j];
+  term[WBC_REW_ENERGY_SQUARE] = sq;
+  term[WBC_REW_SURVIVE] = 1.f;
+  const float ex = fabsf(s.cmd[0] - s.blv[0]);
+  term[WBC_REW_TRACKING_LIN_VEL_X_L1] = -ex + fabsf(s.cmd[0]);
+  term[WBC_REW_TRACKING_LIN_VEL_X_EXP] = expf(-ex / cf.tracking_sigma);
+  const float eyaw = fabsf(s.cmd[2] - s.bav[2]);
+  term[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = expf(-eyaw / cf.tracking_sigma);
+  term[WBC_REW_TRACKING_ANG_VEL_YAW_L1] = -eyaw + fabsf(s.cmd[2]);
+  const float hip = s.act[0] * s.act[0] + s.act[3] * s.act[3] + s.act[6] * s.act[6] + s.act[9] * s.act[9];
+  term[WBC_REW_HIP_ACTION_L2] = hip;
+  float fz = 0.f;
+  for (int f = 0; f < 4; ++f) fz += s.out_sensor[f][2] * s.out_sensor[f][2];
+  term[WBC_REW_FOOT_CONTACTS_Z] = fz;
+  const f3 rel = mk3(ee_pos[0] - s.root[0], ee_pos[1] - s.root[1], ee_pos[2] - cf.z_invariant_offset);
+  const f3 loc = quat_rotate_inverse(yq, rel);
+  const f3 sph = cart2sphere(loc);
+  const float es = fabsf(sph.x - s.goal[G_CURR]) * cf.sphere_error_scale[0] + fabsf(sph.y - s.goal[G_CURR + 1]) * cf.sphere_error_scale[1] +
+                   fabsf(sph.z - s.goal[G_CURR + 2]) * cf.sphere_error_scale[2];
+  term[WBC_REW_TRACKING_EE_SPHERE] = expf(-es / cf.tracking_ee_sigma);
+  const float yq_inv[4] = {-yq[0], -yq[1], -yq[2], yq[3]};
+  const f3 tw = quat_rotate_inverse(yq_inv, ld3(&s.goal[G_CURR_CART]));
+  const float ec = fabsf(ee_pos[0] - (s.root[0] + tw.x)) + fabsf(ee_pos[1] - (s.root[1] + tw.y)) + fabsf(ee_pos[2] - (cf.z_invariant_offset + tw.z));
+  term[WBC_REW_TRACKING_EE_CART] = expf(-ec / cf.tracking_ee_sigma);
+  const f3 eul = euler_from_quat(ee_orn);
+  const float eu[3] = {eul.x, eul.y, eul.z};
+  float eo = 0.f, eo_ry = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float d = wrap_to_pi(s.goal[G_ORN + j] - eu[j]);
+    eo += fabsf(d) * cf.orn_error_scale[j];
+    if (j != 1) eo_ry += fabsf(d * cf.orn_error_scale[j]);
+  }
+  term[WBC_REW_TRACKING_EE_ORN] = expf(-eo / cf.tracking_ee_sigma);
+  term[WBC_REW_TRACKING_EE_ORN_RY] = expf(-eo_ry / cf.tracking_ee_sigma);
+  term[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum;
+  term[WBC_REW_LEG_ENERGY_SUM_ABS] = fabsf(sum);
+  term[WBC_REW_LEG_ACTION_L2] = act_leg;
+  term[WBC_REW_LEG_ENERGY] = sum;
+  term[WBC_REW_ARM_ENERGY_ABS_SUM] = arm_abs;
+  const float dx = s.cmd[0] - s.blv[0], dy = s.cmd[1] - s.blv[1], dz = s.cmd[2] - s.blv[2];
+  term[WBC_REW_TRACKING_LIN_VEL] = expf(-(dx * dx + dy * dy) / cf.tracking_sigma);
+  term[WBC_REW_TRACKING_LIN_VEL_Y_L2] = dy * dy;
+  term[WBC_REW_TRACKING_LIN_VEL_Z_L2] = dz * dz;
+  term[WBC_REW_TORQUES] = tq2;
+  met_src[WBC_REW_ENERGY_SQUARE] = sq; met_src[WBC_REW_TRACKING_LIN_VEL_X_L1] = ex; met_src[WBC_REW_TRACKING_LIN_VEL_X_EXP] = ex;
+  met_src[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = eyaw; met_src[WBC_REW_HIP_ACTION_L2] = hip; met_src[WBC_REW_LEG_ACTION_L2] = act_leg;
+  met_src[WBC_REW_FOOT_CONTACTS_Z] = fz; met_src[WBC_REW_TRACKING_EE_SPHERE] = es; met_src[WBC_REW_TRACKING_EE_CART] = ec;
+  met_src[WBC_REW_TRACKING_EE_ORN_RY] = eo_ry; met_src[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum; met_src[WBC_REW_TORQUES] = tq2;
+  float r = 0.f, ra = 0.f;
+#pragma unroll
+  for (int t = 0; t < WBC_NREW; ++t) {
+    const float sc = C->cur.leg_reward_scale[t];
+    if (sc != 0.f) {
+      const float v = term[t] * sc;
+      r += v; s.ep_sums[t] += v;
+      if (MET_OF[t] >= 0) s.met_sums[MET_OF[t]] += met_src[t];
+    }
+  }
+  if (cf.only_positive_rewards && r < 0.f) r = 0.f;
+  s.rew = r / 100.f;
+#pragma unroll
+  for (int t = 0; t < WBC_NREW; ++t) {
+    const float sc = C->cur.arm_reward_scale[t];
+    if (sc != 0.f) {
+      const float v = term[t] * sc;
+      ra += v; s.ep_sums[t] += v;
+      if (MET_OF[t] >= 0) s.met_sums[MET_OF[t]] += met_src[t];
+    }
+  }
+  if (cf.only_positive_rewards && ra < 0.f) ra = 0.f;
+  s.arm_rew = ra / 100.f;
+}
+
+// Load one env's state from HBM into LDS (consecutive lanes read consecutive words).
+__device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env) {
+  const int lane = threadIdx.x;
+  if (lane < 13) { s.root[lane] = T.root[(size_t)env * 26 + lane]; s.box[lane] = T.root[(size_t)env * 26 + 13 + lane]; }
+  if (lane < 40) { const float v = T.dof[(size_t)env * 40 + lane]; if (lane & 1) s.qd[lane >> 1] = v; else s.q[lane >> 1] = v; }
+  if (lane < 20) s.bp[lane] = T.body_params[(size_t)env * 20 + lane];
+  if (lane < WBC_NACT) s.motor[lane] = T.motor[(size_t)env * WBC_NACT + lane];
+  if (lane < 24) s.goal[lane] = T.goal[(size_t)env * 24 + lane];
+  if (lane < 3) s.cmd[lane] = T.commands[(size_t)env * 3 + lane];
+  if (lane < WBC_NREW) s.ep_sums[lane] = T.ep_sums[(size_t)env * WBC_NREW + lane];
+  if (lane < WBC_NMETRIC) s.met_sums[lane] = T.met_sums[(size_t)env * WBC_NMETRIC + lane];
+  if (lane == 0) {
+    s.friction = T.friction[env];
+    s.mu = fmaxf(0.5f * (s.friction + C->cfg.terrain_friction), 0.f);
+    s.ep_len = (int)T.ep_len[env];
+  }
+}
+
+__device__ void make_chain_regs(ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
+#pragma unroll
+  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+    int i = (chain < WBC_NCHAIN) ? C->chain_body[chain][d] : -1;
+    cr.body[d] = i;
+    const int ii = i < 0 ? 0 : i;
+    cr.par[d] = C->model.parent[ii] < 0 ? 0 : C->model.parent[ii];
+    cr.ax[d] = C->model.axis[ii] < 0 ? 0 : C->model.axis[ii];
+    const int dj = C->model.dof[ii] < 0 ? 0 : C->model.dof[ii];
+    cr.dof[d] = dj;
+    cr.arm[d] = (dj < WBC_NACT) ? C->cfg.joint_armature[dj] : 0.f;
+  }
+}
+
+// _compute_torques (oracle: compute_torques): lanes 0..19
+__device__ __forceinline__ void torque_pass(Smem& s, const DevConst* __restrict__ C) {
+  const int j = threadIdx.x;
+  if (j < WBC_NACT) {
+    const float a_s = s.act[j] * s.motor[j] * C->cfg.action_scale[j];
+    float qw = s.q[j];
+    if (j == WBC_NACT - 8) qw = wrap_to_pi(qw);
+    const float t = C->cfg.p_gains[j] * (a_s + C->cfg.default_dof_pos[j] - qw) - C->cfg.d_gains[j] * s.qd[j];
+    const float lim = C->cfg.torque_limits[j];
+    s.tau[j] = fminf(fmaxf(t, -lim), lim);
+  } else if (j < WBC_NDOF) {
+    s.tau[j] = 0.f;
+  }
+}
+
+// reset_idx for this env (oracle: reset_env); all lanes enter, writes go to LDS
+__device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int start, float base_yaw) {
+  const int lane = threadIdx.x;
+  if (lane < WBC_NDOF) {
+    s.q[lane] = C->cfg.default_dof_pos[lane] * rng_range(C->cfg.dof_reset_lo, C->cfg.dof_reset_hi, seed, env, step, SLOT_RESET_DOF + lane);
+    s.qd[lane] = 0.f;
+  }
+  if (lane < WBC_NREW) { T.ep_sums_done[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane]; }
+  if (lane < WBC_NMETRIC) { T.met_sums_done[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane]; }
+  __syncthreads();
+  if (lane < WBC_NREW) s.ep_sums[lane] = 0.f;
+  if (lane < WBC_NMETRIC) s.met_sums[lane] = 0.f;
+  if (lane == 0) {
+    for (int j = 0; j < 13; ++j) s.root[j] = C->cfg.base_init_state[j];
+    for (int j = 0; j < 3; ++j) s.root[j] += T.origins[(size_t)env * 3 + j];
+    for (int j = 0; j < 2; ++j) s.root[j] += rng_range(-C->cfg.origin_perturb_range, C->cfg.origin_perturb_range, seed, env, step, SLOT_RESET_XY + j);
+    s.box[0] = C->cfg.box_origin_x;
+    s.box[1] = s.root[1] + T.box_dy[env];
+    s.box[2] = C->cfg.box_origin_z;
+    for (int j = 0; j < 6; ++j) s.root[7 + j] = rng_range(-C->cfg.init_vel_perturb_range, C->cfg.init_vel_perturb_range, seed, env, step, SLOT_RESET_VEL + j);
+    if (start || s.time_out) resample_commands(s, C, seed, env, step, SLOT_RESET_CMD);
+    resample_ee_goal(s, C, seed, env, step, SLOT_RESET_GOAL_ORN, SLOT_RESET_GOAL_SPHERE, base_yaw);
+    s.ep_len = 0;
+    s.reset_flag = 1;
+    s.goal[G_TIMER] = 0.f;
+  }
+  __syncthreads();
+}
+
+// compute_observations (oracle) + the HBM write-out of the step's results.
+__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset) {
+  const int lane = threadIdx.x;
+  const wbc_task_cfg& cf = C->cfg;
+  // proprio vector o76, one or two entries per lane
+  for (int e = lane; e < WBC_NPROP; e += LANES) {
+    float val;
+    if (e < 2) { const f3 rpy = euler_from_quat(&s.root[3]); val = (e == 0) ? rpy.x : rpy.y; }
+    else if (e < 5) val = s.bav[e - 2] * cf.obs_scale_ang_vel;
+    else if (e < 25) {
+      const int sj = POLICY_PERM[e - 5];
+      float qw = s.q[sj];
+      if (sj == WBC_NDOF - 8) qw = wrap_to_pi(qw);
+      val = (qw - cf.default_dof_pos[sj]) * cf.obs_scale_dof_pos;
+    } else if (e < 45) val = s.qd[POLICY_PERM[e - 25]] * cf.obs_scale_dof_vel;
+    else if (e < 63) val = was_reset ? 0.f : s.act_last[POLICY_PERM[e - 45]];
+    else if (e < 67) {
+      const int f = e - 63;
+      const float* fs = s.out_sensor[f ^ 1];     // [1,0,3,2]
+      val = sqrtf(dot6(fs, fs)) > 1.5f ? 1.f : 0.f;
+    } else if (e < 70) val = s.cmd[e - 67] * cf.commands_scale[e - 67];
+    else if (e < 73) val = s.goal[G_CURR + e - 70];
+    else val = s.goal[G_DORN + e - 73];
+    s.post.o76[e] = val;
+  }
+  __syncthreads();
+  // obs_buf = [o76, priv24, old history]; history <- shifted / refilled
+  const float clipv = cf.clip_obs;
+  float* obs = T.obs + (size_t)env * WBC_NOBS;
+  float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
+  const bool refill = s.ep_len <= 1;
+  float old[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int idx = lane + r * LANES;
+    old[r] = (idx < WBC_HIST * WBC_NPROP && !was_reset) ? hist[idx] : 0.f;
+  }
+  __syncthreads();   // all history reads done before the in-place shift
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int idx = lane + r * LANES;
+    if (idx < WBC_HIST * WBC_NPROP) {
+      obs[WBC_NPROP + WBC_NPRIV + idx] = clampf(old[r], -clipv, clipv);
+      if (refill) hist[idx] = s.post.o76[idx % WBC_NPROP];
+      else if (idx >= WBC_NPROP) hist[idx - WBC_NPROP] = old[r];
+    }
+  }
+  if (!refill) for (int e = lane; e < WBC_NPROP; e += LANES) hist[(WBC_HIST - 1) * WBC_NPROP + e] = s.post.o76[e];
+  for (int e = lane; e < WBC_NPROP + WBC_NPRIV; e += LANES) {
+    float val;
+    if (e < WBC_NPROP) val = s.post.o76[e];
+    else if (e < WBC_NPROP + 5) val = T.mass_params[(size_t)env * 5 + e - WBC_NPROP];
+    else if (e == WBC_NPROP + 5) val = s.friction;
+    else val = s.motor[e - WBC_NPROP - 6] - 1.f;
+    obs[e] = clampf(val, -clipv, clipv);
+  }
+  // state write-back
+  if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  if (lane < WBC_NDOF) { T.torques[(size_t)env * WBC_NDOF + lane] = s.tau[lane]; T.last_dof_vel[(size_t)env * WBC_NDOF + lane] = s.qd[lane]; }
+  if (lane < WBC_NACT) { T.actions[(size_t)env * WBC_NACT + lane] = s.act[lane]; T.last_actions[(size_t)env * WBC_NACT + lane] = s.act[lane]; }
+  if (lane < 6) T.last_root_vel[(size_t)env * 6 + lane] = s.root[7 + lane];
+  if (lane < 24) T.goal[(size_t)env * 24 + lane] = s.goal[lane];
+  if (lane < 3) { T.commands[(size_t)env * 3 + lane] = s.cmd[lane]; T.base_lin_vel[(size_t)env * 3 + lane] = s.blv[lane]; T.base_ang_vel[(size_t)env * 3 + lane] = s.bav[lane]; }
+  if (lane < WBC_NREW) T.ep_sums[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane];
+  if (lane < WBC_NMETRIC) T.met_sums[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane];
+  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) T.contact[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
+  if (lane < WBC_NFEET * 6) T.sensor[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  if (lane == 0) {
+    T.rew[env] = s.rew; T.arm_rew[env] = s.arm_rew;
+    T.reset_buf[env] = s.reset_flag; T.time_out[env] = (uint8_t)s.time_out; T.ep_len[env] = s.ep_len;
+  }
+}
+
+// WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment.
+extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(DevTensors T, const DevConst* __restrict__ C, const float* __restrict__ actions,
+                                                                    int num_envs, uint64_t seed, uint64_t step) {
+  __shared__ Smem s;
+  const int env = blockIdx.x;
+  if (env >= num_envs) return;
+  const int lane = threadIdx.x;
+  const int chain = lane / CH_LANES, k = lane % CH_LANES;
+  ChainRegs cr;
+  make_chain_regs(cr, C, chain);
+  load_env(s, T, C, env);
+  // action reorder, clip and delay FIFO (WG:1162-1168)
+  if (lane < WBC_NACT) {
+    const float clipa = C->cfg.clip_actions;
+    const float a = clampf(actions[(size_t)env * WBC_NACT + POLICY_PERM[lane]], -clipa, clipa);
+    float* ah = T.act_hist + (size_t)env * (WBC_ADELAY_LEN * WBC_NACT);
+    float used = a;
+    if (C->cfg.action_delay != -1) {
+      float h[WBC_ADELAY_LEN];
+#pragma unroll
+      for (int r = 0; r < WBC_ADELAY_LEN - 1; ++r) h[r] = ah[(r + 1) * WBC_NACT + lane];
+      h[WBC_ADELAY_LEN - 1] = a;
+      const int sel = WBC_ADELAY_LEN - C->cfg.action_delay - 1;
+      used = h[0];
+#pragma unroll
+      for (int r = 0; r < WBC_ADELAY_LEN; ++r) { ah[r * WBC_NACT + lane] = h[r]; used = (r == sel) ? h[r] : used; }
+    }
+    s.act[lane] = used;
+    s.act_last[lane] = a;
+  }
+  __syncthreads();
+  const int dec = C->cfg.decimation;
+  for (int t = 0; t < dec; ++t) {
+    torque_pass(s, C);
+    __syncthreads();
+    physics_substep(s, C, cr, chain, k, t == dec - 1);
+  }
+  // post_physics_step (WG:865-915)
+  rigid_body_pass(s, C, cr, chain, k);
+  float base_yaw = 0.f;
+  if (lane == 0) {
+    s.ep_len += 1;
+    st3(s.blv, quat_rotate_inverse(&s.root[3], ld3(&s.root[7])));
+    st3(s.bav, quat_rotate_inverse(&s.root[3], ld3(&s.root[10])));
+    const f3 rpy = euler_from_quat(&s.root[3]);
+    base_yaw = rpy.z;
+    s.base_yaw = base_yaw;
+    float sy, cy;
+    sincosf(0.5f * base_yaw, &sy, &cy);
+    const float yq[4] = {0.f, 0.f, sy, cy};
+    // update_curr_ee_goal
+    const float tt = clampf(s.goal[G_TIMER] / s.goal[G_TRAJ], 0.f, 1.f);
+    for (int j = 0; j < 3; ++j) s.goal[G_CURR + j] = lerp_torch(s.goal[G_START + j], s.goal[G_GOAL + j], tt);
+    st3(&s.goal[G_CURR_CART], sphere2cart(ld3(&s.goal[G_CURR])));
+    s.goal[G_TIMER] += 1.f;
+    if (s.goal[G_TIMER] > s.goal[G_TOTAL]) resample_ee_goal(s, C, seed, env, step, SLOT_GOAL_ORN, SLOT_GOAL_SPHERE, base_yaw);
+    if (s.ep_len % C->cfg.resample_interval == 0) resample_commands(s, C, seed, env, step, SLOT_CMD);
+    if (C->cfg.push_interval > 0 && (step % (uint64_t)C->cfg.push_interval) == 0) {
+      const float px = rng_range(-C->cfg.max_push_vel, C->cfg.max_push_vel, seed, env, step, SLOT_PUSH);
+      const float py = rng_range(-C->cfg.max_push_vel, C->cfg.max_push_vel, seed, env, step, SLOT_PUSH + 1);
+      const float kk = ((s.cmd[0] + s.cmd[1] + s.cmd[2]) == 0.f) ? 2.5f : 1.f;
+      s.root[7] = px * kk; s.root[8] = py * kk;
+    }
+    const float r = rpy.x, p = rpy.y, z = s.root[2], th = C->cfg.term_rp_threshold;
+    const int r_term = ((r > th) && (s.goal[G_CURR + 2] >= 0.f)) || ((r < -th) && (s.goal[G_CURR + 2] <= 0.f));
+    const int p_term = ((p > th) && (s.goal[G_CURR + 1] >= 0.f)) || ((p < -th) && (s.goal[G_CURR + 1] <= 0.f));
+    const int z_term = z < C->cfg.term_z_threshold;
+    s.time_out = s.ep_len > C->cfg.max_episode_length;
+    s.reset_flag = r_term | p_term | z_term | s.time_out;
+    compute_reward(s, C, yq);
+  }
+  __syncthreads();
+  const bool do_reset = s.reset_flag != 0;
+  if (do_reset) reset_env(s, T, C, seed, env, step, 0, s.base_yaw);
+  if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
+    T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
+    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
+  }
+  observe_and_store(s, T, C, env, do_reset);
+}
+
+// reset_idx(all envs, start=True) (BT:129): one wave per env
+extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step) {
+  __shared__ Smem s;
+  const int env = blockIdx.x;
+  if (env >= num_envs) return;
+  const int lane = threadIdx.x;
+  const int chain = lane / CH_LANES, k = lane % CH_LANES;
+  ChainRegs cr;
+  make_chain_regs(cr, C, chain);
+  load_env(s, T, C, env);
+  if (lane == 0) { s.time_out = 0; s.reset_flag = 0; }
+  __syncthreads();
+  float yaw = 0.f;
+  if (lane == 0) { yaw = euler_from_quat(&s.root[3]).z; s.base_yaw = yaw; }
+  __syncthreads();
+  reset_env(s, T, C, seed, env, step, 1, s.base_yaw);
+  rigid_body_pass(s, C, cr, chain, k);
+  // write back what a reset touches
+  if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  if (lane < 24) T.goal[(size_t)env * 24 + lane] = s.goal[lane];
+  if (lane < 3) T.commands[(size_t)env * 3 + lane] = s.cmd[lane];
+  if (lane < WBC_NREW) T.ep_sums[(size_t)env * WBC_NREW + lane] = 0.f;
+  if (lane < WBC_NMETRIC) T.met_sums[(size_t)env * WBC_NMETRIC + lane] = 0.f;
+  if (lane < WBC_NACT) T.last_actions[(size_t)env * WBC_NACT + lane] = 0.f;
+  if (lane < WBC_NDOF) T.last_dof_vel[(size_t)env * WBC_NDOF + lane] = 0.f;
+  for (int e = lane; e < WBC_HIST * WBC_NPROP; e += LANES) T.obs_hist[(size_t)env * (WBC_HIST * WBC_NPROP) + e] = 0.f;
+  for (int e = lane; e < WBC_ADELAY_LEN * WBC_NACT; e += LANES) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + e] = 0.f;
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  if (lane == 0) { T.reset_buf[env] = 1; T.ep_len[env] = 0; }
+}
+
+// gym.simulate: one substep with the torques tensor as set (no PD, no post-physics)
+extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs) {
+  __shared__ Smem s;
+  const int env = blockIdx.x;
+  if (env >= num_envs) return;
+  const int lane = threadIdx.x;
+  const int chain = lane / CH_LANES, k = lane % CH_LANES;
+  ChainRegs cr;
+  make_chain_regs(cr, C, chain);
+  load_env(s, T, C, env);
+  if (lane < WBC_NDOF) s.tau[lane] = T.torques[(size_t)env * WBC_NDOF + lane];
+  __syncthreads();
+  physics_substep(s, C, cr, chain, k, true);
+  if (lane < 13) T.root[(size_t)env * 26 + lane] = s.root[lane];
+  if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) T.contact[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
+  if (lane < WBC_NFEET * 6) T.sensor[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
+}
+
+// gym.refresh_rigid_body_state_tensor after a state write: forward kinematics only
+extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs) {
+  __shared__ Smem s;
+  const int env = blockIdx.x;
+  if (env >= num_envs) return;
+  const int lane = threadIdx.x;
+  const int chain = lane / CH_LANES, k = lane % CH_LANES;
+  ChainRegs cr;
+  make_chain_regs(cr, C, chain);
+  load_env(s, T, C, env);
+  __syncthreads();
+  rigid_body_pass(s, C, cr, chain, k);
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+}
+
+static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");

@@ -1,0 +1,72 @@
+"""Loader of libwbc_amd.so (the HIP extension, built in-tree by __graft_entry__.build()).
+There is no CPU fallback: if the library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwbc_amd.so")
+_lib = None
+
+c_void, c_int, c_f32p = C.c_void_p, C.c_int, C.c_void_p
+
+
+class WbcError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WbcError(f"{LIB_PATH} not found: build the HIP extension first "
+                           f"(python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(LIB_PATH)
+        L.wbc_last_error.restype = C.c_char_p
+        L.wbc_sim_arena_bytes.restype = C.c_size_t
+        L.wbc_sim_arena_bytes.argtypes = [c_int]
+        L.wbc_sim_create.argtypes = [C.POINTER(abi.WbcModel), C.POINTER(abi.WbcTaskCfg), c_int, c_int, C.c_uint64,
+                                     c_void, C.c_size_t, C.POINTER(c_void)]
+        L.wbc_sim_destroy.argtypes = [c_void]
+        L.wbc_sim_get_tensor.argtypes = [c_void, c_int, C.POINTER(c_void), C.POINTER(C.c_int64), C.POINTER(c_int), C.POINTER(c_int)]
+        L.wbc_sim_set_env_params.argtypes = [c_void] + [c_void] * 9
+        L.wbc_sim_set_heightfield.argtypes = [c_void, c_void, c_int, c_int] + [C.c_float] * 5
+        L.wbc_sim_set_curriculum.argtypes = [c_void, C.POINTER(abi.WbcCurriculum)]
+        L.wbc_sim_step.argtypes = [c_void, c_void, c_void]
+        L.wbc_sim_reset_all.argtypes = [c_void, c_void]
+        L.wbc_sim_set_dof_forces.argtypes = [c_void, c_void, c_void]
+        L.wbc_sim_simulate.argtypes = [c_void, c_void]
+        L.wbc_sim_set_root_state.argtypes = [c_void, c_void, c_void]
+        L.wbc_sim_set_dof_state.argtypes = [c_void, c_void, c_void]
+        L.wbc_sim_set_root_state_indexed.argtypes = [c_void, c_void, c_void, c_int, c_void]
+        L.wbc_sim_set_dof_state_indexed.argtypes = [c_void, c_void, c_void, c_int, c_void]
+        for fn in ("wbc_sim_refresh_dof_state", "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force",
+                   "wbc_sim_refresh_force_sensor"):
+            getattr(L, fn).argtypes = [c_void]
+        L.wbc_sim_refresh_rigid_body_state.argtypes = [c_void, c_void]
+        L.wbc_sim_get_step_counter.argtypes = [c_void, C.POINTER(C.c_int64)]
+        L.wbc_sim_set_step_counter.argtypes = [c_void, C.c_int64]
+        L.wbc_gae_compute.argtypes = [c_void] * 7 + [c_int, c_int, C.c_float, C.c_float, c_void]
+        L.wbc_gae_normalize.argtypes = [c_void, c_void, C.c_int64, c_void]
+        L.wbc_gae_workspace_doubles.argtypes = [c_int]
+        L.wbc_abi_sizes.argtypes = [C.POINTER(c_int)]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "wbc_last_error", "wbc_sim_arena_bytes", "wbc_sim_create", "wbc_sim_destroy", "wbc_sim_get_tensor",
+    "wbc_sim_set_env_params", "wbc_sim_set_heightfield", "wbc_sim_set_curriculum", "wbc_sim_step", "wbc_sim_reset_all",
+    "wbc_sim_set_dof_forces", "wbc_sim_simulate", "wbc_sim_set_root_state", "wbc_sim_set_dof_state",
+    "wbc_sim_set_root_state_indexed", "wbc_sim_set_dof_state_indexed", "wbc_sim_refresh_dof_state",
+    "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force", "wbc_sim_refresh_force_sensor",
+    "wbc_sim_refresh_rigid_body_state", "wbc_sim_get_step_counter", "wbc_sim_set_step_counter", "wbc_gae_compute",
+    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes"]
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise WbcError(f"{what} failed ({rc}): {lib().wbc_last_error().decode()}")

@@ -1,0 +1,137 @@
+"""`WbcSim`: the torch-facing handle of one `wbc_sim` (include/wbc_sim.h). torch provides the
+device arena, the stream and zero-copy tensor views; every computation is a kernel in libwbc_amd.so.
+
+This is the layer that stands where `isaacgym.gymapi` + `gymtorch.wrap_tensor` stand in the
+reference (legged_gym/envs/widowGo1/widowGo1.py:505-551)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import abi
+from .native import check, lib
+
+_TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "u8": torch.uint8}
+
+
+class WbcSim:
+    def __init__(self, model: abi.WbcModel, cfg: abi.WbcTaskCfg, num_envs: int, device: torch.device, seed: int = 1):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("WbcSim needs a ROCm device: the rollout step only exists as HIP kernels")
+        self.L = lib()
+        self.device = device
+        self.num_envs = num_envs
+        self.model, self.cfg = model, cfg
+        nbytes = self.L.wbc_sim_arena_bytes(num_envs)
+        self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        h = C.c_void_p()
+        dev_index = device.index if device.index is not None else torch.cuda.current_device()
+        check(self.L.wbc_sim_create(C.byref(model), C.byref(cfg), num_envs, dev_index, seed,
+                                    self.arena.data_ptr(), nbytes, C.byref(h)), "wbc_sim_create")
+        self.h = h
+        self._views: Dict[str, torch.Tensor] = {}
+        base = self.arena.data_ptr()
+        for name in abi.TENSOR_IDS:
+            p, shape, nd, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int()
+            check(self.L.wbc_sim_get_tensor(self.h, abi.T[name], C.byref(p), shape, C.byref(nd), C.byref(dt)), "wbc_sim_get_tensor")
+            dims = [int(shape[i]) for i in range(nd.value)]
+            tdt = _TORCH_DT[["f32", "i64", "u8"][dt.value]]
+            off = p.value - base
+            nb = int(np.prod(dims)) * torch.empty((), dtype=tdt).element_size()
+            self._views[name] = self.arena[off:off + nb].view(tdt).view(dims)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            torch.cuda.synchronize(self.device)
+            self.L.wbc_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tensors ---------------------------------------------------------------------------
+    def tensor(self, name: str) -> torch.Tensor:
+        """Zero-copy view of a device tensor (names: abi.TENSOR_IDS)."""
+        return self._views[name]
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- setup -----------------------------------------------------------------------------
+    def set_env_params(self, friction=None, base_dmass=None, base_dcom=None, gripper_dmass=None, motor_strength=None,
+                       env_origins=None, box_delta_y=None, traj_timesteps=None, traj_total_timesteps=None):
+        n = self.num_envs
+        keep = []
+
+        def ptr(x, cols):
+            if x is None:
+                return None
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(n * cols))
+            keep.append(a)
+            return a.ctypes.data
+        torch.cuda.synchronize(self.device)
+        check(self.L.wbc_sim_set_env_params(self.h, ptr(friction, 1), ptr(base_dmass, 1), ptr(base_dcom, 3), ptr(gripper_dmass, 1),
+                                            ptr(motor_strength, 18), ptr(env_origins, 3), ptr(box_delta_y, 1),
+                                            ptr(traj_timesteps, 1), ptr(traj_total_timesteps, 1)), "wbc_sim_set_env_params")
+
+    def set_curriculum(self, cur: abi.WbcCurriculum):
+        check(self.L.wbc_sim_set_curriculum(self.h, C.byref(cur)), "wbc_sim_set_curriculum")
+
+    def set_heightfield(self, heights: Optional[np.ndarray], hscale=0.0, vscale=0.0, tx=0.0, ty=0.0, tz=0.0):
+        if heights is None:
+            check(self.L.wbc_sim_set_heightfield(self.h, None, 0, 0, 0, 0, 0, 0, 0), "wbc_sim_set_heightfield")
+            return
+        h = np.ascontiguousarray(heights, dtype=np.int16)
+        check(self.L.wbc_sim_set_heightfield(self.h, h.ctypes.data, h.shape[0], h.shape[1], hscale, vscale, tx, ty, tz),
+              "wbc_sim_set_heightfield")
+
+    @property
+    def step_counter(self) -> int:
+        v = C.c_int64()
+        check(self.L.wbc_sim_get_step_counter(self.h, C.byref(v)))
+        return v.value
+
+    @step_counter.setter
+    def step_counter(self, v: int):
+        check(self.L.wbc_sim_set_step_counter(self.h, int(v)))
+
+    # ---- stepping --------------------------------------------------------------------------
+    def step(self, actions: torch.Tensor) -> None:
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        assert actions.shape == (self.num_envs, abi.NACT)
+        check(self.L.wbc_sim_step(self.h, actions.data_ptr(), self._stream()), "wbc_sim_step")
+
+    def reset_all(self) -> None:
+        check(self.L.wbc_sim_reset_all(self.h, self._stream()), "wbc_sim_reset_all")
+
+    def set_dof_forces(self, torques: torch.Tensor) -> None:
+        assert torques.is_cuda and torques.dtype == torch.float32 and torques.is_contiguous()
+        check(self.L.wbc_sim_set_dof_forces(self.h, torques.data_ptr(), self._stream()), "wbc_sim_set_dof_forces")
+
+    def simulate(self) -> None:
+        check(self.L.wbc_sim_simulate(self.h, self._stream()), "wbc_sim_simulate")
+
+    def set_root_state(self, root: torch.Tensor) -> None:
+        check(self.L.wbc_sim_set_root_state(self.h, root.data_ptr(), self._stream()), "wbc_sim_set_root_state")
+
+    def set_dof_state(self, dof: torch.Tensor) -> None:
+        check(self.L.wbc_sim_set_dof_state(self.h, dof.data_ptr(), self._stream()), "wbc_sim_set_dof_state")
+
+    def set_root_state_indexed(self, root: torch.Tensor, env_ids: torch.Tensor) -> None:
+        ids = env_ids.to(torch.int32).contiguous()
+        check(self.L.wbc_sim_set_root_state_indexed(self.h, root.data_ptr(), ids.data_ptr(), ids.numel(), self._stream()))
+
+    def set_dof_state_indexed(self, dof: torch.Tensor, env_ids: torch.Tensor) -> None:
+        ids = env_ids.to(torch.int32).contiguous()
+        check(self.L.wbc_sim_set_dof_state_indexed(self.h, dof.data_ptr(), ids.data_ptr(), ids.numel(), self._stream()))
+
+    def refresh_rigid_body_state(self) -> None:
+        check(self.L.wbc_sim_refresh_rigid_body_state(self.h, self._stream()), "wbc_sim_refresh_rigid_body_state")

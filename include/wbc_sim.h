@@ -263,13 +263,19 @@ int wbc_sim_set_step_counter(wbc_sim* sim, int64_t value);
 /* RolloutStorage.compute_returns (RS:136-150) as one launch: reverse-time GAE over both
  * reward channels with shared dones, then advantages = returns - values. Device pointers:
  * rewards, values, returns, advantages f32 [T,N,2]; dones u8 [T,N]; last_values f32 [N,2].
- * stats_dev (f64 [3]: count, sum, sum of squares of the raw advantages) is filled for the
- * joint normalisation (RS:150), which wbc_gae_normalize applies with the (optionally
- * all-reduced) statistics. */
+ * stats_dev (f64 [wbc_gae_workspace_doubles(N)]; the first three entries receive count, sum and
+ * sum of squares of the raw advantages) is filled for the joint normalisation (RS:150), which
+ * wbc_gae_normalize applies with the (optionally all-reduced) statistics. */
 int wbc_gae_compute(const float* rewards, const float* values, const uint8_t* dones,
                     const float* last_values, float* returns, float* advantages, double* stats_dev,
                     int T, int N, float gamma, float lam, void* stream);
-int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t count, void* stream);
+/* (advantages - mean) / (std + 1e-8) over `total` = T*N*2 elements with the statistics in stats_dev[0..2]. */
+int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t total, void* stream);
+/* Number of doubles stats_dev must hold for N envs (3 statistics + per-block partials). */
+int wbc_gae_workspace_doubles(int N);
+
+/* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
+void wbc_abi_sizes(int* out3);
 
 #ifdef __cplusplus
 }

@@ -240,35 +240,24 @@ static void fk(const ora_sim* s, const REAL* q, aba_ws* w) {
   }
 }
 
-/* 6x6 SPD inverse by Cholesky (A = L L^T), in place on a copy. */
+/* 6x6 SPD inverse by six Gauss-Jordan sweeps (no pivoting: the matrix is positive definite).
+ * Written entry-wise so that the HIP kernel can run one entry per lane with the same arithmetic. */
 static void spd6_inverse(const REAL* A, REAL* Ainv) {
-  REAL L[36] = {0}, Li[36] = {0};
-  for (int j = 0; j < 6; ++j) {
-    REAL sum = A[j * 6 + j];
-    for (int k = 0; k < j; ++k) sum -= L[j * 6 + k] * L[j * 6 + k];
-    REAL d = sqrt(sum);
-    L[j * 6 + j] = d;
-    for (int i = j + 1; i < 6; ++i) {
-      REAL t = A[i * 6 + j];
-      for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-      L[i * 6 + j] = t / d;
+  REAL M[36], Nw[36];
+  memcpy(M, A, sizeof(M));
+  for (int k = 0; k < 6; ++k) {
+    REAL id = 1 / M[k * 6 + k];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+      REAL v;
+      if (r == k && c == k) v = id;
+      else if (r == k) v = M[k * 6 + c] * id;
+      else if (c == k) v = -M[r * 6 + k] * id;
+      else v = M[r * 6 + c] - M[r * 6 + k] * M[k * 6 + c] * id;
+      Nw[r * 6 + c] = v;
     }
+    memcpy(M, Nw, sizeof(M));
   }
-  for (int j = 0; j < 6; ++j) {            /* Li = L^-1 (lower) */
-    Li[j * 6 + j] = 1 / L[j * 6 + j];
-    for (int i = j + 1; i < 6; ++i) {
-      REAL t = 0;
-      for (int k = j; k < i; ++k) t -= L[i * 6 + k] * Li[k * 6 + j];
-      Li[i * 6 + j] = t / L[i * 6 + i];
-    }
-  }
-  for (int i = 0; i < 6; ++i)              /* Ainv = Li^T Li */
-    for (int j = 0; j < 6; ++j) {
-      REAL t = 0;
-      int k0 = i > j ? i : j;
-      for (int k = k0; k < 6; ++k) t += Li[k * 6 + i] * Li[k * 6 + j];
-      Ainv[i * 6 + j] = t;
-    }
+  memcpy(Ainv, M, sizeof(M));
 }
 
 static void solve3(const REAL* W, const REAL* b, REAL* x) { /* symmetric 3x3, cofactors */

@@ -1,0 +1,135 @@
+"""GPU parity of the fused rollout step (libwbc_amd.so, through the C-ABI) against the oracle on the
+same seeded inputs. Floating-point tolerance: the HIP path computes in fp32; against the fp64 oracle
+(the spec) and its fp32 build, single-step state errors stay below 3e-4 absolute / 5e-4 relative
+(velocities: the contact solve amplifies fp32 rounding of positions by 1/dt). Reset masks,
+time-outs, episode lengths and every random draw are compared bit-exactly."""
+import copy
+
+import numpy as np
+import pytest
+
+import helpers
+from wbc_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+N = 64
+
+
+def _t(g, name):
+    import torch
+    torch.cuda.synchronize()
+    return g.tensor(name).detach().cpu().numpy().astype(np.float64)
+
+
+def test_simulate_substep_matches_oracle(robot):
+    import torch
+    params = helpers.random_env_params(N, seed=3)
+    g = helpers.make_gpu(robot, N, params)
+    o = helpers.make_oracle(robot, N, params, "f64")
+    rng = np.random.default_rng(11)
+    root, dof = helpers.random_standing_state(N, robot["tcfg"], rng)
+    tau = rng.uniform(-8, 8, (N, 20)).astype(np.float32)
+    tau[:, 18:] = 0
+    g.tensor("ROOT_STATES").copy_(torch.from_numpy(root))
+    g.tensor("DOF_STATE").copy_(torch.from_numpy(dof))
+    g.set_dof_forces(torch.from_numpy(tau).cuda())
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", tau)
+    n_contact = 0
+    for it in range(3):
+        g.simulate()
+        o.simulate()
+        np.testing.assert_allclose(_t(g, "DOF_STATE"), o.get("DOF_STATE"), atol=3e-4, rtol=1e-4)
+        np.testing.assert_allclose(_t(g, "ROOT_STATES")[:, 0], o.get("ROOT_STATES")[:, 0], atol=3e-4, rtol=1e-4)
+        fo = o.get("NET_CONTACT_FORCE")
+        np.testing.assert_allclose(_t(g, "NET_CONTACT_FORCE"), fo, atol=0.05, rtol=2e-3)
+        np.testing.assert_allclose(_t(g, "FORCE_SENSOR"), o.get("FORCE_SENSOR"), atol=0.05, rtol=2e-3)
+        n_contact += (np.abs(fo).sum(-1) > 0).sum()
+        helpers.sync_oracle_from_gpu(o, g, ["ROOT_STATES", "DOF_STATE"])
+    assert n_contact > N      # the test states do exercise the contact solver
+    g.close()
+
+
+@pytest.mark.parametrize("precision,atol", [("f64", 3e-4), ("f32", 3e-4)])
+def test_step_matches_oracle_from_synced_state(robot, precision, atol):
+    import torch
+    params = helpers.random_env_params(N, seed=5)
+    g = helpers.make_gpu(robot, N, params)
+    o = helpers.make_oracle(robot, N, params, precision)
+    g.reset_all()
+    o.reset_all()
+    for name in ("ROOT_STATES", "DOF_STATE", "GOAL_STATE", "COMMANDS", "RIGID_BODY_STATE"):
+        np.testing.assert_allclose(_t(g, name), o.get(name), atol=2e-5, rtol=1e-5, err_msg=name)
+    rng = np.random.default_rng(17)
+    resets = 0
+    # a step counter that makes the push (every 150 steps) and the command resampling fire inside the window
+    g.step_counter = 140
+    o.step_counter = 140
+    for step in range(40):
+        helpers.sync_oracle_from_gpu(o, g)
+        a = (0.6 * rng.normal(size=(N, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda())
+        o.step(a)
+        # integer / boolean outputs: bit-exact
+        np.testing.assert_array_equal(_t(g, "RESET_BUF"), o.get("RESET_BUF"), err_msg=f"reset mask, step {step}")
+        np.testing.assert_array_equal(_t(g, "TIME_OUT_BUF"), o.get("TIME_OUT_BUF"))
+        np.testing.assert_array_equal(_t(g, "EPISODE_LENGTH"), o.get("EPISODE_LENGTH"))
+        resets += int(o.get("RESET_BUF").sum())
+        for name in ("DOF_STATE", "ROOT_STATES", "TORQUES", "COMMANDS", "GOAL_STATE", "ACTIONS", "ACTION_HISTORY",
+                     "BASE_LIN_VEL", "BASE_ANG_VEL", "LAST_DOF_VEL", "LAST_ROOT_VEL", "LAST_ACTIONS"):
+            np.testing.assert_allclose(_t(g, name), o.get(name), atol=atol, rtol=5e-4, err_msg=f"{name}, step {step}")
+        np.testing.assert_allclose(_t(g, "RIGID_BODY_STATE"), o.get("RIGID_BODY_STATE"), atol=atol, rtol=1e-4)
+        np.testing.assert_allclose(_t(g, "OBS_BUF"), o.get("OBS_BUF"), atol=5 * atol, rtol=1e-4, err_msg=f"obs, step {step}")
+        np.testing.assert_allclose(_t(g, "OBS_HISTORY"), o.get("OBS_HISTORY"), atol=5 * atol, rtol=1e-4)
+        np.testing.assert_allclose(_t(g, "REW_BUF"), o.get("REW_BUF"), atol=2e-4, rtol=2e-3, err_msg=f"rew, step {step}")
+        np.testing.assert_allclose(_t(g, "ARM_REW_BUF"), o.get("ARM_REW_BUF"), atol=2e-5, rtol=1e-3)
+        np.testing.assert_allclose(_t(g, "EPISODE_SUMS"), o.get("EPISODE_SUMS"), atol=2e-2, rtol=2e-3)
+        np.testing.assert_allclose(_t(g, "FORCE_SENSOR"), o.get("FORCE_SENSOR"), atol=0.1, rtol=5e-3)
+    assert resets > 10     # resets (and therefore the reset path and its random draws) were exercised
+    g.close()
+
+
+def test_free_running_rollout_stays_close(robot):
+    """No state syncing: 8 policy steps (32 substeps) of the HIP path vs the fp64 oracle."""
+    import torch
+    n = 32
+    params = helpers.random_env_params(n, seed=9)
+    tc = copy.copy(robot["tcfg"])
+    tc.term_z_threshold = 0.05        # keep the episodes alive: this test is about the dynamics
+    tc.term_rp_threshold = 10.0
+    g = helpers.make_gpu(robot, n, params, tcfg=tc)
+    o = helpers.make_oracle(robot, n, params, "f64", tcfg=tc)
+    g.reset_all(); o.reset_all()
+    rng = np.random.default_rng(23)
+    for step in range(8):
+        a = (0.3 * rng.normal(size=(n, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda()); o.step(a)
+    assert np.isfinite(_t(g, "OBS_BUF")).all()
+    err = np.abs(_t(g, "DOF_STATE")[:, :, 0] - o.get("DOF_STATE")[:, :, 0]).max(1)
+    # chaotic contact switching may let a few envs drift; the bulk must agree to fp32 accuracy
+    assert np.median(err) < 2e-4 and np.quantile(err, 0.9) < 5e-3
+    np.testing.assert_array_equal(_t(g, "EPISODE_LENGTH"), o.get("EPISODE_LENGTH"))
+    g.close()
+
+
+def test_state_setters_and_fk_refresh(robot):
+    import torch
+    params = helpers.random_env_params(N, seed=2)
+    g = helpers.make_gpu(robot, N, params)
+    o = helpers.make_oracle(robot, N, params, "f64")
+    rng = np.random.default_rng(4)
+    root, dof = helpers.random_standing_state(N, robot["tcfg"], rng)
+    g.set_root_state(torch.from_numpy(root).cuda())
+    g.set_dof_state(torch.from_numpy(dof).cuda())
+    g.refresh_rigid_body_state()
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.refresh_rigid_body_state()
+    np.testing.assert_allclose(_t(g, "RIGID_BODY_STATE"), o.get("RIGID_BODY_STATE"), atol=2e-5, rtol=1e-5)
+    # indexed setters touch only the listed envs
+    root2 = root.copy(); root2[:, 0, 2] += 1.0
+    ids = torch.tensor([1, 5, 7], device="cuda")
+    g.set_root_state_indexed(torch.from_numpy(root2).cuda(), ids)
+    got = _t(g, "ROOT_STATES")
+    mask = np.zeros(N, bool); mask[[1, 5, 7]] = True
+    np.testing.assert_allclose(got[mask, 0, 2], root2[mask, 0, 2], rtol=1e-6)
+    np.testing.assert_allclose(got[~mask, 0, 2], root[~mask, 0, 2], rtol=1e-6)
+    g.close()
