@@ -1,0 +1,47 @@
+"""update_command_curriculum of the task (reference legged_gym/envs/widowGo1/widowGo1.py:675-692):
+host scalars -> wbc_curriculum (command ranges, EE-goal ranges, the two scheduled reward scales and
+the full reward-scale tables with zero = inactive, WG:128-131,145-148)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi
+
+# reward names the reference's config knows but the fused step does not implement (all zero in the
+# shipped widowGo1 config); a non-zero scale for one of these is an error, not a silent drop
+UNIMPLEMENTED_REWARDS = {"termination", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_vel", "dof_acc",
+                         "base_height", "feet_air_time", "collision", "feet_stumble", "action_rate", "stand_still",
+                         "arm_orientation"}
+
+
+def _scales(obj) -> dict:
+    return {k: float(getattr(obj, k)) for k in dir(obj)
+            if not k.startswith("_") and isinstance(getattr(obj, k), (int, float)) and not isinstance(getattr(obj, k), bool)}
+
+
+def curriculum_value(schedule, init, final, counter):
+    """_get_curriculum_value, WG:675-676."""
+    init, final = np.asarray(init, dtype=np.float64), np.asarray(final, dtype=np.float64)
+    return np.clip((counter - schedule[0]) / (schedule[1] - schedule[0]), 0, 1) * (final - init) + init
+
+
+def make_curriculum(cfg, update_counter: int) -> abi.WbcCurriculum:
+    cur = abi.WbcCurriculum()
+    cmd, cr, g, ge = cfg.commands, cfg.commands.ranges, cfg.goal_ee, cfg.goal_ee.ranges
+    abi._set(cur.lin_vel_x_range, curriculum_value(cmd.lin_vel_x_schedule, cr.init_lin_vel_x, cr.final_lin_vel_x, update_counter))
+    abi._set(cur.ang_vel_yaw_range, curriculum_value(cmd.ang_vel_yaw_schedule, cr.init_ang_vel_yaw, cr.final_ang_vel_yaw, update_counter))
+    abi._set(cur.goal_l_range, curriculum_value(g.l_schedule, ge.init_pos_l, ge.final_pos_l, update_counter))
+    abi._set(cur.goal_p_range, curriculum_value(g.p_schedule, ge.init_pos_p, ge.final_pos_p, update_counter))
+    abi._set(cur.goal_y_range, curriculum_value(g.y_schedule, ge.init_pos_y, ge.final_pos_y, update_counter))
+    leg, arm = _scales(cfg.rewards.scales), _scales(cfg.rewards.arm_scales)
+    for table in (leg, arm):
+        for name, val in table.items():
+            if val != 0 and (name in UNIMPLEMENTED_REWARDS or name not in abi.REWARD_TERMS):
+                raise NotImplementedError(f"reward term '{name}' has a non-zero scale but is not implemented by the fused step")
+    leg["tracking_ang_vel_yaw_exp"] = float(curriculum_value(cmd.tracking_ang_vel_yaw_schedule, 0, cr.final_tracking_ang_vel_yaw_exp, update_counter))
+    key = "tracking_ee_sphere" if arm.get("tracking_ee_sphere", 0) != 0 else "tracking_ee_cart"      # WG:689-692
+    arm[key] = float(curriculum_value(g.tracking_ee_reward_schedule, 0, ge.final_tracking_ee_reward, update_counter))
+    for i, name in enumerate(abi.REWARD_TERMS):
+        cur.leg_reward_scale[i] = leg.get(name, 0.0)
+        cur.arm_reward_scale[i] = arm.get(name, 0.0)
+    return cur

@@ -1,0 +1,308 @@
+"""`LeggedRobot` / `WidowGo1`: the task classes with the reference's public surface (constructor
+arguments, attribute names, tensor views, `step` / `reset` / `update_command_curriculum`), backed by
+the fused HIP step instead of Isaac Gym + ~150 eager torch ops.
+
+Reference: legged_gym/envs/widowGo1/widowGo1.py:49 (WidowGo1), legged_gym/envs/base/legged_robot.py:52-77
+and legged_gym/envs/base/base_task.py:41-131 (constructor, buffers, reset). Everything the reference
+computes per step in Python lives in csrc/wbc_step_kernel.hip; this file only does what the reference
+does on the host at construction time (domain randomisation draws, WG:207-228,402-408,431-496,574-575)
+and exposes views.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import abi
+from .curriculum import make_curriculum
+from .rsl_rl.env import VecEnv
+from .sim import WbcSim
+from .urdf_model import RobotModel, build_model
+
+
+class BaseTask(VecEnv):
+    """Buffer/attribute contract of legged_gym/envs/base/base_task.py:41-131 (viewer omitted: headless)."""
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.physics_engine = physics_engine
+        self.sim_device = str(sim_device)
+        self.device = torch.device(self.sim_device)
+        self.headless = headless
+        self.num_envs = cfg.env.num_envs
+        self.num_obs = cfg.env.num_observations
+        self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_actions = cfg.env.num_actions
+        self.privileged_obs_buf = None
+        self.extras = {}
+        self.viewer = None
+        self.enable_viewer_sync = False
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    def reset_idx(self, env_ids):
+        raise NotImplementedError
+
+    def reset(self):
+        """Reset all robots, then one zero-action step (BT:127-131)."""
+        self.reset_idx(torch.arange(self.num_envs, device=self.device), start=True)
+        obs, privileged_obs, _, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self.device))
+        return obs, privileged_obs
+
+    def render(self, sync_frame_time=True):
+        return None
+
+
+class LeggedRobot(BaseTask):
+    """Shared pieces of LR:52-77,279-305: config parsing, DoF limits from the URDF, views."""
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
+                 robot_model: Optional[RobotModel] = None, seed: Optional[int] = None):
+        super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
+        self.debug_viz = False
+        self.init_done = False
+        self.robot_model = robot_model if robot_model is not None else self._load_model(cfg)
+        self._seed = int(seed if seed is not None else getattr(cfg, "seed", 1))
+        self._parse_cfg(cfg)
+        self.create_sim()
+        self._init_buffers()
+        self.init_done = True
+
+    @staticmethod
+    def _load_model(cfg) -> RobotModel:
+        path = cfg.asset.file
+        if "{LEGGED_GYM_ROOT_DIR}" not in path and path.endswith(".urdf"):
+            return build_model(path)
+        return abi.load_default_model()      # the packaged widowGo1 tables (tools/extract_model.py)
+
+
+class WidowGo1(LeggedRobot):
+    def _parse_cfg(self, cfg):                                                     # WG:78-121
+        sim_dt = self.sim_params.dt if self.sim_params is not None and hasattr(self.sim_params, "dt") else cfg.sim.dt
+        self.num_torques = cfg.env.num_torques
+        self.dt = cfg.control.decimation * sim_dt
+        self._sim_dt = sim_dt
+        self.obs_scales = cfg.normalization.obs_scales
+        self.update_counter = 0
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.push_interval = np.ceil(cfg.domain_rand.push_interval_s / self.dt)
+        self.clip_actions = cfg.normalization.clip_actions
+        self.action_delay = cfg.env.action_delay
+        if cfg.terrain.mesh_type not in ["heightfield", "trimesh"]:
+            cfg.terrain.curriculum = False
+        self.collect_episode_stats = True
+
+    # ---- construction ----------------------------------------------------------------------
+    def create_sim(self):                                                           # WG:230-237, 255-429
+        cfg, m, n = self.cfg, self.robot_model, self.num_envs
+        self.wmodel = abi.fill_model(m, foot_name=cfg.asset.foot_name)
+        self.tcfg = abi.fill_task_cfg(cfg, m, sim_dt=self._sim_dt)
+        self.sim = WbcSim(self.wmodel, self.tcfg, n, self.device, seed=self._seed)
+        self.num_dofs, self.num_bodies = m.num_dofs, m.num_rigid_bodies
+        self.dof_names, self.body_names = list(m.dof_names), list(m.rb_names)
+        self.dof_wo_gripper_names = self.dof_names[:-2]
+        self.body_names_to_idx = {n_: i for i, n_ in enumerate(self.body_names)}
+        self.dof_names_to_idx = {n_: i for i, n_ in enumerate(self.dof_names)}
+        self.gripper_idx = self.body_names_to_idx["wx250s/ee_gripper_link"]
+        dev = self.device
+        feet = [i for i, s in enumerate(self.body_names) if cfg.asset.foot_name in s]
+        self.feet_indices = torch.tensor(feet, dtype=torch.long, device=dev)
+        pen = [i for name in cfg.asset.penalize_contacts_on for i, s in enumerate(self.body_names) if name in s]
+        self.penalized_contact_indices = torch.tensor(pen, dtype=torch.long, device=dev)
+        term = [i for name in cfg.asset.terminate_after_contacts_on for i, s in enumerate(self.body_names) if name in s]
+        if term:
+            raise NotImplementedError("terminate_after_contacts_on is empty in the widowGo1 config; contact termination "
+                                      "is not part of the fused step")
+        self.termination_contact_indices = torch.tensor(term, dtype=torch.long, device=dev)
+        self._terrain_setup()
+        self._randomise()
+
+    def _terrain_setup(self):
+        """Flat ground unless a height grid was attached with `set_heightfield` (the Perlin terrain of
+        utils/terrain.py:40-99 is generated by callers; see DESIGN.md, scope row f-2)."""
+        self.height_samples = None
+
+    def set_heightfield(self, heights_i16: np.ndarray, horizontal_scale, vertical_scale, tx, ty, tz):
+        self.sim.set_heightfield(heights_i16, horizontal_scale, vertical_scale, tx, ty, tz)
+        self.height_samples = torch.from_numpy(np.asarray(heights_i16)).to(self.device)
+
+    def _randomise(self):
+        """Host-side draws of _get_env_origins WG:207-228, _process_rigid_shape_props WG:468-496,
+        _process_rigid_body_props WG:431-456, motor strengths WG:402-408, trajectory timing WG:574-575."""
+        cfg, n = self.cfg, self.num_envs
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(self._seed)
+        nprng = np.random.default_rng(self._seed)
+        rand = lambda lo, hi, *shape: (hi - lo) * torch.rand(*shape, generator=gen) + lo   # noqa: E731
+        t, dr = cfg.terrain, cfg.domain_rand
+        half_col = t.tot_cols * t.horizontal_scale / 2
+        half_row = t.tot_rows * t.horizontal_scale / 2
+        origins = torch.zeros(n, 3)
+        origins[:, 0] = rand(-2.5 * half_col / 5, -2 * half_col / 5, n)
+        origins[:, 1] = rand(-half_row + 10, half_row - 10, n)
+        self.env_origins = origins.to(self.device)
+        self.custom_origins = True
+        sign = torch.randint(0, 2, (n,), generator=gen) * 2 - 1
+        box_dy = sign * rand(cfg.box.box_env_origins_y_range[0], cfg.box.box_env_origins_y_range[1], n)
+        if dr.randomize_friction:
+            buckets = rand(dr.friction_range[0], dr.friction_range[1], 1000)
+            friction = buckets[torch.randint(0, 1000, (n,), generator=gen)]
+        else:
+            friction = torch.ones(n)
+        dmass = nprng.uniform(*dr.added_mass_range, size=n) if dr.randomize_base_mass else np.zeros(n)
+        gmass = nprng.uniform(*dr.gripper_added_mass_range, size=n) if dr.randomize_gripper_mass else np.zeros(n)
+        if dr.randomize_base_com:
+            lo = [dr.added_com_range_x[0], dr.added_com_range_y[0], dr.added_com_range_z[0]]
+            hi = [dr.added_com_range_x[1], dr.added_com_range_y[1], dr.added_com_range_z[1]]
+            dcom = nprng.uniform(lo, hi, size=(n, 3))
+        else:
+            dcom = np.zeros((n, 3))
+        if dr.randomize_motor:
+            motor = torch.cat([rand(*dr.leg_motor_strength_range, n, 12), rand(*dr.arm_motor_strength_range, n, 6)], dim=1)
+        else:
+            motor = torch.ones(n, self.num_torques)
+        traj = rand(cfg.goal_ee.traj_time[0], cfg.goal_ee.traj_time[1], n) / self.dt
+        total = traj + rand(cfg.goal_ee.hold_time[0], cfg.goal_ee.hold_time[1], n) / self.dt
+        self.sim.set_env_params(friction=friction.numpy(), base_dmass=dmass, base_dcom=dcom, gripper_dmass=gmass,
+                                motor_strength=motor.numpy(), env_origins=origins.numpy(), box_delta_y=box_dy.numpy(),
+                                traj_timesteps=traj.numpy(), traj_total_timesteps=total.numpy())
+        self.sim.set_curriculum(make_curriculum(cfg, max(self.update_counter, 0)))
+
+    def _init_buffers(self):
+        """Zero-copy views with the attribute names of WG:498-672."""
+        s, dev, tc = self.sim, self.device, self.tcfg
+        T = s.tensor
+        self._root_states = T("ROOT_STATES")
+        self.root_states, self.box_root_state = self._root_states[:, 0, :], self._root_states[:, 1, :]
+        self.dof_state = T("DOF_STATE").view(self.num_envs * self.num_dofs, 2)
+        dv = T("DOF_STATE")
+        self.dof_pos, self.dof_vel = dv[..., 0], dv[..., 1]
+        self.dof_pos_wo_gripper, self.dof_vel_wo_gripper = self.dof_pos[:, :-2], self.dof_vel[:, :-2]
+        self.base_quat = self.root_states[:, 3:7]
+        self._contact_forces = T("NET_CONTACT_FORCE")
+        self.contact_forces, self.box_contact_force = self._contact_forces[:, :-1, :], self._contact_forces[:, -1, :]
+        self._rigid_body_state = T("RIGID_BODY_STATE")
+        self.rigid_body_state, self.box_rigid_body_state = self._rigid_body_state[:, :-1, :], self._rigid_body_state[:, -1, :]
+        self.force_sensor_tensor = T("FORCE_SENSOR")
+        self.ee_pos = self.rigid_body_state[:, self.gripper_idx, :3]
+        self.ee_orn = self.rigid_body_state[:, self.gripper_idx, 3:7]
+        self.ee_vel = self.rigid_body_state[:, self.gripper_idx, 7:]
+        self.box_pos = self.box_root_state[:, 0:3]
+        self.obs_buf = T("OBS_BUF")
+        self.obs_history_buf = T("OBS_HISTORY")
+        self.action_history_buf = T("ACTION_HISTORY")
+        self.rew_buf, self.arm_rew_buf = T("REW_BUF"), T("ARM_REW_BUF")
+        self.reset_buf = T("RESET_BUF")
+        self._episode_length_buf = T("EPISODE_LENGTH")
+        self.time_out_buf = T("TIME_OUT_BUF").view(torch.bool)
+        self.torques, self.actions, self.last_actions = T("TORQUES"), T("ACTIONS"), T("LAST_ACTIONS")
+        self.last_dof_vel, self.last_root_vel = T("LAST_DOF_VEL"), T("LAST_ROOT_VEL")
+        self.commands = T("COMMANDS")
+        self.base_lin_vel, self.base_ang_vel = T("BASE_LIN_VEL"), T("BASE_ANG_VEL")
+        g = T("GOAL_STATE")
+        self.ee_start_sphere, self.ee_goal_sphere, self.ee_goal_cart = g[:, 0:3], g[:, 3:6], g[:, 6:9]
+        self.curr_ee_goal_sphere, self.curr_ee_goal_cart = g[:, 9:12], g[:, 12:15]
+        self.ee_goal_delta_orn_euler, self.ee_goal_orn_euler = g[:, 15:18], g[:, 18:21]
+        self.goal_timer, self.traj_timesteps, self.traj_total_timesteps = g[:, 21], g[:, 22], g[:, 23]
+        self.curr_ee_goal = self.curr_ee_goal_cart if self.cfg.goal_ee.command_mode == "cart" else self.curr_ee_goal_sphere
+        self.mass_params_tensor = T("MASS_PARAMS")
+        self.friction_coeffs_tensor = T("FRICTION")
+        self.motor_strength = T("MOTOR_STRENGTH")
+        self._episode_sums, self._metric_sums = T("EPISODE_SUMS"), T("METRIC_SUMS")
+        self._episode_sums_done, self._metric_sums_done = T("EPISODE_SUMS_DONE"), T("METRIC_SUMS_DONE")
+        self.episode_sums = {name: self._episode_sums[:, i] for i, name in enumerate(abi.REWARD_TERMS)}
+        self.episode_metric_sums = {name: self._metric_sums[:, i] for i, name in enumerate(abi.METRIC_NAMES)}
+        f = lambda arr: torch.tensor(list(arr), dtype=torch.float, device=dev)    # noqa: E731
+        self.p_gains, self.d_gains = f(tc.p_gains), f(tc.d_gains)
+        self.default_dof_pos = f(tc.default_dof_pos)
+        self.default_dof_pos_wo_gripper = self.default_dof_pos[:-2]
+        self.torque_limits = f(tc.torque_limits)
+        self.action_scale = f(tc.action_scale)
+        m = self.robot_model
+        self.dof_pos_limits = torch.tensor(np.stack([m.dof_lower, m.dof_upper], 1), dtype=torch.float, device=dev)   # LR:294-296
+        self.dof_vel_limits = torch.tensor(m.dof_velocity, dtype=torch.float, device=dev)
+        self.commands_scale = f(tc.commands_scale)
+        self.common_step_counter = 0
+        self.extras = {"episode": {}}
+        self._active_terms = None
+        self._refresh_ranges()
+
+    @property
+    def episode_length_buf(self):
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):          # OnPolicyRunner.learn re-binds this attribute (OPR:107-108)
+        self._episode_length_buf.copy_(value)
+
+    # ---- curriculum ------------------------------------------------------------------------
+    def _refresh_ranges(self):
+        cur = make_curriculum(self.cfg, self.update_counter)
+        self._cur = cur
+        self.lin_vel_x_ranges = np.array(list(cur.lin_vel_x_range))
+        self.ang_vel_yaw_ranges = np.array(list(cur.ang_vel_yaw_range))
+        self.goal_ee_l_ranges = np.array(list(cur.goal_l_range))
+        self.goal_ee_p_ranges = np.array(list(cur.goal_p_range))
+        self.goal_ee_y_ranges = np.array(list(cur.goal_y_range))
+        self.reward_scales = {n: cur.leg_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if cur.leg_reward_scale[i] != 0}
+        self.arm_reward_scales = {n: cur.arm_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if cur.arm_reward_scale[i] != 0}
+        self._active_terms = [(i, n) for i, n in enumerate(abi.REWARD_TERMS) if n in self.reward_scales or n in self.arm_reward_scales]
+        return cur
+
+    def update_command_curriculum(self):                                            # WG:678-692
+        self.update_counter += 1
+        self.sim.set_curriculum(self._refresh_ranges())
+
+    # ---- stepping --------------------------------------------------------------------------
+    def reset_idx(self, env_ids, start=False):
+        if len(env_ids) == 0:
+            return
+        if not start or len(env_ids) != self.num_envs:
+            raise NotImplementedError("per-env resets happen inside the fused step; only reset_idx(all, start=True) is exposed")
+        self.sim.reset_all()
+        self._fill_extras(start=True)
+
+    def _fill_extras(self, start=False):
+        """extras['episode'] / extras['time_outs'] of WG:743-754, 902-906, without host syncs."""
+        if self.collect_episode_stats:
+            done = self.reset_buf.to(torch.float32)
+            cnt = done.sum().clamp(min=1.0)
+            ep = {}
+            sums = (self._episode_sums_done * done[:, None]).sum(0) / cnt / self.max_episode_length_s
+            for i, name in self._active_terms:
+                ep["rew_" + name] = sums[i]
+            met = (self._metric_sums_done * done[:, None]).sum(0) / cnt / self.max_episode_length_s
+            for i, name in enumerate(abi.METRIC_NAMES):
+                ep["metric_" + name] = met[i]
+            ep["coeff_lin_vel_x_upper_bound"] = self.lin_vel_x_ranges[1]
+            ep["coeff_lin_vel_x_lower_bound"] = self.lin_vel_x_ranges[0]
+            ep["coeff_ang_vel_yaw_upper_bound"] = self.ang_vel_yaw_ranges[1]
+            ep["coeff_ang_vel_yaw_lower_bound"] = self.ang_vel_yaw_ranges[0]
+            ep["coeff_tracking_ang_vel_yaw_exp"] = self.reward_scales.get("tracking_ang_vel_yaw_exp", 0.0)
+            self.extras["episode"] = ep
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def step(self, actions):
+        """WG:1156-1199 as one kernel launch; returns the reference's 6-tuple (views, overwritten by the
+        next step)."""
+        a = actions.to(self.device, dtype=torch.float32)
+        if not a.is_contiguous():
+            a = a.contiguous()
+        self.sim.step(a)
+        self.common_step_counter += 1
+        self._fill_extras()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.arm_rew_buf, self.reset_buf, self.extras
+
+    # gym-tensor-API style helpers some callers of the reference use
+    def get_foot_contacts(self):                                                    # WG:1090-1098
+        return self.force_sensor_tensor.norm(dim=-1) > 1.5

@@ -21,6 +21,9 @@ class WbcError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64; it must be in the process before this library resolves its HIP
+        # dependency, or two HIP runtimes end up loaded and the second one finds no device
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise WbcError(f"{LIB_PATH} not found: build the HIP extension first "
                            f"(python -c 'import __graft_entry__ as g; g.build()')")

@@ -1,0 +1,260 @@
+"""PPO with two-channel (leg / arm) advantages, Advantage Mixing, Regularized Online Adaptation
+(privileged-latent regulariser + DAgger step for the history encoder) and a minimum policy std
+(reference rsl_rl/algorithms/ppo.py:39-324; the quirks that decide seed-identical parity are
+SURVEY.md section 8a L1-L10 and are kept).
+
+Multi-GPU (not in the reference): with `dist_group` set, every rank owns a shard of the envs and a
+replica of the networks; gradients are flattened into ONE bucket and all-reduced (RCCL over xGMI on
+ROCm, gloo in the CPU tests) once per minibatch between backward() and clip_grad_norm_, so the
+clip acts on the reduced gradient and all ranks take the identical step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from ..modules import ActorCritic
+from ..storage import RolloutStorage
+
+
+class PPO:
+    actor_critic: ActorCritic
+
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
+                 schedule="fixed", desired_kl=0.01, device="cpu", mixing_schedule=[0.5, 2000, 4000], torque_supervision=True,
+                 torque_supervision_schedule=[0.1, 1000, 1000], adaptive_arm_gains=True, min_policy_std=None,
+                 dagger_update_freq=20, priv_reg_coef_schedual=[0, 0, 0], dist_group=None):
+        self.device = device
+        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.actor_critic = actor_critic
+        self.actor_critic.to(self.device)
+        self.storage = None
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        self.transition = RolloutStorage.Transition()
+        self.hist_encoder_optimizer = optim.Adam(self.actor_critic.actor.history_encoder.parameters(), lr=learning_rate)
+        self.priv_reg_coef_schedual = priv_reg_coef_schedual
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.gamma, self.lam, self.max_grad_norm = gamma, lam, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.min_policy_std = torch.tensor(min_policy_std, device=self.device)
+        self.mixing_schedule = mixing_schedule
+        self.torque_supervision, self.torque_supervision_schedule = torque_supervision, torque_supervision_schedule
+        self.adaptive_arm_gains = adaptive_arm_gains
+        self.counter = 0
+        self.arm_fk = self.arm_fk_adaptive_gains if adaptive_arm_gains else self.arm_fk_fixed_gains
+        self.dist_group = dist_group
+        self.world_size = torch.distributed.get_world_size(dist_group) if dist_group is not None else 1
+        self._buckets = {}
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
+        self.storage.dist_group = self.dist_group
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    # ---- rollout side ----------------------------------------------------------------------
+    def act(self, obs, critic_obs, hist_encoding=False):
+        tr, ac = self.transition, self.actor_critic
+        tr.actions = ac.act(obs, hist_encoding).detach()
+        tr.values = ac.evaluate(critic_obs).detach()
+        tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
+        tr.action_mean = ac.action_mean.detach()
+        tr.action_sigma = ac.action_std.detach()
+        # The env may hand out views it overwrites in place on the next step (WidowGo1.obs_buf is one):
+        # park the acting observation in its storage slot now instead of at process_env_step time.
+        st = self.storage
+        if st is not None and st.step < st.num_transitions_per_env:
+            st.observations[st.step].copy_(obs)
+            obs_slot = st.observations[st.step]
+            if st.privileged_observations is not None:
+                st.privileged_observations[st.step].copy_(critic_obs)
+                critic_slot = st.privileged_observations[st.step]
+            else:
+                critic_slot = obs_slot
+            tr.observations, tr.critic_observations = obs_slot, critic_slot
+        else:
+            tr.observations, tr.critic_observations = obs, critic_obs
+        return tr.actions
+
+    def process_env_step(self, rewards, arm_rewards, dones, infos):
+        tr = self.transition
+        tr.rewards = torch.stack([rewards.clone(), arm_rewards.clone()], dim=-1)
+        tr.dones = dones
+        if "time_outs" in infos:       # bootstrap both channels on time-outs (PPO:133-134)
+            tr.rewards += self.gamma * torch.squeeze(tr.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        supervised = "target_arm_torques" in infos
+        if supervised:
+            tr.target_arm_torques = infos["target_arm_torques"].detach()
+            tr.current_arm_dof_pos = infos["current_arm_dof_pos"].detach()
+            tr.current_arm_dof_vel = infos["current_arm_dof_vel"].detach()
+        self.storage.add_transitions(tr, torque_supervision=supervised)
+        tr.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    # ---- gradient exchange -----------------------------------------------------------------
+    def _allreduce_grads(self, params):
+        """One flat bucket, one all-reduce, mean over ranks."""
+        if self.dist_group is None or self.world_size == 1:
+            return
+        params = [p for p in params if p.grad is not None]
+        key = tuple(id(p) for p in params)
+        if key not in self._buckets:
+            n = sum(p.numel() for p in params)
+            self._buckets[key] = torch.empty(n, dtype=params[0].dtype, device=params[0].device)
+        flat = self._buckets[key]
+        off = 0
+        for p in params:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        torch.distributed.all_reduce(flat, group=self.dist_group)
+        flat.div_(self.world_size)
+        off = 0
+        for p in params:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()
+
+    # ---- learner side ----------------------------------------------------------------------
+    def _generator(self):
+        if self.actor_critic.is_recurrent:
+            raise NotImplementedError("recurrent policies are unreachable in the reference as well (SURVEY.md inventory #24)")
+        return self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
+
+    def update(self):
+        ac = self.actor_critic
+        sums = torch.zeros(4, device=self.device)      # value, surrogate, arm-torque, priv-reg loss accumulators
+        value_mixing_ratio = self.get_value_mixing_ratio()
+        torque_supervision_weight = self.get_torque_supervision_weight() if self.torque_supervision else 0
+        priv_reg_coef = 0.0
+        for (obs_b, critic_obs_b, actions_b, target_values_b, adv_b, returns_b, old_logp_b, old_mu_b, old_sigma_b,
+             target_arm_torques, cur_arm_pos, cur_arm_vel, hid_b, masks_b) in self._generator():
+            ac.act(obs_b, hist_encoding=False, masks=masks_b, hidden_states=hid_b[0])   # samples and discards (quirk L1)
+            logp_b = ac.get_actions_log_prob(actions_b)
+            value_b = ac.evaluate(critic_obs_b, masks=masks_b, hidden_states=hid_b[1])
+            mu_b, sigma_b, entropy_b = ac.action_mean, ac.action_std, ac.entropy
+
+            # Regularized Online Adaptation: pull the privileged latent towards the history latent
+            priv_latent = ac.actor.infer_priv_latent(obs_b)
+            with torch.inference_mode():
+                hist_latent = ac.actor.infer_hist_latent(obs_b)
+            priv_reg_loss = (priv_latent - hist_latent.detach()).norm(p=2, dim=1).mean()
+            s = self.priv_reg_coef_schedual
+            stage = min(max((self.counter - s[2]), 0) / s[3], 1)
+            priv_reg_coef = stage * (s[1] - s[0]) + s[0]
+
+            if self.desired_kl is not None and self.schedule == "adaptive":
+                with torch.inference_mode():
+                    kl = torch.sum(torch.log(sigma_b / old_sigma_b + 1.e-5) +
+                                   (torch.square(old_sigma_b) + torch.square(old_mu_b - mu_b)) / (2.0 * torch.square(sigma_b)) - 0.5,
+                                   axis=-1)
+                    kl_mean = torch.mean(kl)
+                    if self.dist_group is not None:
+                        torch.distributed.all_reduce(kl_mean, group=self.dist_group)
+                        kl_mean /= self.world_size
+                    if kl_mean > self.desired_kl * 2.0:
+                        self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+                    elif kl_mean < self.desired_kl / 2.0 and kl_mean > 0.0:
+                        self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+                    for group in self.optimizer.param_groups:
+                        group["lr"] = self.learning_rate
+
+            # Advantage Mixing: each channel's surrogate sees its own advantage plus beta x the other's
+            mixed = torch.stack([adv_b[..., 0] + value_mixing_ratio * adv_b[..., 1],
+                                 adv_b[..., 1] + value_mixing_ratio * adv_b[..., 0]], dim=-1)
+            ratio = torch.exp(logp_b - old_logp_b)
+            surrogate_loss = torch.max(-mixed * ratio, -mixed * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+
+            if self.use_clipped_value_loss:
+                value_clipped = target_values_b + (value_b - target_values_b).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value_b - returns_b).pow(2), (value_clipped - returns_b).pow(2)).mean()
+            else:
+                value_loss = (returns_b - value_b).pow(2).mean()
+
+            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy_b.mean() + priv_reg_coef * priv_reg_loss
+
+            if self.torque_supervision:
+                mean_actions = ac.act_inference(obs_b)
+                if self.adaptive_arm_gains:
+                    target_arm_dof_pos, delta_arm_p_gains = mean_actions[:, 12:-6], mean_actions[:, -6:]
+                else:
+                    target_arm_dof_pos, delta_arm_p_gains = mean_actions[:, -6:], None
+                arm_torques = self.arm_fk(delta_arm_p_gains, target_arm_dof_pos, cur_arm_pos, cur_arm_vel)
+                arm_torques_loss = (arm_torques - target_arm_torques).pow(2).mean()
+                torque_supervision_weight = self.get_torque_supervision_weight()
+                loss = loss + arm_torques_loss * torque_supervision_weight
+                sums[2] += arm_torques_loss.detach()
+
+            self.optimizer.zero_grad()
+            loss.backward()
+            self._allreduce_grads(list(ac.parameters()))
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            sums[0] += value_loss.detach()
+            sums[1] += surrogate_loss.detach()
+            sums[3] += priv_reg_loss.detach()
+
+        num_updates = self.num_learning_epochs * self.num_mini_batches
+        mean_value_loss, mean_surrogate_loss, mean_arm_torques_loss, mean_priv_reg_loss = (sums / num_updates).tolist()
+        self.storage.clear()
+        self.update_counter()
+        self.enforce_min_std()
+        return (mean_value_loss, mean_surrogate_loss, mean_arm_torques_loss, value_mixing_ratio, torque_supervision_weight,
+                mean_priv_reg_loss, priv_reg_coef)
+
+    def update_dagger(self):
+        ac = self.actor_critic
+        total = torch.zeros((), device=self.device)
+        hist_params = list(ac.actor.history_encoder.parameters())
+        for (obs_b, *_rest, hid_b, masks_b) in self._generator():
+            with torch.inference_mode():
+                ac.act(obs_b, hist_encoding=True, masks=masks_b, hidden_states=hid_b[0])
+                priv_latent = ac.actor.infer_priv_latent(obs_b)
+            hist_latent = ac.actor.infer_hist_latent(obs_b)
+            loss = (priv_latent.detach() - hist_latent).norm(p=2, dim=1).mean()
+            self.hist_encoder_optimizer.zero_grad()
+            loss.backward()
+            self._allreduce_grads(hist_params)
+            nn.utils.clip_grad_norm_(hist_params, self.max_grad_norm)
+            self.hist_encoder_optimizer.step()
+            total += loss.detach()
+        num_updates = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        self.update_counter()
+        return (total / num_updates).item()
+
+    def enforce_min_std(self):
+        self.actor_critic.std.data = torch.max(self.actor_critic.std.detach(), self.min_policy_std).detach()
+
+    def update_counter(self):
+        self.counter += 1
+
+    def get_value_mixing_ratio(self):
+        s = self.mixing_schedule
+        return min(max((self.counter - s[1]) / s[2], 0), 1) * s[0]
+
+    def get_torque_supervision_weight(self):
+        s = self.torque_supervision_schedule
+        return (1 - min(max((self.counter - s[1]) / s[2], 0), 1)) * s[0]
+
+    def set_arm_default_coeffs(self, default_arm_p_gains, default_arm_d_gains, default_arm_dof_pos):
+        self.default_arm_p_gains, self.default_arm_d_gains = default_arm_p_gains, default_arm_d_gains
+        self.default_arm_dof_pos = default_arm_dof_pos
+
+    def arm_fk_adaptive_gains(self, delta_arm_p_gains, target_arm_dof_pos, current_arm_dof_pos, current_arm_dof_vel):
+        p = self.default_arm_p_gains + delta_arm_p_gains
+        d = 2 * (p ** 0.5)
+        return p * (target_arm_dof_pos + self.default_arm_dof_pos - current_arm_dof_pos) - d * current_arm_dof_vel
+
+    def arm_fk_fixed_gains(self, _, target_arm_dof_pos, current_arm_dof_pos, current_arm_dof_vel):
+        return (self.default_arm_p_gains * (target_arm_dof_pos + self.default_arm_dof_pos - current_arm_dof_pos)
+                - self.default_arm_d_gains * current_arm_dof_vel)

@@ -1,0 +1,197 @@
+"""ActorCritic of the widowGo1 policy: privileged-latent / history-latent actor with separate leg
+and arm heads, two-head critic, learnable per-action std.
+
+Same constructor arguments, attribute names, state_dict keys/shapes and
+module creation order as the reference (rsl_rl/modules/actor_critic.py:39-353), so that a
+reference checkpoint loads unchanged and the same torch seed yields the same initial weights.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+_ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU,
+                "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+
+
+def get_activation(name: str):
+    cls = _ACTIVATIONS.get(name)
+    if cls is None:
+        print("invalid activation function!")
+        return None
+    return cls()
+
+
+def _stack(sizes: Sequence[int], act: nn.Module, last_act=None, act_after_last=True) -> nn.Sequential:
+    """Linear(sizes[0], sizes[1]), act, Linear(...), act, ...; Sequential indices 0,2,4,... are the
+    Linear layers, which is what the checkpoint key names encode."""
+    layers: List[nn.Module] = []
+    n = len(sizes) - 1
+    for i in range(n):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i < n - 1:
+            layers.append(act)
+        elif last_act is not None:
+            layers.append(last_act)
+        elif act_after_last:
+            layers.append(act)
+    return nn.Sequential(*layers)
+
+
+class StateHistoryEncoder(nn.Module):
+    """Per-step projection + two 1-D convolutions over the proprio history (AC:39-84)."""
+    _CONVS = {   # tsteps -> [(in_mult, out_mult, kernel, stride), ...] in units of channel_size
+        50: [(3, 2, 8, 4), (2, 1, 5, 1), (1, 1, 5, 1)],
+        10: [(3, 2, 4, 2), (2, 1, 2, 1)],
+        20: [(3, 2, 6, 2), (2, 1, 4, 2)],
+    }
+
+    def __init__(self, activation_fn, input_size, tsteps, output_size, tanh_encoder_output=False):
+        super().__init__()
+        if tsteps not in self._CONVS:
+            raise ValueError("tsteps must be 10, 20 or 50")
+        self.activation_fn = activation_fn
+        self.tsteps = tsteps
+        ch = 10
+        self.encoder = nn.Sequential(nn.Linear(input_size, 3 * ch), self.activation_fn)
+        conv: List[nn.Module] = []
+        for cin, cout, ksz, stride in self._CONVS[tsteps]:
+            conv += [nn.Conv1d(cin * ch, cout * ch, kernel_size=ksz, stride=stride), self.activation_fn]
+        conv.append(nn.Flatten())
+        self.conv_layers = nn.Sequential(*conv)
+        self.linear_output = nn.Sequential(nn.Linear(ch * 3, output_size), self.activation_fn)
+
+    def forward(self, obs):          # [B, T, n_proprio]
+        b, t = obs.shape[0], self.tsteps
+        proj = self.encoder(obs.reshape(b * t, -1))
+        feat = self.conv_layers(proj.reshape(b, t, -1).permute(0, 2, 1))
+        return self.linear_output(feat)
+
+
+class _Actor(nn.Module):
+    def __init__(self, num_prop, hidden, act, leg_dims, arm_dims, n_leg, n_arm, adaptive_arm_gains, gains_scale,
+                 num_priv, num_hist, priv_dims):
+        super().__init__()
+        self.adaptive_arm_gains = adaptive_arm_gains
+        self.adaptive_arm_gains_scale = gains_scale
+        self.num_arm_actions = n_arm
+        self.num_priv, self.num_hist, self.num_prop = num_priv, num_hist, num_prop
+        if len(priv_dims) > 0:
+            self.priv_encoder = _stack([num_priv] + list(priv_dims), act)
+            latent = priv_dims[-1]
+        else:
+            self.priv_encoder = nn.Identity()
+            latent = num_priv
+        self.history_encoder = StateHistoryEncoder(act, num_prop, num_hist, latent)
+        if len(hidden) > 0:
+            self.actor_backbone = _stack([num_prop + latent] + list(hidden), act)
+            trunk = hidden[-1]
+        else:
+            self.actor_backbone = nn.Identity()
+            trunk = num_prop + latent
+        self.actor_leg_control_head = _stack([trunk] + list(leg_dims) + [n_leg], act, last_act=nn.Tanh())
+        self.actor_arm_control_head = _stack([trunk] + list(arm_dims) + [n_arm], act, last_act=nn.Tanh())
+
+    def infer_priv_latent(self, obs):
+        return self.priv_encoder(obs[:, self.num_prop: self.num_prop + self.num_priv])
+
+    def infer_hist_latent(self, obs):
+        hist = obs[:, -self.num_hist * self.num_prop:]
+        return self.history_encoder(hist.view(-1, self.num_hist, self.num_prop))
+
+    def forward(self, obs, hist_encoding=False):
+        latent = self.infer_hist_latent(obs) if hist_encoding else self.infer_priv_latent(obs)
+        trunk = self.actor_backbone(torch.cat([obs[:, :self.num_prop], latent], dim=1))
+        leg = self.actor_leg_control_head(trunk)
+        arm = self.actor_arm_control_head(trunk)
+        if self.adaptive_arm_gains:
+            half = self.num_arm_actions // 2
+            arm = torch.cat([arm[:, :half], self.adaptive_arm_gains_scale * arm[:, half:]], dim=-1)
+        return torch.cat([leg, arm], dim=-1)
+
+
+class _Critic(nn.Module):
+    def __init__(self, in_dim, hidden, act, leg_dims, arm_dims, num_priv, num_hist, num_prop):
+        super().__init__()
+        self.num_priv, self.num_hist, self.num_prop = num_priv, num_hist, num_prop
+        if len(hidden) > 0:
+            self.critic_backbone = _stack([in_dim] + list(hidden), act)
+            trunk = hidden[-1]
+        else:
+            self.critic_backbone = nn.Identity()
+            trunk = in_dim
+        self.critic_leg_control_head = _stack([trunk] + list(leg_dims) + [1], act, act_after_last=False)
+        self.critic_arm_control_head = _stack([trunk] + list(arm_dims) + [1], act, act_after_last=False)
+
+    def forward(self, obs):
+        trunk = self.critic_backbone(obs[:, :self.num_prop + self.num_priv])
+        return torch.cat([self.critic_leg_control_head(trunk), self.critic_arm_control_head(trunk)], dim=-1)
+
+
+class ActorCritic(nn.Module):
+    is_recurrent = False
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=[256, 256, 256],
+                 critic_hidden_dims=[256, 256, 256], priv_encoder_dims=[64, 20], activation="elu", init_std=1, **kwargs):
+        super().__init__()
+        self.num_leg_actions = kwargs["num_leg_actions"]
+        self.num_arm_actions = kwargs["num_arm_actions"]
+        adaptive = kwargs["adaptive_arm_gains"]
+        if adaptive:
+            self.num_arm_actions *= 2
+        num_priv, num_hist, num_prop = kwargs["num_priv"], kwargs["num_hist"], kwargs["num_prop"]
+        act = get_activation(activation)
+        self.actor = _Actor(num_actor_obs, actor_hidden_dims, act, kwargs["leg_control_head_hidden_dims"],
+                            kwargs["arm_control_head_hidden_dims"], self.num_leg_actions, self.num_arm_actions, adaptive,
+                            kwargs["adaptive_arm_gains_scale"], num_priv, num_hist, priv_encoder_dims)
+        self.critic = _Critic(num_critic_obs + num_priv, critic_hidden_dims, act, kwargs["leg_control_head_hidden_dims"],
+                              kwargs["arm_control_head_hidden_dims"], num_priv, num_hist, num_prop)
+        if kwargs.get("verbose", False):
+            print(f"Actor MLP: {self.actor}")
+            print(f"Critic MLP: {self.critic}")
+        self.std = nn.Parameter(torch.tensor(init_std))          # [1, num_actions]
+        self.distribution = None
+        Normal.set_default_validate_args = False
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    def _split_sum(self, x):
+        n = self.num_leg_actions
+        return torch.cat([x[:, :n].sum(dim=-1, keepdim=True), x[:, n:].sum(dim=-1, keepdim=True)], dim=-1)
+
+    @property
+    def entropy(self):
+        return self._split_sum(self.distribution.entropy())
+
+    def update_distribution(self, observations, hist_encoding):
+        mean = self.actor(observations, hist_encoding)
+        self.distribution = Normal(mean, mean * 0. + self.std)
+
+    def act(self, observations, hist_encoding, **kwargs):
+        self.update_distribution(observations, hist_encoding)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        """Log-probability summed separately over the leg and the arm action dims -> [B, 2]."""
+        return self._split_sum(self.distribution.log_prob(actions))
+
+    def act_inference(self, observations, hist_encoding=False):
+        return self.actor(observations, hist_encoding)
+
+    def evaluate(self, critic_observations, **kwargs):
+        return self.critic(critic_observations)

@@ -1,0 +1,186 @@
+"""OnPolicyRunner: the rollout / learn loop with the reference's constructor, `learn`, `save`,
+`load` and `get_inference_policy` (rsl_rl/runners/on_policy_runner.py:46-300). The throughput
+figure is the reference's own definition, fps = T*N / (collection_time + learn_time) (OPR:206).
+
+Differences that are deliberate: no wandb/tensorboard dependency (stats go to `self.history` and,
+with a log_dir, to stdout); per-step reward bookkeeping stays on the device (the reference pulls
+lists to the host every step, OPR:147-151); optional `dist_group` for the sharded multi-GPU learner.
+"""
+from __future__ import annotations
+
+import os
+import statistics
+import time
+from collections import deque
+
+import torch
+
+from ..algorithms import PPO
+from ..env import VecEnv
+from ..modules import ActorCritic
+
+_POLICIES = {"ActorCritic": ActorCritic}
+_ALGORITHMS = {"PPO": PPO}
+
+
+class OnPolicyRunner:
+    def __init__(self, env: VecEnv, train_cfg, log_dir=None, device="cpu", dist_group=None):
+        self.cfg, self.alg_cfg, self.policy_cfg = train_cfg["runner"], train_cfg["algorithm"], train_cfg["policy"]
+        self.device, self.env = device, env
+        e = env.cfg.env
+        policy_cls = _POLICIES[self.cfg["policy_class_name"]]
+        actor_critic = policy_cls(e.num_proprio, e.num_proprio, env.num_actions, **self.policy_cfg, num_priv=e.num_priv,
+                                  num_hist=e.history_len, num_prop=e.num_proprio).to(self.device)
+        self.dist_group = dist_group
+        if dist_group is not None:      # identical initial replicas on every rank
+            for p in actor_critic.parameters():
+                torch.distributed.broadcast(p.data, src=torch.distributed.get_global_rank(dist_group, 0), group=dist_group)
+        self.alg: PPO = _ALGORITHMS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, dist_group=dist_group,
+                                                                      **self.alg_cfg)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions])
+        self.log_dir = log_dir
+        self.writer = None
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.dagger_update_freq = self.alg_cfg["dagger_update_freq"]
+        self.history = []
+        if hasattr(env, "collect_episode_stats"):
+            env.collect_episode_stats = log_dir is not None
+        env.reset()
+        self.alg.set_arm_default_coeffs(env.p_gains[12:], env.d_gains[12:], env.default_dof_pos[-7:-2])   # sic, OPR:91 (quirk Q7)
+
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        env, alg = self.env, self.alg
+        if init_at_random_ep_len:
+            env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        obs = env.get_observations()
+        priv = env.get_privileged_observations()
+        critic_obs = priv if priv is not None else obs
+        obs, critic_obs = obs.to(self.device), critic_obs.to(self.device)
+        alg.actor_critic.train()
+        logging = self.log_dir is not None
+        rewbuffer, armrewbuffer, lenbuffer, donebuffer = (deque(maxlen=100) for _ in range(4))
+        n = env.num_envs
+        cur_rew = torch.zeros(n, device=self.device)
+        cur_arm = torch.zeros(n, device=self.device)
+        cur_len = torch.zeros(n, device=self.device)
+        ep_infos = []
+        is_cuda = torch.device(self.device).type == "cuda"
+        sync = (lambda: torch.cuda.synchronize(self.device)) if is_cuda else (lambda: None)
+        loss_stats = dict(mean_value_loss=0., mean_surrogate_loss=0., mean_arm_torques_loss=0., value_mixing_ratio=0.,
+                          torque_supervision_weight=0., mean_hist_latent_loss=0., mean_priv_reg_loss=0., priv_reg_coef=0.)
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            env.update_command_curriculum()
+            sync()
+            start = time.time()
+            hist_encoding = it % self.dagger_update_freq == 0
+            with torch.inference_mode():
+                for _ in range(self.num_steps_per_env):
+                    actions = alg.act(obs, critic_obs, hist_encoding)
+                    obs, priv, rewards, arm_rewards, dones, infos = env.step(actions)
+                    critic_obs = priv if priv is not None else obs
+                    obs, critic_obs, rewards, arm_rewards, dones = (x.to(self.device) for x in (obs, critic_obs, rewards, arm_rewards, dones))
+                    alg.process_env_step(rewards, arm_rewards, dones, infos)
+                    if logging:
+                        if "episode" in infos:
+                            ep_infos.append(infos["episode"])
+                        cur_rew += rewards
+                        cur_arm += arm_rewards
+                        cur_len += 1
+                        new_ids = (dones > 0).nonzero(as_tuple=False)
+                        rewbuffer.extend(cur_rew[new_ids][:, 0].cpu().numpy().tolist())
+                        armrewbuffer.extend(cur_arm[new_ids][:, 0].cpu().numpy().tolist())
+                        lenbuffer.extend(cur_len[new_ids][:, 0].cpu().numpy().tolist())
+                        donebuffer.append(len(new_ids) / n)
+                        cur_rew[new_ids] = 0
+                        cur_arm[new_ids] = 0
+                        cur_len[new_ids] = 0
+                sync()
+                stop = time.time()
+                collection_time = stop - start
+                start = stop
+                alg.compute_returns(critic_obs)
+            if hist_encoding:
+                loss_stats["mean_hist_latent_loss"] = alg.update_dagger()
+            else:
+                (loss_stats["mean_value_loss"], loss_stats["mean_surrogate_loss"], loss_stats["mean_arm_torques_loss"],
+                 loss_stats["value_mixing_ratio"], loss_stats["torque_supervision_weight"], loss_stats["mean_priv_reg_loss"],
+                 loss_stats["priv_reg_coef"]) = alg.update()
+            sync()
+            stop = time.time()
+            learn_time = stop - start
+            fps = int(self.num_steps_per_env * n / (collection_time + learn_time))       # OPR:206
+            rec = dict(it=it, collection_time=collection_time, learn_time=learn_time, fps=fps, **loss_stats)
+            self.tot_timesteps += self.num_steps_per_env * n
+            self.tot_time += collection_time + learn_time
+            if logging:
+                if len(rewbuffer) > 0:
+                    rec.update(mean_reward=statistics.mean(rewbuffer), mean_arm_reward=statistics.mean(armrewbuffer),
+                               mean_episode_length=statistics.mean(lenbuffer), dones=statistics.mean(donebuffer))
+                self.log(rec, ep_infos, tot_iter)
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+            self.history.append(rec)
+            ep_infos.clear()
+        self.current_learning_iteration += num_learning_iterations
+        if logging:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def log(self, rec, ep_infos, tot_iter, width=80, pad=35):
+        lines = ["#" * width, f" Learning iteration {rec['it']}/{tot_iter} ".center(width), ""]
+        lines.append(f"{'Computation:':>{pad}} {rec['fps']:.0f} steps/s (collection: {rec['collection_time']:.3f}s, "
+                     f"learning {rec['learn_time']:.3f}s)")
+        for key, label in (("mean_value_loss", "Value function loss:"), ("mean_surrogate_loss", "Surrogate loss:"),
+                           ("mean_hist_latent_loss", "History latent supervision loss:"),
+                           ("mean_priv_reg_loss", "Privileged info regularizer loss:"),
+                           ("priv_reg_coef", "Privileged info regularizer lambda:"), ("mean_reward", "Mean reward:"),
+                           ("mean_episode_length", "Mean episode length:"), ("dones", "Dones:")):
+            if key in rec:
+                lines.append(f"{label:>{pad}} {rec[key]:.4f}")
+        std = self.alg.actor_critic.std.detach()
+        lines.append(f"{'Leg mean action noise std:':>{pad}} {std[:, :12].mean().item():.2f}")
+        lines.append(f"{'Arm mean action noise std:':>{pad}} {std[:, 12:].mean().item():.2f}")
+        if ep_infos:
+            for key in ep_infos[0]:
+                vals = [torch.as_tensor(info[key], dtype=torch.float32, device=self.device).reshape(-1) for info in ep_infos]
+                lines.append(f"{'Mean episode ' + key + ':':>{pad}} {torch.cat(vals).mean().item():.4f}")
+        lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}", f"{'Total time:':>{pad}} {self.tot_time:.2f}s"]
+        print("\n".join(lines))
+
+    def save(self, path, infos=None):
+        """Reference checkpoint format (OPR:276-282) plus, under 'wbc_extra', what it forgets:
+        history-encoder optimiser, schedule counter, env curriculum counter."""
+        torch.save({
+            "model_state_dict": self.alg.actor_critic.state_dict(),
+            "optimizer_state_dict": self.alg.optimizer.state_dict(),
+            "iter": self.current_learning_iteration,
+            "infos": infos,
+            "wbc_extra": {"hist_encoder_optimizer_state_dict": self.alg.hist_encoder_optimizer.state_dict(),
+                          "ppo_counter": self.alg.counter,
+                          "env_update_counter": getattr(self.env, "update_counter", 0)},
+        }, path)
+
+    def load(self, path, load_optimizer=True):
+        d = torch.load(path, map_location=self.device)
+        self.alg.actor_critic.load_state_dict(d["model_state_dict"])
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = d["iter"]
+        extra = d.get("wbc_extra")
+        if extra is not None:
+            if load_optimizer:
+                self.alg.hist_encoder_optimizer.load_state_dict(extra["hist_encoder_optimizer_state_dict"])
+            self.alg.counter = extra["ppo_counter"]
+            if hasattr(self.env, "update_counter"):
+                self.env.update_counter = extra["env_update_counter"]
+        return d["infos"]
+
+    def get_inference_policy(self, device=None, stochastic=False):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act if stochastic else self.alg.actor_critic.act_inference

@@ -144,25 +144,7 @@ class OracleSim:
 
 
 def default_curriculum(cfg, update_counter: int = 1) -> abi.WbcCurriculum:
-    """update_command_curriculum (WG:675-692) evaluated at `update_counter`."""
-    def cv(schedule, init, final):
-        s = np.clip((update_counter - schedule[0]) / (schedule[1] - schedule[0]), 0, 1)
-        return s * (np.asarray(final, dtype=np.float64) - np.asarray(init, dtype=np.float64)) + np.asarray(init, dtype=np.float64)
-    cur = abi.WbcCurriculum()
-    cr, ge = cfg.commands.ranges, cfg.goal_ee.ranges
-    abi._set(cur.lin_vel_x_range, cv(cfg.commands.lin_vel_x_schedule, cr.init_lin_vel_x, cr.final_lin_vel_x))
-    abi._set(cur.ang_vel_yaw_range, cv(cfg.commands.ang_vel_yaw_schedule, cr.init_ang_vel_yaw, cr.final_ang_vel_yaw))
-    abi._set(cur.goal_l_range, cv(cfg.goal_ee.l_schedule, ge.init_pos_l, ge.final_pos_l))
-    abi._set(cur.goal_p_range, cv(cfg.goal_ee.p_schedule, ge.init_pos_p, ge.final_pos_p))
-    abi._set(cur.goal_y_range, cv(cfg.goal_ee.y_schedule, ge.init_pos_y, ge.final_pos_y))
-    leg = {k: float(getattr(cfg.rewards.scales, k)) for k in dir(cfg.rewards.scales) if not k.startswith("_")
-           and isinstance(getattr(cfg.rewards.scales, k), (int, float))}
-    arm = {k: float(getattr(cfg.rewards.arm_scales, k)) for k in dir(cfg.rewards.arm_scales) if not k.startswith("_")
-           and isinstance(getattr(cfg.rewards.arm_scales, k), (int, float))}
-    leg["tracking_ang_vel_yaw_exp"] = float(cv(cfg.commands.tracking_ang_vel_yaw_schedule, 0, cr.final_tracking_ang_vel_yaw_exp))
-    key = "tracking_ee_sphere" if arm.get("tracking_ee_sphere", 0) != 0 else "tracking_ee_cart"
-    arm[key] = float(cv(cfg.goal_ee.tracking_ee_reward_schedule, 0, ge.final_tracking_ee_reward))
-    for i, name in enumerate(abi.REWARD_TERMS):
-        cur.leg_reward_scale[i] = leg.get(name, 0.0)
-        cur.arm_reward_scale[i] = arm.get(name, 0.0)
-    return cur
+    """update_command_curriculum (WG:675-692) evaluated at `update_counter` (host-side table builder
+    shared with the product: it only fills a struct, it computes nothing on the path)."""
+    from wbc_amd.curriculum import make_curriculum
+    return make_curriculum(cfg, update_counter)
