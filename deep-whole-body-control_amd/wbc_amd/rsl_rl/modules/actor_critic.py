@@ -25,13 +25,53 @@ def get_activation(name: str):
     return cls()
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+    """y = x W^T + b whose weight gradient dW = dY^T X (output <= 128x128, reduction length = batch,
+    40960 in PPO.update) is computed as SPLIT_K independent partial GEMMs + one sum. The library GEMM
+    for that shape uses only out*in/1024 workgroups of a 256-CU chip (measured 106-145 us per layer on
+    MI355X; 26 us split 32 ways, same result to fp32 round-off)."""
+    SPLIT_K = 32
+    MIN_BATCH = 4096
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy @ weight
+        b, s = x.shape[0], _SplitKLinearFn.SPLIT_K
+        if ctx.needs_input_grad[1]:
+            gyc, xc = gy.contiguous(), x.contiguous()
+            gw = torch.bmm(gyc.view(s, b // s, -1).transpose(1, 2), xc.view(s, b // s, -1)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) that routes large training batches through
+    the split-K weight-gradient path."""
+
+    def forward(self, x):
+        if (x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.shape[0] >= _SplitKLinearFn.MIN_BATCH
+                and x.shape[0] % _SplitKLinearFn.SPLIT_K == 0 and self.weight.requires_grad):
+            return _SplitKLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _stack(sizes: Sequence[int], act: nn.Module, last_act=None, act_after_last=True) -> nn.Sequential:
     """Linear(sizes[0], sizes[1]), act, Linear(...), act, ...; Sequential indices 0,2,4,... are the
     Linear layers, which is what the checkpoint key names encode."""
     layers: List[nn.Module] = []
     n = len(sizes) - 1
     for i in range(n):
-        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        layers.append(Linear(sizes[i], sizes[i + 1]))
         if i < n - 1:
             layers.append(act)
         elif last_act is not None:
@@ -56,19 +96,40 @@ class StateHistoryEncoder(nn.Module):
         self.activation_fn = activation_fn
         self.tsteps = tsteps
         ch = 10
-        self.encoder = nn.Sequential(nn.Linear(input_size, 3 * ch), self.activation_fn)
+        self.encoder = nn.Sequential(Linear(input_size, 3 * ch), self.activation_fn)
         conv: List[nn.Module] = []
         for cin, cout, ksz, stride in self._CONVS[tsteps]:
             conv += [nn.Conv1d(cin * ch, cout * ch, kernel_size=ksz, stride=stride), self.activation_fn]
         conv.append(nn.Flatten())
         self.conv_layers = nn.Sequential(*conv)
-        self.linear_output = nn.Sequential(nn.Linear(ch * 3, output_size), self.activation_fn)
+        self.linear_output = nn.Sequential(Linear(ch * 3, output_size), self.activation_fn)
+
+    @staticmethod
+    def _conv1d_as_gemm(x, conv: nn.Conv1d):
+        """x [B, L, Cin] (time-major) -> [B, Lout, Cout]. Same arithmetic as nn.Conv1d on the permuted
+        input, but as ONE rocBLAS GEMM of M = B*Lout rows: MIOpen's 1-D convolution path launches an
+        im2col + GEMM pair per sample at these sizes (measured: 49 % of GPU time of a DAgger iteration)."""
+        k, s = conv.kernel_size[0], conv.stride[0]
+        patches = x.unfold(1, k, s)                                   # [B, Lout, Cin, k]
+        b, lout = patches.shape[0], patches.shape[1]
+        w = conv.weight.reshape(conv.out_channels, -1)                # [Cout, Cin*k], (cin, k) order = patches' last dims
+        flat = patches.reshape(b * lout, -1)
+        if (flat.is_cuda and torch.is_grad_enabled() and flat.shape[0] >= _SplitKLinearFn.MIN_BATCH
+                and flat.shape[0] % _SplitKLinearFn.SPLIT_K == 0 and conv.weight.requires_grad):
+            return _SplitKLinearFn.apply(flat, w, conv.bias).reshape(b, lout, -1)
+        return torch.nn.functional.linear(flat, w, conv.bias).reshape(b, lout, -1)
 
     def forward(self, obs):          # [B, T, n_proprio]
         b, t = obs.shape[0], self.tsteps
-        proj = self.encoder(obs.reshape(b * t, -1))
-        feat = self.conv_layers(proj.reshape(b, t, -1).permute(0, 2, 1))
-        return self.linear_output(feat)
+        x = self.encoder(obs.reshape(b * t, -1)).reshape(b, t, -1)    # [B, T, 30], time-major
+        for layer in self.conv_layers:
+            if isinstance(layer, nn.Conv1d):
+                x = self._conv1d_as_gemm(x, layer)
+            elif isinstance(layer, nn.Flatten):
+                x = x.permute(0, 2, 1).flatten(1)                     # channel-major flatten, as Conv1d output [B, C, L]
+            else:
+                x = layer(x)
+        return self.linear_output(x)
 
 
 class _Actor(nn.Module):
