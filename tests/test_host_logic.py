@@ -1,0 +1,147 @@
+"""CPU tests of the host side: config mirror vs the reference's own config classes (golden JSON made
+by tools/make_golden_config.py), ABI struct sizes, exported symbols of the C-ABI library, the URDF
+loader conventions, and the oracle's env-logic helpers against closed-form cases."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from wbc_amd import abi, native
+from wbc_amd.config import WidowGo1RoughCfg, WidowGo1RoughCfgPPO, class_to_dict
+from wbc_amd.curriculum import make_curriculum
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _flatten(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict) and k not in ("default_joint_angles", "stiffness", "damping"):
+            out.update(_flatten(v, prefix + k + "."))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def _same(a, b):
+    if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (int, float)) and isinstance(b, (int, float)) and not isinstance(a, bool):
+        return math.isclose(a, b, rel_tol=1e-12, abs_tol=1e-15)
+    return a == b
+
+
+@pytest.mark.parametrize("name,cls", [("WidowGo1RoughCfg", WidowGo1RoughCfg), ("WidowGo1RoughCfgPPO", WidowGo1RoughCfgPPO)])
+def test_config_mirror_equals_reference(name, cls):
+    gold = json.load(open(os.path.join(HERE, "golden", "widowgo1_config.json")))[name]
+    mine = _flatten(class_to_dict(cls()))
+    missing = [k for k in gold if k not in mine]
+    assert not missing, missing
+    bad = {k: (gold[k], mine[k]) for k in gold if not _same(gold[k], mine[k])}
+    assert not bad, bad
+
+
+def test_config_subclassing_is_dropin():
+    class MyCfg(WidowGo1RoughCfg):
+        class env(WidowGo1RoughCfg.env):
+            num_envs = 128
+    c = MyCfg()
+    assert c.env.num_envs == 128 and c.env.num_observations == 860 and c.sim.dt == 0.005
+    assert c.control.stiffness == {"joint": 50, "widow": 5}
+
+
+def test_abi_struct_sizes_and_symbols():
+    L = native.lib()        # loads libwbc_amd.so; no compute call
+    sizes = (C.c_int * 3)()
+    L.wbc_abi_sizes(sizes)
+    assert list(sizes) == [C.sizeof(abi.WbcModel), C.sizeof(abi.WbcTaskCfg), C.sizeof(abi.WbcCurriculum)]
+    header = open(os.path.join(HERE, "..", "include", "wbc_sim.h")).read()
+    import re
+    declared = set(re.findall(r"\b(wbc_[a-z_0-9]+)\s*\(", header))
+    for sym in declared:
+        assert hasattr(L, sym), f"{sym} declared in include/wbc_sim.h but not exported"
+    assert set(native.EXPORTED_SYMBOLS) <= declared | {"wbc_last_error"}
+    assert L.wbc_sim_arena_bytes(4096) > 4096 * 860 * 4
+    import oracle
+    o = C.CDLL(os.path.join(HERE, "..", "oracle", "libwbc_oracle_f64.so"))
+    o.ora_abi_sizes(sizes)
+    assert list(sizes) == [C.sizeof(abi.WbcModel), C.sizeof(abi.WbcTaskCfg), C.sizeof(abi.WbcCurriculum)]
+
+
+def test_model_follows_importer_conventions(robot):
+    m = robot["model"]
+    legs = [f"{l}_{j}_joint" for l in ("FL", "FR", "RL", "RR") for j in ("hip", "thigh", "calf")]
+    arm = ["widow_waist", "widow_shoulder", "widow_elbow", "widow_forearm_roll", "widow_wrist_angle", "widow_wrist_rotate"]
+    assert m.dof_names == legs + arm + ["widow_left_finger", "widow_right_finger"]
+    assert m.num_rigid_bodies == 27 and m.rb_names[0] == "base" and m.rb_names[1] == "trunk"
+    assert m.rb_names[-3:] == ["wx250s/ee_gripper_link", "wx250s/left_finger_link", "wx250s/right_finger_link"]
+    assert [n for n in m.rb_names if "foot" in n] == ["FL_foot", "FR_foot", "RL_foot", "RR_foot"]
+    np.testing.assert_allclose(m.mass.sum(), 14.151, atol=1e-3)                           # SURVEY 8c URDF facts
+    np.testing.assert_allclose(m.dof_effort[:12], 23.7)
+    np.testing.assert_allclose(m.dof_effort[12:18], [10, 20, 15, 2, 5, 1])
+    tc = robot["tcfg"]
+    assert tc.max_episode_length == 500 and tc.resample_interval == 150 and tc.push_interval == 150
+    np.testing.assert_allclose(list(tc.p_gains), [50] * 12 + [5] * 6)
+    np.testing.assert_allclose(list(tc.action_scale), [0.4, 0.45, 0.45] * 4 + [2.1, 0.6, 0.6, 0, 0, 0], rtol=1e-6)
+
+
+def test_curriculum_saturates_on_first_call_and_rejects_unimplemented_rewards():
+    cfg = WidowGo1RoughCfg()
+    c0, c1 = make_curriculum(cfg, 0), make_curriculum(cfg, 1)
+    assert list(c0.lin_vel_x_range) == [0, 0] and list(c1.lin_vel_x_range) == [0, pytest.approx(0.9)]
+    assert c1.leg_reward_scale[abi.REWARD_TERMS.index("tracking_ang_vel_yaw_exp")] == pytest.approx(0.15)
+    assert c1.arm_reward_scale[abi.REWARD_TERMS.index("tracking_ee_sphere")] == pytest.approx(0.55)
+    active = [abi.REWARD_TERMS[i] for i in range(abi.NREW) if c1.leg_reward_scale[i] != 0]
+    assert sorted(active) == sorted(["energy_square", "survive", "tracking_lin_vel_x_l1", "tracking_ang_vel_yaw_exp",
+                                     "hip_action_l2", "foot_contacts_z"])                 # SURVEY 8a, compute_reward row
+    cfg.rewards.scales.feet_air_time = 1.0
+    with pytest.raises(NotImplementedError):
+        make_curriculum(cfg, 1)
+
+
+def test_oracle_env_logic_closed_form_cases(robot):
+    """PD torque law with quirk Q2, observation layout (Appendix A), time-out and z termination."""
+    import copy
+    from oracle import OracleSim, default_curriculum
+    tc = copy.copy(robot["tcfg"])
+    tc.push_interval = 0
+    o = OracleSim(robot["wmodel"], tc, 2)
+    o.set_curriculum(default_curriculum(robot["cfg"]))
+    dof = np.zeros((2, 20, 2))
+    dof[:, :, 0] = np.array(tc.default_dof_pos)
+    dof[:, 12, 0] = 3.5                 # waist beyond pi: wrapped in the observation, NOT in the PD law (Q2)
+    dof[:, 0, 1] = 2.0
+    o.set("DOF_STATE", dof)
+    act = np.zeros((2, 18)); act[:, 1] = 1.0
+    o.set("ACTIONS", act)
+    ms = np.ones((2, 18)); ms[1, 1] = 1.2
+    o.set("MOTOR_STRENGTH", ms)
+    o.compute_torques()
+    tq = o.get("TORQUES")
+    assert tq[0, 0] == pytest.approx(-1.0 * 2.0)                              # -Kd*qd
+    assert tq[0, 1] == pytest.approx(50 * 0.45) and tq[1, 1] == pytest.approx(23.7)   # clipped to the effort limit
+    assert tq[0, 12] == pytest.approx(max(-10.0, 5 * (0 - 3.5)))                      # unwrapped waist, clipped
+    assert (tq[:, 18:] == 0).all()
+    # a step from high above the ground: free fall, time-out bookkeeping, observation layout
+    root = np.zeros((2, 2, 13)); root[:, 0, 2] = 5.0; root[:, 0, 6] = 1; root[:, 1, 6] = 1
+    o.set("ROOT_STATES", root)
+    o.set("EPISODE_LENGTH", np.array([10.0, 500.0]))
+    o.set("COMMANDS", np.array([[0.5, 0, 0.7]] * 2))
+    o.step_counter = 7
+    o.step(np.zeros((2, 18)))
+    assert o.get("TIME_OUT_BUF").tolist() == [0, 1] and o.get("RESET_BUF").tolist() == [0, 1]
+    assert o.get("EPISODE_LENGTH").tolist() == [11, 0]
+    obs = o.get("OBS_BUF")
+    assert obs.shape == (2, 860)
+    q_obs = obs[0, 5:25]
+    assert q_obs[12] == pytest.approx(((3.5 + math.pi) % (2 * math.pi)) - math.pi, abs=0.2)   # wrapped waist (moves a bit in 4 substeps)
+    assert obs[0, 67] == pytest.approx(0.5) and obs[0, 69] == pytest.approx(0.7)              # commands * scale
+    np.testing.assert_allclose(obs[0, 82:100], ms[0] - 1)                                       # priv: motor_strength - 1
+    assert (obs[1, 100:] == 0).all()                                                           # reset env: history zeroed before assembly
+    hist = o.get("OBS_HISTORY")
+    np.testing.assert_allclose(hist[1, 0], hist[1, 9])                                          # ... then refilled 10x with the new obs
