@@ -169,10 +169,10 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
 
 extern "C" int wbc_sim_destroy(wbc_sim* s) {
   if (!s) return 0;
-  hipSetDevice(s->device);
-  if (s->own_arena && s->arena) hipFree(s->arena);
-  if (s->dc) hipFree(s->dc);
-  if (s->hf_dev) hipFree(s->hf_dev);
+  (void)hipSetDevice(s->device);
+  if (s->own_arena && s->arena) (void)hipFree(s->arena);
+  if (s->dc) (void)hipFree(s->dc);
+  if (s->hf_dev) (void)hipFree(s->hf_dev);
   delete s;
   return 0;
 }
@@ -247,7 +247,7 @@ extern "C" int wbc_sim_set_heightfield(wbc_sim* s, const int16_t* heights, int r
   if (!s) return fail(-1, "wbc_sim_set_heightfield: null sim");
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipDeviceSynchronize());
-  if (s->hf_dev) { hipFree(s->hf_dev); s->hf_dev = nullptr; }
+  if (s->hf_dev) { (void)hipFree(s->hf_dev); s->hf_dev = nullptr; }
   s->hc.hf = nullptr;
   if (heights) {
     if (rows < 2 || cols < 2) return fail(-1, "wbc_sim_set_heightfield: need at least a 2x2 grid");

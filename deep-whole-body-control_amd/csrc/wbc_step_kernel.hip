@@ -30,7 +30,7 @@ struct __align__(16) Smem {
   };
   float E[WBC_NB][9];
   float pos[WBC_NB][3];
-  float S[WBC_NB][6], v[WBC_NB][6], c[WBC_NB][6], pA[WBC_NB][6], U[WBC_NB][6], a[WBC_NB][6], g[WBC_NB][6];
+  float S[WBC_NB][6], v[WBC_NB][6], c[WBC_NB][6], pA[WBC_NB][6], U[WBC_NB][6], a[WBC_NB][6];
   float D[WBC_NB], u[WBC_NB], uD[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];
   float pa1[WBC_NCHAIN][6];      // depth-1 contributions to the root, summed in fixed order
   float q[WBC_NDOF], qd[WBC_NDOF], tau[WBC_NDOF], act[WBC_NACT];
@@ -46,15 +46,23 @@ struct __align__(16) Smem {
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
   float rew, arm_rew, base_yaw, mu, friction;
   int reset_flag, time_out, ep_len;
+  // per-chain constants (body, parent, axis, dof, armature at each depth); row WBC_NCHAIN is the idle row
+  int ct_body[WBC_NCHAIN + 1][WBC_MAX_DEPTH], ct_par[WBC_NCHAIN + 1][WBC_MAX_DEPTH], ct_ax[WBC_NCHAIN + 1][WBC_MAX_DEPTH],
+      ct_dof[WBC_NCHAIN + 1][WBC_MAX_DEPTH];
+  float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];
 };
 
-// aliases: pD lives in pA, aD in c (both dead once pass 3 has run)
+// aliases: pD lives in pA, aD in c (both dead once pass 3 has run); g (pass 3 only) also lives in pA:
+// pA is last read by the root solve, g is last read by the final K update, pD is first written by the contacts
 #define PD(s) (s).pA
 #define AD(s) (s).c
+#define GG(s) (s).pA
 
-struct ChainRegs {   // per-lane constants of this lane's chain, kept in registers (static indexing only)
-  int body[WBC_MAX_DEPTH], par[WBC_MAX_DEPTH], ax[WBC_MAX_DEPTH], dof[WBC_MAX_DEPTH];
-  float arm[WBC_MAX_DEPTH];
+// Per-lane view of this lane's chain constants: they live in LDS (Smem::ct_*), not in registers, so that
+// the hot loop keeps its VGPRs for the 6x6 algebra (30 long-lived registers spilled the fused kernel).
+struct ChainRegs {
+  const int *body, *par, *ax, *dof;
+  const float* arm;
 };
 
 __device__ __forceinline__ void fk_pass(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, int chain, int k) {
@@ -329,18 +337,18 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
 #pragma unroll
         for (int j = 1; j < 6; ++j) apk = (k == j) ? ap[j] : apk;
         s.a[i][k] = apk + s.S[i][k] * qdd;
-        s.g[i][k] = dot6(&s.IA[p][k * 6], s.U[i]) * invD;
+        GG(s)[i][k] = dot6(&s.IA[p][k * 6], s.U[i]) * invD;
       }
       if (k == 0) s.qdd[i] = qdd;
     }
     __syncthreads();
     if (act) {
       const int p = cr.par[d];
-      const float gam = dot6(s.U[i], s.g[i]) * invD + invD;
+      const float gam = dot6(s.U[i], GG(s)[i]) * invD + invD;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int e = 3 * k + j, r = e / 6, cc = e % 6;
-        s.IA[i][e] = s.IA[p][e] - s.g[i][r] * s.S[i][cc] - s.S[i][r] * s.g[i][cc] + gam * s.S[i][r] * s.S[i][cc];
+        s.IA[i][e] = s.IA[p][e] - GG(s)[i][r] * s.S[i][cc] - s.S[i][r] * GG(s)[i][cc] + gam * s.S[i][r] * s.S[i][cc];
       }
     }
     __syncthreads();
@@ -717,18 +725,22 @@ __device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restric
   }
 }
 
-__device__ void make_chain_regs(ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
-#pragma unroll
-  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-    int i = (chain < WBC_NCHAIN) ? C->chain_body[chain][d] : -1;
-    cr.body[d] = i;
+__device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
+  const int lane = threadIdx.x;
+  if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
+    const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
+    const int i = (ch < WBC_NCHAIN) ? C->chain_body[ch][d] : -1;
     const int ii = i < 0 ? 0 : i;
-    cr.par[d] = C->model.parent[ii] < 0 ? 0 : C->model.parent[ii];
-    cr.ax[d] = C->model.axis[ii] < 0 ? 0 : C->model.axis[ii];
     const int dj = C->model.dof[ii] < 0 ? 0 : C->model.dof[ii];
-    cr.dof[d] = dj;
-    cr.arm[d] = (dj < WBC_NACT) ? C->cfg.joint_armature[dj] : 0.f;
+    s.ct_body[ch][d] = i;
+    s.ct_par[ch][d] = C->model.parent[ii] < 0 ? 0 : C->model.parent[ii];
+    s.ct_ax[ch][d] = C->model.axis[ii] < 0 ? 0 : C->model.axis[ii];
+    s.ct_dof[ch][d] = dj;
+    s.ct_arm[ch][d] = (dj < WBC_NACT) ? C->cfg.joint_armature[dj] : 0.f;
   }
+  const int ch = chain < WBC_NCHAIN ? chain : WBC_NCHAIN;
+  cr.body = s.ct_body[ch]; cr.par = s.ct_par[ch]; cr.ax = s.ct_ax[ch]; cr.dof = s.ct_dof[ch]; cr.arm = s.ct_arm[ch];
+  __syncthreads();
 }
 
 // _compute_torques (oracle: compute_torques): lanes 0..19
@@ -859,7 +871,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(DevTensor
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(cr, C, chain);
+  make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   // action reorder, clip and delay FIFO (WG:1162-1168)
   if (lane < WBC_NACT) {
@@ -939,7 +951,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors 
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(cr, C, chain);
+  make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   if (lane == 0) { s.time_out = 0; s.reset_flag = 0; }
   __syncthreads();
@@ -971,7 +983,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(cr, C, chain);
+  make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   if (lane < WBC_NDOF) s.tau[lane] = T.torques[(size_t)env * WBC_NDOF + lane];
   __syncthreads();
@@ -990,7 +1002,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(cr, C, chain);
+  make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   __syncthreads();
   rigid_body_pass(s, C, cr, chain, k);

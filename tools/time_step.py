@@ -1,5 +1,5 @@
-"""Quick timing of the fused step kernel alone (no policy, no learner)."""
-import sys, os, time
+"""Timing of the fused step kernel alone (no policy, no learner), with knobs to attribute the time."""
+import sys, os, time, copy
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
@@ -8,16 +8,42 @@ from wbc_amd import abi
 from wbc_amd.config import WidowGo1RoughCfg
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+variants = sys.argv[3:] or ["base"]
 m = abi.load_default_model(); cfg = WidowGo1RoughCfg()
-robot = dict(model=m, wmodel=abi.fill_model(m), cfg=cfg, tcfg=abi.fill_task_cfg(cfg, m))
+for var in variants:
+    tc = abi.fill_task_cfg(cfg, m)
+    if var.startswith("dec"): tc.decimation = int(var[3:])
+    if var.startswith("it"): tc.contact_iters = int(var[2:])
+    if var == "nocontact": tc.contact_margin = -1e9
+    if var == "noreset": tc.term_z_threshold = -10.0; tc.term_rp_threshold = 100.0
+    robot = dict(model=m, wmodel=abi.fill_model(m), cfg=cfg, tcfg=tc)
+    g = helpers.make_gpu(robot, n, helpers.random_env_params(n, 0))
+    g.reset_all()
+    acts = [torch.randn(n, 18, device="cuda") * 0.5 for _ in range(8)]
+    for i in range(20): g.step(acts[i % 8])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps): g.step(acts[i % 8])
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    print(f"{var:10s} N={n} step kernel {ms*1000:.1f} us/step -> {n/ms*1000:.3e} env-steps/s (sim only); resets/step {g.tensor('RESET_BUF').float().mean().item():.3f}")
+    g.close()
+
+# simulate-only timing (one substep per launch, no PD / post-physics, no scratch in that kernel)
+tc = abi.fill_task_cfg(cfg, m)
+robot = dict(model=m, wmodel=abi.fill_model(m), cfg=cfg, tcfg=tc)
 g = helpers.make_gpu(robot, n, helpers.random_env_params(n, 0))
 g.reset_all()
-acts = [torch.randn(n, 18, device="cuda") * 0.5 for _ in range(8)]
-for i in range(20): g.step(acts[i % 8])
+for i in range(30): g.step(acts[i % 8])
+for i in range(20): g.simulate()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for i in range(steps): g.step(acts[i % 8])
+for i in range(100): g.simulate()
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / steps
-print(f"N={n} step kernel {ms*1000:.1f} us/step -> {n/ms*1000:.3e} env-steps/s (sim only); resets/step {g.tensor('RESET_BUF').float().mean().item():.3f}")
+print(f"simulate kernel {e0.elapsed_time(e1)/100*1000:.1f} us/substep")
+e0.record()
+for i in range(100): g.refresh_rigid_body_state()
+e1.record(); torch.cuda.synchronize()
+print(f"fk kernel {e0.elapsed_time(e1)/100*1000:.1f} us")
