@@ -56,6 +56,7 @@ def lib():
         L.wbc_gae_normalize.argtypes = [c_void, c_void, C.c_int64, c_void]
         L.wbc_gae_workspace_doubles.argtypes = [c_int]
         L.wbc_abi_sizes.argtypes = [C.POINTER(c_int)]
+        L.wbc_policy_act.argtypes = [c_void] * 7 + [c_int, c_void]
         _lib = L
     return _lib
 
@@ -67,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "wbc_sim_set_root_state_indexed", "wbc_sim_set_dof_state_indexed", "wbc_sim_refresh_dof_state",
     "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force", "wbc_sim_refresh_force_sensor",
     "wbc_sim_refresh_rigid_body_state", "wbc_sim_get_step_counter", "wbc_sim_set_step_counter", "wbc_gae_compute",
-    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes"]
+    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_policy_act"]
 
 
 def check(rc: int, what: str = "") -> None:

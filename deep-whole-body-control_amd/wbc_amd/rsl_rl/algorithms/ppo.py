@@ -45,6 +45,7 @@ class PPO:
         self.adaptive_arm_gains = adaptive_arm_gains
         self.counter = 0
         self.arm_fk = self.arm_fk_adaptive_gains if adaptive_arm_gains else self.arm_fk_fixed_gains
+        self.fused_rollout = True        # use the fused HIP inference kernel in act() where it applies
         self.dist_group = dist_group
         self.world_size = torch.distributed.get_world_size(dist_group) if dist_group is not None else 1
         self._buckets = {}
@@ -62,11 +63,18 @@ class PPO:
     # ---- rollout side ----------------------------------------------------------------------
     def act(self, obs, critic_obs, hist_encoding=False):
         tr, ac = self.transition, self.actor_critic
-        tr.actions = ac.act(obs, hist_encoding).detach()
-        tr.values = ac.evaluate(critic_obs).detach()
-        tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
-        tr.action_mean = ac.action_mean.detach()
-        tr.action_sigma = ac.action_std.detach()
+        if (self.fused_rollout and not hist_encoding and critic_obs is obs and not torch.is_grad_enabled()
+                and ac.fused_act_supported(obs)):
+            # one HIP launch for actor + critic + sample + log-prob (csrc/wbc_policy_kernel.hip)
+            eps = torch.randn(obs.shape[0], 18, device=obs.device)
+            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps)
+            tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
+        else:
+            tr.actions = ac.act(obs, hist_encoding).detach()
+            tr.values = ac.evaluate(critic_obs).detach()
+            tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
+            tr.action_mean = ac.action_mean.detach()
+            tr.action_sigma = ac.action_std.detach()
         # The env may hand out views it overwrites in place on the next step (WidowGo1.obs_buf is one):
         # park the acting observation in its storage slot now instead of at process_env_step time.
         st = self.storage
@@ -233,7 +241,8 @@ class PPO:
         return (total / num_updates).item()
 
     def enforce_min_std(self):
-        self.actor_critic.std.data = torch.max(self.actor_critic.std.detach(), self.min_policy_std).detach()
+        with torch.no_grad():           # in place: kernels hold the parameter's address
+            self.actor_critic.std.copy_(torch.max(self.actor_critic.std, self.min_policy_std))
 
     def update_counter(self):
         self.counter += 1

@@ -251,6 +251,54 @@ class ActorCritic(nn.Module):
         """Log-probability summed separately over the leg and the arm action dims -> [B, 2]."""
         return self._split_sum(self.distribution.log_prob(actions))
 
+    # ---- fused rollout inference (csrc/wbc_policy_kernel.hip) -----------------------------------
+    _FUSED_LAYERS = ("actor.priv_encoder.0", "actor.priv_encoder.2", "actor.actor_backbone.0",
+                     "actor.actor_leg_control_head.0", "actor.actor_leg_control_head.2", "actor.actor_leg_control_head.4",
+                     "actor.actor_arm_control_head.0", "actor.actor_arm_control_head.2", "actor.actor_arm_control_head.4",
+                     "critic.critic_backbone.0",
+                     "critic.critic_leg_control_head.0", "critic.critic_leg_control_head.2", "critic.critic_leg_control_head.4",
+                     "critic.critic_arm_control_head.0", "critic.critic_arm_control_head.2", "critic.critic_arm_control_head.4")
+
+    def fused_act_supported(self, observations) -> bool:
+        """The fused kernel covers the shipped widowGo1 architecture on a ROCm device (teacher latent)."""
+        if not (observations.is_cuda and observations.dtype == torch.float32 and observations.dim() == 2
+                and observations.shape[1] == 860 and observations.is_contiguous()):
+            return False
+        if getattr(self, "_fused_ok", None) is None:
+            sd = dict(self.named_parameters())
+            want = {"actor.priv_encoder.0.weight": (64, 24), "actor.priv_encoder.2.weight": (20, 64),
+                    "actor.actor_backbone.0.weight": (128, 96), "actor.actor_leg_control_head.0.weight": (128, 128),
+                    "actor.actor_leg_control_head.2.weight": (128, 128), "actor.actor_leg_control_head.4.weight": (12, 128),
+                    "actor.actor_arm_control_head.4.weight": (6, 128), "critic.critic_backbone.0.weight": (128, 100),
+                    "critic.critic_leg_control_head.4.weight": (1, 128), "critic.critic_arm_control_head.2.weight": (128, 128)}
+            self._fused_ok = all(k in sd and tuple(sd[k].shape) == v for k, v in want.items()) and \
+                isinstance(self.actor.actor_leg_control_head[1], nn.ELU) and not self.actor.adaptive_arm_gains
+        return self._fused_ok
+
+    def fused_act(self, observations, eps=None):
+        """PPO.act's policy side in one launch: returns (actions, mean, log_prob[.,2], values[.,2]).
+        `eps` = standard normals [B,18] (drawn by the caller from torch's generator); None acts on the mean."""
+        import ctypes as C
+        from ...native import check, lib
+        sd = dict(self.named_parameters())
+        ptrs = []
+        for name in self._FUSED_LAYERS:
+            w, b = sd[name + ".weight"], sd[name + ".bias"]
+            assert w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32
+            ptrs += [w.data_ptr(), b.data_ptr()]
+        ptrs.append(self.std.data_ptr())
+        table = (C.c_void_p * len(ptrs))(*ptrs)
+        n = observations.shape[0]
+        dev = observations.device
+        actions = torch.empty(n, 18, device=dev)
+        mean = torch.empty(n, 18, device=dev)
+        logp = torch.empty(n, 2, device=dev)
+        values = torch.empty(n, 2, device=dev)
+        check(lib().wbc_policy_act(table, observations.data_ptr(), eps.data_ptr() if eps is not None else None, actions.data_ptr(),
+                                   mean.data_ptr(), logp.data_ptr(), values.data_ptr(), n,
+                                   torch.cuda.current_stream(dev).cuda_stream), "wbc_policy_act")
+        return actions, mean, logp, values
+
     def act_inference(self, observations, hist_encoding=False):
         return self.actor(observations, hist_encoding)
 

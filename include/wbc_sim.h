@@ -274,6 +274,17 @@ int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t total,
 /* Number of doubles stats_dev must hold for N envs (3 statistics + per-block partials). */
 int wbc_gae_workspace_doubles(int N);
 
+/* The policy side of one rollout step, PPO.act (rsl_rl/algorithms/ppo.py:115-127) with the privileged
+ * latent: Actor.forward (actor_critic.py:204-221), Critic.forward (:281-286), the action sample
+ * mean + std * eps (Normal.sample, :337-339) and get_actions_log_prob (:341-345) in ONE launch on fp32
+ * MFMA. `params`: 33 device pointers in state_dict order of the layers used (struct PolicyParams in
+ * csrc/wbc_policy_kernel.hip: priv_encoder.{0,2}, actor_backbone.0, leg head {0,2,4}, arm head {0,2,4},
+ * critic_backbone.0, critic leg head {0,2,4}, critic arm head {0,2,4}, each weight then bias, then std).
+ * obs f32 [rows,860]; eps f32 [rows,18] standard normals (NULL: act on the mean); outputs actions/mean
+ * f32 [rows,18], logp/values f32 [rows,2]. */
+int wbc_policy_act(const void* const* params, const float* obs, const float* eps, float* actions,
+                   float* mean, float* logp, float* values, int num_rows, void* stream);
+
 /* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
 void wbc_abi_sizes(int* out3);
 
