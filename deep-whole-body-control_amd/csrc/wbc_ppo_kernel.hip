@@ -1,0 +1,443 @@
+// wbc_ppo_kernel.hip -- one PPO.update() minibatch step (reference rsl_rl/algorithms/ppo.py:163-246, teacher
+// path) as three launches on gfx950 instead of ~350 eager ones:
+//
+//   1. ppo_fwd_bwd_kernel: a workgroup takes 32 minibatch rows (gathered through the permutation index),
+//      runs actor + critic forward on fp32 MFMA with all activations of the tile in LDS, evaluates the loss
+//      terms -- clipped surrogate with Advantage Mixing (PPO:199-206), clipped value loss (PPO:209-214),
+//      Regularized-Online-Adaptation latent regulariser (PPO:174-179) -- and their output gradients in the
+//      epilogue, then back-propagates through every layer (dA = dZ W on MFMA, activation derivatives from
+//      the stashed post-activations). Post-activations and pre-activation gradients go to two global
+//      stashes; per-tile column sums of the latter are the bias-gradient partials.
+//   2. ppo_wgrad_kernel: dW_l = dZ_l^T A_{l-1} for all 16 layers, split 64..80 ways over the rows
+//      (the reduction length is the minibatch, 40960), 32x32x2 MFMA with both operands staged through LDS.
+//   3. ppo_reduce_kernel: fixed-order sums of the split partials into the flat gradient buffer.
+//
+// Everything is deterministic (no atomics). The history-encoder latent that the regulariser targets is an
+// input (its weights do not change during update(), PPO:175-176).
+#include "wbc_mlp.h"
+
+// ---- stash layouts (floats per row) -------------------------------------------------------------
+enum { A_X = 0, A_H1 = 100, A_LAT = 164, A_BB = 184, A_L1 = 312, A_L2 = 440, A_LEG = 568, A_A1 = 580, A_A2 = 708, A_ARM = 836,
+       A_CB = 842, A_CL1 = 970, A_CL2 = 1098, A_CA1 = 1226, A_CA2 = 1354, A_Z = 1482, A_LD = 1584 };
+enum { D_H1 = 0, D_LAT = 64, D_BB = 84, D_L1 = 212, D_L2 = 340, D_LEG = 468, D_A1 = 480, D_A2 = 608, D_ARM = 736, D_CB = 742,
+       D_CL1 = 870, D_CL2 = 998, D_VLEG = 1126, D_CA1 = 1127, D_CA2 = 1255, D_VARM = 1383, D_LD = 1384 };
+#define NLAYERS 16
+
+struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minibatch's row indices
+  const float* obs;               // [TN, 860]
+  const float* actions;           // [TN, 18]
+  const float* old_values;        // [TN, 2]
+  const float* advantages;        // [TN, 2]
+  const float* returns;           // [TN, 2]
+  const float* old_logp;          // [TN, 2]
+  const float* hist_latent;       // [TN, 20]  history-encoder latent of every stored row
+  const int64_t* idx;             // [B]
+  int B;
+  float clip, value_coef, mixing, roa_coef;
+  int use_clipped_value_loss;
+};
+
+struct __align__(16) PpoSmem {
+  float x[PT_ROWS * 101];
+  float a0[PT_ROWS * LDA], a1[PT_ROWS * LDA], a2[PT_ROWS * LDA];
+  float wl[128 * LDA];
+  float outv[PT_ROWS * 21];       // mean 18, values 2
+  float g[PT_ROWS * 41];          // output grads: dmu 18, dv 2, dlat 20
+};
+
+// out[32, IN] (+)= dz[32, OUT] * W[OUT, IN]; W staged through wl (row stride IN_pad + 1). OUT even, <= 128.
+static __device__ void bwd_gemm(const float* dz, int ldz, int OUT, const float* __restrict__ W, int IN, float* out, int ldo, float* wl,
+                                bool accumulate) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int in_pad = (IN + 31) & ~31, ldw = in_pad + 1;
+  for (int e = tid; e < OUT * in_pad; e += PT_THREADS) {
+    const int o = e / in_pad, i = e - o * in_pad;
+    wl[o * ldw + i] = (i < IN) ? W[(size_t)o * IN + i] : 0.f;
+  }
+  __syncthreads();
+  if (wave * 32 < in_pad) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* ap = dz + (lane & 31) * ldz + (lane >> 5);
+    const float* bp = wl + (lane >> 5) * ldw + wave * 32 + (lane & 31);
+#pragma unroll 4
+    for (int k = 0; k < OUT; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * ldw], acc, 0, 0, 0);
+    const int col = wave * 32 + (lane & 31);
+    if (col < IN) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float* o = &out[row * ldo + col];
+        *o = accumulate ? (*o + acc[r]) : acc[r];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// buf[32, n] <- buf * act'(A) with A the stashed post-activation (elu' = a > 0 ? 1 : a + 1, tanh' = 1 - a^2);
+// writes the result to the DZ stash and the tile's column sums (bias-gradient partial) to dbp[dcol + c].
+static __device__ void act_grad(float* buf, int ld, int n, const float* __restrict__ act_stash, int acol, int act, float* __restrict__ dz_stash,
+                                int dcol, float* __restrict__ dbp, int row0, int num_rows) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < PT_ROWS * n; e += PT_THREADS) {
+    const int r = e / n, c = e - r * n;
+    float v = 0.f;
+    if (row0 + r < num_rows) {
+      const float a = act_stash[(size_t)(row0 + r) * A_LD + acol + c];
+      const float d = (act == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : ((act == ACT_TANH) ? 1.f - a * a : 1.f);
+      v = buf[r * ld + c] * d;
+      dz_stash[(size_t)(row0 + r) * D_LD + dcol + c] = v;
+    }
+    buf[r * ld + c] = v;
+  }
+  __syncthreads();
+  if (tid < n) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < PT_ROWS; ++r) sum += buf[r * ld + tid];
+    dbp[dcol + tid] = sum;
+  }
+  __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(PolicyParams P, PpoBatch Bt, float* __restrict__ act_stash,
+                                                                           float* __restrict__ dz_stash, float* __restrict__ db_partial,
+                                                                           float* __restrict__ dstd_partial, float* __restrict__ loss_partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  PpoSmem& s = *reinterpret_cast<PpoSmem*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
+  float* dbp = db_partial + (size_t)tile * D_LD;
+  // gather obs[idx, :100]
+  for (int e = tid; e < PT_ROWS * 100; e += PT_THREADS) {
+    const int r = e / 100, c = e - r * 100;
+    float v = 0.f;
+    if (row0 + r < B) {
+      v = Bt.obs[(size_t)Bt.idx[row0 + r] * PT_NOBS + c];
+      act_stash[(size_t)(row0 + r) * A_LD + A_X + c] = v;
+    }
+    s.x[r * 101 + c] = v;
+  }
+  __syncthreads();
+  // ---------------- forward (same chain as wbc_policy_act_kernel), post-activations stashed
+  fused_layer(s.x + PT_NPROP, 101, PT_NPRIV, P.priv0_w, P.priv0_b, 64, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_H1, row0, B);
+  fused_layer(s.a0, LDA, 64, P.priv2_w, P.priv2_b, 20, s.a1, LDA, PT_NPROP, s.wl, ACT_ELU, act_stash, A_LD, A_LAT, row0, B);
+  for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
+    const int r = e / PT_NPROP, c = e - r * PT_NPROP;
+    s.a1[r * LDA + c] = s.x[r * 101 + c];
+  }
+  __syncthreads();
+  for (int e = tid; e < PT_ROWS * 96; e += PT_THREADS) {          // z = [prop, latent], the backbone's input, for its weight gradient
+    const int r = e / 96, c = e - r * 96;
+    if (row0 + r < B) act_stash[(size_t)(row0 + r) * A_LD + A_Z + c] = s.a1[r * LDA + c];
+  }
+  fused_layer(s.a1, LDA, 96, P.bb_w, P.bb_b, 128, s.a2, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_BB, row0, B);
+  fused_layer(s.a2, LDA, 128, P.leg0_w, P.leg0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_L1, row0, B);
+  fused_layer(s.a0, LDA, 128, P.leg2_w, P.leg2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_L2, row0, B);
+  fused_layer(s.a1, LDA, 128, P.leg4_w, P.leg4_b, PT_NLEG, s.outv, 21, 0, s.wl, ACT_TANH, act_stash, A_LD, A_LEG, row0, B);
+  fused_layer(s.a2, LDA, 128, P.arm0_w, P.arm0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_A1, row0, B);
+  fused_layer(s.a0, LDA, 128, P.arm2_w, P.arm2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_A2, row0, B);
+  fused_layer(s.a1, LDA, 128, P.arm4_w, P.arm4_b, PT_NARM, s.outv, 21, PT_NLEG, s.wl, ACT_TANH, act_stash, A_LD, A_ARM, row0, B);
+  fused_layer(s.x, 101, 100, P.cbb_w, P.cbb_b, 128, s.a2, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CB, row0, B);
+  fused_layer(s.a2, LDA, 128, P.cleg0_w, P.cleg0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CL1, row0, B);
+  fused_layer(s.a0, LDA, 128, P.cleg2_w, P.cleg2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CL2, row0, B);
+  fused_layer(s.a1, LDA, 128, P.cleg4_w, P.cleg4_b, 1, s.outv, 21, 18, s.wl, ACT_NONE);
+  fused_layer(s.a2, LDA, 128, P.carm0_w, P.carm0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CA1, row0, B);
+  fused_layer(s.a0, LDA, 128, P.carm2_w, P.carm2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CA2, row0, B);
+  fused_layer(s.a1, LDA, 128, P.carm4_w, P.carm4_b, 1, s.outv, 21, 19, s.wl, ACT_NONE);
+  // ---------------- losses and output gradients: one row per lane of wave 0
+  if (tid < 64) {
+    const int r = tid & 31;
+    const bool valid = (tid < PT_ROWS) && (row0 + r < B);
+    float surr = 0.f, vls = 0.f, preg = 0.f;
+    float dsd[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dsd[j] = 0.f;
+    if (valid) {
+      const size_t src = (size_t)Bt.idx[row0 + r];
+      const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
+      float lp[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const float mu = s.outv[r * 21 + j], sd = P.std[j];
+        const float d = Bt.actions[src * 18 + j] - mu;
+        lp[j < PT_NLEG ? 0 : 1] += -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+      }
+      const float adv0 = Bt.advantages[src * 2], adv1 = Bt.advantages[src * 2 + 1];
+      const float mixed[2] = {adv0 + Bt.mixing * adv1, adv1 + Bt.mixing * adv0};               // PPO:199-201
+      float dlp[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float ratio = expf(lp[c] - Bt.old_logp[src * 2 + c]);                               // PPO:202
+        const float rc = fminf(fmaxf(ratio, 1.f - Bt.clip), 1.f + Bt.clip);
+        const float s1 = -mixed[c] * ratio, s2 = -mixed[c] * rc;                                  // PPO:203-205
+        surr += fmaxf(s1, s2);
+        const bool inside = (ratio >= 1.f - Bt.clip) && (ratio <= 1.f + Bt.clip);
+        const float dr = (inside || s1 > s2) ? -mixed[c] : 0.f;                                   // d max(s1,s2) / d ratio
+        dlp[c] = inv2B * dr * ratio;
+        // value loss PPO:209-216
+        const float v = s.outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];
+        float dv;
+        if (Bt.use_clipped_value_loss) {
+          const float dlt = v - ov;
+          const float vc = ov + fminf(fmaxf(dlt, -Bt.clip), Bt.clip);
+          const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+          vls += fmaxf(l1, l2);
+          const float m = (dlt >= -Bt.clip && dlt <= Bt.clip) ? 1.f : 0.f;
+          const float g1 = 2.f * (v - R), g2 = 2.f * (vc - R) * m;
+          dv = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+        } else {
+          vls += (R - v) * (R - v);
+          dv = 2.f * (v - R);
+        }
+        s.g[r * 41 + 18 + c] = Bt.value_coef * inv2B * dv;
+      }
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const float mu = s.outv[r * 21 + j], sd = P.std[j];
+        const float d = Bt.actions[src * 18 + j] - mu;
+        const float gl = dlp[j < PT_NLEG ? 0 : 1];
+        s.g[r * 41 + j] = gl * d / (sd * sd);                                                    // d logp / d mu
+        dsd[j] = gl * (d * d / (sd * sd * sd) - 1.f / sd);                                       // d logp / d sigma
+      }
+      // ROA regulariser PPO:174-179: mean_B || priv_latent - hist_latent ||_2
+      float dl[20], nrm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 20; ++k) {
+        dl[k] = act_stash[(size_t)(row0 + r) * A_LD + A_LAT + k] - Bt.hist_latent[src * 20 + k];
+        nrm += dl[k] * dl[k];
+      }
+      nrm = sqrtf(nrm);
+      preg = nrm;
+      const float sc = (nrm > 0.f) ? Bt.roa_coef * invB / nrm : 0.f;
+#pragma unroll
+      for (int k = 0; k < 20; ++k) s.g[r * 41 + 20 + k] = sc * dl[k];
+    } else if (tid < PT_ROWS) {
+      for (int k = 0; k < 40; ++k) s.g[r * 41 + k] = 0.f;
+    }
+    // reduce the tile's loss sums and sigma gradients over the 32 rows (lanes 32..63 carry zeros)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      surr += __shfl_xor(surr, off); vls += __shfl_xor(vls, off); preg += __shfl_xor(preg, off);
+#pragma unroll
+      for (int j = 0; j < 18; ++j) dsd[j] += __shfl_xor(dsd[j], off);
+    }
+    if (tid == 0) {
+      loss_partial[tile * 3 + 0] = surr; loss_partial[tile * 3 + 1] = vls; loss_partial[tile * 3 + 2] = preg;
+#pragma unroll
+      for (int j = 0; j < 18; ++j) dstd_partial[tile * 18 + j] = dsd[j];
+    }
+  }
+  __syncthreads();
+  (void)lane;
+  // ---------------- backward: critic
+  for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) {          // dA_cl2 = dZ_vleg (x) W_cleg4 (1 x 128)
+    const int r = e >> 7, c = e & 127;
+    s.a0[r * LDA + c] = s.g[r * 41 + 18] * P.cleg4_w[c];
+  }
+  if (tid < PT_ROWS && row0 + tid < B) {
+    dz_stash[(size_t)(row0 + tid) * D_LD + D_VLEG] = s.g[tid * 41 + 18];
+    dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = s.g[tid * 41 + 19];
+  }
+  if (tid == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = 0; r < PT_ROWS; ++r) { s0 += s.g[r * 41 + 18]; s1 += s.g[r * 41 + 19]; }
+    dbp[D_VLEG] = s0; dbp[D_VARM] = s1;
+  }
+  __syncthreads();
+  act_grad(s.a0, LDA, 128, act_stash, A_CL2, ACT_ELU, dz_stash, D_CL2, dbp, row0, B);
+  bwd_gemm(s.a0, LDA, 128, P.cleg2_w, 128, s.a1, LDA, s.wl, false);
+  act_grad(s.a1, LDA, 128, act_stash, A_CL1, ACT_ELU, dz_stash, D_CL1, dbp, row0, B);
+  bwd_gemm(s.a1, LDA, 128, P.cleg0_w, 128, s.a2, LDA, s.wl, false);                       // a2 = dA_cb (leg part)
+  for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) {
+    const int r = e >> 7, c = e & 127;
+    s.a0[r * LDA + c] = s.g[r * 41 + 19] * P.carm4_w[c];
+  }
+  __syncthreads();
+  act_grad(s.a0, LDA, 128, act_stash, A_CA2, ACT_ELU, dz_stash, D_CA2, dbp, row0, B);
+  bwd_gemm(s.a0, LDA, 128, P.carm2_w, 128, s.a1, LDA, s.wl, false);
+  act_grad(s.a1, LDA, 128, act_stash, A_CA1, ACT_ELU, dz_stash, D_CA1, dbp, row0, B);
+  bwd_gemm(s.a1, LDA, 128, P.carm0_w, 128, s.a2, LDA, s.wl, true);                        // a2 += arm part
+  act_grad(s.a2, LDA, 128, act_stash, A_CB, ACT_ELU, dz_stash, D_CB, dbp, row0, B);
+  // ---------------- backward: actor
+  for (int e = tid; e < PT_ROWS * PT_NLEG; e += PT_THREADS) {
+    const int r = e / PT_NLEG, c = e - r * PT_NLEG;
+    s.a0[r * LDA + c] = s.g[r * 41 + c];
+  }
+  __syncthreads();
+  act_grad(s.a0, LDA, PT_NLEG, act_stash, A_LEG, ACT_TANH, dz_stash, D_LEG, dbp, row0, B);
+  bwd_gemm(s.a0, LDA, PT_NLEG, P.leg4_w, 128, s.a1, LDA, s.wl, false);
+  act_grad(s.a1, LDA, 128, act_stash, A_L2, ACT_ELU, dz_stash, D_L2, dbp, row0, B);
+  bwd_gemm(s.a1, LDA, 128, P.leg2_w, 128, s.a0, LDA, s.wl, false);
+  act_grad(s.a0, LDA, 128, act_stash, A_L1, ACT_ELU, dz_stash, D_L1, dbp, row0, B);
+  bwd_gemm(s.a0, LDA, 128, P.leg0_w, 128, s.a2, LDA, s.wl, false);                        // a2 = dA_bb (leg part)
+  for (int e = tid; e < PT_ROWS * PT_NARM; e += PT_THREADS) {
+    const int r = e / PT_NARM, c = e - r * PT_NARM;
+    s.a0[r * LDA + c] = s.g[r * 41 + PT_NLEG + c];
+  }
+  __syncthreads();
+  act_grad(s.a0, LDA, PT_NARM, act_stash, A_ARM, ACT_TANH, dz_stash, D_ARM, dbp, row0, B);
+  bwd_gemm(s.a0, LDA, PT_NARM, P.arm4_w, 128, s.a1, LDA, s.wl, false);
+  act_grad(s.a1, LDA, 128, act_stash, A_A2, ACT_ELU, dz_stash, D_A2, dbp, row0, B);
+  bwd_gemm(s.a1, LDA, 128, P.arm2_w, 128, s.a0, LDA, s.wl, false);
+  act_grad(s.a0, LDA, 128, act_stash, A_A1, ACT_ELU, dz_stash, D_A1, dbp, row0, B);
+  bwd_gemm(s.a0, LDA, 128, P.arm0_w, 128, s.a2, LDA, s.wl, true);                         // a2 += arm part
+  act_grad(s.a2, LDA, 128, act_stash, A_BB, ACT_ELU, dz_stash, D_BB, dbp, row0, B);
+  bwd_gemm(s.a2, LDA, 128, P.bb_w, 96, s.a0, LDA, s.wl, false);                            // a0 = dA_z [32, 96]
+  for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {                                   // d latent = dA_z[:, 76:96] + ROA gradient
+    const int r = e / 20, c = e - r * 20;
+    s.a1[r * LDA + c] = s.a0[r * LDA + PT_NPROP + c] + s.g[r * 41 + 20 + c];
+  }
+  __syncthreads();
+  act_grad(s.a1, LDA, 20, act_stash, A_LAT, ACT_ELU, dz_stash, D_LAT, dbp, row0, B);
+  bwd_gemm(s.a1, LDA, 20, P.priv2_w, 64, s.a0, LDA, s.wl, false);
+  act_grad(s.a0, LDA, 64, act_stash, A_H1, ACT_ELU, dz_stash, D_H1, dbp, row0, B);
+}
+
+// ---- weight gradients ---------------------------------------------------------------------------
+struct WgradLayer { int out, in, dcol, acol, goff; };   // goff: offset of this layer's weight gradient in the flat buffer
+struct WgradTable { WgradLayer l[NLAYERS]; };
+#define WG_CHUNK 32
+#define WG_LD 129
+
+extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
+                                                                         const float* __restrict__ dz_stash, float* __restrict__ wpart,
+                                                                         int B, int rows_per_split, int nparams) {
+  __shared__ float dzl[WG_CHUNK * WG_LD], al[WG_CHUNK * WG_LD];
+  const WgradLayer L = tab.l[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int out_pad = (L.out + 31) & ~31, in_pad = (L.in + 31) & ~31;
+  const int r_begin = blockIdx.x * rows_per_split, r_end = min(B, r_begin + rows_per_split);
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool wave_on = wave * 32 < out_pad;
+  for (int r0 = r_begin; r0 < r_end; r0 += WG_CHUNK) {
+    for (int e = tid; e < WG_CHUNK * out_pad; e += PT_THREADS) {
+      const int r = e / out_pad, c = e - r * out_pad;
+      dzl[r * WG_LD + c] = (c < L.out && r0 + r < r_end) ? dz_stash[(size_t)(r0 + r) * D_LD + L.dcol + c] : 0.f;
+    }
+    for (int e = tid; e < WG_CHUNK * in_pad; e += PT_THREADS) {
+      const int r = e / in_pad, c = e - r * in_pad;
+      al[r * WG_LD + c] = (c < L.in && r0 + r < r_end) ? act_stash[(size_t)(r0 + r) * A_LD + L.acol + c] : 0.f;
+    }
+    __syncthreads();
+    if (wave_on) {
+      const float* ap = dzl + (lane >> 5) * WG_LD + wave * 32 + (lane & 31);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b * 32 < in_pad) {
+          const float* bp = al + (lane >> 5) * WG_LD + b * 32 + (lane & 31);
+#pragma unroll 4
+          for (int k = 0; k < WG_CHUNK; k += 2) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * WG_LD], bp[k * WG_LD], acc[b], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave_on) {
+    float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = b * 32 + (lane & 31);
+      if (col < L.in) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (o < L.out) dst[(size_t)o * L.in + col] = acc[b][r];
+        }
+      }
+    }
+  }
+}
+
+// grad[p] = sum_s part[s][p] in a fixed order; `stride` floats between consecutive partials
+extern "C" __global__ void ppo_reduce_kernel(const float* __restrict__ part, int nparts, int stride, int n, float* __restrict__ grad) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < nparts; ++s) acc += part[(size_t)s * stride + p];
+  grad[p] = acc;
+}
+
+// bias gradients: column sums of the per-tile partials, scattered to their place in the flat gradient
+struct BiasMap { int dcol[NLAYERS], n[NLAYERS], goff[NLAYERS]; };
+extern "C" __global__ void ppo_bias_reduce_kernel(BiasMap map, const float* __restrict__ db_partial, int ntiles, float* __restrict__ grad) {
+  const int layer = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= map.n[layer]) return;
+  float acc = 0.f;
+  for (int t = 0; t < ntiles; ++t) acc += db_partial[(size_t)t * D_LD + map.dcol[layer] + c];
+  grad[map.goff[layer] + c] = acc;
+}
+
+// ---- C-ABI ----------------------------------------------------------------------------------------
+// Flat gradient layout: for layer l in PolicyParams order: weight [out*in] then bias [out]; then std [18];
+// then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
+static const int kOut[NLAYERS] = {64, 20, 128, 128, 128, 12, 128, 128, 6, 128, 128, 128, 1, 128, 128, 1};
+static const int kIn[NLAYERS] = {24, 64, 96, 128, 128, 128, 128, 128, 128, 100, 128, 128, 128, 128, 128, 128};
+static const int kDcol[NLAYERS] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM};
+static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, A_BB, A_A1, A_A2, A_X, A_CB, A_CL1, A_CL2, A_CB, A_CA1, A_CA2};
+
+extern "C" int wbc_ppo_grad_floats(void) {
+  int n = 0;
+  for (int l = 0; l < NLAYERS; ++l) n += kOut[l] * kIn[l] + kOut[l];
+  return n + 18 + 3;
+}
+extern "C" int wbc_ppo_num_splits(void) { return 80; }
+// floats of workspace for a minibatch of B rows
+extern "C" size_t wbc_ppo_workspace_floats(int B) {
+  const size_t tiles = (size_t)(B + PT_ROWS - 1) / PT_ROWS;
+  return (size_t)B * (A_LD + D_LD) + tiles * (D_LD + 18 + 3) + (size_t)wbc_ppo_num_splits() * (size_t)wbc_ppo_grad_floats();
+}
+
+// One minibatch: gradients of loss = surrogate + value_coef*value_loss + roa_coef*priv_reg (PPO:218-221, entropy term
+// handled by the caller) w.r.t. the 16 layers' weights/biases and std, into `grad` (wbc_ppo_grad_floats() floats).
+extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions, const float* old_values,
+                                      const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
+                                      const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
+                                      int use_clipped_value_loss, float* workspace, float* grad, void* stream) {
+  if (!params || !obs || !actions || !old_values || !advantages || !returns || !old_logp || !hist_latent || !idx || !workspace || !grad || B <= 0)
+    return -1;
+  PolicyParams P;
+  const float** dst = reinterpret_cast<const float**>(&P);
+  for (int i = 0; i < 33; ++i) {
+    if (!params[i]) return -1;
+    dst[i] = static_cast<const float*>(params[i]);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PpoSmem)) != hipSuccess) return -2;
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = (B + PT_ROWS - 1) / PT_ROWS;
+  const int nsplit = wbc_ppo_num_splits(), ng = wbc_ppo_grad_floats();
+  float* act_stash = workspace;
+  float* dz_stash = act_stash + (size_t)B * A_LD;
+  float* db_partial = dz_stash + (size_t)B * D_LD;
+  float* dstd_partial = db_partial + (size_t)tiles * D_LD;
+  float* loss_partial = dstd_partial + (size_t)tiles * 18;
+  float* wpart = loss_partial + (size_t)tiles * 3;
+  PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
+  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), sizeof(PpoSmem), st, P, Bt, act_stash, dz_stash, db_partial, dstd_partial,
+                     loss_partial);
+  WgradTable tab;
+  BiasMap bm;
+  int off = 0;
+  for (int l = 0; l < NLAYERS; ++l) {
+    tab.l[l] = WgradLayer{kOut[l], kIn[l], kDcol[l], kAcol[l], off};
+    off += kOut[l] * kIn[l];
+    bm.dcol[l] = kDcol[l]; bm.n[l] = kOut[l]; bm.goff[l] = off;
+    off += kOut[l];
+  }
+  int rows_per_split = (B + nsplit - 1) / nsplit;
+  rows_per_split = (rows_per_split + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(nsplit, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, rows_per_split, ng);
+  // weights: sum of the split partials (bias slots of `wpart` are never written and never read: they are overwritten below)
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3((off + 255) / 256), dim3(256), 0, st, wpart, nsplit, ng, off, grad);
+  hipLaunchKernelGGL(ppo_bias_reduce_kernel, dim3(1, NLAYERS), dim3(128), 0, st, bm, db_partial, tiles, grad);
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(64), 0, st, dstd_partial, tiles, 18, 18, grad + off);
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(64), 0, st, loss_partial, tiles, 3, 3, grad + off + 18);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

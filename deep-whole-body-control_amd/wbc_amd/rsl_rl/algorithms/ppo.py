@@ -46,6 +46,8 @@ class PPO:
         self.counter = 0
         self.arm_fk = self.arm_fk_adaptive_gains if adaptive_arm_gains else self.arm_fk_fixed_gains
         self.fused_rollout = True        # use the fused HIP inference kernel in act() where it applies
+        self.fused_update = True         # use the fused HIP minibatch kernels in update() where they apply
+        self._fused = None
         self.dist_group = dist_group
         self.world_size = torch.distributed.get_world_size(dist_group) if dist_group is not None else 1
         self._buckets = {}
@@ -138,7 +140,79 @@ class PPO:
             raise NotImplementedError("recurrent policies are unreachable in the reference as well (SURVEY.md inventory #24)")
         return self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
 
+    # ---- fused update (csrc/wbc_ppo_kernel.hip) -------------------------------------------------
+    def _fused_update_supported(self):
+        st, ac = self.storage, self.actor_critic
+        return (self.fused_update and st.observations.is_cuda and st.privileged_observations is None and not ac.is_recurrent
+                and not self.torque_supervision and not (self.desired_kl is not None and self.schedule == "adaptive")
+                and ac.fused_act_supported(st.observations[0]))
+
+    def _update_fused(self):
+        """update() with each minibatch's forward, losses and backward in the HIP kernels; the optimiser, the
+        gradient clip and (multi-GPU) the all-reduce stay in torch and act on one flat gradient buffer."""
+        import ctypes as C
+        from ...native import check, lib
+        L, st, ac, dev = lib(), self.storage, self.actor_critic, self.storage.observations.device
+        T, N = st.num_transitions_per_env, st.num_envs
+        batch = T * N
+        mb = batch // self.num_mini_batches
+        params = ac.fused_params()
+        if self._fused is None or self._fused["mb"] != mb:
+            ng = L.wbc_ppo_grad_floats()
+            grad = torch.zeros(ng, device=dev)
+            off = 0
+            for p in params:                       # parameter gradients are views of the flat buffer
+                p.grad = grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            assert off == ng - 3
+            self._fused = dict(mb=mb, grad=grad, nparam=off, ws=torch.empty(L.wbc_ppo_workspace_floats(mb), device=dev),
+                               hist=torch.empty(batch, 20, device=dev))
+        F = self._fused
+        for p, g in zip(params, torch.split(F["grad"][:F["nparam"]], [p.numel() for p in params])):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g.view_as(p)
+        for p in ac.actor.history_encoder.parameters():
+            p.grad = None                          # untouched by update() (PPO:175-176)
+        table = ac.fused_param_table()
+        obs = st.observations.view(batch, -1)
+        with torch.inference_mode():               # the regulariser's target: history latent of every stored row
+            for s0 in range(0, batch, 32768):
+                F["hist"][s0:s0 + 32768] = ac.actor.infer_hist_latent(obs[s0:s0 + 32768])
+        flat = lambda x: x.view(batch, -1)         # noqa: E731
+        actions, values, adv, returns, logp = (flat(x) for x in (st.actions, st.values, st.advantages, st.returns, st.actions_log_prob))
+        value_mixing_ratio = self.get_value_mixing_ratio()
+        s = self.priv_reg_coef_schedual
+        priv_reg_coef = min(max((self.counter - s[2]), 0) / s[3], 1) * (s[1] - s[0]) + s[0]
+        indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=dev)
+        sums = torch.zeros(3, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        vcoef = self.value_loss_coef
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                idx = indices[i * mb:(i + 1) * mb]
+                check(L.wbc_ppo_minibatch_grad(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(),
+                                               returns.data_ptr(), logp.data_ptr(), F["hist"].data_ptr(), idx.data_ptr(), mb,
+                                               float(self.clip_param), float(vcoef), float(value_mixing_ratio), float(priv_reg_coef),
+                                               int(self.use_clipped_value_loss), F["ws"].data_ptr(), F["grad"].data_ptr(), stream),
+                      "wbc_ppo_minibatch_grad")
+                if self.entropy_coef != 0.0:       # -coef * entropy.mean(): d/d sigma_j of (1/2) sum_j log sigma_j
+                    ac.std.grad.sub_(self.entropy_coef * 0.5 / ac.std.detach())
+                if self.dist_group is not None and self.world_size > 1:
+                    torch.distributed.all_reduce(F["grad"][:F["nparam"]], group=self.dist_group)
+                    F["grad"][:F["nparam"]].div_(self.world_size)
+                sums += F["grad"][F["nparam"]:]
+                nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                self.optimizer.step()
+        num_updates = self.num_learning_epochs * self.num_mini_batches
+        surr, vls, preg = (sums / num_updates).tolist()
+        self.storage.clear()
+        self.update_counter()
+        self.enforce_min_std()
+        return (vls / (2 * mb), surr / (2 * mb), 0.0, value_mixing_ratio, 0, preg / mb, priv_reg_coef)
+
     def update(self):
+        if self._fused_update_supported():
+            return self._update_fused()
         ac = self.actor_critic
         sums = torch.zeros(4, device=self.device)      # value, surrogate, arm-torque, priv-reg loss accumulators
         value_mixing_ratio = self.get_value_mixing_ratio()

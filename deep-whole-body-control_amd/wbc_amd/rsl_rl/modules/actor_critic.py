@@ -275,19 +275,27 @@ class ActorCritic(nn.Module):
                 isinstance(self.actor.actor_leg_control_head[1], nn.ELU) and not self.actor.adaptive_arm_gains
         return self._fused_ok
 
+    def fused_params(self):
+        """The 33 parameters the fused kernels read, in struct PolicyParams order."""
+        sd = dict(self.named_parameters())
+        out = []
+        for name in self._FUSED_LAYERS:
+            out += [sd[name + ".weight"], sd[name + ".bias"]]
+        out.append(self.std)
+        return out
+
+    def fused_param_table(self):
+        import ctypes as C
+        ps = self.fused_params()
+        for p in ps:
+            assert p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda
+        return (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+
     def fused_act(self, observations, eps=None):
         """PPO.act's policy side in one launch: returns (actions, mean, log_prob[.,2], values[.,2]).
         `eps` = standard normals [B,18] (drawn by the caller from torch's generator); None acts on the mean."""
-        import ctypes as C
         from ...native import check, lib
-        sd = dict(self.named_parameters())
-        ptrs = []
-        for name in self._FUSED_LAYERS:
-            w, b = sd[name + ".weight"], sd[name + ".bias"]
-            assert w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32
-            ptrs += [w.data_ptr(), b.data_ptr()]
-        ptrs.append(self.std.data_ptr())
-        table = (C.c_void_p * len(ptrs))(*ptrs)
+        table = self.fused_param_table()
         n = observations.shape[0]
         dev = observations.device
         actions = torch.empty(n, 18, device=dev)

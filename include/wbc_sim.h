@@ -285,6 +285,23 @@ int wbc_gae_workspace_doubles(int N);
 int wbc_policy_act(const void* const* params, const float* obs, const float* eps, float* actions,
                    float* mean, float* logp, float* values, int num_rows, void* stream);
 
+/* One PPO.update() minibatch (rsl_rl/algorithms/ppo.py:163-246, teacher path, no torque supervision): gathers
+ * the rows `idx` of the flat [T*N, ...] rollout tensors, runs actor + critic forward, the clipped surrogate
+ * with Advantage Mixing (:199-206), the (clipped) value loss (:209-216) and the ROA regulariser (:174-179),
+ * and back-propagates; writes into `grad` (wbc_ppo_grad_floats() floats) the gradient of
+ * surrogate + value_coef*value_loss + roa_coef*priv_reg in the order: for each of the 16 layers of
+ * `params` (same table as wbc_policy_act) weight then bias; std[18]; then the three loss SUMS (surrogate and
+ * value over B*2 entries, priv_reg over B). `hist_latent` f32 [T*N,20]: history-encoder latent of every
+ * stored row (constant during update()). `workspace`: wbc_ppo_workspace_floats(B) floats. Deterministic. */
+int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions,
+                           const float* old_values, const float* advantages, const float* returns,
+                           const float* old_logp, const float* hist_latent, const int64_t* idx, int B,
+                           float clip, float value_coef, float mixing, float roa_coef,
+                           int use_clipped_value_loss, float* workspace, float* grad, void* stream);
+int wbc_ppo_grad_floats(void);
+int wbc_ppo_num_splits(void);
+size_t wbc_ppo_workspace_floats(int B);
+
 /* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
 void wbc_abi_sizes(int* out3);
 
