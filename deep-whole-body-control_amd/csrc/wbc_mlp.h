@@ -1,18 +1,25 @@
-// wbc_mlp.h -- shared pieces of the fused ActorCritic kernels (gfx950, fp32 MFMA 32x32x2):
-// the parameter pointer table and the LDS-resident dense layer used by both the rollout inference
-// kernel (wbc_policy_kernel.hip) and the PPO update kernels (wbc_ppo_kernel.hip).
+// wbc_mlp.h -- shared pieces of the fused ActorCritic kernels (gfx950, fp32 MFMA 32x32x2): the
+// parameter pointer table, the packed-weight layout and the LDS-resident dense layer used by both the
+// rollout inference kernel (wbc_policy_kernel.hip) and the PPO update kernels (wbc_ppo_kernel.hip).
+//
+// Forward GEMMs read their B operand (W^T fragments) from a PRE-PACKED copy of the weights: for layer l,
+// k-pair kb and 32-column block cb, the 64 floats that the 64 lanes of a wave feed to one
+// v_mfma_f32_32x32x2_f32 are contiguous (lane L gets W[cb*32 + (L&31)][2*kb + (L>>5)]), so a wave's
+// operand load is one coalesced 256-byte global load served by L2 (the packed table is 0.7 MB and shared
+// by every workgroup) -- no staging through LDS, no barrier per layer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define PT_ROWS 32          // envs per workgroup
+#define PT_ROWS 32          // rows (envs / minibatch samples) per workgroup
 #define PT_THREADS 256
-#define LDA 129             // activation row stride (odd: conflict-free b32 fragment reads)
+#define LDA 129             // activation row stride in LDS (odd: conflict-free b32 fragment reads)
 #define PT_NPROP 76
 #define PT_NPRIV 24
 #define PT_NOBS 860
 #define PT_NLEG 12
 #define PT_NARM 6
+#define NLAYERS 16
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -27,36 +34,59 @@ struct PolicyParams {       // device pointers to the torch parameters (weight [
   const float* std;         // [18]
 };
 
+// layer order = PolicyParams order
+enum { L_PRIV0 = 0, L_PRIV2, L_BB, L_LEG0, L_LEG2, L_LEG4, L_ARM0, L_ARM2, L_ARM4, L_CBB, L_CLEG0, L_CLEG2, L_CLEG4, L_CARM0, L_CARM2, L_CARM4 };
+__host__ __device__ constexpr int layer_out(int l) {
+  return l == L_PRIV0 ? 64 : l == L_PRIV2 ? 20 : l == L_LEG4 ? 12 : l == L_ARM4 ? 6 : (l == L_CLEG4 || l == L_CARM4) ? 1 : 128;
+}
+__host__ __device__ constexpr int layer_in(int l) { return l == L_PRIV0 ? 24 : l == L_PRIV2 ? 64 : l == L_BB ? 96 : l == L_CBB ? 100 : 128; }
+__host__ __device__ constexpr int layer_nblk(int l) { return (layer_out(l) + 31) / 32; }
+__host__ __device__ constexpr int layer_pack_floats(int l) { return layer_in(l) / 2 * layer_nblk(l) * 64; }
+__host__ __device__ constexpr int layer_pack_off(int l) { return l == 0 ? 0 : layer_pack_off(l - 1) + layer_pack_floats(l - 1); }
+#define WPACK_FLOATS (layer_pack_off(NLAYERS - 1) + layer_pack_floats(NLAYERS - 1))
+
 enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2 };
 
-static __device__ __forceinline__ float apply_act(float x, int act) {
-  if (act == ACT_ELU) return x > 0.f ? x : expm1f(x);
-  if (act == ACT_TANH) return tanhf(x);
+template <int ACT>
+static __device__ __forceinline__ float apply_act(float x) {
+  if (ACT == ACT_ELU) return x > 0.f ? x : expm1f(x);
+  if (ACT == ACT_TANH) return tanhf(x);
   return x;
 }
 
-// out[32, N] = act(in[32, K] * W[N, K]^T + b). `in`/`out` live in LDS with row stride LDA (in may have its
-// own stride ldi); W is staged through `wl` (row stride K+1, odd). N <= 128, K <= 128, K % 2 == 0.
-// All 256 threads call this; wave w owns output columns [32w, 32w+32).
-// If `stash` is given, the activated outputs of valid rows are also written to stash[(row0+row)*lds + scol + col].
-static __device__ void fused_layer(const float* in, int ldi, int K, const float* __restrict__ W, const float* __restrict__ b, int N,
-                            float* out, int ldo, int col_off, float* wl, int act, float* __restrict__ stash = nullptr, int lds = 0,
-                            int scol = 0, int row0 = 0, int num_rows = 0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ldw = K + 1;
-  // stage W (N x K) into LDS, coalesced along K; rows >= N of the 32-wide blocks in use are zero-filled
-  const int n_pad = (N + 31) & ~31;
-  for (int e = tid; e < n_pad * K; e += PT_THREADS) {
-    const int n = e / K, k = e - n * K;
-    wl[n * ldw + k] = (n < N) ? W[(size_t)n * K + k] : 0.f;
+// Pack all 16 weight matrices into the fragment order described above. grid = (blocks, NLAYERS).
+static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict__ wpack) {
+  const int l = blockIdx.y;
+  const float* const* wp = reinterpret_cast<const float* const*>(&P);
+  const float* W = wp[2 * l];
+  int N = 128, K = 128, off = 0;
+  // constexpr tables evaluated per layer at run time
+  for (int j = 0; j < NLAYERS; ++j) if (j == l) { N = layer_out(j); K = layer_in(j); off = layer_pack_off(j); }
+  const int nblk = (N + 31) / 32, total = K / 2 * nblk * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int lane = e & 63, frag = e >> 6;
+    const int cb = frag % nblk, kb = frag / nblk;
+    const int n = cb * 32 + (lane & 31), k = 2 * kb + (lane >> 5);
+    wpack[off + e] = (n < N) ? W[(size_t)n * K + k] : 0.f;
   }
-  __syncthreads();
-  if (wave * 32 < n_pad) {
+}
+
+// out[32, N] = act(in[32, K] * W^T + b) for layer L. `in`/`out` live in LDS (row strides ldi/ldo); the B
+// fragments come from the packed table. All 256 threads call this; wave w owns output columns
+// [32w, 32w+32). If `stash` is given the activated outputs of valid rows also go to
+// stash[(row0+row)*lds + scol + col]. Ends with a barrier (the outputs are visible to all waves).
+template <int L, int ACT>
+static __device__ __forceinline__ void fused_layer(const float* in, int ldi, const float* __restrict__ wpack, const float* __restrict__ b,
+                                                   float* out, int ldo, int col_off, float* __restrict__ stash = nullptr, int lds = 0,
+                                                   int scol = 0, int row0 = 0, int num_rows = 0) {
+  constexpr int N = layer_out(L), K = layer_in(L), NBLK = layer_nblk(L), KB = K / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave < NBLK) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* ap = in + (lane & 31) * ldi + (lane >> 5);
-    const float* bp = wl + (wave * 32 + (lane & 31)) * ldw + (lane >> 5);
-#pragma unroll 8
-    for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
+    const float* bp = wpack + layer_pack_off(L) + wave * 64 + lane;
+#pragma unroll 16
+    for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kb], bp[(size_t)kb * NBLK * 64], acc, 0, 0, 0);
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col = wave * 32 + (lane & 31);
     if (col < N) {
@@ -64,7 +94,7 @@ static __device__ void fused_layer(const float* in, int ldi, int K, const float*
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float v = apply_act(acc[r] + bias, act);
+        const float v = apply_act<ACT>(acc[r] + bias);
         out[row * ldo + col_off + col] = v;
         if (stash && row0 + row < num_rows) stash[(size_t)(row0 + row) * lds + scol + col] = v;
       }
@@ -72,4 +102,3 @@ static __device__ void fused_layer(const float* in, int ldi, int K, const float*
   }
   __syncthreads();
 }
-

@@ -3,8 +3,9 @@
 // Replaces, per policy step, the ~60 eager launches of PPO.act (reference rsl_rl/algorithms/ppo.py:115-127:
 // Actor.forward AC:204-217 with the privileged latent, Critic.forward AC:281-286, Normal.sample,
 // get_actions_log_prob AC:341-345) by ONE launch: a workgroup takes 32 envs, keeps every activation of
-// those 32 rows in LDS, streams each layer's weights [out,in] through LDS once, and runs the GEMMs on
-// v_mfma_f32_32x32x2_f32 (exact fp32, one 32x32 output block per wave, 4 waves = 128 output features).
+// those 32 rows in LDS, reads each layer's weights as pre-packed MFMA fragments straight from L2 (wbc_mlp.h),
+// and runs the GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32, one 32x32 output block per wave, 4 waves =
+// 128 output features).
 // The epilogue samples the action from pre-drawn standard normals and writes mean, action, the two
 // log-probabilities (12 leg / 6 arm dims) and the two values.
 #include "wbc_mlp.h"
@@ -12,16 +13,15 @@
 struct __align__(16) PolicySmem {
   float x[PT_ROWS * 101];        // obs[:, :100], stride 101
   float a0[PT_ROWS * LDA], a1[PT_ROWS * LDA], a2[PT_ROWS * LDA];
-  float wl[128 * LDA];           // staged weights
   float outv[PT_ROWS * 21];      // mean 18 + value 2 (stride 21)
 };
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(PolicyParams P, const float* __restrict__ obs,
-                                                                              const float* __restrict__ eps, float* __restrict__ actions,
-                                                                              float* __restrict__ mean_out, float* __restrict__ logp_out,
-                                                                              float* __restrict__ value_out, int num_rows) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  PolicySmem& s = *reinterpret_cast<PolicySmem*>(smem_raw);
+extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(PolicyParams P, const float* __restrict__ wpack,
+                                                                              const float* __restrict__ obs, const float* __restrict__ eps,
+                                                                              float* __restrict__ actions, float* __restrict__ mean_out,
+                                                                              float* __restrict__ logp_out, float* __restrict__ value_out,
+                                                                              int num_rows) {
+  __shared__ PolicySmem s;
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * PT_ROWS;
   // load obs[:, :100] of 32 rows (rows past the end are zero)
@@ -31,29 +31,29 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
   }
   __syncthreads();
   // ---- actor (AC:204-221): priv encoder 24 -> 64 -> 20, backbone [prop76 | latent20] -> 128, two heads
-  fused_layer(s.x + PT_NPROP, 101, PT_NPRIV, P.priv0_w, P.priv0_b, 64, s.a0, LDA, 0, s.wl, ACT_ELU);
+  fused_layer<L_PRIV0, ACT_ELU>(s.x + PT_NPROP, 101, wpack, P.priv0_b, s.a0, LDA, 0);
   // backbone input z = [prop, latent] assembled in a1: latent goes to columns 76..95
-  fused_layer(s.a0, LDA, 64, P.priv2_w, P.priv2_b, 20, s.a1, LDA, PT_NPROP, s.wl, ACT_ELU);
+  fused_layer<L_PRIV2, ACT_ELU>(s.a0, LDA, wpack, P.priv2_b, s.a1, LDA, PT_NPROP);
   for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
     const int r = e / PT_NPROP, c = e - r * PT_NPROP;
     s.a1[r * LDA + c] = s.x[r * 101 + c];
   }
   __syncthreads();
-  fused_layer(s.a1, LDA, 96, P.bb_w, P.bb_b, 128, s.a2, LDA, 0, s.wl, ACT_ELU);          // a2 = backbone output (kept)
-  fused_layer(s.a2, LDA, 128, P.leg0_w, P.leg0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a0, LDA, 128, P.leg2_w, P.leg2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a1, LDA, 128, P.leg4_w, P.leg4_b, PT_NLEG, s.outv, 21, 0, s.wl, ACT_TANH);
-  fused_layer(s.a2, LDA, 128, P.arm0_w, P.arm0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a0, LDA, 128, P.arm2_w, P.arm2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a1, LDA, 128, P.arm4_w, P.arm4_b, PT_NARM, s.outv, 21, PT_NLEG, s.wl, ACT_TANH);
+  fused_layer<L_BB, ACT_ELU>(s.a1, LDA, wpack, P.bb_b, s.a2, LDA, 0);          // a2 = backbone output (kept)
+  fused_layer<L_LEG0, ACT_ELU>(s.a2, LDA, wpack, P.leg0_b, s.a0, LDA, 0);
+  fused_layer<L_LEG2, ACT_ELU>(s.a0, LDA, wpack, P.leg2_b, s.a1, LDA, 0);
+  fused_layer<L_LEG4, ACT_TANH>(s.a1, LDA, wpack, P.leg4_b, s.outv, 21, 0);
+  fused_layer<L_ARM0, ACT_ELU>(s.a2, LDA, wpack, P.arm0_b, s.a0, LDA, 0);
+  fused_layer<L_ARM2, ACT_ELU>(s.a0, LDA, wpack, P.arm2_b, s.a1, LDA, 0);
+  fused_layer<L_ARM4, ACT_TANH>(s.a1, LDA, wpack, P.arm4_b, s.outv, 21, PT_NLEG);
   // ---- critic (AC:281-286): obs[:, :100] -> 128 -> two heads 128 -> 128 -> 1
-  fused_layer(s.x, 101, 100, P.cbb_w, P.cbb_b, 128, s.a2, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a2, LDA, 128, P.cleg0_w, P.cleg0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a0, LDA, 128, P.cleg2_w, P.cleg2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a1, LDA, 128, P.cleg4_w, P.cleg4_b, 1, s.outv, 21, 18, s.wl, ACT_NONE);
-  fused_layer(s.a2, LDA, 128, P.carm0_w, P.carm0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a0, LDA, 128, P.carm2_w, P.carm2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU);
-  fused_layer(s.a1, LDA, 128, P.carm4_w, P.carm4_b, 1, s.outv, 21, 19, s.wl, ACT_NONE);
+  fused_layer<L_CBB, ACT_ELU>(s.x, 101, wpack, P.cbb_b, s.a2, LDA, 0);
+  fused_layer<L_CLEG0, ACT_ELU>(s.a2, LDA, wpack, P.cleg0_b, s.a0, LDA, 0);
+  fused_layer<L_CLEG2, ACT_ELU>(s.a0, LDA, wpack, P.cleg2_b, s.a1, LDA, 0);
+  fused_layer<L_CLEG4, ACT_NONE>(s.a1, LDA, wpack, P.cleg4_b, s.outv, 21, 18);
+  fused_layer<L_CARM0, ACT_ELU>(s.a2, LDA, wpack, P.carm0_b, s.a0, LDA, 0);
+  fused_layer<L_CARM2, ACT_ELU>(s.a0, LDA, wpack, P.carm2_b, s.a1, LDA, 0);
+  fused_layer<L_CARM4, ACT_NONE>(s.a1, LDA, wpack, P.carm4_b, s.outv, 21, 19);
   // ---- epilogue: sample, log-probabilities (Normal.log_prob summed over leg / arm dims), outputs
   if (tid < PT_ROWS && row0 + tid < num_rows) {
     const int r = tid;
@@ -75,24 +75,32 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
   }
 }
 
-// C-ABI: one fused ActorCritic inference over `num_rows` observations (device pointers).
-// params: 33 device pointers in the order of struct PolicyParams.
-extern "C" int wbc_policy_act(const void* const* params, const float* obs, const float* eps, float* actions, float* mean, float* logp,
-                              float* values, int num_rows, void* stream) {
-  if (!params || !obs || !actions || !mean || !logp || !values || num_rows <= 0) return -1;
-  PolicyParams P;
-  const float** dst = reinterpret_cast<const float**>(&P);
+static int fill_params(const void* const* params, PolicyParams* P) {
+  const float** dst = reinterpret_cast<const float**>(P);
   for (int i = 0; i < 33; ++i) {
     if (!params[i]) return -1;
     dst[i] = static_cast<const float*>(params[i]);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wbc_policy_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PolicySmem)) != hipSuccess) return -2;
-    attr_set = true;
-  }
+  return 0;
+}
+
+// C-ABI. params: 33 device pointers in the order of struct PolicyParams; wpack: wbc_policy_pack_floats() floats.
+extern "C" int wbc_policy_pack_floats(void) { return WPACK_FLOATS; }
+
+// Re-pack the weights into MFMA fragment order (call after the parameters changed).
+extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* stream) {
+  PolicyParams P;
+  if (!params || !wpack || fill_params(params, &P)) return -1;
+  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS), dim3(256), 0, (hipStream_t)stream, P, wpack);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* eps, float* actions, float* mean,
+                              float* logp, float* values, int num_rows, void* stream) {
+  PolicyParams P;
+  if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
   const int blocks = (num_rows + PT_ROWS - 1) / PT_ROWS;
-  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks), dim3(PT_THREADS), sizeof(PolicySmem), (hipStream_t)stream, P, obs, eps, actions, mean,
-                     logp, values, num_rows);
+  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks), dim3(PT_THREADS), 0, (hipStream_t)stream, P, wpack, obs, eps, actions, mean, logp,
+                     values, num_rows);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

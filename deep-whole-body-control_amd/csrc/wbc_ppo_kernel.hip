@@ -21,7 +21,6 @@ enum { A_X = 0, A_H1 = 100, A_LAT = 164, A_BB = 184, A_L1 = 312, A_L2 = 440, A_L
        A_CB = 842, A_CL1 = 970, A_CL2 = 1098, A_CA1 = 1226, A_CA2 = 1354, A_Z = 1482, A_LD = 1584 };
 enum { D_H1 = 0, D_LAT = 64, D_BB = 84, D_L1 = 212, D_L2 = 340, D_LEG = 468, D_A1 = 480, D_A2 = 608, D_ARM = 736, D_CB = 742,
        D_CL1 = 870, D_CL2 = 998, D_VLEG = 1126, D_CA1 = 1127, D_CA2 = 1255, D_VARM = 1383, D_LD = 1384 };
-#define NLAYERS 16
 
 struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minibatch's row indices
   const float* obs;               // [TN, 860]
@@ -40,74 +39,66 @@ struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minib
 struct __align__(16) PpoSmem {
   float x[PT_ROWS * 101];
   float a0[PT_ROWS * LDA], a1[PT_ROWS * LDA], a2[PT_ROWS * LDA];
-  float wl[128 * LDA];
   float outv[PT_ROWS * 21];       // mean 18, values 2
   float g[PT_ROWS * 41];          // output grads: dmu 18, dv 2, dlat 20
 };
 
-// out[32, IN] (+)= dz[32, OUT] * W[OUT, IN]; W staged through wl (row stride IN_pad + 1). OUT even, <= 128.
-static __device__ void bwd_gemm(const float* dz, int ldz, int OUT, const float* __restrict__ W, int IN, float* out, int ldo, float* wl,
-                                bool accumulate) {
+// out[32, IN] (+)= dz[32, OUT] * W[OUT, IN]. The B operand W[k][col] is read straight from global memory:
+// a wave's fragment is two runs of 32 consecutive floats of W (rows k and k+1), i.e. coalesced as stored.
+template <int OUT, int IN, bool ACCUMULATE>
+static __device__ __forceinline__ void bwd_gemm(const float* dz, int ldz, const float* __restrict__ W, float* out, int ldo) {
+  constexpr int NBLK = (IN + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int in_pad = (IN + 31) & ~31, ldw = in_pad + 1;
-  for (int e = tid; e < OUT * in_pad; e += PT_THREADS) {
-    const int o = e / in_pad, i = e - o * in_pad;
-    wl[o * ldw + i] = (i < IN) ? W[(size_t)o * IN + i] : 0.f;
-  }
-  __syncthreads();
-  if (wave * 32 < in_pad) {
+  if (wave < NBLK) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* ap = dz + (lane & 31) * ldz + (lane >> 5);
-    const float* bp = wl + (lane >> 5) * ldw + wave * 32 + (lane & 31);
-#pragma unroll 4
-    for (int k = 0; k < OUT; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k * ldw], acc, 0, 0, 0);
     const int col = wave * 32 + (lane & 31);
-    if (col < IN) {
+    const bool col_ok = col < IN;
+    const float* ap = dz + (lane & 31) * ldz + (lane >> 5);
+    const float* bp = W + (size_t)(lane >> 5) * IN + (col_ok ? col : 0);
+#pragma unroll 16
+    for (int k = 0; k < OUT; k += 2) {
+      const float bv = col_ok ? bp[(size_t)k * IN] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bv, acc, 0, 0, 0);
+    }
+    if (col_ok) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         float* o = &out[row * ldo + col];
-        *o = accumulate ? (*o + acc[r]) : acc[r];
+        *o = ACCUMULATE ? (*o + acc[r]) : acc[r];
       }
     }
   }
   __syncthreads();
 }
 
-// buf[32, n] <- buf * act'(A) with A the stashed post-activation (elu' = a > 0 ? 1 : a + 1, tanh' = 1 - a^2);
-// writes the result to the DZ stash and the tile's column sums (bias-gradient partial) to dbp[dcol + c].
-static __device__ void act_grad(float* buf, int ld, int n, const float* __restrict__ act_stash, int acol, int act, float* __restrict__ dz_stash,
-                                int dcol, float* __restrict__ dbp, int row0, int num_rows) {
+// buf[32, N] <- buf * act'(A) with A the stashed post-activation (elu' = a > 0 ? 1 : a + 1, tanh' = 1 - a^2);
+// the result also goes to the DZ stash.
+template <int N, int ACT>
+static __device__ __forceinline__ void act_grad(float* buf, int ld, const float* __restrict__ act_stash, int acol, float* __restrict__ dz_stash,
+                                                int dcol, int row0, int num_rows) {
   const int tid = threadIdx.x;
-  for (int e = tid; e < PT_ROWS * n; e += PT_THREADS) {
-    const int r = e / n, c = e - r * n;
+#pragma unroll 4
+  for (int e = tid; e < PT_ROWS * N; e += PT_THREADS) {
+    const int r = e / N, c = e - r * N;
     float v = 0.f;
     if (row0 + r < num_rows) {
       const float a = act_stash[(size_t)(row0 + r) * A_LD + acol + c];
-      const float d = (act == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : ((act == ACT_TANH) ? 1.f - a * a : 1.f);
+      const float d = (ACT == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : ((ACT == ACT_TANH) ? 1.f - a * a : 1.f);
       v = buf[r * ld + c] * d;
       dz_stash[(size_t)(row0 + r) * D_LD + dcol + c] = v;
     }
     buf[r * ld + c] = v;
   }
   __syncthreads();
-  if (tid < n) {
-    float sum = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < PT_ROWS; ++r) sum += buf[r * ld + tid];
-    dbp[dcol + tid] = sum;
-  }
-  __syncthreads();
 }
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(PolicyParams P, PpoBatch Bt, float* __restrict__ act_stash,
-                                                                           float* __restrict__ dz_stash, float* __restrict__ db_partial,
+extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(PolicyParams P, const float* __restrict__ wpack, PpoBatch Bt,
+                                                                           float* __restrict__ act_stash, float* __restrict__ dz_stash,
                                                                            float* __restrict__ dstd_partial, float* __restrict__ loss_partial) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  PpoSmem& s = *reinterpret_cast<PpoSmem*>(smem_raw);
+  __shared__ PpoSmem s;
   const int tid = threadIdx.x, lane = tid & 63;
   const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
-  float* dbp = db_partial + (size_t)tile * D_LD;
   // gather obs[idx, :100]
   for (int e = tid; e < PT_ROWS * 100; e += PT_THREADS) {
     const int r = e / 100, c = e - r * 100;
@@ -120,8 +111,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
   }
   __syncthreads();
   // ---------------- forward (same chain as wbc_policy_act_kernel), post-activations stashed
-  fused_layer(s.x + PT_NPROP, 101, PT_NPRIV, P.priv0_w, P.priv0_b, 64, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_H1, row0, B);
-  fused_layer(s.a0, LDA, 64, P.priv2_w, P.priv2_b, 20, s.a1, LDA, PT_NPROP, s.wl, ACT_ELU, act_stash, A_LD, A_LAT, row0, B);
+  fused_layer<L_PRIV0, ACT_ELU>(s.x + PT_NPROP, 101, wpack, P.priv0_b, s.a0, LDA, 0, act_stash, A_LD, A_H1, row0, B);
+  fused_layer<L_PRIV2, ACT_ELU>(s.a0, LDA, wpack, P.priv2_b, s.a1, LDA, PT_NPROP, act_stash, A_LD, A_LAT, row0, B);
   for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
     const int r = e / PT_NPROP, c = e - r * PT_NPROP;
     s.a1[r * LDA + c] = s.x[r * 101 + c];
@@ -131,20 +122,20 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
     const int r = e / 96, c = e - r * 96;
     if (row0 + r < B) act_stash[(size_t)(row0 + r) * A_LD + A_Z + c] = s.a1[r * LDA + c];
   }
-  fused_layer(s.a1, LDA, 96, P.bb_w, P.bb_b, 128, s.a2, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_BB, row0, B);
-  fused_layer(s.a2, LDA, 128, P.leg0_w, P.leg0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_L1, row0, B);
-  fused_layer(s.a0, LDA, 128, P.leg2_w, P.leg2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_L2, row0, B);
-  fused_layer(s.a1, LDA, 128, P.leg4_w, P.leg4_b, PT_NLEG, s.outv, 21, 0, s.wl, ACT_TANH, act_stash, A_LD, A_LEG, row0, B);
-  fused_layer(s.a2, LDA, 128, P.arm0_w, P.arm0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_A1, row0, B);
-  fused_layer(s.a0, LDA, 128, P.arm2_w, P.arm2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_A2, row0, B);
-  fused_layer(s.a1, LDA, 128, P.arm4_w, P.arm4_b, PT_NARM, s.outv, 21, PT_NLEG, s.wl, ACT_TANH, act_stash, A_LD, A_ARM, row0, B);
-  fused_layer(s.x, 101, 100, P.cbb_w, P.cbb_b, 128, s.a2, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CB, row0, B);
-  fused_layer(s.a2, LDA, 128, P.cleg0_w, P.cleg0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CL1, row0, B);
-  fused_layer(s.a0, LDA, 128, P.cleg2_w, P.cleg2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CL2, row0, B);
-  fused_layer(s.a1, LDA, 128, P.cleg4_w, P.cleg4_b, 1, s.outv, 21, 18, s.wl, ACT_NONE);
-  fused_layer(s.a2, LDA, 128, P.carm0_w, P.carm0_b, 128, s.a0, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CA1, row0, B);
-  fused_layer(s.a0, LDA, 128, P.carm2_w, P.carm2_b, 128, s.a1, LDA, 0, s.wl, ACT_ELU, act_stash, A_LD, A_CA2, row0, B);
-  fused_layer(s.a1, LDA, 128, P.carm4_w, P.carm4_b, 1, s.outv, 21, 19, s.wl, ACT_NONE);
+  fused_layer<L_BB, ACT_ELU>(s.a1, LDA, wpack, P.bb_b, s.a2, LDA, 0, act_stash, A_LD, A_BB, row0, B);
+  fused_layer<L_LEG0, ACT_ELU>(s.a2, LDA, wpack, P.leg0_b, s.a0, LDA, 0, act_stash, A_LD, A_L1, row0, B);
+  fused_layer<L_LEG2, ACT_ELU>(s.a0, LDA, wpack, P.leg2_b, s.a1, LDA, 0, act_stash, A_LD, A_L2, row0, B);
+  fused_layer<L_LEG4, ACT_TANH>(s.a1, LDA, wpack, P.leg4_b, s.outv, 21, 0, act_stash, A_LD, A_LEG, row0, B);
+  fused_layer<L_ARM0, ACT_ELU>(s.a2, LDA, wpack, P.arm0_b, s.a0, LDA, 0, act_stash, A_LD, A_A1, row0, B);
+  fused_layer<L_ARM2, ACT_ELU>(s.a0, LDA, wpack, P.arm2_b, s.a1, LDA, 0, act_stash, A_LD, A_A2, row0, B);
+  fused_layer<L_ARM4, ACT_TANH>(s.a1, LDA, wpack, P.arm4_b, s.outv, 21, PT_NLEG, act_stash, A_LD, A_ARM, row0, B);
+  fused_layer<L_CBB, ACT_ELU>(s.x, 101, wpack, P.cbb_b, s.a2, LDA, 0, act_stash, A_LD, A_CB, row0, B);
+  fused_layer<L_CLEG0, ACT_ELU>(s.a2, LDA, wpack, P.cleg0_b, s.a0, LDA, 0, act_stash, A_LD, A_CL1, row0, B);
+  fused_layer<L_CLEG2, ACT_ELU>(s.a0, LDA, wpack, P.cleg2_b, s.a1, LDA, 0, act_stash, A_LD, A_CL2, row0, B);
+  fused_layer<L_CLEG4, ACT_NONE>(s.a1, LDA, wpack, P.cleg4_b, s.outv, 21, 18);
+  fused_layer<L_CARM0, ACT_ELU>(s.a2, LDA, wpack, P.carm0_b, s.a0, LDA, 0, act_stash, A_LD, A_CA1, row0, B);
+  fused_layer<L_CARM2, ACT_ELU>(s.a0, LDA, wpack, P.carm2_b, s.a1, LDA, 0, act_stash, A_LD, A_CA2, row0, B);
+  fused_layer<L_CARM4, ACT_NONE>(s.a1, LDA, wpack, P.carm4_b, s.outv, 21, 19);
   // ---------------- losses and output gradients: one row per lane of wave 0
   if (tid < 64) {
     const int r = tid & 31;
@@ -239,156 +230,177 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
     dz_stash[(size_t)(row0 + tid) * D_LD + D_VLEG] = s.g[tid * 41 + 18];
     dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = s.g[tid * 41 + 19];
   }
-  if (tid == 0) {
-    float s0 = 0.f, s1 = 0.f;
-    for (int r = 0; r < PT_ROWS; ++r) { s0 += s.g[r * 41 + 18]; s1 += s.g[r * 41 + 19]; }
-    dbp[D_VLEG] = s0; dbp[D_VARM] = s1;
-  }
   __syncthreads();
-  act_grad(s.a0, LDA, 128, act_stash, A_CL2, ACT_ELU, dz_stash, D_CL2, dbp, row0, B);
-  bwd_gemm(s.a0, LDA, 128, P.cleg2_w, 128, s.a1, LDA, s.wl, false);
-  act_grad(s.a1, LDA, 128, act_stash, A_CL1, ACT_ELU, dz_stash, D_CL1, dbp, row0, B);
-  bwd_gemm(s.a1, LDA, 128, P.cleg0_w, 128, s.a2, LDA, s.wl, false);                       // a2 = dA_cb (leg part)
+  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_CL2, dz_stash, D_CL2, row0, B);
+  bwd_gemm<128, 128, false>(s.a0, LDA, P.cleg2_w, s.a1, LDA);
+  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_CL1, dz_stash, D_CL1, row0, B);
+  bwd_gemm<128, 128, false>(s.a1, LDA, P.cleg0_w, s.a2, LDA);                       // a2 = dA_cb (leg part)
   for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) {
     const int r = e >> 7, c = e & 127;
     s.a0[r * LDA + c] = s.g[r * 41 + 19] * P.carm4_w[c];
   }
   __syncthreads();
-  act_grad(s.a0, LDA, 128, act_stash, A_CA2, ACT_ELU, dz_stash, D_CA2, dbp, row0, B);
-  bwd_gemm(s.a0, LDA, 128, P.carm2_w, 128, s.a1, LDA, s.wl, false);
-  act_grad(s.a1, LDA, 128, act_stash, A_CA1, ACT_ELU, dz_stash, D_CA1, dbp, row0, B);
-  bwd_gemm(s.a1, LDA, 128, P.carm0_w, 128, s.a2, LDA, s.wl, true);                        // a2 += arm part
-  act_grad(s.a2, LDA, 128, act_stash, A_CB, ACT_ELU, dz_stash, D_CB, dbp, row0, B);
+  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_CA2, dz_stash, D_CA2, row0, B);
+  bwd_gemm<128, 128, false>(s.a0, LDA, P.carm2_w, s.a1, LDA);
+  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_CA1, dz_stash, D_CA1, row0, B);
+  bwd_gemm<128, 128, true>(s.a1, LDA, P.carm0_w, s.a2, LDA);                        // a2 += arm part
+  act_grad<128, ACT_ELU>(s.a2, LDA, act_stash, A_CB, dz_stash, D_CB, row0, B);
   // ---------------- backward: actor
   for (int e = tid; e < PT_ROWS * PT_NLEG; e += PT_THREADS) {
     const int r = e / PT_NLEG, c = e - r * PT_NLEG;
     s.a0[r * LDA + c] = s.g[r * 41 + c];
   }
   __syncthreads();
-  act_grad(s.a0, LDA, PT_NLEG, act_stash, A_LEG, ACT_TANH, dz_stash, D_LEG, dbp, row0, B);
-  bwd_gemm(s.a0, LDA, PT_NLEG, P.leg4_w, 128, s.a1, LDA, s.wl, false);
-  act_grad(s.a1, LDA, 128, act_stash, A_L2, ACT_ELU, dz_stash, D_L2, dbp, row0, B);
-  bwd_gemm(s.a1, LDA, 128, P.leg2_w, 128, s.a0, LDA, s.wl, false);
-  act_grad(s.a0, LDA, 128, act_stash, A_L1, ACT_ELU, dz_stash, D_L1, dbp, row0, B);
-  bwd_gemm(s.a0, LDA, 128, P.leg0_w, 128, s.a2, LDA, s.wl, false);                        // a2 = dA_bb (leg part)
+  act_grad<PT_NLEG, ACT_TANH>(s.a0, LDA, act_stash, A_LEG, dz_stash, D_LEG, row0, B);
+  bwd_gemm<PT_NLEG, 128, false>(s.a0, LDA, P.leg4_w, s.a1, LDA);
+  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_L2, dz_stash, D_L2, row0, B);
+  bwd_gemm<128, 128, false>(s.a1, LDA, P.leg2_w, s.a0, LDA);
+  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_L1, dz_stash, D_L1, row0, B);
+  bwd_gemm<128, 128, false>(s.a0, LDA, P.leg0_w, s.a2, LDA);                        // a2 = dA_bb (leg part)
   for (int e = tid; e < PT_ROWS * PT_NARM; e += PT_THREADS) {
     const int r = e / PT_NARM, c = e - r * PT_NARM;
     s.a0[r * LDA + c] = s.g[r * 41 + PT_NLEG + c];
   }
   __syncthreads();
-  act_grad(s.a0, LDA, PT_NARM, act_stash, A_ARM, ACT_TANH, dz_stash, D_ARM, dbp, row0, B);
-  bwd_gemm(s.a0, LDA, PT_NARM, P.arm4_w, 128, s.a1, LDA, s.wl, false);
-  act_grad(s.a1, LDA, 128, act_stash, A_A2, ACT_ELU, dz_stash, D_A2, dbp, row0, B);
-  bwd_gemm(s.a1, LDA, 128, P.arm2_w, 128, s.a0, LDA, s.wl, false);
-  act_grad(s.a0, LDA, 128, act_stash, A_A1, ACT_ELU, dz_stash, D_A1, dbp, row0, B);
-  bwd_gemm(s.a0, LDA, 128, P.arm0_w, 128, s.a2, LDA, s.wl, true);                         // a2 += arm part
-  act_grad(s.a2, LDA, 128, act_stash, A_BB, ACT_ELU, dz_stash, D_BB, dbp, row0, B);
-  bwd_gemm(s.a2, LDA, 128, P.bb_w, 96, s.a0, LDA, s.wl, false);                            // a0 = dA_z [32, 96]
+  act_grad<PT_NARM, ACT_TANH>(s.a0, LDA, act_stash, A_ARM, dz_stash, D_ARM, row0, B);
+  bwd_gemm<PT_NARM, 128, false>(s.a0, LDA, P.arm4_w, s.a1, LDA);
+  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_A2, dz_stash, D_A2, row0, B);
+  bwd_gemm<128, 128, false>(s.a1, LDA, P.arm2_w, s.a0, LDA);
+  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_A1, dz_stash, D_A1, row0, B);
+  bwd_gemm<128, 128, true>(s.a0, LDA, P.arm0_w, s.a2, LDA);                         // a2 += arm part
+  act_grad<128, ACT_ELU>(s.a2, LDA, act_stash, A_BB, dz_stash, D_BB, row0, B);
+  bwd_gemm<128, 96, false>(s.a2, LDA, P.bb_w, s.a0, LDA);                            // a0 = dA_z [32, 96]
   for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {                                   // d latent = dA_z[:, 76:96] + ROA gradient
     const int r = e / 20, c = e - r * 20;
     s.a1[r * LDA + c] = s.a0[r * LDA + PT_NPROP + c] + s.g[r * 41 + 20 + c];
   }
   __syncthreads();
-  act_grad(s.a1, LDA, 20, act_stash, A_LAT, ACT_ELU, dz_stash, D_LAT, dbp, row0, B);
-  bwd_gemm(s.a1, LDA, 20, P.priv2_w, 64, s.a0, LDA, s.wl, false);
-  act_grad(s.a0, LDA, 64, act_stash, A_H1, ACT_ELU, dz_stash, D_H1, dbp, row0, B);
+  act_grad<20, ACT_ELU>(s.a1, LDA, act_stash, A_LAT, dz_stash, D_LAT, row0, B);
+  bwd_gemm<20, 64, false>(s.a1, LDA, P.priv2_w, s.a0, LDA);
+  act_grad<64, ACT_ELU>(s.a0, LDA, act_stash, A_H1, dz_stash, D_H1, row0, B);
 }
 
-// ---- weight gradients ---------------------------------------------------------------------------
+// ---- weight and bias gradients -------------------------------------------------------------------
+// dW_l[o][i] = sum_rows dZ_l[row][o] * A_{l-1}[row][i], db_l[o] = sum_rows dZ_l[row][o]. grid = (splits, layers);
+// a workgroup owns a row range of one layer, wave w the output rows [32w, 32w+32). Both MFMA operands are read
+// straight from the stashes (a fragment = two runs of 32 consecutive floats: coalesced as stored), the bias
+// gradient falls out of one extra MFMA block whose B operand is the constant 1. No LDS, no atomics.
 struct WgradLayer { int out, in, dcol, acol, goff; };   // goff: offset of this layer's weight gradient in the flat buffer
 struct WgradTable { WgradLayer l[NLAYERS]; };
-#define WG_CHUNK 32
-#define WG_LD 129
 
 extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
                                                                          int B, int rows_per_split, int nparams) {
-  __shared__ float dzl[WG_CHUNK * WG_LD], al[WG_CHUNK * WG_LD];
   const WgradLayer L = tab.l[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int out_pad = (L.out + 31) & ~31, in_pad = (L.in + 31) & ~31;
+  if (wave * 32 >= L.out) return;
+  const int nib = (L.in + 31) / 32;
   const int r_begin = blockIdx.x * rows_per_split, r_end = min(B, r_begin + rows_per_split);
-  f32x16 acc[4];
+  f32x16 acc[5];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool wave_on = wave * 32 < out_pad;
-  for (int r0 = r_begin; r0 < r_end; r0 += WG_CHUNK) {
-    for (int e = tid; e < WG_CHUNK * out_pad; e += PT_THREADS) {
-      const int r = e / out_pad, c = e - r * out_pad;
-      dzl[r * WG_LD + c] = (c < L.out && r0 + r < r_end) ? dz_stash[(size_t)(r0 + r) * D_LD + L.dcol + c] : 0.f;
-    }
-    for (int e = tid; e < WG_CHUNK * in_pad; e += PT_THREADS) {
-      const int r = e / in_pad, c = e - r * in_pad;
-      al[r * WG_LD + c] = (c < L.in && r0 + r < r_end) ? act_stash[(size_t)(r0 + r) * A_LD + L.acol + c] : 0.f;
-    }
-    __syncthreads();
-    if (wave_on) {
-      const float* ap = dzl + (lane >> 5) * WG_LD + wave * 32 + (lane & 31);
+  for (int b = 0; b < 5; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int o = wave * 32 + (lane & 31), half = lane >> 5;
+  const bool o_ok = o < L.out;
+  const float* ap = dz_stash + L.dcol + (o_ok ? o : 0);
+  const float* bp = act_stash + L.acol + (lane & 31);
+  bool c_ok[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b * 32 < in_pad) {
-          const float* bp = al + (lane >> 5) * WG_LD + b * 32 + (lane & 31);
-#pragma unroll 4
-          for (int k = 0; k < WG_CHUNK; k += 2) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * WG_LD], bp[k * WG_LD], acc[b], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
+  for (int b = 0; b < 4; ++b) c_ok[b] = (b * 32 + (lane & 31)) < L.in;
+#pragma unroll 2
+  for (int r = r_begin; r < r_end; r += 2) {
+    const int row = r + half;
+    const bool r_ok = row < r_end;
+    const float av = (o_ok && r_ok) ? ap[(size_t)row * D_LD] : 0.f;
+    float bv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bv[b] = (b < nib && c_ok[b] && r_ok) ? bp[(size_t)row * A_LD + b * 32] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < nib) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[b], acc[b], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, 1.0f, acc[4], 0, 0, 0);
   }
-  if (wave_on) {
-    float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
+  float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = b * 32 + (lane & 31);
-      if (col < L.in) {
+  for (int b = 0; b < 4; ++b) {
+    const int col = b * 32 + (lane & 31);
+    if (b < nib && col < L.in) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (o < L.out) dst[(size_t)o * L.in + col] = acc[b][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int oo = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (oo < L.out) dst[(size_t)oo * L.in + col] = acc[b][r];
       }
+    }
+  }
+  if ((lane & 31) == 0) {
+    float* dbias = dst + (size_t)L.out * L.in;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oo = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (oo < L.out) dbias[oo] = acc[4][r];
     }
   }
 }
 
 // grad[p] = sum_s part[s][p] in a fixed order; `stride` floats between consecutive partials
-extern "C" __global__ void ppo_reduce_kernel(const float* __restrict__ part, int nparts, int stride, int n, float* __restrict__ grad) {
+extern "C" __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict__ part, int nparts, int stride, int n,
+                                                                   float* __restrict__ grad) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   float acc = 0.f;
-  for (int s = 0; s < nparts; ++s) acc += part[(size_t)s * stride + p];
+  int s = 0;
+  for (; s + 8 <= nparts; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s + j) * stride + p];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; s < nparts; ++s) acc += part[(size_t)s * stride + p];
   grad[p] = acc;
 }
 
-// bias gradients: column sums of the per-tile partials, scattered to their place in the flat gradient
-struct BiasMap { int dcol[NLAYERS], n[NLAYERS], goff[NLAYERS]; };
-extern "C" __global__ void ppo_bias_reduce_kernel(BiasMap map, const float* __restrict__ db_partial, int ntiles, float* __restrict__ grad) {
-  const int layer = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= map.n[layer]) return;
+// out[j] = sum_t part[t*width + j] for a few columns and many partials: one block per column, fixed-order tree
+extern "C" __global__ void __launch_bounds__(256) ppo_column_reduce_kernel(const float* __restrict__ part, int nparts, int width,
+                                                                          float* __restrict__ out) {
+  __shared__ float sh[256];
+  const int j = blockIdx.x;
   float acc = 0.f;
-  for (int t = 0; t < ntiles; ++t) acc += db_partial[(size_t)t * D_LD + map.dcol[layer] + c];
-  grad[map.goff[layer] + c] = acc;
+  for (int t = threadIdx.x; t < nparts; t += 256) acc += part[(size_t)t * width + j];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[j] = sh[0];
 }
 
 // ---- C-ABI ----------------------------------------------------------------------------------------
 // Flat gradient layout: for layer l in PolicyParams order: weight [out*in] then bias [out]; then std [18];
 // then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
-static const int kOut[NLAYERS] = {64, 20, 128, 128, 128, 12, 128, 128, 6, 128, 128, 128, 1, 128, 128, 1};
-static const int kIn[NLAYERS] = {24, 64, 96, 128, 128, 128, 128, 128, 128, 100, 128, 128, 128, 128, 128, 128};
 static const int kDcol[NLAYERS] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM};
 static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, A_BB, A_A1, A_A2, A_X, A_CB, A_CL1, A_CL2, A_CB, A_CA1, A_CA2};
+#define PPO_NSPLIT 56
 
 extern "C" int wbc_ppo_grad_floats(void) {
   int n = 0;
-  for (int l = 0; l < NLAYERS; ++l) n += kOut[l] * kIn[l] + kOut[l];
+  for (int l = 0; l < NLAYERS; ++l) n += layer_out(l) * layer_in(l) + layer_out(l);
   return n + 18 + 3;
 }
-extern "C" int wbc_ppo_num_splits(void) { return 80; }
+extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
   const size_t tiles = (size_t)(B + PT_ROWS - 1) / PT_ROWS;
-  return (size_t)B * (A_LD + D_LD) + tiles * (D_LD + 18 + 3) + (size_t)wbc_ppo_num_splits() * (size_t)wbc_ppo_grad_floats();
+  return (size_t)B * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)WPACK_FLOATS;
+}
+
+static int fill_params(const void* const* params, PolicyParams* P) {
+  const float** dst = reinterpret_cast<const float**>(P);
+  for (int i = 0; i < 33; ++i) {
+    if (!params[i]) return -1;
+    dst[i] = static_cast<const float*>(params[i]);
+  }
+  return 0;
 }
 
 // One minibatch: gradients of loss = surrogate + value_coef*value_loss + roa_coef*priv_reg (PPO:218-221, entropy term
@@ -397,47 +409,33 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
                                       const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
                                       const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
                                       int use_clipped_value_loss, float* workspace, float* grad, void* stream) {
-  if (!params || !obs || !actions || !old_values || !advantages || !returns || !old_logp || !hist_latent || !idx || !workspace || !grad || B <= 0)
-    return -1;
   PolicyParams P;
-  const float** dst = reinterpret_cast<const float**>(&P);
-  for (int i = 0; i < 33; ++i) {
-    if (!params[i]) return -1;
-    dst[i] = static_cast<const float*>(params[i]);
-  }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PpoSmem)) != hipSuccess) return -2;
-    attr_set = true;
-  }
+  if (!params || !obs || !actions || !old_values || !advantages || !returns || !old_logp || !hist_latent || !idx || !workspace || !grad ||
+      B <= 0 || fill_params(params, &P))
+    return -1;
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (B + PT_ROWS - 1) / PT_ROWS;
-  const int nsplit = wbc_ppo_num_splits(), ng = wbc_ppo_grad_floats();
+  const int ng = wbc_ppo_grad_floats();
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)B * A_LD;
-  float* db_partial = dz_stash + (size_t)B * D_LD;
-  float* dstd_partial = db_partial + (size_t)tiles * D_LD;
+  float* dstd_partial = dz_stash + (size_t)B * D_LD;
   float* loss_partial = dstd_partial + (size_t)tiles * 18;
   float* wpart = loss_partial + (size_t)tiles * 3;
+  float* wpack = wpart + (size_t)PPO_NSPLIT * ng;
+  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS), dim3(256), 0, st, P, wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
-  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), sizeof(PpoSmem), st, P, Bt, act_stash, dz_stash, db_partial, dstd_partial,
-                     loss_partial);
+  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, wpack, Bt, act_stash, dz_stash, dstd_partial, loss_partial);
   WgradTable tab;
-  BiasMap bm;
   int off = 0;
   for (int l = 0; l < NLAYERS; ++l) {
-    tab.l[l] = WgradLayer{kOut[l], kIn[l], kDcol[l], kAcol[l], off};
-    off += kOut[l] * kIn[l];
-    bm.dcol[l] = kDcol[l]; bm.n[l] = kOut[l]; bm.goff[l] = off;
-    off += kOut[l];
+    tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], kAcol[l], off};
+    off += layer_out(l) * layer_in(l) + layer_out(l);
   }
-  int rows_per_split = (B + nsplit - 1) / nsplit;
-  rows_per_split = (rows_per_split + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(nsplit, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, rows_per_split, ng);
-  // weights: sum of the split partials (bias slots of `wpart` are never written and never read: they are overwritten below)
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3((off + 255) / 256), dim3(256), 0, st, wpart, nsplit, ng, off, grad);
-  hipLaunchKernelGGL(ppo_bias_reduce_kernel, dim3(1, NLAYERS), dim3(128), 0, st, bm, db_partial, tiles, grad);
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(64), 0, st, dstd_partial, tiles, 18, 18, grad + off);
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(64), 0, st, loss_partial, tiles, 3, 3, grad + off + 18);
+  int rows_per_split = (B + PPO_NSPLIT - 1) / PPO_NSPLIT;
+  rows_per_split += rows_per_split & 1;
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, rows_per_split, ng);
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3((off + 255) / 256), dim3(256), 0, st, wpart, PPO_NSPLIT, ng, off, grad);
+  hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);
+  hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(3), dim3(256), 0, st, loss_partial, tiles, 3, grad + off + 18);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -68,6 +68,8 @@ class PPO:
         if (self.fused_rollout and not hist_encoding and critic_obs is obs and not torch.is_grad_enabled()
                 and ac.fused_act_supported(obs)):
             # one HIP launch for actor + critic + sample + log-prob (csrc/wbc_policy_kernel.hip)
+            if self.storage is not None and self.storage.step == 0:
+                ac.mark_params_changed()      # start of a rollout: re-pack once, whoever touched the weights since
             eps = torch.randn(obs.shape[0], 18, device=obs.device)
             tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps)
             tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
@@ -312,11 +314,13 @@ class PPO:
         num_updates = self.num_learning_epochs * self.num_mini_batches
         self.storage.clear()
         self.update_counter()
+        ac.mark_params_changed()
         return (total / num_updates).item()
 
     def enforce_min_std(self):
         with torch.no_grad():           # in place: kernels hold the parameter's address
             self.actor_critic.std.copy_(torch.max(self.actor_critic.std, self.min_policy_std))
+        self.actor_critic.mark_params_changed()
 
     def update_counter(self):
         self.counter += 1

@@ -275,6 +275,16 @@ class ActorCritic(nn.Module):
                 isinstance(self.actor.actor_leg_control_head[1], nn.ELU) and not self.actor.adaptive_arm_gains
         return self._fused_ok
 
+    param_version = 0      # bump (mark_params_changed) whenever parameters are modified: the fused kernels cache a packed copy
+
+    def mark_params_changed(self):
+        self.param_version += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.mark_params_changed()
+        return out
+
     def fused_params(self):
         """The 33 parameters the fused kernels read, in struct PolicyParams order."""
         sd = dict(self.named_parameters())
@@ -296,15 +306,21 @@ class ActorCritic(nn.Module):
         `eps` = standard normals [B,18] (drawn by the caller from torch's generator); None acts on the mean."""
         from ...native import check, lib
         table = self.fused_param_table()
-        n = observations.shape[0]
         dev = observations.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if getattr(self, "_wpack", None) is None or self._wpack.device != dev:
+            self._wpack = torch.empty(lib().wbc_policy_pack_floats(), device=dev)
+            self._wpack_version = -1
+        if self._wpack_version != self.param_version:
+            check(lib().wbc_policy_pack(table, self._wpack.data_ptr(), stream), "wbc_policy_pack")
+            self._wpack_version = self.param_version
+        n = observations.shape[0]
         actions = torch.empty(n, 18, device=dev)
         mean = torch.empty(n, 18, device=dev)
         logp = torch.empty(n, 2, device=dev)
         values = torch.empty(n, 2, device=dev)
-        check(lib().wbc_policy_act(table, observations.data_ptr(), eps.data_ptr() if eps is not None else None, actions.data_ptr(),
-                                   mean.data_ptr(), logp.data_ptr(), values.data_ptr(), n,
-                                   torch.cuda.current_stream(dev).cuda_stream), "wbc_policy_act")
+        check(lib().wbc_policy_act(table, self._wpack.data_ptr(), observations.data_ptr(), eps.data_ptr() if eps is not None else None,
+                                   actions.data_ptr(), mean.data_ptr(), logp.data_ptr(), values.data_ptr(), n, stream), "wbc_policy_act")
         return actions, mean, logp, values
 
     def act_inference(self, observations, hist_encoding=False):

@@ -278,12 +278,15 @@ int wbc_gae_workspace_doubles(int N);
  * latent: Actor.forward (actor_critic.py:204-221), Critic.forward (:281-286), the action sample
  * mean + std * eps (Normal.sample, :337-339) and get_actions_log_prob (:341-345) in ONE launch on fp32
  * MFMA. `params`: 33 device pointers in state_dict order of the layers used (struct PolicyParams in
- * csrc/wbc_policy_kernel.hip: priv_encoder.{0,2}, actor_backbone.0, leg head {0,2,4}, arm head {0,2,4},
+ * csrc/wbc_mlp.h: priv_encoder.{0,2}, actor_backbone.0, leg head {0,2,4}, arm head {0,2,4},
  * critic_backbone.0, critic leg head {0,2,4}, critic arm head {0,2,4}, each weight then bias, then std).
- * obs f32 [rows,860]; eps f32 [rows,18] standard normals (NULL: act on the mean); outputs actions/mean
- * f32 [rows,18], logp/values f32 [rows,2]. */
-int wbc_policy_act(const void* const* params, const float* obs, const float* eps, float* actions,
-                   float* mean, float* logp, float* values, int num_rows, void* stream);
+ * `wpack`: wbc_policy_pack_floats() floats holding the weights in MFMA-fragment order; refresh it with
+ * wbc_policy_pack whenever the parameters changed. obs f32 [rows,860]; eps f32 [rows,18] standard
+ * normals (NULL: act on the mean); outputs actions/mean f32 [rows,18], logp/values f32 [rows,2]. */
+int wbc_policy_pack_floats(void);
+int wbc_policy_pack(const void* const* params, float* wpack, void* stream);
+int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* eps,
+                   float* actions, float* mean, float* logp, float* values, int num_rows, void* stream);
 
 /* One PPO.update() minibatch (rsl_rl/algorithms/ppo.py:163-246, teacher path, no torque supervision): gathers
  * the rows `idx` of the flat [T*N, ...] rollout tensors, runs actor + critic forward, the clipped surrogate
