@@ -49,7 +49,7 @@ enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2 };
 
 template <int ACT>
 static __device__ __forceinline__ float apply_act(float x) {
-  if (ACT == ACT_ELU) return x > 0.f ? x : expm1f(x);
+  if (ACT == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;   // abs error <= 1 ulp(1.0); the derivative uses the stored value
   if (ACT == ACT_TANH) return tanhf(x);
   return x;
 }
@@ -71,34 +71,85 @@ static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict
   }
 }
 
-// out[32, N] = act(in[32, K] * W^T + b) for layer L. `in`/`out` live in LDS (row strides ldi/ldo); the B
-// fragments come from the packed table. All 256 threads call this; wave w owns output columns
-// [32w, 32w+32). If `stash` is given the activated outputs of valid rows also go to
-// stash[(row0+row)*lds + scol + col]. Ends with a barrier (the outputs are visible to all waves).
-template <int L, int ACT>
-static __device__ __forceinline__ void fused_layer(const float* in, int ldi, const float* __restrict__ wpack, const float* __restrict__ b,
-                                                   float* out, int ldo, int col_off, float* __restrict__ stash = nullptr, int lds = 0,
-                                                   int scol = 0, int row0 = 0, int num_rows = 0) {
-  constexpr int N = layer_out(L), K = layer_in(L), NBLK = layer_nblk(L), KB = K / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// x[32, 100] (LDS, row stride 101) <- src rows' first 100 floats. 800 float4 loads, <= 4 per thread, all in flight
+// at once. `row_ptr(r)` returns the global pointer of tile row r (16-byte aligned: 860-float rows are) or nullptr.
+template <typename F>
+static __device__ __forceinline__ void load_x_tile(float* x, F row_ptr) {
+  const int tid = threadIdx.x;
+  float4 v[4];
+  int rr[4], cc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e4 = tid + j * PT_THREADS;
+    rr[j] = e4 / 25; cc[j] = (e4 - rr[j] * 25) * 4;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 < PT_ROWS * 25) {
+      const float* p = row_ptr(rr[j]);
+      if (p) v[j] = *reinterpret_cast<const float4*>(p + cc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (tid + j * PT_THREADS < PT_ROWS * 25) {
+      float* d = x + rr[j] * 101 + cc[j];
+      d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+    }
+  }
+}
+
+// ---- forward layer, split into an operand prefetch and the MFMA chain ---------------------------------
+// load_frags<L>: the K/2 B-fragments of this wave's 32-column block of layer L, one coalesced 256-byte load
+// each, all issued back to back (K/2 <= 64 loads in flight). Call it BEFORE running the previous layer so that
+// the L2 latency hides under that layer's MFMAs.
+template <int L>
+static __device__ __forceinline__ void load_frags(float (&w)[64], const float* __restrict__ wpack) {
+  constexpr int NBLK = layer_nblk(L), KB = layer_in(L) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < NBLK) {
+    const float* bp = wpack + layer_pack_off(L) + wave * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) w[kb] = bp[(size_t)kb * NBLK * 64];
+  }
+}
+
+// out[32, N] = act(in[32, K] * W^T + b) for layer L with the fragments already in registers. `in`/`out` live in
+// LDS (row strides ldi/ldo); wave w owns output columns [32w, 32w+32). With STASH the activated outputs of valid
+// rows also go to stash[(row0+row)*lds + scol + col]. Ends with a barrier.
+template <int L, int ACT, bool STASH>
+static __device__ __forceinline__ void mma_layer(const float* in, int ldi, const float (&w)[64], const float* __restrict__ b, float* out,
+                                                 int ldo, int col_off, float* __restrict__ stash = nullptr, int lds = 0, int scol = 0,
+                                                 int row0 = 0, int num_rows = 0) {
+  constexpr int N = layer_out(L), NBLK = layer_nblk(L), KB = layer_in(L) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave < NBLK) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* ap = in + (lane & 31) * ldi + (lane >> 5);
-    const float* bp = wpack + layer_pack_off(L) + wave * 64 + lane;
-#pragma unroll 16
-    for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kb], bp[(size_t)kb * NBLK * 64], acc, 0, 0, 0);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kb], w[kb], acc, 0, 0, 0);
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col = wave * 32 + (lane & 31);
     if (col < N) {
       const float bias = b[col];
+      const bool full = row0 + PT_ROWS <= num_rows;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const float v = apply_act<ACT>(acc[r] + bias);
         out[row * ldo + col_off + col] = v;
-        if (stash && row0 + row < num_rows) stash[(size_t)(row0 + row) * lds + scol + col] = v;
+        if (STASH && (full || row0 + row < num_rows)) stash[(size_t)(row0 + row) * lds + scol + col] = v;
       }
     }
   }
   __syncthreads();
+}
+
+// one-shot form (operands requested and consumed in the same call)
+template <int L, int ACT>
+static __device__ __forceinline__ void fused_layer(const float* in, int ldi, const float* __restrict__ wpack, const float* __restrict__ b,
+                                                   float* out, int ldo, int col_off, float* __restrict__ stash = nullptr, int lds = 0,
+                                                   int scol = 0, int row0 = 0, int num_rows = 0) {
+  float w[64];
+  load_frags<L>(w, wpack);
+  if (stash) mma_layer<L, ACT, true>(in, ldi, w, b, out, ldo, col_off, stash, lds, scol, row0, num_rows);
+  else mma_layer<L, ACT, false>(in, ldi, w, b, out, ldo, col_off);
 }

@@ -25,35 +25,50 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * PT_ROWS;
   // load obs[:, :100] of 32 rows (rows past the end are zero)
-  for (int e = tid; e < PT_ROWS * 100; e += PT_THREADS) {
-    const int r = e / 100, c = e - r * 100;
-    s.x[r * 101 + c] = (row0 + r < num_rows) ? obs[(size_t)(row0 + r) * PT_NOBS + c] : 0.f;
-  }
+  load_x_tile(s.x, [&](int r) { return (row0 + r < num_rows) ? obs + (size_t)(row0 + r) * PT_NOBS : (const float*)nullptr; });
   __syncthreads();
+  // Two register sets of weight fragments alternate: the next layer's operands are requested from L2 before the
+  // current layer's MFMA chain starts.
+  float wa[64], wb[64];
+  load_frags<L_PRIV0>(wa, wpack);
   // ---- actor (AC:204-221): priv encoder 24 -> 64 -> 20, backbone [prop76 | latent20] -> 128, two heads
-  fused_layer<L_PRIV0, ACT_ELU>(s.x + PT_NPROP, 101, wpack, P.priv0_b, s.a0, LDA, 0);
-  // backbone input z = [prop, latent] assembled in a1: latent goes to columns 76..95
-  fused_layer<L_PRIV2, ACT_ELU>(s.a0, LDA, wpack, P.priv2_b, s.a1, LDA, PT_NPROP);
-  for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
+  load_frags<L_PRIV2>(wb, wpack);
+  mma_layer<L_PRIV0, ACT_ELU, false>(s.x + PT_NPROP, 101, wa, P.priv0_b, s.a0, LDA, 0);
+  load_frags<L_BB>(wa, wpack);
+  mma_layer<L_PRIV2, ACT_ELU, false>(s.a0, LDA, wb, P.priv2_b, s.a1, LDA, PT_NPROP);     // latent -> a1[:, 76:96]
+  for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {                           // a1[:, :76] = prop
     const int r = e / PT_NPROP, c = e - r * PT_NPROP;
     s.a1[r * LDA + c] = s.x[r * 101 + c];
   }
   __syncthreads();
-  fused_layer<L_BB, ACT_ELU>(s.a1, LDA, wpack, P.bb_b, s.a2, LDA, 0);          // a2 = backbone output (kept)
-  fused_layer<L_LEG0, ACT_ELU>(s.a2, LDA, wpack, P.leg0_b, s.a0, LDA, 0);
-  fused_layer<L_LEG2, ACT_ELU>(s.a0, LDA, wpack, P.leg2_b, s.a1, LDA, 0);
-  fused_layer<L_LEG4, ACT_TANH>(s.a1, LDA, wpack, P.leg4_b, s.outv, 21, 0);
-  fused_layer<L_ARM0, ACT_ELU>(s.a2, LDA, wpack, P.arm0_b, s.a0, LDA, 0);
-  fused_layer<L_ARM2, ACT_ELU>(s.a0, LDA, wpack, P.arm2_b, s.a1, LDA, 0);
-  fused_layer<L_ARM4, ACT_TANH>(s.a1, LDA, wpack, P.arm4_b, s.outv, 21, PT_NLEG);
+  load_frags<L_LEG0>(wb, wpack);
+  mma_layer<L_BB, ACT_ELU, false>(s.a1, LDA, wa, P.bb_b, s.a2, LDA, 0);                   // a2 = backbone output (kept)
+  load_frags<L_LEG2>(wa, wpack);
+  mma_layer<L_LEG0, ACT_ELU, false>(s.a2, LDA, wb, P.leg0_b, s.a0, LDA, 0);
+  load_frags<L_LEG4>(wb, wpack);
+  mma_layer<L_LEG2, ACT_ELU, false>(s.a0, LDA, wa, P.leg2_b, s.a1, LDA, 0);
+  load_frags<L_ARM0>(wa, wpack);
+  mma_layer<L_LEG4, ACT_TANH, false>(s.a1, LDA, wb, P.leg4_b, s.outv, 21, 0);
+  load_frags<L_ARM2>(wb, wpack);
+  mma_layer<L_ARM0, ACT_ELU, false>(s.a2, LDA, wa, P.arm0_b, s.a0, LDA, 0);
+  load_frags<L_ARM4>(wa, wpack);
+  mma_layer<L_ARM2, ACT_ELU, false>(s.a0, LDA, wb, P.arm2_b, s.a1, LDA, 0);
+  load_frags<L_CBB>(wb, wpack);
+  mma_layer<L_ARM4, ACT_TANH, false>(s.a1, LDA, wa, P.arm4_b, s.outv, 21, PT_NLEG);
   // ---- critic (AC:281-286): obs[:, :100] -> 128 -> two heads 128 -> 128 -> 1
-  fused_layer<L_CBB, ACT_ELU>(s.x, 101, wpack, P.cbb_b, s.a2, LDA, 0);
-  fused_layer<L_CLEG0, ACT_ELU>(s.a2, LDA, wpack, P.cleg0_b, s.a0, LDA, 0);
-  fused_layer<L_CLEG2, ACT_ELU>(s.a0, LDA, wpack, P.cleg2_b, s.a1, LDA, 0);
-  fused_layer<L_CLEG4, ACT_NONE>(s.a1, LDA, wpack, P.cleg4_b, s.outv, 21, 18);
-  fused_layer<L_CARM0, ACT_ELU>(s.a2, LDA, wpack, P.carm0_b, s.a0, LDA, 0);
-  fused_layer<L_CARM2, ACT_ELU>(s.a0, LDA, wpack, P.carm2_b, s.a1, LDA, 0);
-  fused_layer<L_CARM4, ACT_NONE>(s.a1, LDA, wpack, P.carm4_b, s.outv, 21, 19);
+  load_frags<L_CLEG0>(wa, wpack);
+  mma_layer<L_CBB, ACT_ELU, false>(s.x, 101, wb, P.cbb_b, s.a2, LDA, 0);
+  load_frags<L_CLEG2>(wb, wpack);
+  mma_layer<L_CLEG0, ACT_ELU, false>(s.a2, LDA, wa, P.cleg0_b, s.a0, LDA, 0);
+  load_frags<L_CLEG4>(wa, wpack);
+  mma_layer<L_CLEG2, ACT_ELU, false>(s.a0, LDA, wb, P.cleg2_b, s.a1, LDA, 0);
+  load_frags<L_CARM0>(wb, wpack);
+  mma_layer<L_CLEG4, ACT_NONE, false>(s.a1, LDA, wa, P.cleg4_b, s.outv, 21, 18);
+  load_frags<L_CARM2>(wa, wpack);
+  mma_layer<L_CARM0, ACT_ELU, false>(s.a2, LDA, wb, P.carm0_b, s.a0, LDA, 0);
+  load_frags<L_CARM4>(wb, wpack);
+  mma_layer<L_CARM2, ACT_ELU, false>(s.a0, LDA, wa, P.carm2_b, s.a1, LDA, 0);
+  mma_layer<L_CARM4, ACT_NONE, false>(s.a1, LDA, wb, P.carm4_b, s.outv, 21, 19);
   // ---- epilogue: sample, log-probabilities (Normal.log_prob summed over leg / arm dims), outputs
   if (tid < PT_ROWS && row0 + tid < num_rows) {
     const int r = tid;

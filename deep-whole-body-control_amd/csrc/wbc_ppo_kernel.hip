@@ -17,10 +17,11 @@
 #include "wbc_mlp.h"
 
 // ---- stash layouts (floats per row) -------------------------------------------------------------
+// every block starts at a multiple of 4 floats and the row strides are multiples of 4: float4 accesses stay aligned
 enum { A_X = 0, A_H1 = 100, A_LAT = 164, A_BB = 184, A_L1 = 312, A_L2 = 440, A_LEG = 568, A_A1 = 580, A_A2 = 708, A_ARM = 836,
-       A_CB = 842, A_CL1 = 970, A_CL2 = 1098, A_CA1 = 1226, A_CA2 = 1354, A_Z = 1482, A_LD = 1584 };
-enum { D_H1 = 0, D_LAT = 64, D_BB = 84, D_L1 = 212, D_L2 = 340, D_LEG = 468, D_A1 = 480, D_A2 = 608, D_ARM = 736, D_CB = 742,
-       D_CL1 = 870, D_CL2 = 998, D_VLEG = 1126, D_CA1 = 1127, D_CA2 = 1255, D_VARM = 1383, D_LD = 1384 };
+       A_CB = 844, A_CL1 = 972, A_CL2 = 1100, A_CA1 = 1228, A_CA2 = 1356, A_Z = 1484, A_LD = 1584 };
+enum { D_H1 = 0, D_LAT = 64, D_BB = 84, D_L1 = 212, D_L2 = 340, D_LEG = 468, D_A1 = 480, D_A2 = 608, D_ARM = 736, D_CB = 744,
+       D_CL1 = 872, D_CL2 = 1000, D_VLEG = 1128, D_CA1 = 1132, D_CA2 = 1260, D_VARM = 1388, D_LD = 1392 };
 
 struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minibatch's row indices
   const float* obs;               // [TN, 860]
@@ -43,24 +44,32 @@ struct __align__(16) PpoSmem {
   float g[PT_ROWS * 41];          // output grads: dmu 18, dv 2, dlat 20
 };
 
-// out[32, IN] (+)= dz[32, OUT] * W[OUT, IN]. The B operand W[k][col] is read straight from global memory:
-// a wave's fragment is two runs of 32 consecutive floats of W (rows k and k+1), i.e. coalesced as stored.
-template <int OUT, int IN, bool ACCUMULATE>
-static __device__ __forceinline__ void bwd_gemm(const float* dz, int ldz, const float* __restrict__ W, float* out, int ldo) {
+// Backward GEMM out[32, IN] (+)= dz[32, OUT] * W[OUT, IN]. The B operand W[k][col] is read straight from global
+// memory (a wave's fragment is two runs of 32 consecutive floats of W, i.e. coalesced as stored), prefetched into
+// registers by load_wrows one stage ahead of the MFMA chain that consumes it.
+template <int OUT, int IN>
+static __device__ __forceinline__ void load_wrows(float (&w)[64], const float* __restrict__ W) {
   constexpr int NBLK = (IN + 31) / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < NBLK) {
+    const int col = wave * 32 + (lane & 31);
+    const bool col_ok = col < IN;
+    const float* bp = W + (size_t)(lane >> 5) * IN + (col_ok ? col : 0);
+#pragma unroll
+    for (int t = 0; t < OUT / 2; ++t) { const float v = bp[(size_t)(2 * t) * IN]; w[t] = col_ok ? v : 0.f; }
+  }
+}
+template <int OUT, int IN, bool ACCUMULATE>
+static __device__ __forceinline__ void bwd_mma(const float* dz, int ldz, const float (&w)[64], float* out, int ldo) {
+  constexpr int NBLK = (IN + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave < NBLK) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int col = wave * 32 + (lane & 31);
-    const bool col_ok = col < IN;
     const float* ap = dz + (lane & 31) * ldz + (lane >> 5);
-    const float* bp = W + (size_t)(lane >> 5) * IN + (col_ok ? col : 0);
-#pragma unroll 16
-    for (int k = 0; k < OUT; k += 2) {
-      const float bv = col_ok ? bp[(size_t)k * IN] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bv, acc, 0, 0, 0);
-    }
-    if (col_ok) {
+#pragma unroll
+    for (int t = 0; t < OUT / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t], w[t], acc, 0, 0, 0);
+    if (col < IN) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -73,22 +82,47 @@ static __device__ __forceinline__ void bwd_gemm(const float* dz, int ldz, const 
 }
 
 // buf[32, N] <- buf * act'(A) with A the stashed post-activation (elu' = a > 0 ? 1 : a + 1, tanh' = 1 - a^2);
-// the result also goes to the DZ stash.
+// the result also goes to the DZ stash. float4 global accesses, all of a thread's loads in flight together.
+template <int ACT>
+static __device__ __forceinline__ float act_deriv(float a) {
+  return (ACT == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : ((ACT == ACT_TANH) ? 1.f - a * a : 1.f);
+}
 template <int N, int ACT>
 static __device__ __forceinline__ void act_grad(float* buf, int ld, const float* __restrict__ act_stash, int acol, float* __restrict__ dz_stash,
                                                 int dcol, int row0, int num_rows) {
   const int tid = threadIdx.x;
-#pragma unroll 4
-  for (int e = tid; e < PT_ROWS * N; e += PT_THREADS) {
-    const int r = e / N, c = e - r * N;
-    float v = 0.f;
-    if (row0 + r < num_rows) {
-      const float a = act_stash[(size_t)(row0 + r) * A_LD + acol + c];
-      const float d = (ACT == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : ((ACT == ACT_TANH) ? 1.f - a * a : 1.f);
-      v = buf[r * ld + c] * d;
-      dz_stash[(size_t)(row0 + r) * D_LD + dcol + c] = v;
+  if (N % 4 == 0) {
+    constexpr int Q = N / 4, TOT = PT_ROWS * Q, PER = (TOT + PT_THREADS - 1) / PT_THREADS;
+    float4 a[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = tid + j * PT_THREADS, r = e / Q, c = (e - r * Q) * 4;
+      a[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (e < TOT && row0 + r < num_rows) a[j] = *reinterpret_cast<const float4*>(act_stash + (size_t)(row0 + r) * A_LD + acol + c);
     }
-    buf[r * ld + c] = v;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = tid + j * PT_THREADS, r = e / Q, c = (e - r * Q) * 4;
+      if (e < TOT) {
+        float* bp = buf + r * ld + c;
+        const bool ok = row0 + r < num_rows;
+        float4 v;
+        v.x = ok ? bp[0] * act_deriv<ACT>(a[j].x) : 0.f; v.y = ok ? bp[1] * act_deriv<ACT>(a[j].y) : 0.f;
+        v.z = ok ? bp[2] * act_deriv<ACT>(a[j].z) : 0.f; v.w = ok ? bp[3] * act_deriv<ACT>(a[j].w) : 0.f;
+        bp[0] = v.x; bp[1] = v.y; bp[2] = v.z; bp[3] = v.w;
+        if (ok) *reinterpret_cast<float4*>(dz_stash + (size_t)(row0 + r) * D_LD + dcol + c) = v;
+      }
+    }
+  } else {
+    for (int e = tid; e < PT_ROWS * N; e += PT_THREADS) {
+      const int r = e / N, c = e - r * N;
+      float v = 0.f;
+      if (row0 + r < num_rows) {
+        v = buf[r * ld + c] * act_deriv<ACT>(act_stash[(size_t)(row0 + r) * A_LD + acol + c]);
+        dz_stash[(size_t)(row0 + r) * D_LD + dcol + c] = v;
+      }
+      buf[r * ld + c] = v;
+    }
   }
   __syncthreads();
 }
@@ -99,43 +133,65 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
   __shared__ PpoSmem s;
   const int tid = threadIdx.x, lane = tid & 63;
   const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
-  // gather obs[idx, :100]
-  for (int e = tid; e < PT_ROWS * 100; e += PT_THREADS) {
-    const int r = e / 100, c = e - r * 100;
-    float v = 0.f;
-    if (row0 + r < B) {
-      v = Bt.obs[(size_t)Bt.idx[row0 + r] * PT_NOBS + c];
-      act_stash[(size_t)(row0 + r) * A_LD + A_X + c] = v;
-    }
-    s.x[r * 101 + c] = v;
-  }
+  // gather obs[idx, :100] (float4 loads, all in flight) and stash it as the input of priv0 / critic backbone
+  load_x_tile(s.x, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
   __syncthreads();
-  // ---------------- forward (same chain as wbc_policy_act_kernel), post-activations stashed
-  fused_layer<L_PRIV0, ACT_ELU>(s.x + PT_NPROP, 101, wpack, P.priv0_b, s.a0, LDA, 0, act_stash, A_LD, A_H1, row0, B);
-  fused_layer<L_PRIV2, ACT_ELU>(s.a0, LDA, wpack, P.priv2_b, s.a1, LDA, PT_NPROP, act_stash, A_LD, A_LAT, row0, B);
+  for (int e = tid; e < PT_ROWS * 25; e += PT_THREADS) {
+    const int r = e / 25, c = (e - r * 25) * 4;
+    if (row0 + r < B) {
+      const float* xp = s.x + r * 101 + c;
+      *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_X + c) = make_float4(xp[0], xp[1], xp[2], xp[3]);
+    }
+  }
+  // ---------------- forward (same chain as wbc_policy_act_kernel), post-activations stashed. Two register sets of
+  // weight fragments alternate so that the next layer's operands are in flight during the current MFMA chain.
+  float wa[64], wb[64];
+  load_frags<L_PRIV0>(wa, wpack);
+  load_frags<L_PRIV2>(wb, wpack);
+  mma_layer<L_PRIV0, ACT_ELU, true>(s.x + PT_NPROP, 101, wa, P.priv0_b, s.a0, LDA, 0, act_stash, A_LD, A_H1, row0, B);
+  load_frags<L_BB>(wa, wpack);
+  mma_layer<L_PRIV2, ACT_ELU, true>(s.a0, LDA, wb, P.priv2_b, s.a1, LDA, PT_NPROP, act_stash, A_LD, A_LAT, row0, B);
   for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
     const int r = e / PT_NPROP, c = e - r * PT_NPROP;
     s.a1[r * LDA + c] = s.x[r * 101 + c];
   }
   __syncthreads();
-  for (int e = tid; e < PT_ROWS * 96; e += PT_THREADS) {          // z = [prop, latent], the backbone's input, for its weight gradient
-    const int r = e / 96, c = e - r * 96;
-    if (row0 + r < B) act_stash[(size_t)(row0 + r) * A_LD + A_Z + c] = s.a1[r * LDA + c];
+  for (int e = tid; e < PT_ROWS * 24; e += PT_THREADS) {          // z = [prop, latent], the backbone's input, for its weight gradient
+    const int r = e / 24, c = (e - r * 24) * 4;
+    if (row0 + r < B) {
+      const float* zp = s.a1 + r * LDA + c;
+      *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_Z + c) = make_float4(zp[0], zp[1], zp[2], zp[3]);
+    }
   }
-  fused_layer<L_BB, ACT_ELU>(s.a1, LDA, wpack, P.bb_b, s.a2, LDA, 0, act_stash, A_LD, A_BB, row0, B);
-  fused_layer<L_LEG0, ACT_ELU>(s.a2, LDA, wpack, P.leg0_b, s.a0, LDA, 0, act_stash, A_LD, A_L1, row0, B);
-  fused_layer<L_LEG2, ACT_ELU>(s.a0, LDA, wpack, P.leg2_b, s.a1, LDA, 0, act_stash, A_LD, A_L2, row0, B);
-  fused_layer<L_LEG4, ACT_TANH>(s.a1, LDA, wpack, P.leg4_b, s.outv, 21, 0, act_stash, A_LD, A_LEG, row0, B);
-  fused_layer<L_ARM0, ACT_ELU>(s.a2, LDA, wpack, P.arm0_b, s.a0, LDA, 0, act_stash, A_LD, A_A1, row0, B);
-  fused_layer<L_ARM2, ACT_ELU>(s.a0, LDA, wpack, P.arm2_b, s.a1, LDA, 0, act_stash, A_LD, A_A2, row0, B);
-  fused_layer<L_ARM4, ACT_TANH>(s.a1, LDA, wpack, P.arm4_b, s.outv, 21, PT_NLEG, act_stash, A_LD, A_ARM, row0, B);
-  fused_layer<L_CBB, ACT_ELU>(s.x, 101, wpack, P.cbb_b, s.a2, LDA, 0, act_stash, A_LD, A_CB, row0, B);
-  fused_layer<L_CLEG0, ACT_ELU>(s.a2, LDA, wpack, P.cleg0_b, s.a0, LDA, 0, act_stash, A_LD, A_CL1, row0, B);
-  fused_layer<L_CLEG2, ACT_ELU>(s.a0, LDA, wpack, P.cleg2_b, s.a1, LDA, 0, act_stash, A_LD, A_CL2, row0, B);
-  fused_layer<L_CLEG4, ACT_NONE>(s.a1, LDA, wpack, P.cleg4_b, s.outv, 21, 18);
-  fused_layer<L_CARM0, ACT_ELU>(s.a2, LDA, wpack, P.carm0_b, s.a0, LDA, 0, act_stash, A_LD, A_CA1, row0, B);
-  fused_layer<L_CARM2, ACT_ELU>(s.a0, LDA, wpack, P.carm2_b, s.a1, LDA, 0, act_stash, A_LD, A_CA2, row0, B);
-  fused_layer<L_CARM4, ACT_NONE>(s.a1, LDA, wpack, P.carm4_b, s.outv, 21, 19);
+  load_frags<L_LEG0>(wb, wpack);
+  mma_layer<L_BB, ACT_ELU, true>(s.a1, LDA, wa, P.bb_b, s.a2, LDA, 0, act_stash, A_LD, A_BB, row0, B);
+  load_frags<L_LEG2>(wa, wpack);
+  mma_layer<L_LEG0, ACT_ELU, true>(s.a2, LDA, wb, P.leg0_b, s.a0, LDA, 0, act_stash, A_LD, A_L1, row0, B);
+  load_frags<L_LEG4>(wb, wpack);
+  mma_layer<L_LEG2, ACT_ELU, true>(s.a0, LDA, wa, P.leg2_b, s.a1, LDA, 0, act_stash, A_LD, A_L2, row0, B);
+  load_frags<L_ARM0>(wa, wpack);
+  mma_layer<L_LEG4, ACT_TANH, true>(s.a1, LDA, wb, P.leg4_b, s.outv, 21, 0, act_stash, A_LD, A_LEG, row0, B);
+  load_frags<L_ARM2>(wb, wpack);
+  mma_layer<L_ARM0, ACT_ELU, true>(s.a2, LDA, wa, P.arm0_b, s.a0, LDA, 0, act_stash, A_LD, A_A1, row0, B);
+  load_frags<L_ARM4>(wa, wpack);
+  mma_layer<L_ARM2, ACT_ELU, true>(s.a0, LDA, wb, P.arm2_b, s.a1, LDA, 0, act_stash, A_LD, A_A2, row0, B);
+  load_frags<L_CBB>(wb, wpack);
+  mma_layer<L_ARM4, ACT_TANH, true>(s.a1, LDA, wa, P.arm4_b, s.outv, 21, PT_NLEG, act_stash, A_LD, A_ARM, row0, B);
+  load_frags<L_CLEG0>(wa, wpack);
+  mma_layer<L_CBB, ACT_ELU, true>(s.x, 101, wb, P.cbb_b, s.a2, LDA, 0, act_stash, A_LD, A_CB, row0, B);
+  load_frags<L_CLEG2>(wb, wpack);
+  mma_layer<L_CLEG0, ACT_ELU, true>(s.a2, LDA, wa, P.cleg0_b, s.a0, LDA, 0, act_stash, A_LD, A_CL1, row0, B);
+  load_frags<L_CLEG4>(wa, wpack);
+  mma_layer<L_CLEG2, ACT_ELU, true>(s.a0, LDA, wb, P.cleg2_b, s.a1, LDA, 0, act_stash, A_LD, A_CL2, row0, B);
+  load_frags<L_CARM0>(wb, wpack);
+  mma_layer<L_CLEG4, ACT_NONE, false>(s.a1, LDA, wa, P.cleg4_b, s.outv, 21, 18);
+  load_frags<L_CARM2>(wa, wpack);
+  mma_layer<L_CARM0, ACT_ELU, true>(s.a2, LDA, wb, P.carm0_b, s.a0, LDA, 0, act_stash, A_LD, A_CA1, row0, B);
+  load_frags<L_CARM4>(wb, wpack);
+  mma_layer<L_CARM2, ACT_ELU, true>(s.a0, LDA, wa, P.carm2_b, s.a1, LDA, 0, act_stash, A_LD, A_CA2, row0, B);
+  mma_layer<L_CARM4, ACT_NONE, false>(s.a1, LDA, wb, P.carm4_b, s.outv, 21, 19);
+  // first backward operands: requested now, consumed after the loss epilogue
+  load_wrows<128, 128>(wa, P.cleg2_w);
   // ---------------- losses and output gradients: one row per lane of wave 0
   if (tid < 64) {
     const int r = tid & 31;
@@ -232,18 +288,22 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
   }
   __syncthreads();
   act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_CL2, dz_stash, D_CL2, row0, B);
-  bwd_gemm<128, 128, false>(s.a0, LDA, P.cleg2_w, s.a1, LDA);
+  load_wrows<128, 128>(wb, P.cleg0_w);
+  bwd_mma<128, 128, false>(s.a0, LDA, wa, s.a1, LDA);
   act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_CL1, dz_stash, D_CL1, row0, B);
-  bwd_gemm<128, 128, false>(s.a1, LDA, P.cleg0_w, s.a2, LDA);                       // a2 = dA_cb (leg part)
+  load_wrows<128, 128>(wa, P.carm2_w);
+  bwd_mma<128, 128, false>(s.a1, LDA, wb, s.a2, LDA);                                     // a2 = dA_cb (leg part)
   for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) {
     const int r = e >> 7, c = e & 127;
     s.a0[r * LDA + c] = s.g[r * 41 + 19] * P.carm4_w[c];
   }
   __syncthreads();
   act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_CA2, dz_stash, D_CA2, row0, B);
-  bwd_gemm<128, 128, false>(s.a0, LDA, P.carm2_w, s.a1, LDA);
+  load_wrows<128, 128>(wb, P.carm0_w);
+  bwd_mma<128, 128, false>(s.a0, LDA, wa, s.a1, LDA);
   act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_CA1, dz_stash, D_CA1, row0, B);
-  bwd_gemm<128, 128, true>(s.a1, LDA, P.carm0_w, s.a2, LDA);                        // a2 += arm part
+  load_wrows<PT_NLEG, 128>(wa, P.leg4_w);
+  bwd_mma<128, 128, true>(s.a1, LDA, wb, s.a2, LDA);                                      // a2 += arm part
   act_grad<128, ACT_ELU>(s.a2, LDA, act_stash, A_CB, dz_stash, D_CB, row0, B);
   // ---------------- backward: actor
   for (int e = tid; e < PT_ROWS * PT_NLEG; e += PT_THREADS) {
@@ -252,31 +312,38 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
   }
   __syncthreads();
   act_grad<PT_NLEG, ACT_TANH>(s.a0, LDA, act_stash, A_LEG, dz_stash, D_LEG, row0, B);
-  bwd_gemm<PT_NLEG, 128, false>(s.a0, LDA, P.leg4_w, s.a1, LDA);
+  load_wrows<128, 128>(wb, P.leg2_w);
+  bwd_mma<PT_NLEG, 128, false>(s.a0, LDA, wa, s.a1, LDA);
   act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_L2, dz_stash, D_L2, row0, B);
-  bwd_gemm<128, 128, false>(s.a1, LDA, P.leg2_w, s.a0, LDA);
+  load_wrows<128, 128>(wa, P.leg0_w);
+  bwd_mma<128, 128, false>(s.a1, LDA, wb, s.a0, LDA);
   act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_L1, dz_stash, D_L1, row0, B);
-  bwd_gemm<128, 128, false>(s.a0, LDA, P.leg0_w, s.a2, LDA);                        // a2 = dA_bb (leg part)
+  load_wrows<PT_NARM, 128>(wb, P.arm4_w);
+  bwd_mma<128, 128, false>(s.a0, LDA, wa, s.a2, LDA);                                     // a2 = dA_bb (leg part)
   for (int e = tid; e < PT_ROWS * PT_NARM; e += PT_THREADS) {
     const int r = e / PT_NARM, c = e - r * PT_NARM;
     s.a0[r * LDA + c] = s.g[r * 41 + PT_NLEG + c];
   }
   __syncthreads();
   act_grad<PT_NARM, ACT_TANH>(s.a0, LDA, act_stash, A_ARM, dz_stash, D_ARM, row0, B);
-  bwd_gemm<PT_NARM, 128, false>(s.a0, LDA, P.arm4_w, s.a1, LDA);
+  load_wrows<128, 128>(wa, P.arm2_w);
+  bwd_mma<PT_NARM, 128, false>(s.a0, LDA, wb, s.a1, LDA);
   act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_A2, dz_stash, D_A2, row0, B);
-  bwd_gemm<128, 128, false>(s.a1, LDA, P.arm2_w, s.a0, LDA);
+  load_wrows<128, 128>(wb, P.arm0_w);
+  bwd_mma<128, 128, false>(s.a1, LDA, wa, s.a0, LDA);
   act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_A1, dz_stash, D_A1, row0, B);
-  bwd_gemm<128, 128, true>(s.a0, LDA, P.arm0_w, s.a2, LDA);                         // a2 += arm part
+  load_wrows<128, 96>(wa, P.bb_w);
+  bwd_mma<128, 128, true>(s.a0, LDA, wb, s.a2, LDA);                                      // a2 += arm part
   act_grad<128, ACT_ELU>(s.a2, LDA, act_stash, A_BB, dz_stash, D_BB, row0, B);
-  bwd_gemm<128, 96, false>(s.a2, LDA, P.bb_w, s.a0, LDA);                            // a0 = dA_z [32, 96]
-  for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {                                   // d latent = dA_z[:, 76:96] + ROA gradient
+  load_wrows<20, 64>(wb, P.priv2_w);
+  bwd_mma<128, 96, false>(s.a2, LDA, wa, s.a0, LDA);                                      // a0 = dA_z [32, 96]
+  for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {                                  // d latent = dA_z[:, 76:96] + ROA gradient
     const int r = e / 20, c = e - r * 20;
     s.a1[r * LDA + c] = s.a0[r * LDA + PT_NPROP + c] + s.g[r * 41 + 20 + c];
   }
   __syncthreads();
   act_grad<20, ACT_ELU>(s.a1, LDA, act_stash, A_LAT, dz_stash, D_LAT, row0, B);
-  bwd_gemm<20, 64, false>(s.a1, LDA, P.priv2_w, s.a0, LDA);
+  bwd_mma<20, 64, false>(s.a1, LDA, wb, s.a0, LDA);
   act_grad<64, ACT_ELU>(s.a0, LDA, act_stash, A_H1, dz_stash, D_H1, row0, B);
 }
 
@@ -288,57 +355,89 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
 struct WgradLayer { int out, in, dcol, acol, goff; };   // goff: offset of this layer's weight gradient in the flat buffer
 struct WgradTable { WgradLayer l[NLAYERS]; };
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
-                                                                         const float* __restrict__ dz_stash, float* __restrict__ wpart,
-                                                                         int B, int rows_per_split, int nparams) {
-  const WgradLayer L = tab.l[blockIdx.y];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave * 32 >= L.out) return;
-  const int nib = (L.in + 31) / 32;
-  const int r_begin = blockIdx.x * rows_per_split, r_end = min(B, r_begin + rows_per_split);
-  f32x16 acc[5];
+template <int NIB>
+static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const float* __restrict__ act_stash, const float* __restrict__ dz_stash,
+                                                  float* __restrict__ dst, int r_begin, int r_end) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  f32x16 acc[NIB + 1];
 #pragma unroll
-  for (int b = 0; b < 5; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int o = wave * 32 + (lane & 31), half = lane >> 5;
+  for (int b = 0; b <= NIB; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int o = wave * 32 + (lane & 31);
   const bool o_ok = o < L.out;
-  const float* ap = dz_stash + L.dcol + (o_ok ? o : 0);
-  const float* bp = act_stash + L.acol + (lane & 31);
-  bool c_ok[4];
+  const float* ap = dz_stash + L.dcol + (o_ok ? o : 0);          // clamped address + select: loads stay unconditional
+  const float* bp[NIB];
+  bool c_ok[NIB];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) c_ok[b] = (b * 32 + (lane & 31)) < L.in;
-#pragma unroll 2
-  for (int r = r_begin; r < r_end; r += 2) {
+  for (int b = 0; b < NIB; ++b) {
+    const int c = b * 32 + (lane & 31);
+    c_ok[b] = c < L.in;
+    bp[b] = act_stash + L.acol + (c_ok[b] ? c : 0);
+  }
+  constexpr int U = 4;                                             // k-steps (row pairs) per unrolled iteration
+  int r = r_begin;
+  for (; r + 2 * U <= r_end; r += 2 * U) {
+    float av[U], bv[U][NIB];
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      const size_t row = (size_t)(r + 2 * t + half);
+      av[t] = ap[row * D_LD];
+#pragma unroll
+      for (int b = 0; b < NIB; ++b) bv[t][b] = bp[b][row * A_LD];
+    }
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      const float a = o_ok ? av[t] : 0.f;
+#pragma unroll
+      for (int b = 0; b < NIB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c_ok[b] ? bv[t][b] : 0.f, acc[b], 0, 0, 0);
+      acc[NIB] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[NIB], 0, 0, 0);
+    }
+  }
+  for (; r < r_end; r += 2) {                                      // ragged tail
     const int row = r + half;
     const bool r_ok = row < r_end;
-    const float av = (o_ok && r_ok) ? ap[(size_t)row * D_LD] : 0.f;
-    float bv[4];
+    const size_t rc = (size_t)(r_ok ? row : r);
+    const float a = (o_ok && r_ok) ? ap[rc * D_LD] : 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bv[b] = (b < nib && c_ok[b] && r_ok) ? bp[(size_t)row * A_LD + b * 32] : 0.f;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-      if (b < nib) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[b], acc[b], 0, 0, 0);
-    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, 1.0f, acc[4], 0, 0, 0);
+    for (int b = 0; b < NIB; ++b) {
+      const float v = bp[b][rc * A_LD];
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, (c_ok[b] && r_ok) ? v : 0.f, acc[b], 0, 0, 0);
+    }
+    acc[NIB] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, r_ok ? 1.0f : 0.f, acc[NIB], 0, 0, 0);
   }
-  float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NIB; ++b) {
     const int col = b * 32 + (lane & 31);
-    if (b < nib && col < L.in) {
+    if (col < L.in) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int oo = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (oo < L.out) dst[(size_t)oo * L.in + col] = acc[b][r];
+      for (int q = 0; q < 16; ++q) {
+        const int oo = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (oo < L.out) dst[(size_t)oo * L.in + col] = acc[b][q];
       }
     }
   }
   if ((lane & 31) == 0) {
     float* dbias = dst + (size_t)L.out * L.in;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int oo = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (oo < L.out) dbias[oo] = acc[4][r];
+    for (int q = 0; q < 16; ++q) {
+      const int oo = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (oo < L.out) dbias[oo] = acc[NIB][q];
     }
   }
+}
+
+extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
+                                                                         const float* __restrict__ dz_stash, float* __restrict__ wpart,
+                                                                         int B, int rows_per_split, int nparams) {
+  const WgradLayer L = tab.l[blockIdx.y];
+  const int wave = threadIdx.x >> 6;
+  if (wave * 32 >= L.out) return;
+  const int r_begin = blockIdx.x * rows_per_split, r_end = min(B, r_begin + rows_per_split);
+  float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
+  const int nib = (L.in + 31) / 32;                                // uniform per workgroup
+  if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end);
+  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end);
+  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end);
+  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end);
 }
 
 // grad[p] = sum_s part[s][p] in a fixed order; `stride` floats between consecutive partials
@@ -432,7 +531,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
     off += layer_out(l) * layer_in(l) + layer_out(l);
   }
   int rows_per_split = (B + PPO_NSPLIT - 1) / PPO_NSPLIT;
-  rows_per_split += rows_per_split & 1;
+  rows_per_split = (rows_per_split + 7) / 8 * 8;
   hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, rows_per_split, ng);
   hipLaunchKernelGGL(ppo_reduce_kernel, dim3((off + 255) / 256), dim3(256), 0, st, wpart, PPO_NSPLIT, ng, off, grad);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);

@@ -1,0 +1,18 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import golden_procedure as gp
+from wbc_amd.rsl_rl.modules import ActorCritic
+torch.manual_seed(0)
+ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
+for n in (4096, 40960):
+    obs = torch.randn(n, 860, device="cuda"); eps = torch.randn(n, 18, device="cuda")
+    with torch.inference_mode():
+        for _ in range(5): ac.fused_act(obs, eps)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): ac.fused_act(obs, eps)
+        e1.record(); torch.cuda.synchronize()
+    print(f"fused_act rows={n}: {e0.elapsed_time(e1)/50*1000:.1f} us")
