@@ -1,12 +1,15 @@
-// wbc_mlp.h -- shared pieces of the fused ActorCritic kernels (gfx950, fp32 MFMA 32x32x2): the
-// parameter pointer table, the packed-weight layout and the LDS-resident dense layer used by both the
-// rollout inference kernel (wbc_policy_kernel.hip) and the PPO update kernels (wbc_ppo_kernel.hip).
+// wbc_mlp.h -- shared pieces of the fused ActorCritic kernels (gfx950, fp32 MFMA 32x32x2): the parameter
+// pointer table, the packed-weight layout and the table-driven dense-layer loop used by both the rollout
+// inference kernel (wbc_policy_kernel.hip) and the PPO update kernels (wbc_ppo_kernel.hip).
 //
-// Forward GEMMs read their B operand (W^T fragments) from a PRE-PACKED copy of the weights: for layer l,
-// k-pair kb and 32-column block cb, the 64 floats that the 64 lanes of a wave feed to one
-// v_mfma_f32_32x32x2_f32 are contiguous (lane L gets W[cb*32 + (L&31)][2*kb + (L>>5)]), so a wave's
-// operand load is one coalesced 256-byte global load served by L2 (the packed table is 0.7 MB and shared
-// by every workgroup) -- no staging through LDS, no barrier per layer.
+// Two measured facts shape this file (profiles/ and DESIGN.md section 5):
+//  * Forward GEMMs read their B operand (W^T fragments) from a PRE-PACKED copy of the weights: for layer l,
+//    k-pair kb and 32-column block cb, the 64 floats that the 64 lanes of a wave feed to one
+//    v_mfma_f32_32x32x2_f32 are contiguous (lane L gets W[cb*32 + (L&31)][2*kb + (L>>5)]), so a wave's operand
+//    load is one coalesced 256-byte global load served by L2, requested one layer ahead of its use.
+//  * The layer chain is a LOOP over a descriptor table, not 16 unrolled template instances: fully unrolled, the
+//    inference kernel was 51 KB of straight-line code (the update kernel 123 KB) against a 64 KB instruction
+//    cache, and ran at ~300 cycles per 64-byte instruction line -- 3.5x slower than its MFMA time.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,25 +46,59 @@ __host__ __device__ constexpr int layer_in(int l) { return l == L_PRIV0 ? 24 : l
 __host__ __device__ constexpr int layer_nblk(int l) { return (layer_out(l) + 31) / 32; }
 __host__ __device__ constexpr int layer_pack_floats(int l) { return layer_in(l) / 2 * layer_nblk(l) * 64; }
 __host__ __device__ constexpr int layer_pack_off(int l) { return l == 0 ? 0 : layer_pack_off(l - 1) + layer_pack_floats(l - 1); }
-#define WPACK_FLOATS (layer_pack_off(NLAYERS - 1) + layer_pack_floats(NLAYERS - 1))
+__host__ __device__ constexpr int layer_bias_off(int l) { return l == 0 ? 0 : layer_bias_off(l - 1) + layer_out(l - 1); }
+#define WPACK_WEIGHT_FLOATS (layer_pack_off(NLAYERS - 1) + layer_pack_floats(NLAYERS - 1))
+#define WPACK_BIAS_FLOATS (layer_bias_off(NLAYERS - 1) + layer_out(NLAYERS - 1))
+#define WPACK_FLOATS (WPACK_WEIGHT_FLOATS + WPACK_BIAS_FLOATS)      // packed weights, then all biases back to back
 
 enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2 };
 
-template <int ACT>
-static __device__ __forceinline__ float apply_act(float x) {
-  if (ACT == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;   // abs error <= 1 ulp(1.0); the derivative uses the stored value
-  if (ACT == ACT_TANH) return tanhf(x);
+// LDS layout shared by the kernels: offsets in floats from the workgroup's LDS base
+#define S_X 0                                   // x[32][101]: obs[:, :100]
+#define S_A0 (PT_ROWS * 101)                    // a0, a1, a2 [32][LDA]
+#define S_A1 (S_A0 + PT_ROWS * LDA)
+#define S_A2 (S_A1 + PT_ROWS * LDA)
+#define S_OUTV (S_A2 + PT_ROWS * LDA)           // outv[32][21]: mean 18, values 2
+#define S_END (S_OUTV + PT_ROWS * 21)
+
+struct FwdDesc {            // one forward layer: out = act(in * W^T + b)
+  int woff, boff, kb, nblk, n;       // packed-weight offset, bias offset (from the bias region), K/2, 32-col blocks, outputs
+  int in_off, ldi, out_off, ldo;     // LDS float offsets (out_off includes the column offset) and row strides
+  int act, scol;                     // activation; column in the activation stash (-1: not stashed)
+};
+struct FwdTable { FwdDesc l[NLAYERS]; };
+
+// The 16 layers of the teacher-path ActorCritic. priv2 writes the latent next to the proprio block that the caller
+// has already copied into a1[:, :76], so the backbone reads z = [prop, latent] from a1 with no step in between.
+static inline FwdTable make_fwd_table(const int* stash_cols /* NLAYERS entries or nullptr */) {
+  FwdTable t;
+  const int in_off[NLAYERS] = {S_X + PT_NPROP, S_A0, S_A1, S_A2, S_A0, S_A1, S_A2, S_A0, S_A1, S_X, S_A2, S_A0, S_A1, S_A2, S_A0, S_A1};
+  const int ldi[NLAYERS] = {101, LDA, LDA, LDA, LDA, LDA, LDA, LDA, LDA, 101, LDA, LDA, LDA, LDA, LDA, LDA};
+  const int out_off[NLAYERS] = {S_A0, S_A1 + PT_NPROP, S_A2, S_A0, S_A1, S_OUTV, S_A0, S_A1, S_OUTV + PT_NLEG, S_A2, S_A0, S_A1, S_OUTV + 18,
+                                S_A0, S_A1, S_OUTV + 19};
+  const int ldo[NLAYERS] = {LDA, LDA, LDA, LDA, LDA, 21, LDA, LDA, 21, LDA, LDA, LDA, 21, LDA, LDA, 21};
+  const int act[NLAYERS] = {ACT_ELU, ACT_ELU, ACT_ELU, ACT_ELU, ACT_ELU, ACT_TANH, ACT_ELU, ACT_ELU, ACT_TANH, ACT_ELU, ACT_ELU, ACT_ELU, ACT_NONE,
+                            ACT_ELU, ACT_ELU, ACT_NONE};
+  for (int l = 0; l < NLAYERS; ++l)
+    t.l[l] = FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off[l], ldi[l], out_off[l], ldo[l],
+                     act[l], stash_cols ? stash_cols[l] : -1};
+  return t;
+}
+
+static __device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;   // abs error <= 1 ulp(1.0); the derivative uses the stored value
+  if (act == ACT_TANH) return tanhf(x);
   return x;
 }
 
-// Pack all 16 weight matrices into the fragment order described above. grid = (blocks, NLAYERS).
+// Pack all 16 weight matrices into the fragment order described above and append the biases. grid = (blocks, NLAYERS).
 static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict__ wpack) {
   const int l = blockIdx.y;
   const float* const* wp = reinterpret_cast<const float* const*>(&P);
   const float* W = wp[2 * l];
-  int N = 128, K = 128, off = 0;
-  // constexpr tables evaluated per layer at run time
-  for (int j = 0; j < NLAYERS; ++j) if (j == l) { N = layer_out(j); K = layer_in(j); off = layer_pack_off(j); }
+  const float* bsrc = wp[2 * l + 1];
+  int N = 128, K = 128, off = 0, boff = 0;
+  for (int j = 0; j < NLAYERS; ++j) if (j == l) { N = layer_out(j); K = layer_in(j); off = layer_pack_off(j); boff = layer_bias_off(j); }
   const int nblk = (N + 31) / 32, total = K / 2 * nblk * 64;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int lane = e & 63, frag = e >> 6;
@@ -69,6 +106,8 @@ static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict
     const int n = cb * 32 + (lane & 31), k = 2 * kb + (lane >> 5);
     wpack[off + e] = (n < N) ? W[(size_t)n * K + k] : 0.f;
   }
+  if (blockIdx.x == 0)
+    for (int e = threadIdx.x; e < N; e += blockDim.x) wpack[WPACK_WEIGHT_FLOATS + boff + e] = bsrc[e];
 }
 
 // x[32, 100] (LDS, row stride 101) <- src rows' first 100 floats. 800 float4 loads, <= 4 per thread, all in flight
@@ -97,59 +136,89 @@ static __device__ __forceinline__ void load_x_tile(float* x, F row_ptr) {
   }
 }
 
-// ---- forward layer, split into an operand prefetch and the MFMA chain ---------------------------------
-// load_frags<L>: the K/2 B-fragments of this wave's 32-column block of layer L, one coalesced 256-byte load
-// each, all issued back to back (K/2 <= 64 loads in flight). Call it BEFORE running the previous layer so that
-// the L2 latency hides under that layer's MFMAs.
-template <int L>
-static __device__ __forceinline__ void load_frags(float (&w)[64], const float* __restrict__ wpack) {
-  constexpr int NBLK = layer_nblk(L), KB = layer_in(L) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < NBLK) {
-    const float* bp = wpack + layer_pack_off(L) + wave * 64 + lane;
+// ---- one MFMA operand set: 64 registers per lane ---------------------------------------------------------
+// The B fragments of a wave's 32-column block, k-pairs 0..kb-1, requested in chunks of 16 (a uniform predicate per
+// chunk keeps the code compact: the same 64 load instructions serve every layer). `base` points at this wave's first
+// fragment for this lane; consecutive k-pairs are `stride` floats apart; loads past kb re-read k-pair 0 (unused).
+static __device__ __forceinline__ void load_operands(float (&w)[64], const float* __restrict__ base, size_t stride, int kb, bool active) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) w[kb] = bp[(size_t)kb * NBLK * 64];
+  for (int c = 0; c < 4; ++c) {
+    if (active && c * 16 < kb) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = c * 16 + j;
+        w[k] = base[(size_t)(k < kb ? k : 0) * stride];
+      }
+    }
   }
 }
 
-// out[32, N] = act(in[32, K] * W^T + b) for layer L with the fragments already in registers. `in`/`out` live in
-// LDS (row strides ldi/ldo); wave w owns output columns [32w, 32w+32). With STASH the activated outputs of valid
-// rows also go to stash[(row0+row)*lds + scol + col]. Ends with a barrier.
-template <int L, int ACT, bool STASH>
-static __device__ __forceinline__ void mma_layer(const float* in, int ldi, const float (&w)[64], const float* __restrict__ b, float* out,
-                                                 int ldo, int col_off, float* __restrict__ stash = nullptr, int lds = 0, int scol = 0,
-                                                 int row0 = 0, int num_rows = 0) {
-  constexpr int N = layer_out(L), NBLK = layer_nblk(L), KB = layer_in(L) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < NBLK) {
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* ap = in + (lane & 31) * ldi + (lane >> 5);
+// acc += sum_{k < kb} A[.., 2k + half] * w[k], A from LDS (ap = this lane's row/half). Each chunk of 16 k-pairs
+// reads its 16 A operands first and then issues its MFMAs; chunks are guarded by uniform predicates.
+static __device__ __forceinline__ void mfma_chain(const float* ap, const float (&w)[64], int kb, f32x16& acc) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kb], w[kb], acc, 0, 0, 0);
+  for (int c = 0; c < 4; ++c) {
+    if (c * 16 < kb) {
+      float a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = ap[2 * (c * 16 + j)];       // reads past the row's k range stay inside LDS
+      if (c * 16 + 16 <= kb) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[c * 16 + j], acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (c * 16 + j < kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[c * 16 + j], acc, 0, 0, 0);
+      }
+    }
+  }
+}
+
+// Request the fragments of forward layer d for this wave.
+static __device__ __forceinline__ void fwd_load(float (&w)[64], const FwdDesc& d, const float* __restrict__ wpack) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_operands(w, wpack + d.woff + wave * 64 + lane, (size_t)d.nblk * 64, d.kb, wave < d.nblk);
+}
+
+// Run forward layer d with its fragments in `w`. smem = LDS base (floats). Outputs go to LDS and, if d.scol >= 0, to
+// stash[(row0+row)*lds + d.scol + col] for valid rows. Ends with a barrier.
+static __device__ __forceinline__ void fwd_run(const float (&w)[64], const FwdDesc& d, float* smem, const float* __restrict__ bias_base,
+                                               float* __restrict__ stash, int lds, int row0, int num_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < d.nblk) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5), w, d.kb, acc);
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col = wave * 32 + (lane & 31);
-    if (col < N) {
-      const float bias = b[col];
+    if (col < d.n) {
+      const float bias = bias_base[d.boff + col];
+      float* out = smem + d.out_off + col;
+      const bool do_stash = stash != nullptr && d.scol >= 0;
       const bool full = row0 + PT_ROWS <= num_rows;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float v = apply_act<ACT>(acc[r] + bias);
-        out[row * ldo + col_off + col] = v;
-        if (STASH && (full || row0 + row < num_rows)) stash[(size_t)(row0 + row) * lds + scol + col] = v;
+        const float v = apply_act(acc[r] + bias, d.act);
+        out[row * d.ldo] = v;
+        if (do_stash && (full || row0 + row < num_rows)) stash[(size_t)(row0 + row) * lds + d.scol + col] = v;
       }
     }
   }
   __syncthreads();
 }
 
-// one-shot form (operands requested and consumed in the same call)
-template <int L, int ACT>
-static __device__ __forceinline__ void fused_layer(const float* in, int ldi, const float* __restrict__ wpack, const float* __restrict__ b,
-                                                   float* out, int ldo, int col_off, float* __restrict__ stash = nullptr, int lds = 0,
-                                                   int scol = 0, int row0 = 0, int num_rows = 0) {
-  float w[64];
-  load_frags<L>(w, wpack);
-  if (stash) mma_layer<L, ACT, true>(in, ldi, w, b, out, ldo, col_off, stash, lds, scol, row0, num_rows);
-  else mma_layer<L, ACT, false>(in, ldi, w, b, out, ldo, col_off);
+// The whole 16-layer forward chain: two register sets alternate so that layer l+1's operands are in flight while
+// layer l's MFMA chain runs. The loop body (two layers) is the only copy of the layer code in the kernel.
+static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem, const float* __restrict__ wpack, float* __restrict__ stash,
+                                                 int lds, int row0, int num_rows) {
+  const float* bias_base = wpack + WPACK_WEIGHT_FLOATS;
+  float wa[64], wb[64];
+  fwd_load(wa, T.l[0], wpack);
+#pragma unroll 1
+  for (int l = 0; l < NLAYERS; l += 2) {
+    fwd_load(wb, T.l[l + 1], wpack);
+    fwd_run(wa, T.l[l], smem, bias_base, stash, lds, row0, num_rows);
+    if (l + 2 < NLAYERS) fwd_load(wa, T.l[l + 2], wpack);
+    fwd_run(wb, T.l[l + 1], smem, bias_base, stash, lds, row0, num_rows);
+  }
 }

@@ -37,161 +37,165 @@ struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minib
   int use_clipped_value_loss;
 };
 
-struct __align__(16) PpoSmem {
-  float x[PT_ROWS * 101];
-  float a0[PT_ROWS * LDA], a1[PT_ROWS * LDA], a2[PT_ROWS * LDA];
-  float outv[PT_ROWS * 21];       // mean 18, values 2
-  float g[PT_ROWS * 41];          // output grads: dmu 18, dv 2, dlat 20
+#define S_G S_END                      // g[32][41]: output grads dmu 18, dv 2, dlat 20
+#define S_PPO_END (S_G + PT_ROWS * 41)
+
+// ---- backward stages ------------------------------------------------------------------------------------
+// stage = [pre-step] ; buf <- buf * act'(A) (also to the DZ stash) ; [out (+)= buf * W on MFMA]
+enum { PRE_NONE = 0, PRE_OUTER_V0, PRE_OUTER_V1, PRE_COPY_LEG, PRE_COPY_ARM, PRE_LATENT };
+struct BwdDesc {
+  int pre; const float* wvec; int src_off;       // pre-step; for PRE_OUTER_*: the [128] last-layer weight row; for PRE_LATENT: dA_z buffer
+  int buf_off, n, act, acol, dcol;                // activation-derivative pass over buf[32, n]
+  int has_mma; const float* W; int out_dim, in_dim, out_off, accumulate;   // out[32, in_dim] (+)= buf[32, out_dim] * W[out_dim, in_dim]
 };
+#define NBWD 14
+struct BwdTable { BwdDesc s[NBWD]; };
 
-// Backward GEMM out[32, IN] (+)= dz[32, OUT] * W[OUT, IN]. The B operand W[k][col] is read straight from global
-// memory (a wave's fragment is two runs of 32 consecutive floats of W, i.e. coalesced as stored), prefetched into
-// registers by load_wrows one stage ahead of the MFMA chain that consumes it.
-template <int OUT, int IN>
-static __device__ __forceinline__ void load_wrows(float (&w)[64], const float* __restrict__ W) {
-  constexpr int NBLK = (IN + 31) / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < NBLK) {
-    const int col = wave * 32 + (lane & 31);
-    const bool col_ok = col < IN;
-    const float* bp = W + (size_t)(lane >> 5) * IN + (col_ok ? col : 0);
-#pragma unroll
-    for (int t = 0; t < OUT / 2; ++t) { const float v = bp[(size_t)(2 * t) * IN]; w[t] = col_ok ? v : 0.f; }
-  }
-}
-template <int OUT, int IN, bool ACCUMULATE>
-static __device__ __forceinline__ void bwd_mma(const float* dz, int ldz, const float (&w)[64], float* out, int ldo) {
-  constexpr int NBLK = (IN + 31) / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < NBLK) {
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int col = wave * 32 + (lane & 31);
-    const float* ap = dz + (lane & 31) * ldz + (lane >> 5);
-#pragma unroll
-    for (int t = 0; t < OUT / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t], w[t], acc, 0, 0, 0);
-    if (col < IN) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float* o = &out[row * ldo + col];
-        *o = ACCUMULATE ? (*o + acc[r]) : acc[r];
-      }
-    }
-  }
-  __syncthreads();
+static BwdTable make_bwd_table(const PolicyParams& P) {
+  BwdTable t;
+  int i = 0;
+  auto add = [&](int pre, const float* wvec, int src, int buf, int n, int act, int acol, int dcol, const float* W, int od, int id, int out, int acc) {
+    t.s[i++] = BwdDesc{pre, wvec, src, buf, n, act, acol, dcol, W != nullptr, W, od, id, out, acc};
+  };
+  // critic
+  add(PRE_OUTER_V0, P.cleg4_w, 0, S_A0, 128, ACT_ELU, A_CL2, D_CL2, P.cleg2_w, 128, 128, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CL1, D_CL1, P.cleg0_w, 128, 128, S_A2, 0);
+  add(PRE_OUTER_V1, P.carm4_w, 0, S_A0, 128, ACT_ELU, A_CA2, D_CA2, P.carm2_w, 128, 128, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CA1, D_CA1, P.carm0_w, 128, 128, S_A2, 1);
+  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_CB, D_CB, nullptr, 0, 0, 0, 0);
+  // actor
+  add(PRE_COPY_LEG, nullptr, 0, S_A0, PT_NLEG, ACT_TANH, A_LEG, D_LEG, P.leg4_w, PT_NLEG, 128, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_L2, D_L2, P.leg2_w, 128, 128, S_A0, 0);
+  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_L1, D_L1, P.leg0_w, 128, 128, S_A2, 0);
+  add(PRE_COPY_ARM, nullptr, 0, S_A0, PT_NARM, ACT_TANH, A_ARM, D_ARM, P.arm4_w, PT_NARM, 128, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_A2, D_A2, P.arm2_w, 128, 128, S_A0, 0);
+  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_A1, D_A1, P.arm0_w, 128, 128, S_A2, 1);
+  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_BB, D_BB, P.bb_w, 128, 96, S_A0, 0);
+  add(PRE_LATENT, nullptr, S_A0, S_A1, 20, ACT_ELU, A_LAT, D_LAT, P.priv2_w, 20, 64, S_A0, 0);
+  add(PRE_NONE, nullptr, 0, S_A0, 64, ACT_ELU, A_H1, D_H1, nullptr, 0, 0, 0, 0);
+  return t;
 }
 
-// buf[32, N] <- buf * act'(A) with A the stashed post-activation (elu' = a > 0 ? 1 : a + 1, tanh' = 1 - a^2);
-// the result also goes to the DZ stash. float4 global accesses, all of a thread's loads in flight together.
-template <int ACT>
+// Request the B operand of a backward stage: W[k][col] straight from global memory (a wave's fragment is two runs of
+// 32 consecutive floats of W, coalesced as stored). Columns past in_dim read column 0 and are zeroed.
+static __device__ __forceinline__ void bwd_load(float (&w)[64], const BwdDesc& d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = wave * 32 + (lane & 31);
+  const bool active = d.has_mma && wave * 32 < d.in_dim;
+  const bool col_ok = col < d.in_dim;
+  load_operands(w, d.W + (size_t)(lane >> 5) * d.in_dim + (col_ok ? col : 0), (size_t)2 * d.in_dim, d.out_dim / 2, active);
+  if (active && !col_ok) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) w[k] = 0.f;
+  }
+}
+
+template <int ACTV>
 static __device__ __forceinline__ float act_deriv(float a) {
-  return (ACT == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : ((ACT == ACT_TANH) ? 1.f - a * a : 1.f);
-}
-template <int N, int ACT>
-static __device__ __forceinline__ void act_grad(float* buf, int ld, const float* __restrict__ act_stash, int acol, float* __restrict__ dz_stash,
-                                                int dcol, int row0, int num_rows) {
-  const int tid = threadIdx.x;
-  if (N % 4 == 0) {
-    constexpr int Q = N / 4, TOT = PT_ROWS * Q, PER = (TOT + PT_THREADS - 1) / PT_THREADS;
-    float4 a[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int e = tid + j * PT_THREADS, r = e / Q, c = (e - r * Q) * 4;
-      a[j] = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (e < TOT && row0 + r < num_rows) a[j] = *reinterpret_cast<const float4*>(act_stash + (size_t)(row0 + r) * A_LD + acol + c);
-    }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int e = tid + j * PT_THREADS, r = e / Q, c = (e - r * Q) * 4;
-      if (e < TOT) {
-        float* bp = buf + r * ld + c;
-        const bool ok = row0 + r < num_rows;
-        float4 v;
-        v.x = ok ? bp[0] * act_deriv<ACT>(a[j].x) : 0.f; v.y = ok ? bp[1] * act_deriv<ACT>(a[j].y) : 0.f;
-        v.z = ok ? bp[2] * act_deriv<ACT>(a[j].z) : 0.f; v.w = ok ? bp[3] * act_deriv<ACT>(a[j].w) : 0.f;
-        bp[0] = v.x; bp[1] = v.y; bp[2] = v.z; bp[3] = v.w;
-        if (ok) *reinterpret_cast<float4*>(dz_stash + (size_t)(row0 + r) * D_LD + dcol + c) = v;
-      }
-    }
-  } else {
-    for (int e = tid; e < PT_ROWS * N; e += PT_THREADS) {
-      const int r = e / N, c = e - r * N;
-      float v = 0.f;
-      if (row0 + r < num_rows) {
-        v = buf[r * ld + c] * act_deriv<ACT>(act_stash[(size_t)(row0 + r) * A_LD + acol + c]);
-        dz_stash[(size_t)(row0 + r) * D_LD + dcol + c] = v;
-      }
-      buf[r * ld + c] = v;
-    }
-  }
-  __syncthreads();
+  return (ACTV == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : 1.f - a * a;
 }
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(PolicyParams P, const float* __restrict__ wpack, PpoBatch Bt,
-                                                                           float* __restrict__ act_stash, float* __restrict__ dz_stash,
-                                                                           float* __restrict__ dstd_partial, float* __restrict__ loss_partial) {
-  __shared__ PpoSmem s;
-  const int tid = threadIdx.x, lane = tid & 63;
+static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDesc& d, float* smem, const float* __restrict__ act_stash,
+                                               float* __restrict__ dz_stash, int row0, int num_rows) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* buf = smem + d.buf_off;
+  const float* g = smem + S_G;
+  // pre-step
+  if (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) {          // dA = dZ_v (x) W_last (1 x 128)
+    const int gi = (d.pre == PRE_OUTER_V0) ? 18 : 19;
+    for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) { const int r = e >> 7, c = e & 127; buf[r * LDA + c] = g[r * 41 + gi] * d.wvec[c]; }
+    __syncthreads();
+  } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
+    const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
+    for (int e = tid; e < PT_ROWS * n; e += PT_THREADS) { const int r = e / n, c = e - r * n; buf[r * LDA + c] = g[r * 41 + go + c]; }
+    __syncthreads();
+  } else if (d.pre == PRE_LATENT) {                                // d latent = dA_z[:, 76:96] + ROA gradient
+    const float* src = smem + d.src_off;
+    for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) { const int r = e / 20, c = e - r * 20; buf[r * LDA + c] = src[r * LDA + PT_NPROP + c] + g[r * 41 + 20 + c]; }
+    __syncthreads();
+  }
+  // buf <- buf * act'(A) with A the stashed post-activation; float2 global accesses, up to 8 per thread in flight
+  {
+    const int q = d.n >> 1, tot = PT_ROWS * q;
+    float2 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
+      a[j] = make_float2(1.f, 1.f);
+      if (e < tot && row0 + r < num_rows) a[j] = *reinterpret_cast<const float2*>(act_stash + (size_t)(row0 + r) * A_LD + d.acol + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
+      if (e < tot) {
+        float* bp = buf + r * LDA + c;
+        const bool ok = row0 + r < num_rows;
+        float2 v;
+        if (d.act == ACT_ELU) { v.x = bp[0] * act_deriv<ACT_ELU>(a[j].x); v.y = bp[1] * act_deriv<ACT_ELU>(a[j].y); }
+        else { v.x = bp[0] * act_deriv<ACT_TANH>(a[j].x); v.y = bp[1] * act_deriv<ACT_TANH>(a[j].y); }
+        if (!ok) v = make_float2(0.f, 0.f);
+        bp[0] = v.x; bp[1] = v.y;
+        if (ok) *reinterpret_cast<float2*>(dz_stash + (size_t)(row0 + r) * D_LD + d.dcol + c) = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (d.has_mma) {
+    if (wave * 32 < d.in_dim) {
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      mfma_chain(buf + (lane & 31) * LDA + (lane >> 5), w, d.out_dim / 2, acc);
+      const int col = wave * 32 + (lane & 31);
+      if (col < d.in_dim) {
+        float* out = smem + d.out_off + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          out[row * LDA] = d.accumulate ? out[row * LDA] + acc[r] : acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(PolicyParams P, FwdTable FT, BwdTable BT, const float* __restrict__ wpack,
+                                                                           PpoBatch Bt, float* __restrict__ act_stash,
+                                                                           float* __restrict__ dz_stash, float* __restrict__ dstd_partial,
+                                                                           float* __restrict__ loss_partial) {
+  __shared__ float smem[S_PPO_END];
+  const int tid = threadIdx.x;
   const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
-  // gather obs[idx, :100] (float4 loads, all in flight) and stash it as the input of priv0 / critic backbone
-  load_x_tile(s.x, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
+  // gather obs[idx, :100] (float4 loads, all in flight); stash it (input of priv0 / critic backbone) and copy the proprio
+  // block to a1[:, :76], next to where priv2 will put the latent
+  load_x_tile(smem + S_X, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
   __syncthreads();
   for (int e = tid; e < PT_ROWS * 25; e += PT_THREADS) {
     const int r = e / 25, c = (e - r * 25) * 4;
     if (row0 + r < B) {
-      const float* xp = s.x + r * 101 + c;
+      const float* xp = smem + S_X + r * 101 + c;
       *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_X + c) = make_float4(xp[0], xp[1], xp[2], xp[3]);
     }
   }
-  // ---------------- forward (same chain as wbc_policy_act_kernel), post-activations stashed. Two register sets of
-  // weight fragments alternate so that the next layer's operands are in flight during the current MFMA chain.
-  float wa[64], wb[64];
-  load_frags<L_PRIV0>(wa, wpack);
-  load_frags<L_PRIV2>(wb, wpack);
-  mma_layer<L_PRIV0, ACT_ELU, true>(s.x + PT_NPROP, 101, wa, P.priv0_b, s.a0, LDA, 0, act_stash, A_LD, A_H1, row0, B);
-  load_frags<L_BB>(wa, wpack);
-  mma_layer<L_PRIV2, ACT_ELU, true>(s.a0, LDA, wb, P.priv2_b, s.a1, LDA, PT_NPROP, act_stash, A_LD, A_LAT, row0, B);
   for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
     const int r = e / PT_NPROP, c = e - r * PT_NPROP;
-    s.a1[r * LDA + c] = s.x[r * 101 + c];
+    smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
   }
+  // ---------------- forward (table-driven, wbc_mlp.h), post-activations stashed
+  fwd_chain(FT, smem, wpack, act_stash, A_LD, row0, B);
+  __threadfence_block();
   __syncthreads();
-  for (int e = tid; e < PT_ROWS * 24; e += PT_THREADS) {          // z = [prop, latent], the backbone's input, for its weight gradient
+  // z = [prop, latent], the backbone's input, for its weight gradient: prop from x, latent from the stash just written
+  for (int e = tid; e < PT_ROWS * 24; e += PT_THREADS) {
     const int r = e / 24, c = (e - r * 24) * 4;
     if (row0 + r < B) {
-      const float* zp = s.a1 + r * LDA + c;
-      *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_Z + c) = make_float4(zp[0], zp[1], zp[2], zp[3]);
+      float4 v;
+      if (c < PT_NPROP) { const float* xp = smem + S_X + r * 101 + c; v = make_float4(xp[0], xp[1], xp[2], xp[3]); }
+      else v = *reinterpret_cast<const float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_LAT + (c - PT_NPROP));
+      *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_Z + c) = v;
     }
   }
-  load_frags<L_LEG0>(wb, wpack);
-  mma_layer<L_BB, ACT_ELU, true>(s.a1, LDA, wa, P.bb_b, s.a2, LDA, 0, act_stash, A_LD, A_BB, row0, B);
-  load_frags<L_LEG2>(wa, wpack);
-  mma_layer<L_LEG0, ACT_ELU, true>(s.a2, LDA, wb, P.leg0_b, s.a0, LDA, 0, act_stash, A_LD, A_L1, row0, B);
-  load_frags<L_LEG4>(wb, wpack);
-  mma_layer<L_LEG2, ACT_ELU, true>(s.a0, LDA, wa, P.leg2_b, s.a1, LDA, 0, act_stash, A_LD, A_L2, row0, B);
-  load_frags<L_ARM0>(wa, wpack);
-  mma_layer<L_LEG4, ACT_TANH, true>(s.a1, LDA, wb, P.leg4_b, s.outv, 21, 0, act_stash, A_LD, A_LEG, row0, B);
-  load_frags<L_ARM2>(wb, wpack);
-  mma_layer<L_ARM0, ACT_ELU, true>(s.a2, LDA, wa, P.arm0_b, s.a0, LDA, 0, act_stash, A_LD, A_A1, row0, B);
-  load_frags<L_ARM4>(wa, wpack);
-  mma_layer<L_ARM2, ACT_ELU, true>(s.a0, LDA, wb, P.arm2_b, s.a1, LDA, 0, act_stash, A_LD, A_A2, row0, B);
-  load_frags<L_CBB>(wb, wpack);
-  mma_layer<L_ARM4, ACT_TANH, true>(s.a1, LDA, wa, P.arm4_b, s.outv, 21, PT_NLEG, act_stash, A_LD, A_ARM, row0, B);
-  load_frags<L_CLEG0>(wa, wpack);
-  mma_layer<L_CBB, ACT_ELU, true>(s.x, 101, wb, P.cbb_b, s.a2, LDA, 0, act_stash, A_LD, A_CB, row0, B);
-  load_frags<L_CLEG2>(wb, wpack);
-  mma_layer<L_CLEG0, ACT_ELU, true>(s.a2, LDA, wa, P.cleg0_b, s.a0, LDA, 0, act_stash, A_LD, A_CL1, row0, B);
-  load_frags<L_CLEG4>(wa, wpack);
-  mma_layer<L_CLEG2, ACT_ELU, true>(s.a0, LDA, wb, P.cleg2_b, s.a1, LDA, 0, act_stash, A_LD, A_CL2, row0, B);
-  load_frags<L_CARM0>(wb, wpack);
-  mma_layer<L_CLEG4, ACT_NONE, false>(s.a1, LDA, wa, P.cleg4_b, s.outv, 21, 18);
-  load_frags<L_CARM2>(wa, wpack);
-  mma_layer<L_CARM0, ACT_ELU, true>(s.a2, LDA, wb, P.carm0_b, s.a0, LDA, 0, act_stash, A_LD, A_CA1, row0, B);
-  load_frags<L_CARM4>(wb, wpack);
-  mma_layer<L_CARM2, ACT_ELU, true>(s.a0, LDA, wa, P.carm2_b, s.a1, LDA, 0, act_stash, A_LD, A_CA2, row0, B);
-  mma_layer<L_CARM4, ACT_NONE, false>(s.a1, LDA, wb, P.carm4_b, s.outv, 21, 19);
-  // first backward operands: requested now, consumed after the loss epilogue
-  load_wrows<128, 128>(wa, P.cleg2_w);
+  const float* outv = smem + S_OUTV;
+  float* gbuf = smem + S_G;
   // ---------------- losses and output gradients: one row per lane of wave 0
   if (tid < 64) {
     const int r = tid & 31;
@@ -206,7 +210,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
       float lp[2] = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 18; ++j) {
-        const float mu = s.outv[r * 21 + j], sd = P.std[j];
+        const float mu = outv[r * 21 + j], sd = P.std[j];
         const float d = Bt.actions[src * 18 + j] - mu;
         lp[j < PT_NLEG ? 0 : 1] += -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
       }
@@ -223,7 +227,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
         const float dr = (inside || s1 > s2) ? -mixed[c] : 0.f;                                   // d max(s1,s2) / d ratio
         dlp[c] = inv2B * dr * ratio;
         // value loss PPO:209-216
-        const float v = s.outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];
+        const float v = outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];
         float dv;
         if (Bt.use_clipped_value_loss) {
           const float dlt = v - ov;
@@ -237,14 +241,14 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
           vls += (R - v) * (R - v);
           dv = 2.f * (v - R);
         }
-        s.g[r * 41 + 18 + c] = Bt.value_coef * inv2B * dv;
+        gbuf[r * 41 + 18 + c] = Bt.value_coef * inv2B * dv;
       }
 #pragma unroll
       for (int j = 0; j < 18; ++j) {
-        const float mu = s.outv[r * 21 + j], sd = P.std[j];
+        const float mu = outv[r * 21 + j], sd = P.std[j];
         const float d = Bt.actions[src * 18 + j] - mu;
         const float gl = dlp[j < PT_NLEG ? 0 : 1];
-        s.g[r * 41 + j] = gl * d / (sd * sd);                                                    // d logp / d mu
+        gbuf[r * 41 + j] = gl * d / (sd * sd);                                                    // d logp / d mu
         dsd[j] = gl * (d * d / (sd * sd * sd) - 1.f / sd);                                       // d logp / d sigma
       }
       // ROA regulariser PPO:174-179: mean_B || priv_latent - hist_latent ||_2
@@ -258,9 +262,9 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
       preg = nrm;
       const float sc = (nrm > 0.f) ? Bt.roa_coef * invB / nrm : 0.f;
 #pragma unroll
-      for (int k = 0; k < 20; ++k) s.g[r * 41 + 20 + k] = sc * dl[k];
+      for (int k = 0; k < 20; ++k) gbuf[r * 41 + 20 + k] = sc * dl[k];
     } else if (tid < PT_ROWS) {
-      for (int k = 0; k < 40; ++k) s.g[r * 41 + k] = 0.f;
+      for (int k = 0; k < 40; ++k) gbuf[r * 41 + k] = 0.f;
     }
     // reduce the tile's loss sums and sigma gradients over the 32 rows (lanes 32..63 carry zeros)
 #pragma unroll
@@ -276,75 +280,22 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
     }
   }
   __syncthreads();
-  (void)lane;
-  // ---------------- backward: critic
-  for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) {          // dA_cl2 = dZ_vleg (x) W_cleg4 (1 x 128)
-    const int r = e >> 7, c = e & 127;
-    s.a0[r * LDA + c] = s.g[r * 41 + 18] * P.cleg4_w[c];
-  }
+  // ---------------- backward: 14 table-driven stages, the next stage's weight rows in flight during the current one
   if (tid < PT_ROWS && row0 + tid < B) {
-    dz_stash[(size_t)(row0 + tid) * D_LD + D_VLEG] = s.g[tid * 41 + 18];
-    dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = s.g[tid * 41 + 19];
+    dz_stash[(size_t)(row0 + tid) * D_LD + D_VLEG] = gbuf[tid * 41 + 18];
+    dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = gbuf[tid * 41 + 19];
   }
-  __syncthreads();
-  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_CL2, dz_stash, D_CL2, row0, B);
-  load_wrows<128, 128>(wb, P.cleg0_w);
-  bwd_mma<128, 128, false>(s.a0, LDA, wa, s.a1, LDA);
-  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_CL1, dz_stash, D_CL1, row0, B);
-  load_wrows<128, 128>(wa, P.carm2_w);
-  bwd_mma<128, 128, false>(s.a1, LDA, wb, s.a2, LDA);                                     // a2 = dA_cb (leg part)
-  for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) {
-    const int r = e >> 7, c = e & 127;
-    s.a0[r * LDA + c] = s.g[r * 41 + 19] * P.carm4_w[c];
+  {
+    float wa[64], wb[64];
+    bwd_load(wa, BT.s[0]);
+#pragma unroll 1
+    for (int st = 0; st < NBWD; st += 2) {
+      bwd_load(wb, BT.s[st + 1]);
+      bwd_run(wa, BT.s[st], smem, act_stash, dz_stash, row0, B);
+      if (st + 2 < NBWD) bwd_load(wa, BT.s[st + 2]);
+      bwd_run(wb, BT.s[st + 1], smem, act_stash, dz_stash, row0, B);
+    }
   }
-  __syncthreads();
-  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_CA2, dz_stash, D_CA2, row0, B);
-  load_wrows<128, 128>(wb, P.carm0_w);
-  bwd_mma<128, 128, false>(s.a0, LDA, wa, s.a1, LDA);
-  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_CA1, dz_stash, D_CA1, row0, B);
-  load_wrows<PT_NLEG, 128>(wa, P.leg4_w);
-  bwd_mma<128, 128, true>(s.a1, LDA, wb, s.a2, LDA);                                      // a2 += arm part
-  act_grad<128, ACT_ELU>(s.a2, LDA, act_stash, A_CB, dz_stash, D_CB, row0, B);
-  // ---------------- backward: actor
-  for (int e = tid; e < PT_ROWS * PT_NLEG; e += PT_THREADS) {
-    const int r = e / PT_NLEG, c = e - r * PT_NLEG;
-    s.a0[r * LDA + c] = s.g[r * 41 + c];
-  }
-  __syncthreads();
-  act_grad<PT_NLEG, ACT_TANH>(s.a0, LDA, act_stash, A_LEG, dz_stash, D_LEG, row0, B);
-  load_wrows<128, 128>(wb, P.leg2_w);
-  bwd_mma<PT_NLEG, 128, false>(s.a0, LDA, wa, s.a1, LDA);
-  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_L2, dz_stash, D_L2, row0, B);
-  load_wrows<128, 128>(wa, P.leg0_w);
-  bwd_mma<128, 128, false>(s.a1, LDA, wb, s.a0, LDA);
-  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_L1, dz_stash, D_L1, row0, B);
-  load_wrows<PT_NARM, 128>(wb, P.arm4_w);
-  bwd_mma<128, 128, false>(s.a0, LDA, wa, s.a2, LDA);                                     // a2 = dA_bb (leg part)
-  for (int e = tid; e < PT_ROWS * PT_NARM; e += PT_THREADS) {
-    const int r = e / PT_NARM, c = e - r * PT_NARM;
-    s.a0[r * LDA + c] = s.g[r * 41 + PT_NLEG + c];
-  }
-  __syncthreads();
-  act_grad<PT_NARM, ACT_TANH>(s.a0, LDA, act_stash, A_ARM, dz_stash, D_ARM, row0, B);
-  load_wrows<128, 128>(wa, P.arm2_w);
-  bwd_mma<PT_NARM, 128, false>(s.a0, LDA, wb, s.a1, LDA);
-  act_grad<128, ACT_ELU>(s.a1, LDA, act_stash, A_A2, dz_stash, D_A2, row0, B);
-  load_wrows<128, 128>(wb, P.arm0_w);
-  bwd_mma<128, 128, false>(s.a1, LDA, wa, s.a0, LDA);
-  act_grad<128, ACT_ELU>(s.a0, LDA, act_stash, A_A1, dz_stash, D_A1, row0, B);
-  load_wrows<128, 96>(wa, P.bb_w);
-  bwd_mma<128, 128, true>(s.a0, LDA, wb, s.a2, LDA);                                      // a2 += arm part
-  act_grad<128, ACT_ELU>(s.a2, LDA, act_stash, A_BB, dz_stash, D_BB, row0, B);
-  load_wrows<20, 64>(wb, P.priv2_w);
-  bwd_mma<128, 96, false>(s.a2, LDA, wa, s.a0, LDA);                                      // a0 = dA_z [32, 96]
-  for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {                                  // d latent = dA_z[:, 76:96] + ROA gradient
-    const int r = e / 20, c = e - r * 20;
-    s.a1[r * LDA + c] = s.a0[r * LDA + PT_NPROP + c] + s.g[r * 41 + 20 + c];
-  }
-  __syncthreads();
-  act_grad<20, ACT_ELU>(s.a1, LDA, act_stash, A_LAT, dz_stash, D_LAT, row0, B);
-  bwd_mma<20, 64, false>(s.a1, LDA, wb, s.a0, LDA);
-  act_grad<64, ACT_ELU>(s.a0, LDA, act_stash, A_H1, dz_stash, D_H1, row0, B);
 }
 
 // ---- weight and bias gradients -------------------------------------------------------------------
@@ -523,7 +474,10 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   float* wpack = wpart + (size_t)PPO_NSPLIT * ng;
   hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS), dim3(256), 0, st, P, wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
-  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, wpack, Bt, act_stash, dz_stash, dstd_partial, loss_partial);
+  static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
+  const FwdTable FT = make_fwd_table(kStashCols);
+  const BwdTable BT = make_bwd_table(P);
+  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, FT, BT, wpack, Bt, act_stash, dz_stash, dstd_partial, loss_partial);
   WgradTable tab;
   int off = 0;
   for (int l = 0; l < NLAYERS; ++l) {

@@ -16,3 +16,20 @@ for n in (4096, 40960):
         for _ in range(50): ac.fused_act(obs, eps)
         e1.record(); torch.cuda.synchronize()
     print(f"fused_act rows={n}: {e0.elapsed_time(e1)/50*1000:.1f} us")
+
+# stage timing of block 0 (clock64 stamps)
+import ctypes as C
+from wbc_amd.native import lib
+L = lib()
+L.wbc_debug_set_policy_timing.argtypes = [C.c_void_p]
+buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+L.wbc_debug_set_policy_timing(buf.data_ptr())
+obs = torch.randn(4096, 860, device="cuda"); eps = torch.randn(4096, 18, device="cuda")
+with torch.inference_mode():
+    ac.fused_act(obs, eps); torch.cuda.synchronize()
+t = buf.cpu().numpy()
+n = int((t != 0).sum())
+d = (t[1:n] - t[:n-1])
+print("stamps", n, "total cycles", t[n-1] - t[0])
+print("stage cycles:", d.tolist())
+L.wbc_debug_set_policy_timing(None)
