@@ -12,7 +12,7 @@
 
 #include "wbc_device.h"
 
-extern "C" __global__ void wbc_step_kernel(DevTensors T, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
+extern "C" __global__ void wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
                                            uint64_t seed, uint64_t step);
 extern "C" __global__ void wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step);
 extern "C" __global__ void wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
@@ -52,6 +52,7 @@ struct wbc_sim {
   DevConst hc;
   DevConst* dc = nullptr;
   DevTensors T;
+  DevTensors* dT = nullptr;
   void* ptr[WBC_T_COUNT];
   char* arena = nullptr;
   bool own_arena = false;
@@ -161,6 +162,8 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
     HIP_OK(hipMemcpy(T.body_params, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(T.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
   }
+  HIP_OK(hipMalloc((void**)&s->dT, sizeof(DevTensors)));
+  HIP_OK(hipMemcpy(s->dT, &s->T, sizeof(DevTensors), hipMemcpyHostToDevice));
   HIP_OK(hipMalloc((void**)&s->dc, sizeof(DevConst)));
   HIP_OK(hipMemcpy(s->dc, &s->hc, sizeof(DevConst), hipMemcpyHostToDevice));
   *out = s;
@@ -172,6 +175,7 @@ extern "C" int wbc_sim_destroy(wbc_sim* s) {
   (void)hipSetDevice(s->device);
   if (s->own_arena && s->arena) (void)hipFree(s->arena);
   if (s->dc) (void)hipFree(s->dc);
+  if (s->dT) (void)hipFree(s->dT);
   if (s->hf_dev) (void)hipFree(s->hf_dev);
   delete s;
   return 0;
@@ -272,7 +276,7 @@ extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
 extern "C" int wbc_sim_step(wbc_sim* s, const float* actions_dev, void* stream) {
   if (!s || !actions_dev) return fail(-1, "wbc_sim_step: bad arguments");
   s->step_counter += 1;
-  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter);
+  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter);
   HIP_OK(hipGetLastError());
   return 0;
 }

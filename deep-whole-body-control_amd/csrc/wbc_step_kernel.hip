@@ -15,6 +15,10 @@
 #include "wbc_device.h"
 
 #define LANES 64
+
+// development aid: phase timestamps of block 0 (see tools/time_step.py); null in normal operation
+__device__ long long* g_step_dbg = nullptr;
+#define STAMP(i) do { if (g_step_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_step_dbg[i] = clock64(); } while (0)
 #define CH_LANES 12
 
 struct PostBuf {                  // post-physics staging; shares LDS with IA (dead once the substeps are done)
@@ -70,7 +74,7 @@ __device__ __forceinline__ void fk_pass(Smem& s, const DevConst* __restrict__ C,
   if (lane < 9) s.E[0][lane] = (lane % 4 == 0) ? 1.f : 0.f;
   if (lane < 3) s.pos[0][lane] = 0.f;
   __syncthreads();
-#pragma unroll
+#pragma unroll 1
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     const int i = cr.body[d];
     if (chain < WBC_NCHAIN && i >= 0) {
@@ -158,7 +162,9 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     st3(s.vb, matT_mul(s.R, ld3(&s.root[7])));
     st3(s.gF, matT_mul(s.R, ld3(C->cfg.gravity)));
   }
+  STAMP(0);
   fk_pass(s, C, cr, chain, k);   // begins with a barrier after the identity write, ends with one
+  STAMP(1);
   // joint screws S for all 18 joints: 108 entries
   for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
     const int i = 1 + t / 6, kk = t % 6;
@@ -174,7 +180,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   // velocities: each (chain, k<6) lane carries component k down its chain in a register
   if (in_chain && k < 6) {
     float vr = s.v[0][k];
-#pragma unroll
+#pragma unroll 1
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
       const int i = cr.body[d];
       if (i >= 0) { vr += s.S[i][k] * s.qd[cr.dof[d]]; s.v[i][k] = vr; }
@@ -192,6 +198,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     else { const f3 t2 = cross(w, jl) + cross(vl, ja); val = (kk == 3) ? t2.x : ((kk == 4) ? t2.y : t2.z); }
     s.c[i][kk] = val;
   }
+  STAMP(2);
   // spatial inertias in frame F and bias forces: one body per lane
   if (lane < WBC_NB) {
     const int i = lane;
@@ -233,8 +240,9 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     st3(&s.pA[i][3], cross(w, ff));
   }
   __syncthreads();
+  STAMP(3);
   // pass 2, inward: level d+1 of every chain in parallel
-#pragma unroll
+#pragma unroll 1
   for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
     const int i = cr.body[d];
     const bool act = in_chain && i >= 0;
@@ -285,6 +293,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     }
     __syncthreads();
   }
+  STAMP(4);
   // root: sum the five depth-1 contributions in fixed chain order
   if (lane < 36) {
     float acc = s.IA[0][lane];
@@ -302,7 +311,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   // K0 = IA0^-1 by six Gauss-Jordan sweeps, one matrix entry per lane
   {
     const int r = lane / 6, cc = lane % 6;
-#pragma unroll
+#pragma unroll 1
     for (int kk = 0; kk < 6; ++kk) {
       float val = 0.f;
       if (lane < 36) {
@@ -319,8 +328,9 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   }
   if (lane < 6) s.a[0][lane] = -dot6(&s.IA[0][lane * 6], s.pA[0]);
   __syncthreads();
+  STAMP(5);
   // pass 3 and inverse articulated inertias, outward
-#pragma unroll
+#pragma unroll 1
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     const int i = cr.body[d];
     const bool act = in_chain && i >= 0;
@@ -353,6 +363,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     }
     __syncthreads();
   }
+  STAMP(6);
   // contacts: one contact sphere per lane
   if (lane < WBC_NCP) {
     const int kc = lane;
@@ -404,6 +415,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
   if (lane < 6) AD(s)[0][lane] = 0.f;
   __syncthreads();
+  STAMP(7);
   int any = 0;
 #pragma unroll
   for (int kc = 0; kc < WBC_NCP; ++kc) any |= s.cactive[kc];
@@ -432,7 +444,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
       }
       __syncthreads();
-#pragma unroll
+#pragma unroll 1
       for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
         const int i = cr.body[d];
         if (in_chain && i >= 0 && k < 6) {
@@ -452,7 +464,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       __syncthreads();
       if (lane < 6) AD(s)[0][lane] = -dot6(&s.IA[0][lane * 6], PD(s)[0]);
       __syncthreads();
-#pragma unroll
+#pragma unroll 1
       for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
         const int i = cr.body[d];
         if (in_chain && i >= 0 && k < 6) {
@@ -471,6 +483,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       __syncthreads();
     }
   }
+  STAMP(8);
   // contact force outputs (world-frame net force per rigid body, foot-frame sensor wrench)
   if (want_outputs) {
     if (lane < WBC_NRB_ENV) {
@@ -492,6 +505,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       st3(&s.out_sensor[ft][0], fa); st3(&s.out_sensor[ft][3], ta);
     }
   }
+  STAMP(9);
   // integrate (semi-implicit Euler)
   float a0[6];
 #pragma unroll
@@ -521,6 +535,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     for (int j = 0; j < 4; ++j) s.root[3 + j] = nq[j] * nn;
   }
   __syncthreads();
+  STAMP(10);
 }
 
 // rigid_body_state of the 27 robot bodies + box from the LDS state (oracle: update_rigid_body_state).
@@ -535,7 +550,7 @@ __device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const C
   fk_pass(s, C, cr, chain, k);
   // one lane per chain walks it: world angular velocity, origin velocity, orientation
   if (chain < WBC_NCHAIN && k == 0) {
-#pragma unroll
+#pragma unroll 1
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
       const int i = cr.body[d];
       if (i >= 0) {
@@ -863,9 +878,10 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
 }
 
 // WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment.
-extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(DevTensors T, const DevConst* __restrict__ C, const float* __restrict__ actions,
+extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions,
                                                                     int num_envs, uint64_t seed, uint64_t step) {
   __shared__ Smem s;
+  const DevTensors& T = *Tp;        // read on demand through the scalar path: 32 pointers held in SGPRs spilled the kernel
   const int env = blockIdx.x;
   if (env >= num_envs) return;
   const int lane = threadIdx.x;
@@ -1010,3 +1026,8 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
+
+extern "C" void wbc_debug_set_step_timing(void* dev_buf) {
+  long long* p = (long long*)dev_buf;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_dbg), &p, sizeof(p));
+}

@@ -47,3 +47,14 @@ e0.record()
 for i in range(100): g.refresh_rigid_body_state()
 e1.record(); torch.cuda.synchronize()
 print(f"fk kernel {e0.elapsed_time(e1)/100*1000:.1f} us")
+
+import ctypes as C
+from wbc_amd.native import lib
+L = lib(); L.wbc_debug_set_step_timing.argtypes = [C.c_void_p]
+buf = torch.zeros(16, dtype=torch.int64, device="cuda")
+L.wbc_debug_set_step_timing(buf.data_ptr())
+g.simulate(); torch.cuda.synchronize()
+t = buf.cpu().numpy()
+names = ["fk", "S,v", "c(+inertia start)", "inertia", "pass2", "root inv", "pass3+K", "contact detect", "contact iters", "outputs", "integrate"]
+print("substep phase cycles (block 0):", {names[i]: int(t[i+1]-t[i]) for i in range(10)}, "total", int(t[10]-t[0]))
+L.wbc_debug_set_step_timing(None)
