@@ -137,6 +137,7 @@ def main():
 
     cfg = WidowGo1RoughCfg()
     cfg.env.num_envs = args.envs_per_gpu
+    cfg.terrain.mesh_type = "plane"                   # BASELINE.json configs[1]: flat terrain (the shipped default is the Perlin trimesh)
     train_cfg = WidowGo1RoughCfgPPO()
     torch.manual_seed(train_cfg.seed)                 # identical replicas; env RNG differs per rank
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)

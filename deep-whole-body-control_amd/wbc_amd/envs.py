@@ -127,9 +127,17 @@ class WidowGo1(LeggedRobot):
         self._randomise()
 
     def _terrain_setup(self):
-        """Flat ground unless a height grid was attached with `set_heightfield` (the Perlin terrain of
-        utils/terrain.py:40-99 is generated by callers; see DESIGN.md, scope row f-2)."""
+        """create_sim's terrain part (WG:235-253): mesh_type 'plane' / None is flat ground at z = 0; 'trimesh' or
+        'heightfield' with the widowGo1 Perlin parameters (zScale, tot_cols, tot_rows) generates the fractal
+        terrain of utils/terrain.py:40-99 and attaches its height grid to the contact kernel."""
+        t = self.cfg.terrain
         self.height_samples = None
+        self.terrain = None
+        if t.mesh_type in ("trimesh", "heightfield") and hasattr(t, "zScale"):
+            from .terrain import TerrainPerlin
+            self.terrain = TerrainPerlin(t, seed=self._seed)
+            self.set_heightfield(self.terrain.heightsamples, self.terrain.horizontal_scale, self.terrain.vertical_scale,
+                                 *self.terrain.transform)
 
     def set_heightfield(self, heights_i16: np.ndarray, horizontal_scale, vertical_scale, tx, ty, tz):
         self.sim.set_heightfield(heights_i16, horizontal_scale, vertical_scale, tx, ty, tz)
@@ -255,7 +263,10 @@ class WidowGo1(LeggedRobot):
         self.goal_ee_y_ranges = np.array(list(cur.goal_y_range))
         self.reward_scales = {n: cur.leg_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if cur.leg_reward_scale[i] != 0}
         self.arm_reward_scales = {n: cur.arm_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if cur.arm_reward_scale[i] != 0}
-        self._active_terms = [(i, n) for i, n in enumerate(abi.REWARD_TERMS) if n in self.reward_scales or n in self.arm_reward_scales]
+        if self._active_terms is None:     # episode_sums keys = the config's non-zero scales, fixed at construction (WG:128-163)
+            from .curriculum import _scales
+            cfg_leg, cfg_arm = _scales(self.cfg.rewards.scales), _scales(self.cfg.rewards.arm_scales)
+            self._active_terms = [(i, n) for i, n in enumerate(abi.REWARD_TERMS) if cfg_leg.get(n, 0) != 0 or cfg_arm.get(n, 0) != 0]
         return cur
 
     def update_command_curriculum(self):                                            # WG:678-692

@@ -133,3 +133,99 @@ def test_state_setters_and_fk_refresh(robot):
     np.testing.assert_allclose(got[mask, 0, 2], root2[mask, 0, 2], rtol=1e-6)
     np.testing.assert_allclose(got[~mask, 0, 2], root[~mask, 0, 2], rtol=1e-6)
     g.close()
+
+
+def _make_heightfield(rows=80, cols=120, seed=0):
+    """A small rough height grid (int16 samples, as Terrain builds them: utils/terrain.py:51) around the origin."""
+    rng = np.random.default_rng(seed)
+    x = np.linspace(0, 4 * np.pi, rows)[:, None]
+    y = np.linspace(0, 6 * np.pi, cols)[None, :]
+    h = 0.04 * np.sin(x) * np.cos(y) + 0.01 * rng.standard_normal((rows, cols))
+    return np.round(h / 0.005).astype(np.int16)          # vertical_scale 0.005 (legged_robot_config.py:45)
+
+
+def test_heightfield_contact_matches_oracle(robot):
+    """BASELINE config 3's contact path: spheres against the triangulated height grid (terrain indexing by
+    truncation + clipping as LR:816-829 is integer work and must agree exactly; forces to tolerance)."""
+    import torch
+    n = 48
+    params = helpers.random_env_params(n, seed=12)
+    params["env_origins"] = np.zeros((n, 3), dtype=np.float32)
+    hf = _make_heightfield()
+    hs, vs = 0.1, 0.005
+    tx, ty, tz = -0.5 * hf.shape[0] * hs, -0.5 * hf.shape[1] * hs, 0.0
+    g = helpers.make_gpu(robot, n, params)
+    o = helpers.make_oracle(robot, n, params, "f64")
+    g.set_heightfield(hf, hs, vs, tx, ty, tz)
+    o.set_heightfield(hf, hs, vs, tx, ty, tz)
+    rng = np.random.default_rng(31)
+    root, dof = helpers.random_standing_state(n, robot["tcfg"], rng, height=(0.28, 0.40))
+    root[:, 0, 0:2] = rng.uniform(-3.5, 3.5, (n, 2))
+    root[:5, 0, 0] = -100.0              # off the grid: indices clip to the border cells
+    root[5:8, 0, 1] = 100.0
+    tau = rng.uniform(-5, 5, (n, 20)).astype(np.float32)
+    tau[:, 18:] = 0
+    g.tensor("ROOT_STATES").copy_(torch.from_numpy(root)); g.tensor("DOF_STATE").copy_(torch.from_numpy(dof))
+    g.set_dof_forces(torch.from_numpy(tau).cuda())
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", tau)
+    touched = 0
+    for it in range(4):
+        g.simulate(); o.simulate()
+        fo = o.get("NET_CONTACT_FORCE")
+        np.testing.assert_array_equal(np.abs(_t(g, "NET_CONTACT_FORCE")).sum(-1) > 0, np.abs(fo).sum(-1) > 0)   # same active set
+        np.testing.assert_allclose(_t(g, "NET_CONTACT_FORCE"), fo, atol=0.08, rtol=3e-3)
+        np.testing.assert_allclose(_t(g, "DOF_STATE"), o.get("DOF_STATE"), atol=4e-4, rtol=2e-4)
+        np.testing.assert_allclose(_t(g, "ROOT_STATES")[:, 0], o.get("ROOT_STATES")[:, 0], atol=4e-4, rtol=2e-4)
+        touched += (np.abs(fo).sum(-1) > 0).sum()
+        helpers.sync_oracle_from_gpu(o, g, ["ROOT_STATES", "DOF_STATE"])
+    assert touched > n
+    # sloped contact: some force has a horizontal component through the terrain normal
+    g.set_heightfield(None)
+    g.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 257])
+def test_ragged_env_counts(robot, n):
+    """Sizes that are not multiples of anything; N=1 is the minimum."""
+    import torch
+    params = helpers.random_env_params(n, seed=n)
+    g = helpers.make_gpu(robot, n, params)
+    o = helpers.make_oracle(robot, n, params, "f64")
+    g.reset_all(); o.reset_all()
+    rng = np.random.default_rng(n)
+    for step in range(3):
+        helpers.sync_oracle_from_gpu(o, g)
+        a = (0.5 * rng.normal(size=(n, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda()); o.step(a)
+        np.testing.assert_array_equal(_t(g, "RESET_BUF"), o.get("RESET_BUF"))
+        np.testing.assert_allclose(_t(g, "OBS_BUF"), o.get("OBS_BUF"), atol=1.5e-3, rtol=5e-4)
+        np.testing.assert_allclose(_t(g, "DOF_STATE"), o.get("DOF_STATE"), atol=3e-4, rtol=5e-4)
+    g.close()
+
+
+def test_action_clip_timeout_and_episode_boundaries(robot):
+    """Edge cases the reference's logic has: actions beyond +-clip_actions, episodes at max length (time-out bootstrap
+    flag, command resampling only for timed-out envs), goal timers at their resample threshold."""
+    import torch
+    n = 32
+    params = helpers.random_env_params(n, seed=40)
+    g = helpers.make_gpu(robot, n, params)
+    o = helpers.make_oracle(robot, n, params, "f64")
+    g.reset_all(); o.reset_all()
+    torch.cuda.synchronize()
+    ep = np.zeros(n); ep[:8] = 500; ep[8:16] = 149; ep[16:24] = 499      # 500 -> 501 > max: time-out; 149 -> 150: command resample
+    g.tensor("EPISODE_LENGTH").copy_(torch.from_numpy(ep).long())
+    goal = _t(g, "GOAL_STATE"); goal[24:, 21] = goal[24:, 23]            # goal_timer at traj_total: resample next step
+    g.tensor("GOAL_STATE").copy_(torch.from_numpy(goal).float())
+    helpers.sync_oracle_from_gpu(o, g)
+    a = np.full((n, 18), 250.0, dtype=np.float32); a[::2] *= -1          # clipped to +-100 (WGC:114)
+    g.step(torch.from_numpy(a).cuda()); o.step(a)
+    np.testing.assert_array_equal(_t(g, "TIME_OUT_BUF"), o.get("TIME_OUT_BUF"))
+    assert _t(g, "TIME_OUT_BUF")[:8].all() and not _t(g, "TIME_OUT_BUF")[8:].any()
+    np.testing.assert_array_equal(_t(g, "RESET_BUF"), o.get("RESET_BUF"))
+    np.testing.assert_array_equal(_t(g, "EPISODE_LENGTH"), o.get("EPISODE_LENGTH"))
+    assert np.abs(_t(g, "ACTION_HISTORY")[_t(g, "RESET_BUF") == 0]).max() <= 100.0
+    for name in ("COMMANDS", "GOAL_STATE", "ACTION_HISTORY", "ROOT_STATES", "DOF_STATE"):
+        np.testing.assert_allclose(_t(g, name), o.get(name), atol=5e-4, rtol=5e-4, err_msg=name)
+    np.testing.assert_allclose(_t(g, "EPISODE_SUMS_DONE"), o.get("EPISODE_SUMS_DONE"), atol=2e-2, rtol=2e-3)
+    g.close()

@@ -145,3 +145,25 @@ def test_oracle_env_logic_closed_form_cases(robot):
     assert (obs[1, 100:] == 0).all()                                                           # reset env: history zeroed before assembly
     hist = o.get("OBS_HISTORY")
     np.testing.assert_allclose(hist[1, 0], hist[1, 9])                                          # ... then refilled 10x with the new obs
+
+
+def test_perlin_terrain_matches_reference_statistics():
+    """TerrainPerlin (utils/terrain.py:40-99 restated): shape, value range, octave structure and quirk Q3."""
+    from wbc_amd.terrain import TerrainPerlin, perlin_2d
+    cfg = WidowGo1RoughCfg().terrain
+    cfg.tot_cols, cfg.tot_rows = 400, 200               # small grid: 10 m x 5 m at 0.025 m
+    t = TerrainPerlin(cfg, seed=4)
+    assert t.heightsamples.shape == (400, 200) and t.heightsamples.dtype == np.int16
+    near = t.heightsamples[: t.flat_beyond_row].astype(np.float64) * cfg.vertical_scale
+    far = t.heightsamples[t.flat_beyond_row:]
+    assert (far == 0).all()                               # Q3: flat beyond row tot_cols//2 - 100
+    # each octave lies in [0, zScale * amp]; two octaves with gain 0.25: total within [0, 1.25 * zScale]
+    assert near.min() >= -1e-9 and near.max() <= 1.25 * cfg.zScale + 1e-9
+    assert 0.3 * cfg.zScale < near.mean() < 0.95 * cfg.zScale
+    # gradient noise vanishes at lattice nodes (value 0.5 after the affine map) and is smooth in between
+    p = perlin_2d((64, 64), (4, 4), np.random.default_rng(0))
+    np.testing.assert_allclose(p[::16, ::16], 0.5, atol=1e-12)
+    assert np.abs(np.diff(p, axis=0)).max() < 0.2
+    # determinism in the seed
+    np.testing.assert_array_equal(TerrainPerlin(cfg, seed=4).heightsamples, t.heightsamples)
+    assert (TerrainPerlin(cfg, seed=5).heightsamples != t.heightsamples).any()
