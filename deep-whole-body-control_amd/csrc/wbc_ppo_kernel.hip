@@ -425,6 +425,52 @@ extern "C" __global__ void __launch_bounds__(256) ppo_column_reduce_kernel(const
   if (threadIdx.x == 0) out[j] = sh[0];
 }
 
+// ---- gradient clip + Adam on the flat gradient (nn.utils.clip_grad_norm_ + optim.Adam.step, PPO:243-246) ----
+#define ADAM_NBLK 64
+// partial sums of g^2: block b takes elements b*256+tid, +64*256, ... ; fixed-order tree inside the block
+extern "C" __global__ void __launch_bounds__(256) ppo_sqnorm_kernel(const float* __restrict__ g, int n, float* __restrict__ part) {
+  __shared__ float sh[256];
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += ADAM_NBLK * 256) acc += g[i] * g[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+struct AdamTable {
+  float* p[33];
+  int off[34];                    // flat offset of parameter j; off[33] = total
+};
+
+// g <- g * min(1, max_norm / (||g|| + 1e-6)); m, v, p as torch.optim.Adam (no weight decay, no amsgrad):
+// m += (g-m)(1-b1); v = v b2 + (1-b2) g g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                                 const float* __restrict__ part, float max_norm, float beta1, float beta2,
+                                                                 float eps, float step_size, float bc2_sqrt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T.off[33]) return;
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    float tot = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < ADAM_NBLK; ++b) tot += part[b];
+    coef = fminf(max_norm / (sqrtf(tot) + 1e-6f), 1.f);
+  }
+  int lo = 0, hi = 33;            // parameter j with off[j] <= i < off[j+1]
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.off[mid] <= i) lo = mid; else hi = mid; }
+  const float gi = g[i] * coef;
+  g[i] = gi;
+  const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+  const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  float* pp = T.p[lo] + (i - T.off[lo]);
+  *pp = *pp - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+}
+
 // ---- C-ABI ----------------------------------------------------------------------------------------
 // Flat gradient layout: for layer l in PolicyParams order: weight [out*in] then bias [out]; then std [18];
 // then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
@@ -490,5 +536,28 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   hipLaunchKernelGGL(ppo_reduce_kernel, dim3((off + 255) / 256), dim3(256), 0, st, wpart, PPO_NSPLIT, ng, off, grad);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(3), dim3(256), 0, st, loss_partial, tiles, 3, grad + off + 18);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// clip_grad_norm_(params, max_norm) followed by Adam.step() for the 33 parameters of `params`, whose gradients are
+// grad[0 : wbc_ppo_grad_floats()-3] in the layout above; exp_avg / exp_avg_sq: flat state in the same layout.
+// step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) (computed by the caller in double, as torch does).
+// max_norm <= 0: no clipping. workspace: >= 64 floats.
+extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
+                                 float beta2, float eps, float step_size, float bc2_sqrt, float* workspace, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return -1;
+  AdamTable T;
+  int off = 0, j = 0;
+  for (int l = 0; l < NLAYERS; ++l) {
+    if (!params[2 * l] || !params[2 * l + 1]) return -1;
+    T.p[j] = (float*)params[2 * l]; T.off[j++] = off; off += layer_out(l) * layer_in(l);
+    T.p[j] = (float*)params[2 * l + 1]; T.off[j++] = off; off += layer_out(l);
+  }
+  if (!params[32]) return -1;
+  T.p[32] = (float*)params[32]; T.off[32] = off; off += 18; T.off[33] = off;
+  hipStream_t st = (hipStream_t)stream;
+  if (max_norm > 0.f) hipLaunchKernelGGL(ppo_sqnorm_kernel, dim3(ADAM_NBLK), dim3(256), 0, st, grad, off, workspace);
+  hipLaunchKernelGGL(ppo_adam_kernel, dim3((off + 255) / 256), dim3(256), 0, st, T, grad, exp_avg, exp_avg_sq, workspace, max_norm, beta1, beta2, eps,
+                     step_size, bc2_sqrt);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -8,7 +8,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwbc_amd.so")
+LIB_PATH = os.environ.get("WBC_AMD_LIB") or os.path.join(_HERE, "libwbc_amd.so")   # override: kernel-variant A/B runs
 _lib = None
 
 c_void, c_int, c_f32p = C.c_void_p, C.c_int, C.c_void_p
@@ -59,6 +59,7 @@ def lib():
         L.wbc_policy_act.argtypes = [c_void] * 8 + [c_int, c_void]
         L.wbc_policy_pack.argtypes = [c_void, c_void, c_void]
         L.wbc_ppo_minibatch_grad.argtypes = [c_void] * 9 + [c_int] + [C.c_float] * 4 + [c_int, c_void, c_void, c_void]
+        L.wbc_ppo_clip_adam.argtypes = [c_void] * 4 + [C.c_float] * 6 + [c_void, c_void]
         L.wbc_ppo_workspace_floats.argtypes = [c_int]
         L.wbc_ppo_workspace_floats.restype = C.c_size_t
         _lib = L
@@ -72,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "wbc_sim_set_root_state_indexed", "wbc_sim_set_dof_state_indexed", "wbc_sim_refresh_dof_state",
     "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force", "wbc_sim_refresh_force_sensor",
     "wbc_sim_refresh_rigid_body_state", "wbc_sim_get_step_counter", "wbc_sim_set_step_counter", "wbc_gae_compute",
-    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_grad_floats",
+    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_clip_adam", "wbc_ppo_grad_floats",
     "wbc_ppo_num_splits", "wbc_ppo_workspace_floats"]
 
 

@@ -168,7 +168,8 @@ class PPO:
                 off += p.numel()
             assert off == ng - 3
             self._fused = dict(mb=mb, grad=grad, nparam=off, ws=torch.empty(L.wbc_ppo_workspace_floats(mb), device=dev),
-                               hist=torch.empty(batch, 20, device=dev))
+                               hist=torch.empty(batch, 20, device=dev), m=torch.zeros(off, device=dev), v=torch.zeros(off, device=dev),
+                               adam_ws=torch.empty(64, device=dev))
         F = self._fused
         for p, g in zip(params, torch.split(F["grad"][:F["nparam"]], [p.numel() for p in params])):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
@@ -203,14 +204,54 @@ class PPO:
                     torch.distributed.all_reduce(F["grad"][:F["nparam"]], group=self.dist_group)
                     F["grad"][:F["nparam"]].div_(self.world_size)
                 sums += F["grad"][F["nparam"]:]
-                nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-                self.optimizer.step()
+                steps = self._bind_adam_state(params, F)
+                if steps is None:                  # optimiser options the fused kernel does not cover
+                    nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                    self.optimizer.step()
+                else:                              # clip_grad_norm_ + Adam.step in two launches on the flat buffers
+                    g0 = self.optimizer.param_groups[0]
+                    t = float(steps[0]) + 1.0
+                    b1, b2 = g0["betas"]
+                    check(L.wbc_ppo_clip_adam(table, F["grad"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(),
+                                              float(self.max_grad_norm), b1, b2, g0["eps"], g0["lr"] / (1.0 - b1 ** t),
+                                              (1.0 - b2 ** t) ** 0.5, F["adam_ws"].data_ptr(), stream), "wbc_ppo_clip_adam")
+                    torch._foreach_add_(steps, 1.0)
         num_updates = self.num_learning_epochs * self.num_mini_batches
         surr, vls, preg = (sums / num_updates).tolist()
         self.storage.clear()
         self.update_counter()
         self.enforce_min_std()
         return (vls / (2 * mb), surr / (2 * mb), 0.0, value_mixing_ratio, 0, preg / mb, priv_reg_coef)
+
+    def _bind_adam_state(self, params, F):
+        """Make self.optimizer's Adam moments of the fused parameters views of the flat buffers F['m'], F['v'] (so
+        that state_dict()/load_state_dict() and the eager step keep working on the same memory). Returns the list of
+        the parameters' step counters, or None if the optimiser is not a plain Adam the fused kernel reproduces."""
+        opt = self.optimizer
+        if type(opt) is not optim.Adam or len(opt.param_groups) != 1:
+            return None
+        g0 = opt.param_groups[0]
+        if (g0.get("weight_decay", 0) != 0 or g0.get("amsgrad", False) or g0.get("maximize", False) or g0.get("capturable", False)
+                or g0.get("fused", False) or isinstance(g0["lr"], torch.Tensor)):
+            return None
+        steps, off = [], 0
+        for p in params:
+            n = p.numel()
+            mv, vv = F["m"][off:off + n].view_as(p), F["v"][off:off + n].view_as(p)
+            st = opt.state[p]
+            if len(st) == 0:                      # as Adam._init_group
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"], st["exp_avg_sq"] = mv.zero_(), vv.zero_()
+            elif st["exp_avg"].data_ptr() != mv.data_ptr() or st["exp_avg_sq"].data_ptr() != vv.data_ptr():
+                mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"])      # eager steps / load_state_dict happened in between
+                st["exp_avg"], st["exp_avg_sq"] = mv, vv
+            if st["step"].is_cuda:
+                return None
+            steps.append(st["step"])
+            off += n
+        if any(float(x) != float(steps[0]) for x in steps):
+            return None
+        return steps
 
     def update(self):
         if self._fused_update_supported():

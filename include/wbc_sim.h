@@ -301,6 +301,13 @@ int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const fl
                            const float* old_logp, const float* hist_latent, const int64_t* idx, int B,
                            float clip, float value_coef, float mixing, float roa_coef,
                            int use_clipped_value_loss, float* workspace, float* grad, void* stream);
+/* nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (ppo.py:243-246) for the 33 parameters of
+ * `params`, reading their gradients from grad[0 : wbc_ppo_grad_floats()-3] (scaled in place by the clip factor);
+ * exp_avg / exp_avg_sq are flat Adam moments in the same layout. step_size = lr/(1-beta1^t), bc2_sqrt =
+ * sqrt(1-beta2^t). max_norm <= 0 disables the clip. workspace: >= 64 floats. Deterministic. */
+int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm,
+                      float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* workspace,
+                      void* stream);
 int wbc_ppo_grad_floats(void);
 int wbc_ppo_num_splits(void);
 size_t wbc_ppo_workspace_floats(int B);
