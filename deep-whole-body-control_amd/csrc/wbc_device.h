@@ -18,6 +18,12 @@ struct DevConst {
   int32_t body_chain[WBC_NB];                      // chain of each body (-1 root)
   int32_t body_depth[WBC_NB];                      // 0 root, 1.. along the chain
   int32_t cp_foot[WBC_NCP];                        // force-sensor index fed by contact k, -1 none
+  int32_t cp_depth[WBC_NCP];                       // chain depth of contact k's body (0 = root)
+  // bit-packed copies the step kernel keeps in registers / LDS (built by build_chains)
+  uint32_t chain_pack_body[WBC_NCHAIN + 1];        // 6 x 5 bits: body at depth d (31 = none); row WBC_NCHAIN = idle lanes
+  uint32_t chain_pack_dof[WBC_NCHAIN + 1];         // 6 x 5 bits: dof of that body
+  uint32_t chain_pack_ax[WBC_NCHAIN + 1];          // 6 x 2 bits: joint axis
+  uint32_t body_pack[WBC_NB];                      // axis | dof << 2 | (bit mask of the contact spheres on the body) << 7
   // heightfield (optional)
   const int16_t* hf;
   int32_t hf_rows, hf_cols;

@@ -97,6 +97,25 @@ static int build_chains(DevConst& hc) {
   for (int k = 0; k < WBC_NCP; ++k) {
     hc.cp_foot[k] = -1;
     for (int f = 0; f < WBC_NFEET; ++f) if (k < m.ncp && m.feet_rb[f] == m.cp_rb[k]) hc.cp_foot[k] = f;
+    if (m.cp_body[k] < 0 || m.cp_body[k] >= WBC_NB) return -1;
+    hc.cp_depth[k] = hc.body_depth[m.cp_body[k]];
+  }
+  static_assert(WBC_NB <= 31 && WBC_NDOF <= 32 && WBC_MAX_DEPTH * 5 <= 32 && WBC_NCP + 7 <= 32, "bit packing of the chain tables");
+  for (int c = 0; c <= WBC_NCHAIN; ++c) {
+    uint32_t pb = 0, pd = 0, pa = 0;
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+      const int i = (c < WBC_NCHAIN) ? hc.chain_body[c][d] : -1;
+      const int ii = i < 0 ? 0 : i;
+      pb |= (uint32_t)(i < 0 ? 31 : i) << (5 * d);
+      pd |= (uint32_t)(m.dof[ii] < 0 ? 0 : m.dof[ii]) << (5 * d);
+      pa |= (uint32_t)(m.axis[ii] < 0 ? 0 : m.axis[ii]) << (2 * d);
+    }
+    hc.chain_pack_body[c] = pb; hc.chain_pack_dof[c] = pd; hc.chain_pack_ax[c] = pa;
+  }
+  for (int i = 0; i < WBC_NB; ++i) {
+    uint32_t mask = 0;
+    for (int k = 0; k < WBC_NCP; ++k) if (m.cp_body[k] == i) mask |= 1u << k;
+    hc.body_pack[i] = (uint32_t)(m.axis[i] < 0 ? 0 : m.axis[i]) | (uint32_t)(m.dof[i] < 0 ? 0 : m.dof[i]) << 2 | mask << 7;
   }
   return 0;
 }

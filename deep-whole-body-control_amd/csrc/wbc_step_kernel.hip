@@ -16,10 +16,25 @@
 
 #define LANES 64
 
-// development aid: phase timestamps of block 0 (see tools/time_step.py); null in normal operation
+// development aid: phase timestamps of block 0 (tools/time_step.py builds a variant with -DWBC_STEP_TIMING)
 __device__ long long* g_step_dbg = nullptr;
+#ifdef WBC_STEP_TIMING
 #define STAMP(i) do { if (g_step_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_step_dbg[i] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #define CH_LANES 12
+
+// A workgroup is ONE wavefront: its LDS operations execute in program order, so cross-lane hand-over through LDS
+// needs no s_waitcnt/s_barrier, only that the compiler keeps the order (wavefront-scope fences emit no code).
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division sequence on the dependent chains
+__device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], VALU speed, no LDS
+__device__ __forceinline__ float pair_swap(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
 
 struct PostBuf {                  // post-physics staging; shares LDS with IA (dead once the substeps are done)
   float out_rb[WBC_NRB_ENV][13];
@@ -35,7 +50,7 @@ struct __align__(16) Smem {
   float E[WBC_NB][9];
   float pos[WBC_NB][3];
   float S[WBC_NB][6], v[WBC_NB][6], c[WBC_NB][6], pA[WBC_NB][6], U[WBC_NB][6], a[WBC_NB][6];
-  float D[WBC_NB], u[WBC_NB], uD[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];
+  float iD[WBC_NB], u[WBC_NB], uD[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];   // iD = 1/D
   float pa1[WBC_NCHAIN][6];      // depth-1 contributions to the root, summed in fixed order
   float q[WBC_NDOF], qd[WBC_NDOF], tau[WBC_NDOF], act[WBC_NACT];
   float root[13], box[13], R[9], wb[3], vb[3], gF[3];
@@ -50,10 +65,13 @@ struct __align__(16) Smem {
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
   float rew, arm_rew, base_yaw, mu, friction;
   int reset_flag, time_out, ep_len;
-  // per-chain constants (body, parent, axis, dof, armature at each depth); row WBC_NCHAIN is the idle row
-  int ct_body[WBC_NCHAIN + 1][WBC_MAX_DEPTH], ct_par[WBC_NCHAIN + 1][WBC_MAX_DEPTH], ct_ax[WBC_NCHAIN + 1][WBC_MAX_DEPTH],
-      ct_dof[WBC_NCHAIN + 1][WBC_MAX_DEPTH];
-  float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];
+  float sq[WBC_NDOF], cq[WBC_NDOF];      // sin/cos of the joint angles of this substep
+  float viol[WBC_NDOF], limd[WBC_NDOF];  // joint-limit violation and (if moving further out) the joint velocity
+  // model constants the dependent chains index per lane (LDS instead of a global load on the critical path)
+  float k_jxyz[WBC_NB][3];
+  uint32_t k_body[WBC_NB];               // DevConst::body_pack
+  float k_qdlim[WBC_NDOF];
+  float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];   // joint armature at (chain, depth); row WBC_NCHAIN is the idle row
 };
 
 // aliases: pD lives in pA, aD in c (both dead once pass 3 has run); g (pass 3 only) also lives in pA:
@@ -61,40 +79,53 @@ struct __align__(16) Smem {
 #define PD(s) (s).pA
 #define AD(s) (s).c
 #define GG(s) (s).pA
+// TT: one 6-vector of cross-lane terms per body; lives in a (free in pass 2; in pass 3 and the contact sweeps a[i] is
+// either about to be written by the same lanes or dead: only a[0] and the contact set-up read it)
+#define TT(s) (s).a
 
-// Per-lane view of this lane's chain constants: they live in LDS (Smem::ct_*), not in registers, so that
-// the hot loop keeps its VGPRs for the 6x6 algebra (30 long-lived registers spilled the fused kernel).
+// This lane's chain, bit-packed into three registers (DevConst::chain_pack_*): body / dof / axis at each depth.
 struct ChainRegs {
-  const int *body, *par, *ax, *dof;
-  const float* arm;
+  uint32_t body, dof, ax;
+  const float* arm;             // LDS row of joint armatures
 };
+#define CH_NONE 31
+__device__ __forceinline__ int ch_body(const ChainRegs& cr, int d) { return (cr.body >> (5 * d)) & 31; }
+__device__ __forceinline__ int ch_par(const ChainRegs& cr, int d) { return d ? ((cr.body >> (5 * d - 5)) & 31) : 0; }
+__device__ __forceinline__ int ch_dof(const ChainRegs& cr, int d) { return (cr.dof >> (5 * d)) & 31; }
+__device__ __forceinline__ int ch_ax(const ChainRegs& cr, int d) { return (cr.ax >> (2 * d)) & 3; }
 
 __device__ __forceinline__ void fk_pass(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, int chain, int k) {
   const int lane = threadIdx.x;
   if (lane < 9) s.E[0][lane] = (lane % 4 == 0) ? 1.f : 0.f;
   if (lane < 3) s.pos[0][lane] = 0.f;
-  __syncthreads();
+  WSYNC();
+  // every lane: out = base + sum_j E_p[row][j] w_j. Lanes k<9 (entry (row, col) of E_i = E_p Rot(ax, q)): w = column
+  // col of the joint rotation, base 0; lanes 9..11 (component row of the origin): w = joint offset, base = pos_p[row].
+  const bool isE = k < 9;
+  const int row = isE ? k / 3 : k - 9, col = k % 3;
 #pragma unroll 1
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-    const int i = cr.body[d];
-    if (chain < WBC_NCHAIN && i >= 0) {
-      const int p = cr.par[d], ax = cr.ax[d];
-      if (k < 9) {
-        const int row = k / 3, col = k % 3;
-        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-        float sq, cq;
-        sincosf(s.q[cr.dof[d]], &sq, &cq);
-        const float e0 = s.E[p][row * 3 + ax], e1 = s.E[p][row * 3 + a1], e2 = s.E[p][row * 3 + a2];
-        float val = (col == ax) ? e0 : ((col == a1) ? (cq * e1 + sq * e2) : (-sq * e1 + cq * e2));
-        s.E[i][k] = val;
-      } else {
-        const int comp = k - 9;
-        const float* Ep = &s.E[p][comp * 3];
-        const float* r = C->model.joint_xyz[i];
-        s.pos[i][comp] = s.pos[p][comp] + Ep[0] * r[0] + Ep[1] * r[1] + Ep[2] * r[2];
+    const int i = ch_body(cr, d);
+    if (i != CH_NONE) {
+      const int p = ch_par(cr, d), ax = ch_ax(cr, d), dj = ch_dof(cr, d);
+      const float e0 = s.E[p][row * 3], e1 = s.E[p][row * 3 + 1], e2 = s.E[p][row * 3 + 2];
+      const float base = s.pos[p][row], sq = s.sq[dj], cq = s.cq[dj];
+      const float r0 = s.k_jxyz[i][0], r1 = s.k_jxyz[i][1], r2 = s.k_jxyz[i][2];
+      // Rot(ax,q)[j][col]: 1 on (ax,ax); c on the other two diagonal entries; (a1,a2) = -s, (a2,a1) = +s; else 0
+      const int a1 = (ax == 2) ? 0 : ax + 1;
+      const bool col_ax = col == ax;
+      float w[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float off = (j == col) ? cq : ((j == a1) ? -sq : sq);
+        w[j] = (j == ax) ? (col_ax ? 1.f : 0.f) : (col_ax ? 0.f : off);
       }
+      const float w0 = isE ? w[0] : r0, w1 = isE ? w[1] : r1, w2 = isE ? w[2] : r2;
+      const float val = (isE ? 0.f : base) + e0 * w0 + e1 * w1 + e2 * w2;
+      float* dst = isE ? &s.E[i][k] : &s.pos[i][row];
+      *dst = val;
     }
-    __syncthreads();
+    WSYNC();
   }
 }
 
@@ -105,26 +136,26 @@ __device__ __forceinline__ void contact_solve(const float* W, f3 n, float vn_tgt
   if (vn >= vn_tgt) return;
   const f3 Wn = mat_mul(W, n);
   const float nWn = dot(n, Wn);
-  const float lam_fl = (vn_tgt - vn) / nWn;
+  const float lam_fl = (vn_tgt - vn) * rcpf(nWn);
   const f3 rhs = n * vn_tgt - vref;
   // symmetric 3x3 solve by cofactors
   const float a = W[0], b = W[1], c = W[2], d = W[4], e = W[5], f = W[8];
   const float c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
   const float det = a * c00 + b * c01 + c * c02;
   const float c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
-  const float id = 1.f / det;
+  const float id = rcpf(det);
   const f3 st = mk3((c00 * rhs.x + c01 * rhs.y + c02 * rhs.z) * id, (c01 * rhs.x + c11 * rhs.y + c12 * rhs.z) * id,
                     (c02 * rhs.x + c12 * rhs.y + c22 * rhs.z) * id);
   const float ln = dot(n, st);
   const f3 lt = st - n * ln;
-  const float ltn = sqrtf(dot(lt, lt));
+  const float ltn = __builtin_amdgcn_sqrtf(dot(lt, lt));
   if (ln > 0.f && ltn <= mu * ln) { lam[0] = st.x; lam[1] = st.y; lam[2] = st.z; return; }
   if (ln <= 0.f || ltn <= 1e-12f) { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
-  const f3 dir = n + lt * (mu / ltn);
+  const f3 dir = n + lt * (mu * rcpf(ltn));
   const f3 Wd = mat_mul(W, dir);
   const float den = dot(n, Wd);
   if (den <= 0.05f * nWn) { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
-  float l = (vn_tgt - vn) / den;
+  float l = (vn_tgt - vn) * rcpf(den);
   l = fmaxf(l, 0.f);
   lam[0] = dir.x * l; lam[1] = dir.y * l; lam[2] = dir.z * l;
 }
@@ -149,12 +180,37 @@ __device__ __forceinline__ void terrain_query(const DevConst* __restrict__ C, fl
   *n = mk3(-gx * inv, -gy * inv, inv);
 }
 
+// sin/cos of every joint angle and the joint-limit terms of this substep: lanes 32..51, one DoF each
+__device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restrict__ C) {
+  const int j = (int)threadIdx.x - 32;
+  if (j >= 0 && j < WBC_NDOF) {
+    const float qq = s.q[j], qdv = s.qd[j];
+    float sq, cq;
+    sincosf(qq, &sq, &cq);
+    s.sq[j] = sq; s.cq[j] = cq;
+    const float lo = C->model.q_lower[j], hi = C->model.q_upper[j];
+    float viol = 0.f;
+    if (lo < hi) { if (qq > hi) viol = qq - hi; else if (qq < lo) viol = qq - lo; }
+    s.viol[j] = viol;
+    s.limd[j] = (qdv * viol > 0.f) ? qdv : 0.f;
+  }
+}
+
 // One physics substep on the LDS-resident state (oracle: physics_substep).
 __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, const int chain, const int k,
                                 const bool want_outputs) {
   const int lane = threadIdx.x;
   const float dt = C->cfg.sim_dt;
-  const bool in_chain = chain < WBC_NCHAIN;
+  const float idt = 1.f / dt;
+  // constants of the one-body-per-lane phases: issued here, consumed after the kinematics (latency hidden)
+  float bm = 0.f, bcom[3] = {0.f, 0.f, 0.f}, bI6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (lane < WBC_NB) {
+    bm = C->model.mass[lane];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bcom[j] = C->model.com[lane][j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bI6[j] = C->model.inertia[lane][j];
+  }
   // root-frame quantities
   if (lane == 0) {
     quat_to_mat(&s.root[3], s.R);
@@ -162,13 +218,14 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     st3(s.vb, matT_mul(s.R, ld3(&s.root[7])));
     st3(s.gF, matT_mul(s.R, ld3(C->cfg.gravity)));
   }
+  joint_pre_pass(s, C);
   STAMP(0);
   fk_pass(s, C, cr, chain, k);   // begins with a barrier after the identity write, ends with one
   STAMP(1);
   // joint screws S for all 18 joints: 108 entries
   for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
     const int i = 1 + t / 6, kk = t % 6;
-    const int ax = C->model.axis[i];
+    const int ax = s.k_body[i] & 3;
     const f3 sv = mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax]);
     float val;
     if (kk < 3) val = (kk == 0) ? sv.x : ((kk == 1) ? sv.y : sv.z);
@@ -176,21 +233,21 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     s.S[i][kk] = val;
   }
   if (lane < 6) { s.v[0][lane] = (lane < 3) ? s.wb[lane] : s.vb[lane - 3]; s.S[0][lane] = 0.f; s.c[0][lane] = 0.f; }
-  __syncthreads();
+  WSYNC();
   // velocities: each (chain, k<6) lane carries component k down its chain in a register
-  if (in_chain && k < 6) {
+  if (k < 6) {
     float vr = s.v[0][k];
 #pragma unroll 1
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-      const int i = cr.body[d];
-      if (i >= 0) { vr += s.S[i][k] * s.qd[cr.dof[d]]; s.v[i][k] = vr; }
+      const int i = ch_body(cr, d);
+      if (i != CH_NONE) { vr += s.S[i][k] * s.qd[ch_dof(cr, d)]; s.v[i][k] = vr; }
     }
   }
-  __syncthreads();
+  WSYNC();
   // velocity-product accelerations c: 108 entries
   for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
     const int i = 1 + t / 6, kk = t % 6;
-    const float qd = s.qd[C->model.dof[i]];
+    const float qd = s.qd[(s.k_body[i] >> 2) & 31];
     const f3 w = ld3(&s.v[i][0]), vl = ld3(&s.v[i][3]);
     const f3 ja = ld3(&s.S[i][0]) * qd, jl = ld3(&s.S[i][3]) * qd;
     float val;
@@ -202,10 +259,19 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   // spatial inertias in frame F and bias forces: one body per lane
   if (lane < WBC_NB) {
     const int i = lane;
-    float m, com[3], I6[6];
-    if (i == 0) { m = s.bp[0]; for (int j = 0; j < 3; ++j) com[j] = s.bp[1 + j]; for (int j = 0; j < 6; ++j) I6[j] = s.bp[4 + j]; }
-    else if (i == C->model.gripper_body) { m = s.bp[10]; for (int j = 0; j < 3; ++j) com[j] = s.bp[11 + j]; for (int j = 0; j < 6; ++j) I6[j] = s.bp[14 + j]; }
-    else { m = C->model.mass[i]; for (int j = 0; j < 3; ++j) com[j] = C->model.com[i][j]; for (int j = 0; j < 6; ++j) I6[j] = C->model.inertia[i][j]; }
+    float m = bm, com[3], I6[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) com[j] = bcom[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) I6[j] = bI6[j];
+    if (i == 0 || i == C->model.gripper_body) {     // randomised per env (body_params)
+      const float* bp = &s.bp[i == 0 ? 0 : 10];
+      m = bp[0];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) com[j] = bp[1 + j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) I6[j] = bp[4 + j];
+    }
     const float* E = s.E[i];
     const f3 Cc = ld3(s.pos[i]) + mat_mul(E, mk3(com[0], com[1], com[2]));
     const float Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
@@ -239,60 +305,62 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     st3(&s.pA[i][0], cross(w, nn) + cross(vl, ff));
     st3(&s.pA[i][3], cross(w, ff));
   }
-  __syncthreads();
+  WSYNC();
   STAMP(3);
-  // pass 2, inward: level d+1 of every chain in parallel
+  // pass 2, inward: level d+1 of every chain in parallel. Lane (chain,k) owns entries (mr, mc..mc+2) of the chain's
+  // articulated inertia and the lane pair (2r,2r+1) component r of its bias force; the children's contributions
+  // travel inward in registers (acc3, pacc), the body's own inertia / bias force are read from LDS (s.IA, s.pA, never
+  // modified here). One LDS hand-over per level: U and the terms of S.pA out, then D, u and the rank-1 downdate.
+  const float kap_dt2 = C->cfg.limit_kappa * idt * idt, del_dt = C->cfg.limit_delta * idt;
+  const int mr = k >> 1, mc = (k & 1) * 3;
+  {
+    float acc3[3] = {0.f, 0.f, 0.f}, pacc = 0.f;
 #pragma unroll 1
-  for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
-    const int i = cr.body[d];
-    const bool act = in_chain && i >= 0;
-    if (act && k < 6) s.U[i][k] = dot6(&s.IA[i][k * 6], s.S[i]);
-    __syncthreads();
-    float Ia3[3] = {0.f, 0.f, 0.f}, pa = 0.f;
-    if (act) {
-      const int dj = cr.dof[d];
-      const float D = dot6(s.S[i], s.U[i]) + cr.arm[d];
-      float tau = s.tau[dj];
-      const float lo = C->model.q_lower[dj], hi = C->model.q_upper[dj];
-      if (lo < hi) {
-        const float qq = s.q[dj], qdv = s.qd[dj];
-        float viol = 0.f;
-        if (qq > hi) viol = qq - hi; else if (qq < lo) viol = qq - lo;
-        if (viol != 0.f) {
-          float tl = -C->cfg.limit_kappa * D / (dt * dt) * viol;
-          if (qdv * viol > 0.f) tl -= C->cfg.limit_delta * D / dt * qdv;
-          tau += tl;
+    for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
+      const int i = ch_body(cr, d);
+      const bool act = i != CH_NONE;
+      float IA3[3] = {0.f, 0.f, 0.f}, S3[3] = {0.f, 0.f, 0.f}, pAr = 0.f, Ur = 0.f;
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { IA3[j] = s.IA[i][3 * k + j] + acc3[j]; S3[j] = s.S[i][mc + j]; }
+        pAr = s.pA[i][mr] + pacc;
+        const float up = IA3[0] * S3[0] + IA3[1] * S3[1] + IA3[2] * S3[2];
+        Ur = up + pair_swap(up);                    // U[mr] = row mr of IA times S
+        s.U[i][mr] = Ur;                            // both lanes of the pair write the same value
+        TT(s)[i][mr] = s.S[i][mr] * pAr;
+      }
+      WSYNC();
+      if (act) {
+        const int dj = ch_dof(cr, d);
+        float U3[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) U3[j] = s.U[i][mc + j];
+        const float dp = S3[0] * U3[0] + S3[1] * U3[1] + S3[2] * U3[2];
+        const float D = (dp + pair_swap(dp)) + cr.arm[d];
+        // joint-limit stop (scaled by D): -kappa D/dt^2 viol - delta D/dt qd if moving further out
+        const float tau = s.tau[dj] - D * (kap_dt2 * s.viol[dj] + del_dt * s.limd[dj]);
+        const float* t = TT(s)[i];
+        const float u = tau - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5]);
+        const float invD = rcpf(D);
+        if (k == 0) { s.iD[i] = invD; s.u[i] = u; }
+        float Ia3[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Ia3[j] = IA3[j] - Ur * U3[j] * invD;     // (U_r U_c)/D: stays exactly symmetric
+        const float pp = Ia3[0] * s.c[i][mc] + Ia3[1] * s.c[i][mc + 1] + Ia3[2] * s.c[i][mc + 2];
+        const float pa = pAr + (pp + pair_swap(pp)) + Ur * u * invD;         // component mr of pA + Ia c + U u/D
+        if (d > 0) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc3[j] = Ia3[j];
+          pacc = pa;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) s.IA[i][3 * k + j] = Ia3[j];           // depth-1 contribution to the root
+          s.pa1[chain][mr] = pa;
         }
       }
-      const float u = tau - dot6(s.S[i], s.pA[i]);
-      const float invD = 1.f / D;
-      if (k == 0) { s.D[i] = D; s.u[i] = u; }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int e = 3 * k + j, r = e / 6, cc = e % 6;
-        Ia3[j] = s.IA[i][e] - s.U[i][r] * s.U[i][cc] * invD;
-      }
-      if (k < 6) {
-        // row k of Ia times c = row of IA times c - U_k (U.c)/D
-        const float Uc = dot6(s.U[i], s.c[i]);
-        pa = s.pA[i][k] + (dot6(&s.IA[i][k * 6], s.c[i]) - s.U[i][k] * Uc * invD) + s.U[i][k] * u * invD;
-      }
     }
-    __syncthreads();
-    if (act) {
-      const int p = cr.par[d];
-      if (d > 0) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) s.IA[p][3 * k + j] += Ia3[j];
-        if (k < 6) s.pA[p][k] += pa;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) s.IA[i][3 * k + j] = Ia3[j];
-        if (k < 6) s.pa1[chain][k] = pa;
-      }
-    }
-    __syncthreads();
   }
+  WSYNC();
   STAMP(4);
   // root: sum the five depth-1 contributions in fixed chain order
   if (lane < 36) {
@@ -307,72 +375,88 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][r];
     s.pA[0][r] = acc;
   }
-  __syncthreads();
-  // K0 = IA0^-1 by six Gauss-Jordan sweeps, one matrix entry per lane
-  {
+  WSYNC();
+  // K0 = IA0^-1 by six Gauss-Jordan sweeps, one matrix entry per lane (all reads of a sweep precede its writes:
+  // one wavefront, LDS in program order)
+  if (lane < 36) {
     const int r = lane / 6, cc = lane % 6;
 #pragma unroll 1
     for (int kk = 0; kk < 6; ++kk) {
-      float val = 0.f;
-      if (lane < 36) {
-        const float id = 1.f / s.IA[0][kk * 6 + kk];
-        if (r == kk && cc == kk) val = id;
-        else if (r == kk) val = s.IA[0][kk * 6 + cc] * id;
-        else if (cc == kk) val = -s.IA[0][r * 6 + kk] * id;
-        else val = s.IA[0][r * 6 + cc] - s.IA[0][r * 6 + kk] * s.IA[0][kk * 6 + cc] * id;
-      }
-      __syncthreads();
-      if (lane < 36) s.IA[0][lane] = val;
-      __syncthreads();
+      const float piv = s.IA[0][kk * 6 + kk], rowv = s.IA[0][kk * 6 + cc], colv = s.IA[0][r * 6 + kk], own = s.IA[0][lane];
+      const float id = rcpf(piv);
+      const float on_row = (cc == kk) ? id : rowv * id;
+      const float off_row = (cc == kk) ? -colv * id : own - colv * rowv * id;
+      WSYNC();
+      s.IA[0][lane] = (r == kk) ? on_row : off_row;
+      WSYNC();
     }
   }
+  WSYNC();
   if (lane < 6) s.a[0][lane] = -dot6(&s.IA[0][lane * 6], s.pA[0]);
-  __syncthreads();
+  WSYNC();
   STAMP(5);
-  // pass 3 and inverse articulated inertias, outward
-#pragma unroll 1
-  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-    const int i = cr.body[d];
-    const bool act = in_chain && i >= 0;
-    float invD = 0.f;
-    if (act) {
-      const int p = cr.par[d];
-      float ap[6];
+  // contact-sphere constants of this lane: issued before pass 3, consumed after it
+  int cpb = 0;
+  float cpp[3] = {0.f, 0.f, 0.f}, cpr = 0.f;
+  if (lane < WBC_NCP) {
+    cpb = C->model.cp_body[lane];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) ap[j] = s.a[p][j] + s.c[i][j];
-      invD = 1.f / s.D[i];
-      const float qdd = (s.u[i] - dot6(s.U[i], ap)) * invD;
-      if (k < 6) {
-        float apk = ap[0];
-#pragma unroll
-        for (int j = 1; j < 6; ++j) apk = (k == j) ? ap[j] : apk;
-        s.a[i][k] = apk + s.S[i][k] * qdd;
-        GG(s)[i][k] = dot6(&s.IA[p][k * 6], s.U[i]) * invD;
-      }
-      if (k == 0) s.qdd[i] = qdd;
-    }
-    __syncthreads();
-    if (act) {
-      const int p = cr.par[d];
-      const float gam = dot6(s.U[i], GG(s)[i]) * invD + invD;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int e = 3 * k + j, r = e / 6, cc = e % 6;
-        s.IA[i][e] = s.IA[p][e] - GG(s)[i][r] * s.S[i][cc] - s.S[i][r] * GG(s)[i][cc] + gam * s.S[i][r] * s.S[i][cc];
-      }
-    }
-    __syncthreads();
+    for (int j = 0; j < 3; ++j) cpp[j] = C->model.cp_pos[lane][j];
+    cpr = C->model.cp_radius[lane];
   }
+  // pass 3 and inverse articulated inertias, outward: the parent's K entries (K3) and acceleration component (apr)
+  // travel down the chain in registers; one LDS hand-over per level (g = K_p U / D and the terms of U.(a_p + c)).
+  {
+    float K3[3], apr = s.a[0][mr];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) K3[j] = s.IA[0][3 * k + j];
+#pragma unroll 1
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+      const int i = ch_body(cr, d);
+      const bool act = i != CH_NONE;
+      float U3[3] = {0.f, 0.f, 0.f}, gr = 0.f, apc = 0.f, invD = 0.f;
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) U3[j] = s.U[i][mc + j];
+        invD = s.iD[i];
+        const float gp = K3[0] * U3[0] + K3[1] * U3[1] + K3[2] * U3[2];
+        gr = (gp + pair_swap(gp)) * invD;           // g[mr] = row mr of K_p times U / D
+        apc = apr + s.c[i][mr];
+        GG(s)[i][mr] = gr;
+        TT(s)[i][mr] = s.U[i][mr] * apc;
+      }
+      WSYNC();
+      if (act) {
+        float g3[3], S3[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { g3[j] = GG(s)[i][mc + j]; S3[j] = s.S[i][mc + j]; }
+        const float* t = TT(s)[i];
+        const float qdd = (s.u[i] - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * invD;
+        const float ug = U3[0] * g3[0] + U3[1] * g3[1] + U3[2] * g3[2];
+        const float gam = (ug + pair_swap(ug)) * invD + invD;
+        const float sr = s.S[i][mr];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          K3[j] = K3[j] - gr * S3[j] - sr * g3[j] + gam * sr * S3[j];
+          s.IA[i][3 * k + j] = K3[j];
+        }
+        apr = apc + sr * qdd;
+        s.a[i][mr] = apr;                           // after every lane's read of t (program order within the wavefront)
+        if (k == 0) s.qdd[i] = qdd;
+      }
+    }
+  }
+  WSYNC();
   STAMP(6);
   // contacts: one contact sphere per lane
   if (lane < WBC_NCP) {
     const int kc = lane;
-    const int b = C->model.cp_body[kc];
-    const f3 xk = ld3(s.pos[b]) + mat_mul(s.E[b], ld3(C->model.cp_pos[kc]));
+    const int b = cpb;
+    const f3 xk = ld3(s.pos[b]) + mat_mul(s.E[b], mk3(cpp[0], cpp[1], cpp[2]));
     const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
     float h; f3 nw;
     terrain_query(C, Xw.x, Xw.y, &h, &nw);
-    const float rad = C->model.cp_radius[kc];
+    const float rad = cpr;
     const float gap = (Xw.z - h) * nw.z - rad;
     const int active = gap < C->cfg.contact_margin;
     s.cactive[kc] = active;
@@ -382,7 +466,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       const f3 n = matT_mul(s.R, nw);
       const f3 xc = xk - n * rad;
       st3(s.cn[kc], n); st3(s.cxc[kc], xc);
-      s.cvtgt[kc] = (gap >= 0.f) ? -gap / dt : fminf(C->cfg.contact_erp * (-gap) / dt, C->cfg.max_depenetration_vel);
+      s.cvtgt[kc] = (gap >= 0.f) ? -gap * idt : fminf(C->cfg.contact_erp * (-gap) * idt, C->cfg.max_depenetration_vel);
       const float* K = s.IA[b];
       const float X[9] = {0.f, -xc.z, xc.y, xc.z, 0.f, -xc.x, -xc.y, xc.x, 0.f};
       float J[18];
@@ -414,13 +498,20 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
   if (lane < 6) AD(s)[0][lane] = 0.f;
-  __syncthreads();
+  WSYNC();
   STAMP(7);
-  int any = 0;
+  // dmax: deepest chain level that carries an active contact. Deeper levels see no contact wrench, so the inward
+  // sweep skips them exactly; the outward sweep needs them only in the last iteration (joint accelerations).
+  int any = 0, dmax = 1;
 #pragma unroll
-  for (int kc = 0; kc < WBC_NCP; ++kc) any |= s.cactive[kc];
+  for (int kc = 0; kc < WBC_NCP; ++kc) {
+    const int a = s.cactive[kc];
+    any |= a;
+    dmax = max(dmax, a ? C->cp_depth[kc] : 0);
+  }
   if (any) {
-    for (int it = 0; it < C->cfg.contact_iters; ++it) {
+    const int iters = C->cfg.contact_iters;
+    for (int it = 0; it < iters; ++it) {
       if (lane < WBC_NCP && s.cactive[lane]) {
         const int kc = lane;
         const f3 own = mat_mul(s.cW[kc], ld3(s.clam[kc]));
@@ -429,58 +520,81 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         contact_solve(s.cW[kc], ld3(s.cn[kc]), s.cvtgt[kc], s.mu, vref, lam);
         s.clam[kc][0] = lam[0]; s.clam[kc][1] = lam[1]; s.clam[kc][2] = lam[2];
       }
-      __syncthreads();
+      WSYNC();
       // gather contact wrenches per body (fixed order), pD = -f_ext
       if (lane < WBC_NB) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int kc = 0; kc < WBC_NCP; ++kc) {
-          if (s.cactive[kc] && C->model.cp_body[kc] == lane) {
-            const f3 f = ld3(s.clam[kc]) * (1.f / dt);
+        uint32_t mask = s.k_body[lane] >> 7;       // the contact spheres on this body, ascending
+        while (mask) {
+          const int kc = __ffs(mask) - 1;
+          mask &= mask - 1;
+          if (s.cactive[kc]) {
+            const f3 f = ld3(s.clam[kc]) * idt;
             const f3 mom = cross(ld3(s.cxc[kc]), f);
             acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
           }
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
+        s.uD[lane] = 0.f;                          // levels the inward sweep skips
       }
-      __syncthreads();
+      WSYNC();
+      {   // inward: lane (chain, k<6) carries component k of the accumulated wrench in a register
+        float carry = 0.f;
 #pragma unroll 1
-      for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
-        const int i = cr.body[d];
-        if (in_chain && i >= 0 && k < 6) {
-          const float uD = -dot6(s.S[i], PD(s)[i]);
-          const float val = PD(s)[i][k] + s.U[i][k] * (uD / s.D[i]);
-          if (k == 0) s.uD[i] = uD;
-          if (d > 0) PD(s)[cr.par[d]][k] += val; else s.pa1[chain][k] = val;
+        for (int d = dmax - 1; d >= 0; --d) {
+          const int i = ch_body(cr, d);
+          const bool act = i != CH_NONE && k < 6;
+          float pk = 0.f;
+          if (act) { pk = PD(s)[i][k] + carry; TT(s)[i][k] = s.S[i][k] * pk; }
+          WSYNC();
+          if (act) {
+            const float* t = TT(s)[i];
+            const float uD = -(((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5]);
+            if (k == 0) s.uD[i] = uD;
+            carry = pk + s.U[i][k] * (uD * s.iD[i]);
+            if (d == 0) s.pa1[chain][k] = carry;
+          }
         }
-        __syncthreads();
+        WSYNC();
       }
-      if (lane < 6) {
-        float acc = PD(s)[0][lane];
+      if (lane < 6) {       // root: sum of the depth-1 contributions (fixed order), then a0 = -K0 pD0
+        float pd0[6];
 #pragma unroll
-        for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][lane];
-        PD(s)[0][lane] = acc;
-      }
-      __syncthreads();
-      if (lane < 6) AD(s)[0][lane] = -dot6(&s.IA[0][lane * 6], PD(s)[0]);
-      __syncthreads();
-#pragma unroll 1
-      for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-        const int i = cr.body[d];
-        if (in_chain && i >= 0 && k < 6) {
-          const int p = cr.par[d];
-          const float qdd = (s.uD[i] - dot6(s.U[i], AD(s)[p])) / s.D[i];
-          AD(s)[i][k] = AD(s)[p][k] + s.S[i][k] * qdd;
-          if (k == 0) s.qddD[i] = qdd;
+        for (int j = 0; j < 6; ++j) {
+          float acc = PD(s)[0][j];
+#pragma unroll
+          for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][j];
+          pd0[j] = acc;
         }
-        __syncthreads();
+        AD(s)[0][lane] = -dot6(&s.IA[0][lane * 6], pd0);
+      }
+      WSYNC();
+      const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
+      {   // outward: component k of the parent's acceleration change travels in a register
+        float adk = (k < 6) ? AD(s)[0][k] : 0.f;
+#pragma unroll 1
+        for (int d = 0; d < dout; ++d) {
+          const int i = ch_body(cr, d);
+          const bool act = i != CH_NONE && k < 6;
+          if (act) TT(s)[i][k] = s.U[i][k] * adk;
+          WSYNC();
+          if (act) {
+            const float* t = TT(s)[i];
+            const float qdd = (s.uD[i] - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * s.iD[i];
+            adk += s.S[i][k] * qdd;
+            AD(s)[i][k] = adk;
+            if (k == 0) s.qddD[i] = qdd;
+          }
+        }
+        WSYNC();
       }
       if (lane < WBC_NCP && s.cactive[lane]) {
-        const int kc = lane, b = C->model.cp_body[kc];
+        const int kc = lane, b = cpb;
         const f3 t = cross(ld3(&AD(s)[b][0]), ld3(s.cxc[kc]));
         st3(s.cdv[kc], (ld3(&AD(s)[b][3]) + t) * dt);
       }
-      __syncthreads();
+      WSYNC();
     }
   }
   STAMP(8);
@@ -489,7 +603,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     if (lane < WBC_NRB_ENV) {
       f3 acc = mk3(0.f, 0.f, 0.f);
       for (int kc = 0; kc < WBC_NCP; ++kc)
-        if (s.cactive[kc] && C->model.cp_rb[kc] == lane) acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * (1.f / dt));
+        if (s.cactive[kc] && C->model.cp_rb[kc] == lane) acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * idt);
       st3(s.out_contact[lane], acc);
     } else if (lane >= 32 && lane < 32 + WBC_NFEET) {
       const int ft = lane - 32;
@@ -497,7 +611,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       for (int kc = 0; kc < WBC_NCP; ++kc)
         if (s.cactive[kc] && C->cp_foot[kc] == ft) {
           const int b = C->model.cp_body[kc];
-          const f3 f = ld3(s.clam[kc]) * (1.f / dt);
+          const f3 f = ld3(s.clam[kc]) * idt;
           const f3 arm = ld3(s.cn[kc]) * (-C->model.cp_radius[kc]);
           fa = fa + matT_mul(s.E[b], f);
           ta = ta + matT_mul(s.E[b], cross(arm, f));
@@ -510,11 +624,11 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   float a0[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) a0[j] = s.a[0][j] + AD(s)[0][j];
-  __syncthreads();
+  WSYNC();
   if (lane >= 1 && lane < WBC_NB) {
-    const int dj = C->model.dof[lane];
+    const int dj = (s.k_body[lane] >> 2) & 31;
     float qd = s.qd[dj] + dt * (s.qdd[lane] + s.qddD[lane]);
-    const float lim = C->model.qd_limit[dj];
+    const float lim = s.k_qdlim[dj];
     if (lim > 0.f) qd = fminf(fmaxf(qd, -lim), lim);
     s.qd[dj] = qd;
     s.q[dj] += dt * qd;
@@ -530,11 +644,11 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     quat_mul(om, &s.root[3], dq);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { nq[j] = s.root[3 + j] + 0.5f * dt * dq[j]; nn += nq[j] * nq[j]; }
-    nn = 1.f / sqrtf(nn);
+    nn = __builtin_amdgcn_rsqf(nn);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s.root[3 + j] = nq[j] * nn;
   }
-  __syncthreads();
+  WSYNC();
   STAMP(10);
 }
 
@@ -547,14 +661,15 @@ __device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const C
     for (int j = 0; j < 3; ++j) { s.post.omB[0][j] = s.root[10 + j]; s.post.voB[0][j] = s.root[7 + j]; }
     for (int j = 0; j < 4; ++j) s.post.quatB[0][j] = s.root[3 + j];
   }
+  joint_pre_pass(s, C);
   fk_pass(s, C, cr, chain, k);
   // one lane per chain walks it: world angular velocity, origin velocity, orientation
-  if (chain < WBC_NCHAIN && k == 0) {
+  if (k == 0) {
 #pragma unroll 1
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-      const int i = cr.body[d];
-      if (i >= 0) {
-        const int p = cr.par[d], ax = cr.ax[d], dj = cr.dof[d];
+      const int i = ch_body(cr, d);
+      if (i != CH_NONE) {
+        const int p = ch_par(cr, d), ax = ch_ax(cr, d), dj = ch_dof(cr, d);
         const f3 relw = mat_mul(s.R, ld3(s.pos[i]) - ld3(s.pos[p]));
         st3(s.post.voB[i], ld3(s.post.voB[p]) + cross(ld3(s.post.omB[p]), relw));
         const f3 sw = mat_mul(s.R, mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax]));
@@ -567,7 +682,7 @@ __device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const C
       }
     }
   }
-  __syncthreads();
+  WSYNC();
   if (lane < WBC_NRB) {
     const int r = lane, b = C->model.rb_body[r];
     const f3 t = mat_mul(s.E[b], ld3(C->model.rb_offset[r]));
@@ -580,7 +695,7 @@ __device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const C
   } else if (lane == WBC_NRB) {
     for (int j = 0; j < 13; ++j) s.post.out_rb[WBC_NRB][j] = s.box[j];
   }
-  __syncthreads();
+  WSYNC();
 }
 
 __device__ __forceinline__ void resample_commands(Smem& s, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int slot) {
@@ -742,20 +857,18 @@ __device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restric
 
 __device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
   const int lane = threadIdx.x;
+  if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = (&C->model.joint_xyz[0][0])[lane];
+  if (lane < WBC_NB) s.k_body[lane] = C->body_pack[lane];
+  if (lane < WBC_NDOF) s.k_qdlim[lane] = C->model.qd_limit[lane];
   if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
     const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
-    const int i = (ch < WBC_NCHAIN) ? C->chain_body[ch][d] : -1;
-    const int ii = i < 0 ? 0 : i;
-    const int dj = C->model.dof[ii] < 0 ? 0 : C->model.dof[ii];
-    s.ct_body[ch][d] = i;
-    s.ct_par[ch][d] = C->model.parent[ii] < 0 ? 0 : C->model.parent[ii];
-    s.ct_ax[ch][d] = C->model.axis[ii] < 0 ? 0 : C->model.axis[ii];
-    s.ct_dof[ch][d] = dj;
-    s.ct_arm[ch][d] = (dj < WBC_NACT) ? C->cfg.joint_armature[dj] : 0.f;
+    const int dj = (C->chain_pack_dof[ch] >> (5 * d)) & 31;
+    const bool have = ((C->chain_pack_body[ch] >> (5 * d)) & 31) != CH_NONE;
+    s.ct_arm[ch][d] = (have && dj < WBC_NACT) ? C->cfg.joint_armature[dj] : 0.f;
   }
   const int ch = chain < WBC_NCHAIN ? chain : WBC_NCHAIN;
-  cr.body = s.ct_body[ch]; cr.par = s.ct_par[ch]; cr.ax = s.ct_ax[ch]; cr.dof = s.ct_dof[ch]; cr.arm = s.ct_arm[ch];
-  __syncthreads();
+  cr.body = C->chain_pack_body[ch]; cr.dof = C->chain_pack_dof[ch]; cr.ax = C->chain_pack_ax[ch]; cr.arm = s.ct_arm[ch];
+  WSYNC();
 }
 
 // _compute_torques (oracle: compute_torques): lanes 0..19
@@ -782,7 +895,7 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
   }
   if (lane < WBC_NREW) { T.ep_sums_done[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane]; }
   if (lane < WBC_NMETRIC) { T.met_sums_done[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane]; }
-  __syncthreads();
+  WSYNC();
   if (lane < WBC_NREW) s.ep_sums[lane] = 0.f;
   if (lane < WBC_NMETRIC) s.met_sums[lane] = 0.f;
   if (lane == 0) {
@@ -799,7 +912,7 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
     s.reset_flag = 1;
     s.goal[G_TIMER] = 0.f;
   }
-  __syncthreads();
+  WSYNC();
 }
 
 // compute_observations (oracle) + the HBM write-out of the step's results.
@@ -827,7 +940,7 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
     else val = s.goal[G_DORN + e - 73];
     s.post.o76[e] = val;
   }
-  __syncthreads();
+  WSYNC();
   // obs_buf = [o76, priv24, old history]; history <- shifted / refilled
   const float clipv = cf.clip_obs;
   float* obs = T.obs + (size_t)env * WBC_NOBS;
@@ -839,7 +952,7 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
     const int idx = lane + r * LANES;
     old[r] = (idx < WBC_HIST * WBC_NPROP && !was_reset) ? hist[idx] : 0.f;
   }
-  __syncthreads();   // all history reads done before the in-place shift
+  WSYNC();   // all history reads done before the in-place shift
 #pragma unroll
   for (int r = 0; r < 12; ++r) {
     const int idx = lane + r * LANES;
@@ -908,11 +1021,11 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     s.act[lane] = used;
     s.act_last[lane] = a;
   }
-  __syncthreads();
+  WSYNC();
   const int dec = C->cfg.decimation;
   for (int t = 0; t < dec; ++t) {
     torque_pass(s, C);
-    __syncthreads();
+    WSYNC();
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
   // post_physics_step (WG:865-915)
@@ -949,7 +1062,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     s.reset_flag = r_term | p_term | z_term | s.time_out;
     compute_reward(s, C, yq);
   }
-  __syncthreads();
+  WSYNC();
   const bool do_reset = s.reset_flag != 0;
   if (do_reset) reset_env(s, T, C, seed, env, step, 0, s.base_yaw);
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
@@ -970,10 +1083,10 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors 
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   if (lane == 0) { s.time_out = 0; s.reset_flag = 0; }
-  __syncthreads();
+  WSYNC();
   float yaw = 0.f;
   if (lane == 0) { yaw = euler_from_quat(&s.root[3]).z; s.base_yaw = yaw; }
-  __syncthreads();
+  WSYNC();
   reset_env(s, T, C, seed, env, step, 1, s.base_yaw);
   rigid_body_pass(s, C, cr, chain, k);
   // write back what a reset touches
@@ -1002,7 +1115,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   if (lane < WBC_NDOF) s.tau[lane] = T.torques[(size_t)env * WBC_NDOF + lane];
-  __syncthreads();
+  WSYNC();
   physics_substep(s, C, cr, chain, k, true);
   if (lane < 13) T.root[(size_t)env * 26 + lane] = s.root[lane];
   if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
@@ -1020,7 +1133,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
   ChainRegs cr;
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
-  __syncthreads();
+  WSYNC();
   rigid_body_pass(s, C, cr, chain, k);
   for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
 }

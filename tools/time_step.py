@@ -2,6 +2,9 @@
 import sys, os, time, copy
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+_timing_lib = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_timing.so")   # tools/build_variant.py timing -DWBC_STEP_TIMING
+if os.path.exists(_timing_lib) and os.environ.get("WBC_STAMPS"):
+    os.environ["WBC_AMD_LIB"] = _timing_lib
 import numpy as np, torch
 import helpers
 from wbc_amd import abi
@@ -55,6 +58,6 @@ buf = torch.zeros(16, dtype=torch.int64, device="cuda")
 L.wbc_debug_set_step_timing(buf.data_ptr())
 g.simulate(); torch.cuda.synchronize()
 t = buf.cpu().numpy()
-names = ["fk", "S,v", "c(+inertia start)", "inertia", "pass2", "root inv", "pass3+K", "contact detect", "contact iters", "outputs", "integrate"]
+names = ["fk", "S,v,c", "inertia", "pass2", "root inv", "pass3+K", "contact detect", "contact iters", "outputs", "integrate"]
 print("substep phase cycles (block 0):", {names[i]: int(t[i+1]-t[i]) for i in range(10)}, "total", int(t[10]-t[0]))
 L.wbc_debug_set_step_timing(None)
