@@ -23,6 +23,7 @@ struct DevConst {
   uint32_t chain_pack_body[WBC_NCHAIN + 1];        // 6 x 5 bits: body at depth d (31 = none); row WBC_NCHAIN = idle lanes
   uint32_t chain_pack_dof[WBC_NCHAIN + 1];         // 6 x 5 bits: dof of that body
   uint32_t chain_pack_ax[WBC_NCHAIN + 1];          // 6 x 2 bits: joint axis
+  uint32_t out_cp_mask[32 + WBC_NFEET];            // [rb]: contacts feeding net_contact_force row rb; [32+f]: contacts of foot sensor f
   uint32_t body_pack[WBC_NB];                      // axis | dof << 2 | (bit mask of the contact spheres on the body) << 7
   // heightfield (optional)
   const int16_t* hf;

@@ -83,3 +83,27 @@ extern "C" int wbc_gae_normalize(float* advantages, const double* stats_dev, int
   hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)blocks), dim3(GAE_BLOCK), 0, (hipStream_t)stream, advantages, stats_dev, total);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- PPO.process_env_step's tensor work in one launch (rsl_rl/algorithms/ppo.py:129-141, rollout_storage.py:70-72) ----
+// rewards[n] = (rew[n], arm_rew[n]) + gamma * values[n] * time_out[n] (bootstrap of both channels on time-outs),
+// dones[n] = reset_buf[n] as uint8, written straight into the rollout-storage slot of this step.
+extern "C" __global__ void __launch_bounds__(256) rollout_store_kernel(const float* __restrict__ rew, const float* __restrict__ arm_rew,
+                                                                      const int64_t* __restrict__ dones, const uint8_t* __restrict__ time_outs,
+                                                                      const float* __restrict__ values, float gamma,
+                                                                      float* __restrict__ out_rewards, uint8_t* __restrict__ out_dones, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float to = time_outs ? (float)time_outs[i] : 0.f;
+  float r0 = rew[i], r1 = arm_rew[i];
+  if (time_outs) { r0 += gamma * (values[2 * i] * to); r1 += gamma * (values[2 * i + 1] * to); }
+  out_rewards[2 * i] = r0; out_rewards[2 * i + 1] = r1;
+  out_dones[i] = (uint8_t)(dones[i] != 0);
+}
+
+extern "C" int wbc_rollout_store(const float* rew, const float* arm_rew, const int64_t* dones, const uint8_t* time_outs, const float* values,
+                                 float gamma, float* out_rewards, uint8_t* out_dones, int n, void* stream) {
+  if (!rew || !arm_rew || !dones || !values || !out_rewards || !out_dones || n <= 0) return -1;
+  hipLaunchKernelGGL(rollout_store_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, arm_rew, dones, time_outs, values, gamma,
+                     out_rewards, out_dones, n);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

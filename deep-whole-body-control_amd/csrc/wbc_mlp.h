@@ -207,18 +207,21 @@ static __device__ __forceinline__ void fwd_run(const float (&w)[64], const FwdDe
   __syncthreads();
 }
 
-// The whole 16-layer forward chain: two register sets alternate so that layer l+1's operands are in flight while
-// layer l's MFMA chain runs. The loop body (two layers) is the only copy of the layer code in the kernel.
+// The forward chain over layers [lbeg, lend): two register sets alternate so that layer l+1's operands are in flight
+// while layer l's MFMA chain runs. The loop body (two layers) is the only copy of the layer code in the kernel.
 static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem, const float* __restrict__ wpack, float* __restrict__ stash,
-                                                 int lds, int row0, int num_rows) {
+                                                 int lds, int row0, int num_rows, int lbeg = 0, int lend = NLAYERS) {
   const float* bias_base = wpack + WPACK_WEIGHT_FLOATS;
   float wa[64], wb[64];
-  fwd_load(wa, T.l[0], wpack);
+  fwd_load(wa, T.l[lbeg], wpack);
 #pragma unroll 1
-  for (int l = 0; l < NLAYERS; l += 2) {
-    fwd_load(wb, T.l[l + 1], wpack);
+  for (int l = lbeg; l < lend; l += 2) {
+    const bool two = l + 1 < lend;
+    if (two) fwd_load(wb, T.l[l + 1], wpack);
     fwd_run(wa, T.l[l], smem, bias_base, stash, lds, row0, num_rows);
-    if (l + 2 < NLAYERS) fwd_load(wa, T.l[l + 2], wpack);
-    fwd_run(wb, T.l[l + 1], smem, bias_base, stash, lds, row0, num_rows);
+    if (two) {
+      if (l + 2 < lend) fwd_load(wa, T.l[l + 2], wpack);
+      fwd_run(wb, T.l[l + 1], smem, bias_base, stash, lds, row0, num_rows);
+    }
   }
 }

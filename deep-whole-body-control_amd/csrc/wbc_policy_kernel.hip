@@ -8,6 +8,8 @@
 // 128 output features).
 // The epilogue samples the action from pre-drawn standard normals and writes mean, action, the two
 // log-probabilities (12 leg / 6 arm dims) and the two values.
+// Grid = (row tiles, 2): blockIdx.y = 0 runs the actor (9 layers), 1 the critic (7 layers), so that 4096 envs give
+// 256 workgroups (one per CU) and the dependent layer chain per workgroup is half as long.
 #include "wbc_mlp.h"
 
 extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(PolicyParams P, FwdTable T, const float* __restrict__ wpack,
@@ -19,21 +21,30 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * PT_ROWS;
   int dbg_i = 0;
-#define DBG_STAMP() do { if (dbg && blockIdx.x == 0 && tid == 0) dbg[dbg_i] = clock64(); ++dbg_i; } while (0)
+#define DBG_STAMP() do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) dbg[dbg_i] = clock64(); ++dbg_i; } while (0)
   DBG_STAMP();
   // load obs[:, :100] of 32 rows (rows past the end are zero); the proprio block also goes to a1[:, :76], next to
   // where priv2 will put the latent (the backbone input z = [prop, latent])
   load_x_tile(smem + S_X, [&](int r) { return (row0 + r < num_rows) ? obs + (size_t)(row0 + r) * PT_NOBS : (const float*)nullptr; });
   __syncthreads();
-  for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
-    const int r = e / PT_NPROP, c = e - r * PT_NPROP;
-    smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
-  }
+  const bool critic = blockIdx.y != 0;
+  if (!critic)
+    for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
+      const int r = e / PT_NPROP, c = e - r * PT_NPROP;
+      smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
+    }
   DBG_STAMP();
-  // actor (AC:204-221) then critic (AC:281-286): 16 layers, table-driven (wbc_mlp.h)
-  fwd_chain(T, smem, wpack, nullptr, 0, row0, num_rows);
+  // actor (AC:204-221): layers 0..8; critic (AC:281-286): layers 9..15; table-driven (wbc_mlp.h)
+  fwd_chain(T, smem, wpack, nullptr, 0, row0, num_rows, critic ? L_CBB : 0, critic ? NLAYERS : L_CBB);
   DBG_STAMP();
   const float* outv = smem + S_OUTV;
+  if (critic) {
+    if (tid < PT_ROWS && row0 + tid < num_rows) {
+      const size_t g = (size_t)(row0 + tid);
+      value_out[g * 2] = outv[tid * 21 + 18]; value_out[g * 2 + 1] = outv[tid * 21 + 19];
+    }
+    return;
+  }
   // ---- epilogue: sample, log-probabilities (Normal.log_prob summed over leg / arm dims), outputs
   if (tid < PT_ROWS && row0 + tid < num_rows) {
     const int r = tid;
@@ -51,7 +62,6 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
       mean_out[g * 18 + j] = mu;
     }
     logp_out[g * 2] = lp_leg; logp_out[g * 2 + 1] = lp_arm;
-    value_out[g * 2] = outv[r * 21 + 18]; value_out[g * 2 + 1] = outv[r * 21 + 19];
   }
   DBG_STAMP();
 #undef DBG_STAMP
@@ -87,7 +97,7 @@ extern "C" int wbc_policy_act(const void* const* params, const float* wpack, con
   if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
   const int blocks = (num_rows + PT_ROWS - 1) / PT_ROWS;
   static const FwdTable T = make_fwd_table(nullptr);
-  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T, wpack, obs, eps, actions, mean, logp,
+  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T, wpack, obs, eps, actions, mean, logp,
                      values, num_rows, g_policy_dbg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

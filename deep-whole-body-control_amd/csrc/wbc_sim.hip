@@ -112,6 +112,12 @@ static int build_chains(DevConst& hc) {
     }
     hc.chain_pack_body[c] = pb; hc.chain_pack_dof[c] = pd; hc.chain_pack_ax[c] = pa;
   }
+  static_assert(WBC_NRB_ENV <= 32, "out_cp_mask layout");
+  for (int r = 0; r < 32 + WBC_NFEET; ++r) hc.out_cp_mask[r] = 0;
+  for (int k = 0; k < WBC_NCP; ++k) {
+    if (m.cp_rb[k] >= 0 && m.cp_rb[k] < WBC_NRB_ENV) hc.out_cp_mask[m.cp_rb[k]] |= 1u << k;
+    if (hc.cp_foot[k] >= 0) hc.out_cp_mask[32 + hc.cp_foot[k]] |= 1u << k;
+  }
   for (int i = 0; i < WBC_NB; ++i) {
     uint32_t mask = 0;
     for (int k = 0; k < WBC_NCP; ++k) if (m.cp_body[k] == i) mask |= 1u << k;
@@ -361,6 +367,39 @@ extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
   hipLaunchKernelGGL(wbc_fk_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n);
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// extras["episode"] of reset_idx (WG:743-754): mean over the envs that reset in the last step of their finished
+// episode's reward sums [WBC_NREW] and metric sums [WBC_NMETRIC], times `scale` (1 / max_episode_length_s).
+// One block per column, fixed-order tree: deterministic. No reset -> zeros (the reference divides by max(count,1) too
+// in this framework's host layer).
+static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* __restrict__ ep_done, const float* __restrict__ met_done,
+                                                                  const int64_t* __restrict__ reset_buf, int n, float scale, float* __restrict__ out) {
+  __shared__ float sh[256];
+  __shared__ float shc[256];
+  const int col = blockIdx.x;
+  const float* src = col < WBC_NREW ? ep_done + col : met_done + (col - WBC_NREW);
+  const int width = col < WBC_NREW ? WBC_NREW : WBC_NMETRIC;
+  float acc = 0.f, cnt = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const bool d = reset_buf[i] != 0;
+    acc += d ? src[(size_t)i * width] : 0.f;
+    cnt += d ? 1.f : 0.f;
+  }
+  sh[threadIdx.x] = acc; shc[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { sh[threadIdx.x] += sh[threadIdx.x + off]; shc[threadIdx.x] += shc[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[col] = sh[0] / fmaxf(shc[0], 1.f) * scale;
+}
+
+extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, float* out, void* stream) {
+  if (!s || !out) return fail(-1, "wbc_sim_episode_stats: null argument");
+  hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC), dim3(256), 0, (hipStream_t)stream, s->T.ep_sums_done, s->T.met_sums_done,
+                     s->T.reset_buf, s->n, scale, out);
+  return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
 }
 
 extern "C" int wbc_sim_get_step_counter(wbc_sim* s, int64_t* out) { if (!s || !out) return fail(-1, "null"); *out = s->step_counter; return 0; }

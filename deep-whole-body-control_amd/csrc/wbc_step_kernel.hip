@@ -180,7 +180,9 @@ __device__ __forceinline__ void terrain_query(const DevConst* __restrict__ C, fl
   *n = mk3(-gx * inv, -gy * inv, inv);
 }
 
-// sin/cos of every joint angle and the joint-limit terms of this substep: lanes 32..51, one DoF each
+// sin/cos of every joint angle and the joint-limit terms of this substep: lanes 32..51, one DoF each.
+// HALF (post-physics): the limit slots receive sin/cos of the half angles instead (joint quaternions).
+template <bool HALF>
 __device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restrict__ C) {
   const int j = (int)threadIdx.x - 32;
   if (j >= 0 && j < WBC_NDOF) {
@@ -188,6 +190,12 @@ __device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restri
     float sq, cq;
     sincosf(qq, &sq, &cq);
     s.sq[j] = sq; s.cq[j] = cq;
+    if (HALF) {
+      float sh, ch;
+      sincosf(0.5f * qq, &sh, &ch);
+      s.viol[j] = sh; s.limd[j] = ch;
+      return;
+    }
     const float lo = C->model.q_lower[j], hi = C->model.q_upper[j];
     float viol = 0.f;
     if (lo < hi) { if (qq > hi) viol = qq - hi; else if (qq < lo) viol = qq - lo; }
@@ -218,7 +226,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     st3(s.vb, matT_mul(s.R, ld3(&s.root[7])));
     st3(s.gF, matT_mul(s.R, ld3(C->cfg.gravity)));
   }
-  joint_pre_pass(s, C);
+  joint_pre_pass<false>(s, C);
   STAMP(0);
   fk_pass(s, C, cr, chain, k);   // begins with a barrier after the identity write, ends with one
   STAMP(1);
@@ -589,7 +597,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         }
         WSYNC();
       }
-      if (lane < WBC_NCP && s.cactive[lane]) {
+      if (it < iters - 1 && lane < WBC_NCP && s.cactive[lane]) {      // the last sweep's contact-point response is not used
         const int kc = lane, b = cpb;
         const f3 t = cross(ld3(&AD(s)[b][0]), ld3(s.cxc[kc]));
         st3(s.cdv[kc], (ld3(&AD(s)[b][3]) + t) * dt);
@@ -600,22 +608,30 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(8);
   // contact force outputs (world-frame net force per rigid body, foot-frame sensor wrench)
   if (want_outputs) {
+    // lanes 0..27: net force on rigid body `lane`; lanes 32..35: sensor wrench of foot lane-32 (contact masks, ascending)
+    uint32_t mask = C->out_cp_mask[lane < 32 + WBC_NFEET ? lane : 0];
     if (lane < WBC_NRB_ENV) {
       f3 acc = mk3(0.f, 0.f, 0.f);
-      for (int kc = 0; kc < WBC_NCP; ++kc)
-        if (s.cactive[kc] && C->model.cp_rb[kc] == lane) acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * idt);
+      while (mask) {
+        const int kc = __ffs(mask) - 1;
+        mask &= mask - 1;
+        if (s.cactive[kc]) acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * idt);
+      }
       st3(s.out_contact[lane], acc);
     } else if (lane >= 32 && lane < 32 + WBC_NFEET) {
       const int ft = lane - 32;
       f3 fa = mk3(0.f, 0.f, 0.f), ta = mk3(0.f, 0.f, 0.f);
-      for (int kc = 0; kc < WBC_NCP; ++kc)
-        if (s.cactive[kc] && C->cp_foot[kc] == ft) {
+      while (mask) {
+        const int kc = __ffs(mask) - 1;
+        mask &= mask - 1;
+        if (s.cactive[kc]) {
           const int b = C->model.cp_body[kc];
           const f3 f = ld3(s.clam[kc]) * idt;
           const f3 arm = ld3(s.cn[kc]) * (-C->model.cp_radius[kc]);
           fa = fa + matT_mul(s.E[b], f);
           ta = ta + matT_mul(s.E[b], cross(arm, f));
         }
+      }
       st3(&s.out_sensor[ft][0], fa); st3(&s.out_sensor[ft][3], ta);
     }
   }
@@ -661,24 +677,44 @@ __device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const C
     for (int j = 0; j < 3; ++j) { s.post.omB[0][j] = s.root[10 + j]; s.post.voB[0][j] = s.root[7 + j]; }
     for (int j = 0; j < 4; ++j) s.post.quatB[0][j] = s.root[3 + j];
   }
-  joint_pre_pass(s, C);
+  joint_pre_pass<true>(s, C);
   fk_pass(s, C, cr, chain, k);
-  // one lane per chain walks it: world angular velocity, origin velocity, orientation
+  // per body, in parallel (lane (chain, d<6) = the chain's body at depth d): world-frame lever from the parent's
+  // origin and the joint's angular-velocity contribution, parked in voB / omB
+  if (k < WBC_MAX_DEPTH) {
+    const int i = ch_body(cr, k);
+    if (i != CH_NONE) {
+      const int p = ch_par(cr, k), ax = ch_ax(cr, k);
+      st3(s.post.voB[i], mat_mul(s.R, ld3(s.pos[i]) - ld3(s.pos[p])));
+      st3(s.post.omB[i], mat_mul(s.R, mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax])) * s.qd[ch_dof(cr, k)]);
+    }
+  }
+  WSYNC();
+  // two lanes per chain walk it with the running state in registers: k=0 velocities, k=1 orientation
   if (k == 0) {
+    f3 om = ld3(s.post.omB[0]), vo = ld3(s.post.voB[0]);
 #pragma unroll 1
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
       const int i = ch_body(cr, d);
       if (i != CH_NONE) {
-        const int p = ch_par(cr, d), ax = ch_ax(cr, d), dj = ch_dof(cr, d);
-        const f3 relw = mat_mul(s.R, ld3(s.pos[i]) - ld3(s.pos[p]));
-        st3(s.post.voB[i], ld3(s.post.voB[p]) + cross(ld3(s.post.omB[p]), relw));
-        const f3 sw = mat_mul(s.R, mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax]));
-        st3(s.post.omB[i], ld3(s.post.omB[p]) + sw * s.qd[dj]);
-        float sh, ch;
-        sincosf(0.5f * s.q[dj], &sh, &ch);
-        float qa[4] = {0.f, 0.f, 0.f, ch};
-        qa[0] = (ax == 0) ? sh : 0.f; qa[1] = (ax == 1) ? sh : 0.f; qa[2] = (ax == 2) ? sh : 0.f;
-        quat_mul(s.post.quatB[p], qa, s.post.quatB[i]);
+        vo = vo + cross(om, ld3(s.post.voB[i]));
+        om = om + ld3(s.post.omB[i]);
+        st3(s.post.voB[i], vo); st3(s.post.omB[i], om);
+      }
+    }
+  } else if (k == 1) {
+    float qp[4] = {s.post.quatB[0][0], s.post.quatB[0][1], s.post.quatB[0][2], s.post.quatB[0][3]};
+#pragma unroll 1
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+      const int i = ch_body(cr, d);
+      if (i != CH_NONE) {
+        const int ax = ch_ax(cr, d), dj = ch_dof(cr, d);
+        const float sh = s.viol[dj], ch = s.limd[dj];
+        const float qa[4] = {(ax == 0) ? sh : 0.f, (ax == 1) ? sh : 0.f, (ax == 2) ? sh : 0.f, ch};
+        float qn[4];
+        quat_mul(qp, qa, qn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qp[j] = qn[j]; s.post.quatB[i][j] = qn[j]; }
       }
     }
   }
@@ -1000,6 +1036,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
+  STAMP(11);
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
   // action reorder, clip and delay FIFO (WG:1162-1168)
@@ -1023,13 +1060,16 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   }
   WSYNC();
   const int dec = C->cfg.decimation;
+  STAMP(12);
   for (int t = 0; t < dec; ++t) {
     torque_pass(s, C);
     WSYNC();
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
+  STAMP(13);
   // post_physics_step (WG:865-915)
   rigid_body_pass(s, C, cr, chain, k);
+  STAMP(14);
   float base_yaw = 0.f;
   if (lane == 0) {
     s.ep_len += 1;
@@ -1063,13 +1103,16 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     compute_reward(s, C, yq);
   }
   WSYNC();
+  STAMP(15);
   const bool do_reset = s.reset_flag != 0;
   if (do_reset) reset_env(s, T, C, seed, env, step, 0, s.base_yaw);
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
     T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
   }
+  STAMP(16);
   observe_and_store(s, T, C, env, do_reset);
+  STAMP(17);
 }
 
 // reset_idx(all envs, start=True) (BT:129): one wave per env

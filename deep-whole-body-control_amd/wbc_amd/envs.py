@@ -285,15 +285,12 @@ class WidowGo1(LeggedRobot):
     def _fill_extras(self, start=False):
         """extras['episode'] / extras['time_outs'] of WG:743-754, 902-906, without host syncs."""
         if self.collect_episode_stats:
-            done = self.reset_buf.to(torch.float32)
-            cnt = done.sum().clamp(min=1.0)
+            st = self.sim.episode_stats(1.0 / self.max_episode_length_s).unbind(0)      # one launch, 31 scalar views
             ep = {}
-            sums = (self._episode_sums_done * done[:, None]).sum(0) / cnt / self.max_episode_length_s
             for i, name in self._active_terms:
-                ep["rew_" + name] = sums[i]
-            met = (self._metric_sums_done * done[:, None]).sum(0) / cnt / self.max_episode_length_s
+                ep["rew_" + name] = st[i]
             for i, name in enumerate(abi.METRIC_NAMES):
-                ep["metric_" + name] = met[i]
+                ep["metric_" + name] = st[abi.NREW + i]
             ep["coeff_lin_vel_x_upper_bound"] = self.lin_vel_x_ranges[1]
             ep["coeff_lin_vel_x_lower_bound"] = self.lin_vel_x_ranges[0]
             ep["coeff_ang_vel_yaw_upper_bound"] = self.ang_vel_yaw_ranges[1]

@@ -71,7 +71,11 @@ class PPO:
             if self.storage is not None and self.storage.step == 0:
                 ac.mark_params_changed()      # start of a rollout: re-pack once, whoever touched the weights since
             eps = torch.randn(obs.shape[0], 18, device=obs.device)
-            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps)
+            st, out = self.storage, None
+            if (st is not None and st.step < st.num_transitions_per_env and st.actions.is_cuda and st.actions.shape[1:] == (obs.shape[0], 18)):
+                i = st.step                       # write straight into this step's storage slots
+                out = (st.actions[i], st.mu[i], st.actions_log_prob[i], st.values[i])
+            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps, out)
             tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
         else:
             tr.actions = ac.act(obs, hist_encoding).detach()
@@ -95,12 +99,34 @@ class PPO:
             tr.observations, tr.critic_observations = obs, critic_obs
         return tr.actions
 
+    def _process_env_step_fused(self, rewards, arm_rewards, dones, infos):
+        """rewards (+ time-out bootstrap) and dones of this step into their storage slots with one launch."""
+        st, tr = self.storage, self.transition
+        if not (self.fused_rollout and st is not None and st.step < st.num_transitions_per_env and st.rewards.is_cuda
+                and rewards.is_cuda and rewards.dtype == torch.float32 and arm_rewards.dtype == torch.float32
+                and dones.dtype == torch.int64 and rewards.is_contiguous() and arm_rewards.is_contiguous() and dones.is_contiguous()
+                and tr.values is not None and tr.values.is_cuda and tr.values.is_contiguous() and tr.values.dtype == torch.float32
+                and tr.values.shape == (rewards.shape[0], 2)):
+            return False
+        to = infos.get("time_outs")
+        if to is not None:
+            if not (to.is_cuda and to.is_contiguous() and to.dtype in (torch.bool, torch.uint8) and to.shape == rewards.shape):
+                return False
+        from ...native import check, lib
+        i = st.step
+        check(lib().wbc_rollout_store(rewards.data_ptr(), arm_rewards.data_ptr(), dones.data_ptr(), to.data_ptr() if to is not None else None,
+                                      tr.values.data_ptr(), float(self.gamma), st.rewards[i].data_ptr(), st.dones[i].data_ptr(),
+                                      rewards.shape[0], torch.cuda.current_stream(rewards.device).cuda_stream), "wbc_rollout_store")
+        tr.rewards, tr.dones = st.rewards[i], st.dones[i]
+        return True
+
     def process_env_step(self, rewards, arm_rewards, dones, infos):
         tr = self.transition
-        tr.rewards = torch.stack([rewards.clone(), arm_rewards.clone()], dim=-1)
-        tr.dones = dones
-        if "time_outs" in infos:       # bootstrap both channels on time-outs (PPO:133-134)
-            tr.rewards += self.gamma * torch.squeeze(tr.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        if not self._process_env_step_fused(rewards, arm_rewards, dones, infos):
+            tr.rewards = torch.stack([rewards.clone(), arm_rewards.clone()], dim=-1)
+            tr.dones = dones
+            if "time_outs" in infos:       # bootstrap both channels on time-outs (PPO:133-134)
+                tr.rewards += self.gamma * torch.squeeze(tr.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
         supervised = "target_arm_torques" in infos
         if supervised:
             tr.target_arm_torques = infos["target_arm_torques"].detach()

@@ -287,12 +287,15 @@ class ActorCritic(nn.Module):
 
     def fused_params(self):
         """The 33 parameters the fused kernels read, in struct PolicyParams order."""
-        sd = dict(self.named_parameters())
-        out = []
-        for name in self._FUSED_LAYERS:
-            out += [sd[name + ".weight"], sd[name + ".bias"]]
-        out.append(self.std)
-        return out
+        cached = self.__dict__.get("_fused_param_list")
+        if cached is None:
+            sd = dict(self.named_parameters())
+            cached = []
+            for name in self._FUSED_LAYERS:
+                cached += [sd[name + ".weight"], sd[name + ".bias"]]
+            cached.append(self.std)
+            self.__dict__["_fused_param_list"] = cached       # Parameter objects survive .to()/load_state_dict (data is swapped)
+        return cached
 
     def fused_param_table(self):
         import ctypes as C
@@ -301,9 +304,10 @@ class ActorCritic(nn.Module):
             assert p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda
         return (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
 
-    def fused_act(self, observations, eps=None):
+    def fused_act(self, observations, eps=None, out=None):
         """PPO.act's policy side in one launch: returns (actions, mean, log_prob[.,2], values[.,2]).
-        `eps` = standard normals [B,18] (drawn by the caller from torch's generator); None acts on the mean."""
+        `eps` = standard normals [B,18] (drawn by the caller from torch's generator); None acts on the mean.
+        `out`: optional 4-tuple of contiguous float32 destination tensors (e.g. rollout-storage slots)."""
         from ...native import check, lib
         table = self.fused_param_table()
         dev = observations.device
@@ -315,10 +319,15 @@ class ActorCritic(nn.Module):
             check(lib().wbc_policy_pack(table, self._wpack.data_ptr(), stream), "wbc_policy_pack")
             self._wpack_version = self.param_version
         n = observations.shape[0]
-        actions = torch.empty(n, 18, device=dev)
-        mean = torch.empty(n, 18, device=dev)
-        logp = torch.empty(n, 2, device=dev)
-        values = torch.empty(n, 2, device=dev)
+        if out is not None:
+            actions, mean, logp, values = out
+            for t, w in ((actions, 18), (mean, 18), (logp, 2), (values, 2)):
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n, w)
+        else:
+            actions = torch.empty(n, 18, device=dev)
+            mean = torch.empty(n, 18, device=dev)
+            logp = torch.empty(n, 2, device=dev)
+            values = torch.empty(n, 2, device=dev)
         check(lib().wbc_policy_act(table, self._wpack.data_ptr(), observations.data_ptr(), eps.data_ptr() if eps is not None else None,
                                    actions.data_ptr(), mean.data_ptr(), logp.data_ptr(), values.data_ptr(), n, stream), "wbc_policy_act")
         return actions, mean, logp, values

@@ -54,12 +54,15 @@ class RolloutStorage:
         if self.privileged_observations is not None and \
                 transition.critic_observations.data_ptr() != self.privileged_observations[i].data_ptr():
             self.privileged_observations[i].copy_(transition.critic_observations)
-        self.actions[i].copy_(transition.actions)
-        self.rewards[i].copy_(transition.rewards)
-        self.dones[i].copy_(transition.dones.view(-1, 1))
-        self.values[i].copy_(transition.values)
-        self.actions_log_prob[i].copy_(transition.actions_log_prob)
-        self.mu[i].copy_(transition.action_mean)
+        def put(dst, src):                     # the fused rollout path writes the slots directly: nothing to copy then
+            if src.data_ptr() != dst.data_ptr() or src.dtype != dst.dtype:
+                dst.copy_(src)
+        put(self.actions[i], transition.actions)
+        put(self.rewards[i], transition.rewards)
+        put(self.dones[i], transition.dones.view(-1, 1))
+        put(self.values[i], transition.values)
+        put(self.actions_log_prob[i], transition.actions_log_prob)
+        put(self.mu[i], transition.action_mean)
         self.sigma[i].copy_(transition.action_sigma)
         if torque_supervision:
             self.target_arm_torques[i].copy_(transition.target_arm_torques)

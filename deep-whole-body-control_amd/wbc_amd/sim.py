@@ -112,6 +112,13 @@ class WbcSim:
     def reset_all(self) -> None:
         check(self.L.wbc_sim_reset_all(self.h, self._stream()), "wbc_sim_reset_all")
 
+    def episode_stats(self, scale: float) -> torch.Tensor:
+        """Means over the envs that reset in the last step of their finished episode's reward sums [NREW] and metric
+        sums [NMETRIC], times `scale`, as one fresh device tensor (WG:743-754 without a host sync)."""
+        out = torch.empty(abi.NREW + abi.NMETRIC, dtype=torch.float32, device=self.device)
+        check(self.L.wbc_sim_episode_stats(self.h, float(scale), out.data_ptr(), self._stream()), "wbc_sim_episode_stats")
+        return out
+
     def set_dof_forces(self, torques: torch.Tensor) -> None:
         assert torques.is_cuda and torques.dtype == torch.float32 and torques.is_contiguous()
         check(self.L.wbc_sim_set_dof_forces(self.h, torques.data_ptr(), self._stream()), "wbc_sim_set_dof_forces")

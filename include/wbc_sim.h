@@ -312,6 +312,17 @@ int wbc_ppo_grad_floats(void);
 int wbc_ppo_num_splits(void);
 size_t wbc_ppo_workspace_floats(int B);
 
+/* extras["episode"] of reset_idx (widowGo1.py:743-754): out[0:WBC_NREW] = mean over the envs that reset in the last
+ * step of their finished episode's reward sums, out[WBC_NREW:+WBC_NMETRIC] the same for the metric sums, both
+ * times `scale` (1 / max_episode_length_s). `out`: device, WBC_NREW + WBC_NMETRIC floats. */
+int wbc_sim_episode_stats(wbc_sim* sim, float scale, float* out, void* stream);
+
+/* PPO.process_env_step's tensor work (rsl_rl/algorithms/ppo.py:129-141 + rollout_storage.py:70-72) in one launch:
+ * out_rewards[n] = (rew[n], arm_rew[n]) + gamma * values[n] * time_outs[n], out_dones[n] = dones[n] != 0.
+ * time_outs may be NULL (no bootstrap). All pointers device; out_* are the rollout-storage slots of this step. */
+int wbc_rollout_store(const float* rew, const float* arm_rew, const int64_t* dones, const uint8_t* time_outs,
+                      const float* values, float gamma, float* out_rewards, uint8_t* out_dones, int n, void* stream);
+
 /* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
 void wbc_abi_sizes(int* out3);
 

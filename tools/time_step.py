@@ -54,10 +54,14 @@ print(f"fk kernel {e0.elapsed_time(e1)/100*1000:.1f} us")
 import ctypes as C
 from wbc_amd.native import lib
 L = lib(); L.wbc_debug_set_step_timing.argtypes = [C.c_void_p]
-buf = torch.zeros(16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(32, dtype=torch.int64, device="cuda")
 L.wbc_debug_set_step_timing(buf.data_ptr())
 g.simulate(); torch.cuda.synchronize()
 t = buf.cpu().numpy()
 names = ["fk", "S,v,c", "inertia", "pass2", "root inv", "pass3+K", "contact detect", "contact iters", "outputs", "integrate"]
 print("substep phase cycles (block 0):", {names[i]: int(t[i+1]-t[i]) for i in range(10)}, "total", int(t[10]-t[0]))
+g.step(acts[0]); torch.cuda.synchronize()
+t = buf.cpu().numpy()
+n2 = ["setup+load+action", "4 substeps", "rigid bodies", "lane-0 task logic + rewards", "reset", "observe+store"]
+print("step phase cycles (block 0):", {n2[i]: int(t[12+i]-t[11+i]) for i in range(6)}, "total", int(t[17]-t[11]))
 L.wbc_debug_set_step_timing(None)
