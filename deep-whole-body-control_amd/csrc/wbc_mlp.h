@@ -3,10 +3,13 @@
 // inference kernel (wbc_policy_kernel.hip) and the PPO update kernels (wbc_ppo_kernel.hip).
 //
 // Two measured facts shape this file (profiles/ and DESIGN.md section 5):
-//  * Forward GEMMs read their B operand (W^T fragments) from a PRE-PACKED copy of the weights: for layer l,
-//    k-pair kb and 32-column block cb, the 64 floats that the 64 lanes of a wave feed to one
-//    v_mfma_f32_32x32x2_f32 are contiguous (lane L gets W[cb*32 + (L&31)][2*kb + (L>>5)]), so a wave's operand
-//    load is one coalesced 256-byte global load served by L2, requested one layer ahead of its use.
+//  * GEMMs read their B operand from a PRE-PACKED copy of the weights in fragment order: for layer l, group kg of
+//    four k-pairs and 32-column block cb, lane L's four B values (k-pairs 4kg..4kg+3 of one
+//    v_mfma_f32_32x32x2_f32 each: W[cb*32 + (L&31)][2*kb + (L>>5)]) are one float4, and the 64 lanes' float4s are
+//    contiguous: a layer's operands are 16 coalesced 1-KB loads per wave, requested one layer ahead of their use.
+//    (64 single-dword loads per layer defeated the prefetch: s_waitcnt vmcnt counts at most 63 outstanding
+//    operations, so waiting for the current layer's operands also waited for the next layer's.)
+//    The backward (dgrad) GEMMs use a second, transposed pack of the same weights.
 //  * The layer chain is a LOOP over a descriptor table, not 16 unrolled template instances: fully unrolled, the
 //    inference kernel was 51 KB of straight-line code (the update kernel 123 KB) against a 64 KB instruction
 //    cache, and ran at ~300 cycles per 64-byte instruction line -- 3.5x slower than its MFMA time.
@@ -44,10 +47,18 @@ __host__ __device__ constexpr int layer_out(int l) {
 }
 __host__ __device__ constexpr int layer_in(int l) { return l == L_PRIV0 ? 24 : l == L_PRIV2 ? 64 : l == L_BB ? 96 : l == L_CBB ? 100 : 128; }
 __host__ __device__ constexpr int layer_nblk(int l) { return (layer_out(l) + 31) / 32; }
-__host__ __device__ constexpr int layer_pack_floats(int l) { return layer_in(l) / 2 * layer_nblk(l) * 64; }
+// forward pack: k over the inputs, 32-column blocks over the outputs; groups of 4 k-pairs (zero padded)
+__host__ __device__ constexpr int layer_kg(int l) { return (layer_in(l) / 2 + 3) / 4; }
+__host__ __device__ constexpr int layer_pack_floats(int l) { return layer_kg(l) * layer_nblk(l) * 256; }
 __host__ __device__ constexpr int layer_pack_off(int l) { return l == 0 ? 0 : layer_pack_off(l - 1) + layer_pack_floats(l - 1); }
+#define WPACK_FWD_FLOATS (layer_pack_off(NLAYERS - 1) + layer_pack_floats(NLAYERS - 1))
+// transposed pack (dgrad: dIn = dOut * W): k over the outputs, 32-column blocks over the inputs
+__host__ __device__ constexpr int layer_kgT(int l) { return ((layer_out(l) + 1) / 2 + 3) / 4; }
+__host__ __device__ constexpr int layer_nblkT(int l) { return (layer_in(l) + 31) / 32; }
+__host__ __device__ constexpr int layer_packT_floats(int l) { return layer_kgT(l) * layer_nblkT(l) * 256; }
+__host__ __device__ constexpr int layer_packT_off(int l) { return l == 0 ? WPACK_FWD_FLOATS : layer_packT_off(l - 1) + layer_packT_floats(l - 1); }
 __host__ __device__ constexpr int layer_bias_off(int l) { return l == 0 ? 0 : layer_bias_off(l - 1) + layer_out(l - 1); }
-#define WPACK_WEIGHT_FLOATS (layer_pack_off(NLAYERS - 1) + layer_pack_floats(NLAYERS - 1))
+#define WPACK_WEIGHT_FLOATS (layer_packT_off(NLAYERS - 1) + layer_packT_floats(NLAYERS - 1))
 #define WPACK_BIAS_FLOATS (layer_bias_off(NLAYERS - 1) + layer_out(NLAYERS - 1))
 #define WPACK_FLOATS (WPACK_WEIGHT_FLOATS + WPACK_BIAS_FLOATS)      // packed weights, then all biases back to back
 
@@ -91,22 +102,32 @@ static __device__ __forceinline__ float apply_act(float x, int act) {
   return x;
 }
 
-// Pack all 16 weight matrices into the fragment order described above and append the biases. grid = (blocks, NLAYERS).
+// Pack all 16 weight matrices into the fragment orders described above (blockIdx.z = 0: forward, 1: transposed) and
+// append the biases. grid = (blocks, NLAYERS, 2). `wpack` must be 16-byte aligned.
 static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict__ wpack) {
   const int l = blockIdx.y;
+  const bool tr = blockIdx.z != 0;
   const float* const* wp = reinterpret_cast<const float* const*>(&P);
   const float* W = wp[2 * l];
   const float* bsrc = wp[2 * l + 1];
-  int N = 128, K = 128, off = 0, boff = 0;
-  for (int j = 0; j < NLAYERS; ++j) if (j == l) { N = layer_out(j); K = layer_in(j); off = layer_pack_off(j); boff = layer_bias_off(j); }
-  const int nblk = (N + 31) / 32, total = K / 2 * nblk * 64;
+  int N = 128, K = 128, off = 0, boff = 0, total = 0, nblk = 1;
+  for (int j = 0; j < NLAYERS; ++j)
+    if (j == l) {
+      N = layer_out(j); K = layer_in(j); boff = layer_bias_off(j);
+      off = tr ? layer_packT_off(j) : layer_pack_off(j);
+      total = tr ? layer_packT_floats(j) : layer_pack_floats(j);
+      nblk = tr ? layer_nblkT(j) : layer_nblk(j);
+    }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int lane = e & 63, frag = e >> 6;
-    const int cb = frag % nblk, kb = frag / nblk;
-    const int n = cb * 32 + (lane & 31), k = 2 * kb + (lane >> 5);
-    wpack[off + e] = (n < N) ? W[(size_t)n * K + k] : 0.f;
+    const int j = e & 3, lane = (e >> 2) & 63, frag = e >> 8;
+    const int cb = frag % nblk, kb = 4 * (frag / nblk) + j;
+    const int c = cb * 32 + (lane & 31), k = 2 * kb + (lane >> 5);
+    float v;
+    if (!tr) v = (c < N && k < K) ? W[(size_t)c * K + k] : 0.f;      // B[k][c] = W[c][k]
+    else v = (k < N && c < K) ? W[(size_t)k * K + c] : 0.f;          // B[k][c] = W[k][c]
+    wpack[off + e] = v;
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0 && !tr)
     for (int e = threadIdx.x; e < N; e += blockDim.x) wpack[WPACK_WEIGHT_FLOATS + boff + e] = bsrc[e];
 }
 
@@ -137,91 +158,120 @@ static __device__ __forceinline__ void load_x_tile(float* x, F row_ptr) {
 }
 
 // ---- one MFMA operand set: 64 registers per lane ---------------------------------------------------------
-// The B fragments of a wave's 32-column block, k-pairs 0..kb-1, requested in chunks of 16 (a uniform predicate per
-// chunk keeps the code compact: the same 64 load instructions serve every layer). `base` points at this wave's first
-// fragment for this lane; consecutive k-pairs are `stride` floats apart; loads past kb re-read k-pair 0 (unused).
-static __device__ __forceinline__ void load_operands(float (&w)[64], const float* __restrict__ base, size_t stride, int kb, bool active) {
+// The B fragments of a wave's 32-column block, k-pairs 0..kb-1, as 16 float4 loads of 4 k-pairs each. `base` points
+// at the layer's pack (uniform), `lane_off` is this lane's float4 within a k-group; consecutive k-groups are `stride4`
+// float4s apart. All 16 loads are issued
+// UNCONDITIONALLY (k-groups past kb re-read group 0): with loads under predicates the compiler cannot know how many
+// are outstanding and its s_waitcnt for the current layer's operands also drains the next layer's prefetch.
+template <int NW>
+static __device__ __forceinline__ void load_operands(float (&w)[NW], const float4* __restrict__ ubase, int lane_off, int stride4, int kb) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (active && c * 16 < kb) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int k = c * 16 + j;
-        w[k] = base[(size_t)(k < kb ? k : 0) * stride];
-      }
-    }
+  for (int kg = 0; kg < 16; ++kg) {
+    const float4* pu = ubase + (kg * 4 < kb ? kg : 0) * stride4;    // uniform part (scalar registers); lane_off is the per-lane part
+    const float4 v = pu[lane_off];
+    w[kg * 4] = v.x; w[kg * 4 + 1] = v.y; w[kg * 4 + 2] = v.z; w[kg * 4 + 3] = v.w;
   }
 }
 
 // acc += sum_{k < kb} A[.., 2k + half] * w[k], A from LDS (ap = this lane's row/half). Each chunk of 16 k-pairs
-// reads its 16 A operands first and then issues its MFMAs; chunks are guarded by uniform predicates.
-static __device__ __forceinline__ void mfma_chain(const float* ap, const float (&w)[64], int kb, f32x16& acc) {
+// reads its 16 A operands first and then issues its MFMAs; chunks and the MFMAs of a ragged last chunk are guarded
+// by uniform predicates (one copy of the chain serves every layer shape).
+template <int NW>
+static __device__ __forceinline__ void mfma_chain(const float* ap, const float (&w)[NW], int kb, f32x16& acc) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c * 16 < kb) {
       float a[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) a[j] = ap[2 * (c * 16 + j)];       // reads past the row's k range stay inside LDS
-      if (c * 16 + 16 <= kb) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[c * 16 + j], acc, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (c * 16 + j < kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[c * 16 + j], acc, 0, 0, 0);
-      }
+      for (int j = 0; j < 16; ++j)
+        if (c * 16 + j < kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[c * 16 + j], acc, 0, 0, 0);
     }
   }
 }
 
-// Request the fragments of forward layer d for this wave.
-static __device__ __forceinline__ void fwd_load(float (&w)[64], const FwdDesc& d, const float* __restrict__ wpack) {
+// development aid (-DWBC_PPO_TIMING): workgroup 0 / thread 0 stamps inside the forward layers, slots 32 + 4*layer + i
+#ifdef WBC_PPO_TIMING
+static __device__ long long* g_mlp_dbg = nullptr;
+#define LSTAMP(l, i) do { if (g_mlp_dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mlp_dbg[32 + 4 * (l) + (i)] = clock64(); } while (0)
+#else
+#define LSTAMP(l, i) do { } while (0)
+#endif
+
+// Request the fragments of forward layer d for this wave, and this lane's bias (w[64]).
+static __device__ __forceinline__ void fwd_load(float (&w)[65], const FwdDesc& d, const float* __restrict__ wpack) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_operands(w, wpack + d.woff + wave * 64 + lane, (size_t)d.nblk * 64, d.kb, wave < d.nblk);
+  const int cb = wave < d.nblk ? wave : 0;       // idle waves fetch block 0 (unused)
+  load_operands(w, reinterpret_cast<const float4*>(wpack + d.woff), cb * 64 + lane, d.nblk * 64, d.kb);
+  const int col = wave * 32 + (lane & 31);
+  w[64] = wpack[WPACK_WEIGHT_FLOATS + d.boff + (col < d.n ? col : 0)];
 }
 
 // Run forward layer d with its fragments in `w`. smem = LDS base (floats). Outputs go to LDS and, if d.scol >= 0, to
 // stash[(row0+row)*lds + d.scol + col] for valid rows. Ends with a barrier.
-static __device__ __forceinline__ void fwd_run(const float (&w)[64], const FwdDesc& d, float* smem, const float* __restrict__ bias_base,
-                                               float* __restrict__ stash, int lds, int row0, int num_rows) {
+static __device__ __forceinline__ void fwd_run(const float (&w)[65], const FwdDesc& d, float* smem,
+                                               float* __restrict__ stash, int lds, int row0, int num_rows, int dbg_l = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LSTAMP(dbg_l, 0);
   if (wave < d.nblk) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5), w, d.kb, acc);
+#ifdef WBC_PPO_TIMING
+    asm volatile("s_nop 0" :: "v"(acc[0]));      // stamp 1 after the last MFMA has produced its result
+#endif
+    LSTAMP(dbg_l, 1);
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col = wave * 32 + (lane & 31);
     if (col < d.n) {
-      const float bias = bias_base[d.boff + col];
-      float* out = smem + d.out_off + col;
-      const bool do_stash = stash != nullptr && d.scol >= 0;
-      const bool full = row0 + PT_ROWS <= num_rows;
+      const float bias = w[64];
+      float v[16];
+      if (d.act == ACT_ELU) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float v = apply_act(acc[r] + bias, d.act);
-        out[row * d.ldo] = v;
-        if (do_stash && (full || row0 + row < num_rows)) stash[(size_t)(row0 + row) * lds + d.scol + col] = v;
+        for (int r = 0; r < 16; ++r) { const float x = acc[r] + bias; v[r] = x > 0.f ? x : __expf(x) - 1.f; }   // abs error <= 1 ulp(1.0)
+      } else if (d.act == ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = tanhf(acc[r] + bias);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+      }
+      const int rbase = 4 * (lane >> 5);                 // this lane's rows: rbase + (r & 3) + 8 * (r >> 2)
+      float* out = smem + d.out_off + col + rbase * d.ldo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * d.ldo] = v[r];
+      if (stash != nullptr && d.scol >= 0) {
+        float* sp = stash + (size_t)(row0 + rbase) * lds + d.scol + col;
+        if (row0 + PT_ROWS <= num_rows) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * lds] = v[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (row0 + rbase + (r & 3) + 8 * (r >> 2) < num_rows) sp[((r & 3) + 8 * (r >> 2)) * lds] = v[r];
+        }
       }
     }
   }
+  LSTAMP(dbg_l, 2);
   __syncthreads();
+  LSTAMP(dbg_l, 3);
 }
 
 // The forward chain over layers [lbeg, lend): two register sets alternate so that layer l+1's operands are in flight
 // while layer l's MFMA chain runs. The loop body (two layers) is the only copy of the layer code in the kernel.
 static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem, const float* __restrict__ wpack, float* __restrict__ stash,
                                                  int lds, int row0, int num_rows, int lbeg = 0, int lend = NLAYERS) {
-  const float* bias_base = wpack + WPACK_WEIGHT_FLOATS;
-  float wa[64], wb[64];
+  float wa[65], wb[65];
   fwd_load(wa, T.l[lbeg], wpack);
 #pragma unroll 1
   for (int l = lbeg; l < lend; l += 2) {
     const bool two = l + 1 < lend;
     if (two) fwd_load(wb, T.l[l + 1], wpack);
-    fwd_run(wa, T.l[l], smem, bias_base, stash, lds, row0, num_rows);
+    fwd_run(wa, T.l[l], smem, stash, lds, row0, num_rows, l);
     if (two) {
       if (l + 2 < lend) fwd_load(wa, T.l[l + 2], wpack);
-      fwd_run(wb, T.l[l + 1], smem, bias_base, stash, lds, row0, num_rows);
+      fwd_run(wb, T.l[l + 1], smem, stash, lds, row0, num_rows, l + 1);
     }
   }
 }

@@ -86,8 +86,8 @@ extern "C" int wbc_policy_pack_floats(void) { return WPACK_FLOATS; }
 // Re-pack the weights into MFMA fragment order (call after the parameters changed).
 extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* stream) {
   PolicyParams P;
-  if (!params || !wpack || fill_params(params, &P)) return -1;
-  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS), dim3(256), 0, (hipStream_t)stream, P, wpack);
+  if (!params || !wpack || (reinterpret_cast<uintptr_t>(wpack) & 15) || fill_params(params, &P)) return -1;
+  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, (hipStream_t)stream, P, wpack);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -37,6 +37,21 @@ struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minib
   int use_clipped_value_loss;
 };
 
+// development aid (tools/time_ppo.py builds a variant with -DWBC_PPO_TIMING): clock64 stamps of workgroup 0
+__device__ long long* g_ppo_dbg = nullptr;
+#ifdef WBC_PPO_TIMING
+#define PSTAMP(i) do { if (g_ppo_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_ppo_dbg[i] = clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+extern "C" void wbc_debug_set_ppo_timing(void* dev_buf) {
+  long long* p = (long long*)dev_buf;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ppo_dbg), &p, sizeof(p));
+#ifdef WBC_PPO_TIMING
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_dbg), &p, sizeof(p));
+#endif
+}
+
 #define S_G S_END                      // g[32][41]: output grads dmu 18, dv 2, dlat 20
 #define S_PPO_END (S_G + PT_ROWS * 41)
 
@@ -46,7 +61,7 @@ enum { PRE_NONE = 0, PRE_OUTER_V0, PRE_OUTER_V1, PRE_COPY_LEG, PRE_COPY_ARM, PRE
 struct BwdDesc {
   int pre; const float* wvec; int src_off;       // pre-step; for PRE_OUTER_*: the [128] last-layer weight row; for PRE_LATENT: dA_z buffer
   int buf_off, n, act, acol, dcol;                // activation-derivative pass over buf[32, n]
-  int has_mma; const float* W; int out_dim, in_dim, out_off, accumulate;   // out[32, in_dim] (+)= buf[32, out_dim] * W[out_dim, in_dim]
+  int has_mma, woffT, nblkT, out_dim, in_dim, out_off, accumulate;   // out[32, in_dim] (+)= buf[32, out_dim] * W[out_dim, in_dim] (transposed pack)
 };
 #define NBWD 14
 struct BwdTable { BwdDesc s[NBWD]; };
@@ -54,40 +69,35 @@ struct BwdTable { BwdDesc s[NBWD]; };
 static BwdTable make_bwd_table(const PolicyParams& P) {
   BwdTable t;
   int i = 0;
-  auto add = [&](int pre, const float* wvec, int src, int buf, int n, int act, int acol, int dcol, const float* W, int od, int id, int out, int acc) {
-    t.s[i++] = BwdDesc{pre, wvec, src, buf, n, act, acol, dcol, W != nullptr, W, od, id, out, acc};
+  // lw = layer whose weight the stage multiplies by (-1: no GEMM)
+  auto add = [&](int pre, const float* wvec, int src, int buf, int n, int act, int acol, int dcol, int lw, int out, int acc) {
+    t.s[i++] = BwdDesc{pre, wvec, src, buf, n, act, acol, dcol, lw >= 0, lw >= 0 ? layer_packT_off(lw) : 0, lw >= 0 ? layer_nblkT(lw) : 0,
+                       lw >= 0 ? layer_out(lw) : 0, lw >= 0 ? layer_in(lw) : 0, out, acc};
   };
   // critic
-  add(PRE_OUTER_V0, P.cleg4_w, 0, S_A0, 128, ACT_ELU, A_CL2, D_CL2, P.cleg2_w, 128, 128, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CL1, D_CL1, P.cleg0_w, 128, 128, S_A2, 0);
-  add(PRE_OUTER_V1, P.carm4_w, 0, S_A0, 128, ACT_ELU, A_CA2, D_CA2, P.carm2_w, 128, 128, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CA1, D_CA1, P.carm0_w, 128, 128, S_A2, 1);
-  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_CB, D_CB, nullptr, 0, 0, 0, 0);
+  add(PRE_OUTER_V0, P.cleg4_w, 0, S_A0, 128, ACT_ELU, A_CL2, D_CL2, L_CLEG2, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CL1, D_CL1, L_CLEG0, S_A2, 0);
+  add(PRE_OUTER_V1, P.carm4_w, 0, S_A0, 128, ACT_ELU, A_CA2, D_CA2, L_CARM2, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CA1, D_CA1, L_CARM0, S_A2, 1);
+  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_CB, D_CB, -1, 0, 0);
   // actor
-  add(PRE_COPY_LEG, nullptr, 0, S_A0, PT_NLEG, ACT_TANH, A_LEG, D_LEG, P.leg4_w, PT_NLEG, 128, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_L2, D_L2, P.leg2_w, 128, 128, S_A0, 0);
-  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_L1, D_L1, P.leg0_w, 128, 128, S_A2, 0);
-  add(PRE_COPY_ARM, nullptr, 0, S_A0, PT_NARM, ACT_TANH, A_ARM, D_ARM, P.arm4_w, PT_NARM, 128, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_A2, D_A2, P.arm2_w, 128, 128, S_A0, 0);
-  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_A1, D_A1, P.arm0_w, 128, 128, S_A2, 1);
-  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_BB, D_BB, P.bb_w, 128, 96, S_A0, 0);
-  add(PRE_LATENT, nullptr, S_A0, S_A1, 20, ACT_ELU, A_LAT, D_LAT, P.priv2_w, 20, 64, S_A0, 0);
-  add(PRE_NONE, nullptr, 0, S_A0, 64, ACT_ELU, A_H1, D_H1, nullptr, 0, 0, 0, 0);
+  add(PRE_COPY_LEG, nullptr, 0, S_A0, PT_NLEG, ACT_TANH, A_LEG, D_LEG, L_LEG4, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_L2, D_L2, L_LEG2, S_A0, 0);
+  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_L1, D_L1, L_LEG0, S_A2, 0);
+  add(PRE_COPY_ARM, nullptr, 0, S_A0, PT_NARM, ACT_TANH, A_ARM, D_ARM, L_ARM4, S_A1, 0);
+  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_A2, D_A2, L_ARM2, S_A0, 0);
+  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_A1, D_A1, L_ARM0, S_A2, 1);
+  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_BB, D_BB, L_BB, S_A0, 0);
+  add(PRE_LATENT, nullptr, S_A0, S_A1, 20, ACT_ELU, A_LAT, D_LAT, L_PRIV2, S_A0, 0);
+  add(PRE_NONE, nullptr, 0, S_A0, 64, ACT_ELU, A_H1, D_H1, -1, 0, 0);
   return t;
 }
 
-// Request the B operand of a backward stage: W[k][col] straight from global memory (a wave's fragment is two runs of
-// 32 consecutive floats of W, coalesced as stored). Columns past in_dim read column 0 and are zeroed.
-static __device__ __forceinline__ void bwd_load(float (&w)[64], const BwdDesc& d) {
+// Request the B operand of a backward stage from the transposed pack (columns past in_dim are packed as zeros).
+static __device__ __forceinline__ void bwd_load(float (&w)[64], const BwdDesc& d, const float* __restrict__ wpack) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = wave * 32 + (lane & 31);
-  const bool active = d.has_mma && wave * 32 < d.in_dim;
-  const bool col_ok = col < d.in_dim;
-  load_operands(w, d.W + (size_t)(lane >> 5) * d.in_dim + (col_ok ? col : 0), (size_t)2 * d.in_dim, d.out_dim / 2, active);
-  if (active && !col_ok) {
-#pragma unroll
-    for (int k = 0; k < 64; ++k) w[k] = 0.f;
-  }
+  const int cb = wave < d.nblkT ? wave : 0;      // idle waves / stages without a GEMM fetch valid, unused data
+  load_operands(w, reinterpret_cast<const float4*>(wpack + d.woffT), cb * 64 + lane, d.nblkT * 64, (d.out_dim + 1) / 2);
 }
 
 template <int ACTV>
@@ -95,7 +105,24 @@ static __device__ __forceinline__ float act_deriv(float a) {
   return (ACTV == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : 1.f - a * a;
 }
 
-static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDesc& d, float* smem, const float* __restrict__ act_stash,
+// This stage's activation-stash values (8 float2 per thread) and, for the critic-head stages, this thread's element of
+// the head's weight row: requested BEFORE the next stage's operand prefetch so that waiting for them leaves it in flight.
+struct BwdFetch { float2 a[8]; float wv; };
+static __device__ __forceinline__ void bwd_fetch(BwdFetch& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows) {
+  const int tid = threadIdx.x;
+  const int q = d.n >> 1, tot = PT_ROWS * q;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
+    const bool ok = e < tot && row0 + r < num_rows;
+    const float2 v = *reinterpret_cast<const float2*>(act_stash + (size_t)(ok ? row0 + r : row0) * A_LD + d.acol + (ok ? c : 0));   // unconditional
+    f.a[j] = ok ? v : make_float2(1.f, 1.f);
+  }
+  const float* wv = (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) ? d.wvec : act_stash;
+  f.wv = wv[tid & 127];
+}
+
+static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDesc& d, const BwdFetch& f, float* smem,
                                                float* __restrict__ dz_stash, int row0, int num_rows) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* buf = smem + d.buf_off;
@@ -103,7 +130,7 @@ static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDe
   // pre-step
   if (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) {          // dA = dZ_v (x) W_last (1 x 128)
     const int gi = (d.pre == PRE_OUTER_V0) ? 18 : 19;
-    for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) { const int r = e >> 7, c = e & 127; buf[r * LDA + c] = g[r * 41 + gi] * d.wvec[c]; }
+    for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) { const int r = e >> 7, c = e & 127; buf[r * LDA + c] = g[r * 41 + gi] * f.wv; }
     __syncthreads();
   } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
     const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
@@ -114,16 +141,9 @@ static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDe
     for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) { const int r = e / 20, c = e - r * 20; buf[r * LDA + c] = src[r * LDA + PT_NPROP + c] + g[r * 41 + 20 + c]; }
     __syncthreads();
   }
-  // buf <- buf * act'(A) with A the stashed post-activation; float2 global accesses, up to 8 per thread in flight
+  // buf <- buf * act'(A) with A the stashed post-activation (fetched by bwd_fetch)
   {
     const int q = d.n >> 1, tot = PT_ROWS * q;
-    float2 a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
-      a[j] = make_float2(1.f, 1.f);
-      if (e < tot && row0 + r < num_rows) a[j] = *reinterpret_cast<const float2*>(act_stash + (size_t)(row0 + r) * A_LD + d.acol + c);
-    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
@@ -131,8 +151,8 @@ static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDe
         float* bp = buf + r * LDA + c;
         const bool ok = row0 + r < num_rows;
         float2 v;
-        if (d.act == ACT_ELU) { v.x = bp[0] * act_deriv<ACT_ELU>(a[j].x); v.y = bp[1] * act_deriv<ACT_ELU>(a[j].y); }
-        else { v.x = bp[0] * act_deriv<ACT_TANH>(a[j].x); v.y = bp[1] * act_deriv<ACT_TANH>(a[j].y); }
+        if (d.act == ACT_ELU) { v.x = bp[0] * act_deriv<ACT_ELU>(f.a[j].x); v.y = bp[1] * act_deriv<ACT_ELU>(f.a[j].y); }
+        else { v.x = bp[0] * act_deriv<ACT_TANH>(f.a[j].x); v.y = bp[1] * act_deriv<ACT_TANH>(f.a[j].y); }
         if (!ok) v = make_float2(0.f, 0.f);
         bp[0] = v.x; bp[1] = v.y;
         if (ok) *reinterpret_cast<float2*>(dz_stash + (size_t)(row0 + r) * D_LD + d.dcol + c) = v;
@@ -141,9 +161,9 @@ static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDe
     __syncthreads();
   }
   if (d.has_mma) {
-    if (wave * 32 < d.in_dim) {
+    if (wave < d.nblkT) {
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      mfma_chain(buf + (lane & 31) * LDA + (lane >> 5), w, d.out_dim / 2, acc);
+      mfma_chain(buf + (lane & 31) * LDA + (lane >> 5), w, (d.out_dim + 1) / 2, acc);
       const int col = wave * 32 + (lane & 31);
       if (col < d.in_dim) {
         float* out = smem + d.out_off + col;
@@ -158,13 +178,14 @@ static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDe
   }
 }
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(PolicyParams P, FwdTable FT, BwdTable BT, const float* __restrict__ wpack,
+extern "C" __global__ void __launch_bounds__(PT_THREADS, 2) ppo_fwd_bwd_kernel(PolicyParams P, FwdTable FT, BwdTable BT, const float* __restrict__ wpack,
                                                                            PpoBatch Bt, float* __restrict__ act_stash,
                                                                            float* __restrict__ dz_stash, float* __restrict__ dstd_partial,
                                                                            float* __restrict__ loss_partial) {
   __shared__ float smem[S_PPO_END];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
+  PSTAMP(0);
   // gather obs[idx, :100] (float4 loads, all in flight); stash it (input of priv0 / critic backbone) and copy the proprio
   // block to a1[:, :76], next to where priv2 will put the latent
   load_x_tile(smem + S_X, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
@@ -180,8 +201,10 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
     const int r = e / PT_NPROP, c = e - r * PT_NPROP;
     smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
   }
+  PSTAMP(1);
   // ---------------- forward (table-driven, wbc_mlp.h), post-activations stashed
   fwd_chain(FT, smem, wpack, act_stash, A_LD, row0, B);
+  PSTAMP(2);
   __threadfence_block();
   __syncthreads();
   // z = [prop, latent], the backbone's input, for its weight gradient: prop from x, latent from the stash just written
@@ -196,6 +219,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
   }
   const float* outv = smem + S_OUTV;
   float* gbuf = smem + S_G;
+  PSTAMP(3);
   // ---------------- losses and output gradients: one row per lane of wave 0
   if (tid < 64) {
     const int r = tid & 31;
@@ -287,13 +311,19 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_fwd_bwd_kernel(Poli
   }
   {
     float wa[64], wb[64];
-    bwd_load(wa, BT.s[0]);
+    BwdFetch f;
+    PSTAMP(4);
+    bwd_load(wa, BT.s[0], wpack);
 #pragma unroll 1
     for (int st = 0; st < NBWD; st += 2) {
-      bwd_load(wb, BT.s[st + 1]);
-      bwd_run(wa, BT.s[st], smem, act_stash, dz_stash, row0, B);
-      if (st + 2 < NBWD) bwd_load(wa, BT.s[st + 2]);
-      bwd_run(wb, BT.s[st + 1], smem, act_stash, dz_stash, row0, B);
+      bwd_fetch(f, BT.s[st], act_stash, row0, B);
+      bwd_load(wb, BT.s[st + 1], wpack);
+      bwd_run(wa, BT.s[st], f, smem, dz_stash, row0, B);
+      PSTAMP(5 + st);
+      bwd_fetch(f, BT.s[st + 1], act_stash, row0, B);
+      if (st + 2 < NBWD) bwd_load(wa, BT.s[st + 2], wpack);
+      bwd_run(wb, BT.s[st + 1], f, smem, dz_stash, row0, B);
+      PSTAMP(6 + st);
     }
   }
 }
@@ -487,7 +517,7 @@ extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
   const size_t tiles = (size_t)(B + PT_ROWS - 1) / PT_ROWS;
-  return (size_t)B * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)WPACK_FLOATS;
+  return (size_t)B * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)WPACK_FLOATS + 4;
 }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
@@ -517,8 +547,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   float* dstd_partial = dz_stash + (size_t)B * D_LD;
   float* loss_partial = dstd_partial + (size_t)tiles * 18;
   float* wpart = loss_partial + (size_t)tiles * 3;
-  float* wpack = wpart + (size_t)PPO_NSPLIT * ng;
-  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS), dim3(256), 0, st, P, wpack);
+  float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
+  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
   const FwdTable FT = make_fwd_table(kStashCols);
