@@ -122,9 +122,10 @@ static __device__ __forceinline__ void bwd_fetch(BwdFetch& f, const BwdDesc& d, 
   f.wv = wv[tid & 127];
 }
 
-static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDesc& d, const BwdFetch& f, float* smem,
-                                               float* __restrict__ dz_stash, int row0, int num_rows) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// First half of a stage: pre-step and buf <- buf * act'(A) (+ dZ stash). Consumes f.
+static __device__ __forceinline__ void bwd_pre_act(const BwdDesc& d, const BwdFetch& f, float* smem, float* __restrict__ dz_stash,
+                                                   int row0, int num_rows) {
+  const int tid = threadIdx.x;
   float* buf = smem + d.buf_off;
   const float* g = smem + S_G;
   // pre-step
@@ -160,6 +161,12 @@ static __device__ __forceinline__ void bwd_run(const float (&w)[64], const BwdDe
     }
     __syncthreads();
   }
+}
+
+// Second half: out (+)= buf * W on the MFMA.
+static __device__ __forceinline__ void bwd_mma(const float (&w)[64], const BwdDesc& d, float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* buf = smem + d.buf_off;
   if (d.has_mma) {
     if (wave < d.nblkT) {
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -310,19 +317,23 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 2) ppo_fwd_bwd_kernel(P
     dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = gbuf[tid * 41 + 19];
   }
   {
+    // per stage: act' pass with the stash values fetched during the previous stage's GEMM, then request the next stage's
+    // operands and stash values, then this stage's GEMM: every global latency sits behind an MFMA chain
     float wa[64], wb[64];
     BwdFetch f;
     PSTAMP(4);
     bwd_load(wa, BT.s[0], wpack);
+    bwd_fetch(f, BT.s[0], act_stash, row0, B);
 #pragma unroll 1
     for (int st = 0; st < NBWD; st += 2) {
-      bwd_fetch(f, BT.s[st], act_stash, row0, B);
+      bwd_pre_act(BT.s[st], f, smem, dz_stash, row0, B);
       bwd_load(wb, BT.s[st + 1], wpack);
-      bwd_run(wa, BT.s[st], f, smem, dz_stash, row0, B);
-      PSTAMP(5 + st);
       bwd_fetch(f, BT.s[st + 1], act_stash, row0, B);
-      if (st + 2 < NBWD) bwd_load(wa, BT.s[st + 2], wpack);
-      bwd_run(wb, BT.s[st + 1], f, smem, dz_stash, row0, B);
+      bwd_mma(wa, BT.s[st], smem);
+      PSTAMP(5 + st);
+      bwd_pre_act(BT.s[st + 1], f, smem, dz_stash, row0, B);
+      if (st + 2 < NBWD) { bwd_load(wa, BT.s[st + 2], wpack); bwd_fetch(f, BT.s[st + 2], act_stash, row0, B); }
+      bwd_mma(wb, BT.s[st + 1], smem);
       PSTAMP(6 + st);
     }
   }
