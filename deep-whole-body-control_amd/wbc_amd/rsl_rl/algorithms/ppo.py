@@ -205,8 +205,11 @@ class PPO:
         table = ac.fused_param_table()
         obs = st.observations.view(batch, -1)
         with torch.inference_mode():               # the regulariser's target: history latent of every stored row
-            for s0 in range(0, batch, 32768):
-                F["hist"][s0:s0 + 32768] = ac.actor.infer_hist_latent(obs[s0:s0 + 32768])
+            if ac.actor._fused_hist_supported(obs):
+                F["hist"] = ac.actor.infer_hist_latent(obs)          # one launch (csrc/wbc_hist_kernel.hip)
+            else:
+                for s0 in range(0, batch, 32768):
+                    F["hist"][s0:s0 + 32768] = ac.actor.infer_hist_latent(obs[s0:s0 + 32768])
         flat = lambda x: x.view(batch, -1)         # noqa: E731
         actions, values, adv, returns, logp = (flat(x) for x in (st.actions, st.values, st.advantages, st.returns, st.actions_log_prob))
         value_mixing_ratio = self.get_value_mixing_ratio()

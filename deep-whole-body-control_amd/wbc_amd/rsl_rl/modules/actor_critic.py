@@ -160,8 +160,39 @@ class _Actor(nn.Module):
         return self.priv_encoder(obs[:, self.num_prop: self.num_prop + self.num_priv])
 
     def infer_hist_latent(self, obs):
+        if not torch.is_grad_enabled() and self._fused_hist_supported(obs):
+            return self._fused_hist_latent(obs)
         hist = obs[:, -self.num_hist * self.num_prop:]
         return self.history_encoder(hist.view(-1, self.num_hist, self.num_prop))
+
+    def _fused_hist_supported(self, obs):
+        """csrc/wbc_hist_kernel.hip covers the shipped encoder (10 x 76 history, ELU) on a ROCm device, no gradient."""
+        if not (obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 2 and obs.shape[1] == 860 and obs.is_contiguous()):
+            return False
+        ok = self.__dict__.get("_fused_hist_ok")
+        if ok is None:
+            he = self.history_encoder
+            ok = (self.num_hist == 10 and self.num_prop == 76 and self.num_priv == 24 and isinstance(he.activation_fn, nn.ELU)
+                  and he.activation_fn.alpha == 1.0 and len(he.conv_layers) == 5
+                  and tuple(he.encoder[0].weight.shape) == (30, 76) and tuple(he.conv_layers[0].weight.shape) == (20, 30, 4)
+                  and tuple(he.conv_layers[2].weight.shape) == (10, 20, 2) and he.conv_layers[0].stride == (2,)
+                  and he.conv_layers[2].stride == (1,) and tuple(he.linear_output[0].weight.shape) == (20, 30))
+            self.__dict__["_fused_hist_ok"] = ok
+        return ok
+
+    def _fused_hist_latent(self, obs):
+        import ctypes as C
+        from ...native import check, lib
+        he = self.history_encoder
+        ps = [he.encoder[0].weight, he.encoder[0].bias, he.conv_layers[0].weight, he.conv_layers[0].bias,
+              he.conv_layers[2].weight, he.conv_layers[2].bias, he.linear_output[0].weight, he.linear_output[0].bias]
+        for p in ps:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        table = (C.c_void_p * 8)(*[p.data_ptr() for p in ps])
+        out = torch.empty(obs.shape[0], 20, device=obs.device)
+        check(lib().wbc_hist_latent(table, obs.data_ptr(), out.data_ptr(), obs.shape[0],
+                                    torch.cuda.current_stream(obs.device).cuda_stream), "wbc_hist_latent")
+        return out
 
     def forward(self, obs, hist_encoding=False):
         latent = self.infer_hist_latent(obs) if hist_encoding else self.infer_priv_latent(obs)

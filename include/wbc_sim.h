@@ -288,6 +288,12 @@ int wbc_policy_pack(const void* const* params, float* wpack, void* stream);
 int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* eps,
                    float* actions, float* mean, float* logp, float* values, int num_rows, void* stream);
 
+/* StateHistoryEncoder forward without gradient (rsl_rl/modules/actor_critic.py:39-84, tsteps = 10), the regulariser
+ * target of PPO.update (ppo.py:174-176). params: 8 device pointers (encoder.0.weight [30,76], .bias,
+ * conv_layers.0.weight [20,30,4], .bias, conv_layers.2.weight [10,20,2], .bias, linear_output.0.weight [20,30],
+ * .bias); reads obs[:, 100:860] of f32 [rows,860]; writes out f32 [rows,20]. ELU activations. */
+int wbc_hist_latent(const void* const* params, const float* obs, float* out, int rows, void* stream);
+
 /* One PPO.update() minibatch (rsl_rl/algorithms/ppo.py:163-246, teacher path, no torque supervision): gathers
  * the rows `idx` of the flat [T*N, ...] rollout tensors, runs actor + critic forward, the clipped surrogate
  * with Advantage Mixing (:199-206), the (clipped) value loss (:209-216) and the ROA regulariser (:174-179),

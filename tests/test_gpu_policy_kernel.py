@@ -64,3 +64,20 @@ def test_fused_act_is_what_ppo_act_uses():
         else:
             np.testing.assert_allclose(f.cpu().numpy(), e.cpu().numpy(), atol=tol, rtol=1e-5)
     assert fused[0].shape == eager[0].shape == (64, 18)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 24, 25, 4096, 5000])
+def test_fused_history_encoder_matches_torch(n):
+    """wbc_hist_latent (csrc/wbc_hist_kernel.hip) against the module's own torch forward (AC:39-84): same weights, random
+    history blocks; fp32 sums in a different order -> 2e-6 absolute on O(1) outputs."""
+    torch.manual_seed(5)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
+    obs = torch.randn(n, 860, device="cuda")
+    with torch.no_grad():
+        assert ac.actor._fused_hist_supported(obs)
+        fused = ac.actor.infer_hist_latent(obs)
+        hist = obs[:, -760:]
+        ref = ac.actor.history_encoder(hist.view(-1, 10, 76))
+    assert fused.shape == ref.shape == (n, 20)
+    np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-6)
