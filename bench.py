@@ -143,6 +143,7 @@ def main():
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)
     train = class_to_dict(train_cfg)
     runner = OnPolicyRunner(env, train, log_dir=None, device=device, dist_group=group)
+    torch.manual_seed(train_cfg.seed + 1000 * rank)   # replicas are identical (broadcast at construction); exploration noise is per rank
     T = runner.num_steps_per_env
 
     # HIP-event timing of every fused-step launch in the timed region (torch's current stream is the

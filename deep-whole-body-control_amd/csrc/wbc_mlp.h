@@ -103,21 +103,25 @@ static __device__ __forceinline__ float apply_act(float x, int act) {
 }
 
 // Pack all 16 weight matrices into the fragment orders described above (blockIdx.z = 0: forward, 1: transposed) and
-// append the biases. grid = (blocks, NLAYERS, 2). `wpack` must be 16-byte aligned.
-static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict__ wpack) {
+// append the biases. grid = (blocks, NLAYERS, 2). `wpack` must be 16-byte aligned. The per-layer offsets come in a
+// host-built table (evaluating the constexpr recursions per thread at run time cost 40 us per launch).
+struct PackTable { int n[NLAYERS], k[NLAYERS], off[NLAYERS], offT[NLAYERS], boff[NLAYERS]; };
+static inline PackTable make_pack_table() {
+  PackTable t;
+  for (int l = 0; l < NLAYERS; ++l) { t.n[l] = layer_out(l); t.k[l] = layer_in(l); t.off[l] = layer_pack_off(l); t.offT[l] = layer_packT_off(l); t.boff[l] = layer_bias_off(l); }
+  return t;
+}
+static __global__ void wbc_pack_weights_kernel(PolicyParams P, PackTable T, float* __restrict__ wpack) {
   const int l = blockIdx.y;
   const bool tr = blockIdx.z != 0;
   const float* const* wp = reinterpret_cast<const float* const*>(&P);
   const float* W = wp[2 * l];
   const float* bsrc = wp[2 * l + 1];
-  int N = 128, K = 128, off = 0, boff = 0, total = 0, nblk = 1;
-  for (int j = 0; j < NLAYERS; ++j)
-    if (j == l) {
-      N = layer_out(j); K = layer_in(j); boff = layer_bias_off(j);
-      off = tr ? layer_packT_off(j) : layer_pack_off(j);
-      total = tr ? layer_packT_floats(j) : layer_pack_floats(j);
-      nblk = tr ? layer_nblkT(j) : layer_nblk(j);
-    }
+  const int N = T.n[l], K = T.k[l];
+  const int off = tr ? T.offT[l] : T.off[l];
+  const int nblk = tr ? (K + 31) / 32 : (N + 31) / 32;
+  const int kg = tr ? ((N + 1) / 2 + 3) / 4 : (K / 2 + 3) / 4;
+  const int total = kg * nblk * 256;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int j = e & 3, lane = (e >> 2) & 63, frag = e >> 8;
     const int cb = frag % nblk, kb = 4 * (frag / nblk) + j;
@@ -128,7 +132,7 @@ static __global__ void wbc_pack_weights_kernel(PolicyParams P, float* __restrict
     wpack[off + e] = v;
   }
   if (blockIdx.x == 0 && !tr)
-    for (int e = threadIdx.x; e < N; e += blockDim.x) wpack[WPACK_WEIGHT_FLOATS + boff + e] = bsrc[e];
+    for (int e = threadIdx.x; e < N; e += blockDim.x) wpack[WPACK_WEIGHT_FLOATS + T.boff[l] + e] = bsrc[e];
 }
 
 // x[32, 100] (LDS, row stride 101) <- src rows' first 100 floats. 800 float4 loads, <= 4 per thread, all in flight

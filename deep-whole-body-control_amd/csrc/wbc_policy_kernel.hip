@@ -87,7 +87,7 @@ extern "C" int wbc_policy_pack_floats(void) { return WPACK_FLOATS; }
 extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* stream) {
   PolicyParams P;
   if (!params || !wpack || (reinterpret_cast<uintptr_t>(wpack) & 15) || fill_params(params, &P)) return -1;
-  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, (hipStream_t)stream, P, wpack);
+  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, (hipStream_t)stream, P, make_pack_table(), wpack);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

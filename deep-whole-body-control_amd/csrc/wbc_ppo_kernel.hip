@@ -559,7 +559,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   float* loss_partial = dstd_partial + (size_t)tiles * 18;
   float* wpart = loss_partial + (size_t)tiles * 3;
   float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
-  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, wpack);
+  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, make_pack_table(), wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
   const FwdTable FT = make_fwd_table(kStashCols);

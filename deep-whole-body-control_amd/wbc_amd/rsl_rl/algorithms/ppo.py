@@ -143,7 +143,7 @@ class PPO:
     # ---- gradient exchange -----------------------------------------------------------------
     def _allreduce_grads(self, params):
         """One flat bucket, one all-reduce, mean over ranks."""
-        if self.dist_group is None or self.world_size == 1:
+        if self.dist_group is None:
             return
         params = [p for p in params if p.grad is not None]
         key = tuple(id(p) for p in params)
@@ -229,7 +229,7 @@ class PPO:
                       "wbc_ppo_minibatch_grad")
                 if self.entropy_coef != 0.0:       # -coef * entropy.mean(): d/d sigma_j of (1/2) sum_j log sigma_j
                     ac.std.grad.sub_(self.entropy_coef * 0.5 / ac.std.detach())
-                if self.dist_group is not None and self.world_size > 1:
+                if self.dist_group is not None:
                     torch.distributed.all_reduce(F["grad"][:F["nparam"]], group=self.dist_group)
                     F["grad"][:F["nparam"]].div_(self.world_size)
                 sums += F["grad"][F["nparam"]:]

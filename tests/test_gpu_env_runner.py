@@ -90,3 +90,26 @@ def test_runner_learn_save_load_roundtrip(tmp_path):
     policy = runner2.get_inference_policy(device="cuda:0")
     act = policy(env2.get_observations())
     assert act.shape == (128, 18) and torch.isfinite(act).all()
+
+
+@pytest.mark.gpu
+def test_runner_with_rccl_process_group_single_rank():
+    """The sharded-learner code path on the real backend: a 1-rank RCCL ("nccl") group exercises every collective
+    the multi-GPU run issues (parameter broadcast, advantage statistics, per-minibatch gradient all-reduce in the
+    fused and the DAgger update) on device tensors; with one rank the results must equal the group-less run."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        outs = []
+        for group in (None, dist.group.WORLD):
+            torch.manual_seed(3)
+            env = WidowGo1(_cfg(256), sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, seed=11)
+            train = class_to_dict(WidowGo1RoughCfgPPO())
+            train["runner"]["num_steps_per_env"] = 8
+            runner = OnPolicyRunner(env, train, log_dir=None, device="cuda:0", dist_group=group)
+            runner.learn(3)                    # iteration 0 is a DAgger update, 1 and 2 are PPO updates
+            outs.append(torch.cat([p.detach().flatten() for p in runner.alg.actor_critic.parameters()]).cpu().numpy())
+        np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
