@@ -32,7 +32,7 @@ ALGO_BYTES_PER_ENV_STEP = 11.1e3      # fused sim step, SURVEY.md section 8(d): 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-CPU_BASELINE_ENVS = 256              # bounded sample: 256 envs x 40 steps = 1/16 of one iteration of the workload
+CPU_BASELINE_ENVS = 4096             # bounded sample: one full iteration of the workload (40 s guard on the rollout part for slow hosts)
 CPU_BASELINE_THREADS = 8
 
 
