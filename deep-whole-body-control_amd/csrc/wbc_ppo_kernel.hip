@@ -351,9 +351,10 @@ template <int NIB>
 static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const float* __restrict__ act_stash, const float* __restrict__ dz_stash,
                                                   float* __restrict__ dst, int r_begin, int r_end) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-  f32x16 acc[NIB + 1];
+  f32x16 acc[NIB];
 #pragma unroll
-  for (int b = 0; b <= NIB; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < NIB; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;        // bias gradient: this lane's column of dZ summed over its rows (even rows on lanes 0..31, odd on 32..63)
   const int o = wave * 32 + (lane & 31);
   const bool o_ok = o < L.out;
   const float* ap = dz_stash + L.dcol + (o_ok ? o : 0);          // clamped address + select: loads stay unconditional
@@ -381,7 +382,7 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
       const float a = o_ok ? av[t] : 0.f;
 #pragma unroll
       for (int b = 0; b < NIB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c_ok[b] ? bv[t][b] : 0.f, acc[b], 0, 0, 0);
-      acc[NIB] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[NIB], 0, 0, 0);
+      bsum += a;
     }
   }
   for (; r < r_end; r += 2) {                                      // ragged tail
@@ -394,7 +395,7 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
       const float v = bp[b][rc * A_LD];
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, (c_ok[b] && r_ok) ? v : 0.f, acc[b], 0, 0, 0);
     }
-    acc[NIB] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, r_ok ? 1.0f : 0.f, acc[NIB], 0, 0, 0);
+    bsum += a;
   }
 #pragma unroll
   for (int b = 0; b < NIB; ++b) {
@@ -407,14 +408,8 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
       }
     }
   }
-  if ((lane & 31) == 0) {
-    float* dbias = dst + (size_t)L.out * L.in;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int oo = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-      if (oo < L.out) dbias[oo] = acc[NIB][q];
-    }
-  }
+  bsum += __shfl_xor(bsum, 32);                                    // even-row + odd-row halves
+  if (lane < 32 && o_ok) dst[(size_t)L.out * L.in + o] = bsum;
 }
 
 extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
