@@ -71,11 +71,13 @@ enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2 };
 #define S_A2 (S_A1 + PT_ROWS * LDA)
 #define S_OUTV (S_A2 + PT_ROWS * LDA)           // outv[32][21]: mean 18, values 2
 #define S_END (S_OUTV + PT_ROWS * 21)
+static_assert(PT_ROWS * LDA >= 4 * 1024 + 32, "K-split partials + bias fit in one activation buffer");
 
 struct FwdDesc {            // one forward layer: out = act(in * W^T + b)
   int woff, boff, kb, nblk, n;       // packed-weight offset, bias offset (from the bias region), K/2, 32-col blocks, outputs
   int in_off, ldi, out_off, ldo;     // LDS float offsets (out_off includes the column offset) and row strides
   int act, scol;                     // activation; column in the activation stash (-1: not stashed)
+  int ksplit;                        // head layers (one 32-column block, K = 128): the 4 waves split K instead of idling
 };
 struct FwdTable { FwdDesc l[NLAYERS]; };
 
@@ -92,7 +94,7 @@ static inline FwdTable make_fwd_table(const int* stash_cols /* NLAYERS entries o
                             ACT_ELU, ACT_ELU, ACT_NONE};
   for (int l = 0; l < NLAYERS; ++l)
     t.l[l] = FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off[l], ldi[l], out_off[l], ldo[l],
-                     act[l], stash_cols ? stash_cols[l] : -1};
+                     act[l], stash_cols ? stash_cols[l] : -1, (layer_nblk(l) == 1 && layer_in(l) == 128 && in_off[l] == S_A1) ? 1 : 0};
   return t;
 }
 
@@ -168,10 +170,10 @@ static __device__ __forceinline__ void load_x_tile(float* x, F row_ptr) {
 // UNCONDITIONALLY (k-groups past kb re-read group 0): with loads under predicates the compiler cannot know how many
 // are outstanding and its s_waitcnt for the current layer's operands also drains the next layer's prefetch.
 template <int NW>
-static __device__ __forceinline__ void load_operands(float (&w)[NW], const float4* __restrict__ ubase, int lane_off, int stride4, int kb) {
+static __device__ __forceinline__ void load_operands(float (&w)[NW], const float4* __restrict__ ubase, int lane_off, int stride4, int kb, int kg0 = 0) {
 #pragma unroll
   for (int kg = 0; kg < 16; ++kg) {
-    const float4* pu = ubase + (kg * 4 < kb ? kg : 0) * stride4;    // uniform part (scalar registers); lane_off is the per-lane part
+    const float4* pu = ubase + (kg * 4 < kb ? kg0 + kg : 0) * stride4;    // uniform part (scalar registers); lane_off is the per-lane part
     const float4 v = pu[lane_off];
     w[kg * 4] = v.x; w[kg * 4 + 1] = v.y; w[kg * 4 + 2] = v.z; w[kg * 4 + 3] = v.w;
   }
@@ -207,7 +209,8 @@ static __device__ long long* g_mlp_dbg = nullptr;
 static __device__ __forceinline__ void fwd_load(float (&w)[65], const FwdDesc& d, const float* __restrict__ wpack) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cb = wave < d.nblk ? wave : 0;       // idle waves fetch block 0 (unused)
-  load_operands(w, reinterpret_cast<const float4*>(wpack + d.woff), cb * 64 + lane, d.nblk * 64, d.kb);
+  if (d.ksplit) load_operands(w, reinterpret_cast<const float4*>(wpack + d.woff), lane, 64, d.kb >> 2, wave * (d.kb >> 4));   // this wave's quarter of K
+  else load_operands(w, reinterpret_cast<const float4*>(wpack + d.woff), cb * 64 + lane, d.nblk * 64, d.kb);
   const int col = wave * 32 + (lane & 31);
   w[64] = wpack[WPACK_WEIGHT_FLOATS + d.boff + (col < d.n ? col : 0)];
 }
@@ -218,6 +221,32 @@ static __device__ __forceinline__ void fwd_run(const float (&w)[65], const FwdDe
                                                float* __restrict__ stash, int lds, int row0, int num_rows, int dbg_l = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   LSTAMP(dbg_l, 0);
+  if (d.ksplit) {
+    // each wave: its quarter of K into a partial 32x32 block in a0 (dead at every head layer), then all threads
+    // reduce the 4 partials, add the bias, activate and write the n (<= 32) real columns
+    const int kq = d.kb >> 2;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5) + 2 * wave * kq, w, kq, acc);
+    float* part = smem + S_A0 + wave * 1024 + (lane & 31) + 4 * (lane >> 5) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
+    if (wave == 0 && lane < 32) smem[S_A0 + 4096 + lane] = w[64];
+    LSTAMP(dbg_l, 1);
+    __syncthreads();
+    const float* p = smem + S_A0;
+    for (int e = threadIdx.x; e < PT_ROWS * d.n; e += PT_THREADS) {
+      const int row = e / d.n, col = e - row * d.n;
+      const int q = row * 32 + col;
+      const float x = ((p[q] + p[1024 + q]) + (p[2048 + q] + p[3072 + q])) + p[4096 + col];
+      const float v = d.act == ACT_TANH ? tanhf(x) : (d.act == ACT_ELU ? (x > 0.f ? x : __expf(x) - 1.f) : x);
+      smem[d.out_off + row * d.ldo + col] = v;
+      if (stash != nullptr && d.scol >= 0 && row0 + row < num_rows) stash[(size_t)(row0 + row) * lds + d.scol + col] = v;
+    }
+    LSTAMP(dbg_l, 2);
+    __syncthreads();
+    LSTAMP(dbg_l, 3);
+    return;
+  }
   if (wave < d.nblk) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5), w, d.kb, acc);
