@@ -13,7 +13,8 @@
 #include "wbc_mlp.h"
 
 extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(PolicyParams P, FwdTable T, const float* __restrict__ wpack,
-                                                                              const float* __restrict__ obs, const float* __restrict__ eps,
+                                                                              const float* __restrict__ obs, const float* __restrict__ latent,
+                                                                              const float* __restrict__ eps,
                                                                               float* __restrict__ actions, float* __restrict__ mean_out,
                                                                               float* __restrict__ logp_out, float* __restrict__ value_out,
                                                                               int num_rows, long long* __restrict__ dbg) {
@@ -28,14 +29,21 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
   load_x_tile(smem + S_X, [&](int r) { return (row0 + r < num_rows) ? obs + (size_t)(row0 + r) * PT_NOBS : (const float*)nullptr; });
   __syncthreads();
   const bool critic = blockIdx.y != 0;
-  if (!critic)
+  if (!critic) {
     for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
       const int r = e / PT_NPROP, c = e - r * PT_NPROP;
       smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
     }
+    if (latent)       // student path (hist_encoding=True, AC:206-209): the given latent replaces the privileged encoder's
+      for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {
+        const int r = e / 20, c = e - r * 20;
+        smem[S_A1 + r * LDA + PT_NPROP + c] = (row0 + r < num_rows) ? latent[(size_t)(row0 + r) * 20 + c] : 0.f;
+      }
+    __syncthreads();
+  }
   DBG_STAMP();
   // actor (AC:204-221): layers 0..8; critic (AC:281-286): layers 9..15; table-driven (wbc_mlp.h)
-  fwd_chain(T, smem, wpack, nullptr, 0, row0, num_rows, critic ? L_CBB : 0, critic ? NLAYERS : L_CBB);
+  fwd_chain(T, smem, wpack, nullptr, 0, row0, num_rows, critic ? L_CBB : (latent ? L_BB : 0), critic ? NLAYERS : L_CBB);
   DBG_STAMP();
   const float* outv = smem + S_OUTV;
   if (critic) {
@@ -91,13 +99,13 @@ extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* st
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* eps, float* actions, float* mean,
-                              float* logp, float* values, int num_rows, void* stream) {
+extern "C" int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* latent, const float* eps,
+                              float* actions, float* mean, float* logp, float* values, int num_rows, void* stream) {
   PolicyParams P;
   if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
   const int blocks = (num_rows + PT_ROWS - 1) / PT_ROWS;
   static const FwdTable T = make_fwd_table(nullptr);
-  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T, wpack, obs, eps, actions, mean, logp,
+  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T, wpack, obs, latent, eps, actions, mean, logp,
                      values, num_rows, g_policy_dbg);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

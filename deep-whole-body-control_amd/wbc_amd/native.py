@@ -59,7 +59,7 @@ def lib():
         L.wbc_hist_latent.argtypes = [c_void, c_void, c_void, c_int, c_void]
         L.wbc_sim_episode_stats.argtypes = [c_void, C.c_float, c_void, c_void]
         L.wbc_rollout_store.argtypes = [c_void] * 5 + [C.c_float, c_void, c_void, c_int, c_void]
-        L.wbc_policy_act.argtypes = [c_void] * 8 + [c_int, c_void]
+        L.wbc_policy_act.argtypes = [c_void] * 9 + [c_int, c_void]
         L.wbc_policy_pack.argtypes = [c_void, c_void, c_void]
         L.wbc_ppo_minibatch_grad.argtypes = [c_void] * 9 + [c_int] + [C.c_float] * 4 + [c_int, c_void, c_void, c_void]
         L.wbc_ppo_clip_adam.argtypes = [c_void] * 4 + [C.c_float] * 6 + [c_void, c_void]

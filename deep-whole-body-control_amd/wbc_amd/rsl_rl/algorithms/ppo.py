@@ -65,8 +65,8 @@ class PPO:
     # ---- rollout side ----------------------------------------------------------------------
     def act(self, obs, critic_obs, hist_encoding=False):
         tr, ac = self.transition, self.actor_critic
-        if (self.fused_rollout and not hist_encoding and critic_obs is obs and not torch.is_grad_enabled()
-                and ac.fused_act_supported(obs)):
+        if (self.fused_rollout and critic_obs is obs and not torch.is_grad_enabled() and ac.fused_act_supported(obs)
+                and (not hist_encoding or ac.actor._fused_hist_supported(obs))):
             # one HIP launch for actor + critic + sample + log-prob (csrc/wbc_policy_kernel.hip)
             if self.storage is not None and self.storage.step == 0:
                 ac.mark_params_changed()      # start of a rollout: re-pack once, whoever touched the weights since
@@ -75,7 +75,8 @@ class PPO:
             if (st is not None and st.step < st.num_transitions_per_env and st.actions.is_cuda and st.actions.shape[1:] == (obs.shape[0], 18)):
                 i = st.step                       # write straight into this step's storage slots
                 out = (st.actions[i], st.mu[i], st.actions_log_prob[i], st.values[i])
-            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps, out)
+            latent = ac.actor.infer_hist_latent(obs) if hist_encoding else None      # student rollouts (DAgger iterations)
+            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps, out, latent)
             tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
         else:
             tr.actions = ac.act(obs, hist_encoding).detach()

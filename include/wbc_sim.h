@@ -282,11 +282,14 @@ int wbc_gae_workspace_doubles(int N);
  * critic_backbone.0, critic leg head {0,2,4}, critic arm head {0,2,4}, each weight then bias, then std).
  * `wpack`: wbc_policy_pack_floats() floats holding the weights in MFMA-fragment order; refresh it with
  * wbc_policy_pack whenever the parameters changed. obs f32 [rows,860]; eps f32 [rows,18] standard
- * normals (NULL: act on the mean); outputs actions/mean f32 [rows,18], logp/values f32 [rows,2]. */
+ * normals (NULL: act on the mean); outputs actions/mean f32 [rows,18], logp/values f32 [rows,2].
+ * `latent` f32 [rows,20] or NULL: if given (student path, hist_encoding=True, actor_critic.py:206-209) it replaces
+ * the privileged encoder's output (e.g. the result of wbc_hist_latent). */
 int wbc_policy_pack_floats(void);
 int wbc_policy_pack(const void* const* params, float* wpack, void* stream);
-int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* eps,
-                   float* actions, float* mean, float* logp, float* values, int num_rows, void* stream);
+int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* latent,
+                   const float* eps, float* actions, float* mean, float* logp, float* values, int num_rows,
+                   void* stream);
 
 /* StateHistoryEncoder forward without gradient (rsl_rl/modules/actor_critic.py:39-84, tsteps = 10), the regulariser
  * target of PPO.update (ppo.py:174-176). params: 8 device pointers (encoder.0.weight [30,76], .bias,

@@ -81,3 +81,20 @@ def test_fused_history_encoder_matches_torch(n):
         ref = ac.actor.history_encoder(hist.view(-1, 10, 76))
     assert fused.shape == ref.shape == (n, 20)
     np.testing.assert_allclose(fused.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_fused_act_student_path_matches_torch():
+    """hist_encoding=True (AC:206-209): the history latent (wbc_hist_latent) replaces the privileged encoder's output in
+    the fused inference kernel; mean action and values against the module's eager forward."""
+    torch.manual_seed(9)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
+    obs = torch.randn(1000, 860, device="cuda")
+    with torch.no_grad():
+        latent = ac.actor.infer_hist_latent(obs)
+        actions, mean, logp, values = ac.fused_act(obs, None, latent=latent)
+        ref_mean = ac.actor(obs, hist_encoding=True)
+        ref_val = ac.evaluate(obs)
+    np.testing.assert_allclose(mean.cpu().numpy(), ref_mean.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(actions.cpu().numpy(), mean.cpu().numpy(), rtol=0, atol=0)      # eps=None acts on the mean
+    np.testing.assert_allclose(values.cpu().numpy(), ref_val.cpu().numpy(), rtol=2e-5, atol=2e-5)
