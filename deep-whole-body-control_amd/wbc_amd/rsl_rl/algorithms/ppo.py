@@ -372,7 +372,12 @@ class PPO:
         hist_params = list(ac.actor.history_encoder.parameters())
         for (obs_b, *_rest, hid_b, masks_b) in self._generator():
             with torch.inference_mode():
-                ac.act(obs_b, hist_encoding=True, masks=masks_b, hidden_states=hid_b[0])
+                if self.fused_rollout and obs_b.is_cuda:
+                    # the reference's act() here only samples and discards (quirk L1): keep the generator advancing by one
+                    # [mb, 18] normal draw, skip the 17 launches of the unused forward
+                    torch.empty(obs_b.shape[0], ac.std.shape[0], device=obs_b.device).normal_()
+                else:
+                    ac.act(obs_b, hist_encoding=True, masks=masks_b, hidden_states=hid_b[0])
                 priv_latent = ac.actor.infer_priv_latent(obs_b)
             hist_latent = ac.actor.infer_hist_latent(obs_b)
             loss = (priv_latent.detach() - hist_latent).norm(p=2, dim=1).mean()
