@@ -512,7 +512,9 @@ extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, f
 // then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
 static const int kDcol[NLAYERS] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM};
 static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, A_BB, A_A1, A_A2, A_X, A_CB, A_CL1, A_CL2, A_CB, A_CA1, A_CA2};
-#define PPO_NSPLIT 56
+#ifndef PPO_NSPLIT
+#define PPO_NSPLIT 48
+#endif
 
 extern "C" int wbc_ppo_grad_floats(void) {
   int n = 0;

@@ -31,6 +31,21 @@ __device__ long long* g_step_dbg = nullptr;
                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division sequence on the dependent chains
 __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+// sin and cos with Cody-Waite reduction by pi/2 and the cephes single-precision polynomials: ~1 ulp for |x| < 1e3
+// (joint angles), 25 instructions instead of libm's ~150 (its large-argument path is inlined everywhere)
+__device__ __forceinline__ void fast_sincosf(float x, float* sp, float* cp) {
+  const float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-k, 1.5703125f, x);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188e-8f, r);
+  const float z = r * r;
+  const float sn = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float cs = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.f));
+  const int q = (int)k;
+  const float s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+  *sp = (q & 2) ? -s0 : s0;
+  *cp = ((q + 1) & 2) ? -c0 : c0;
+}
 // value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], VALU speed, no LDS
 __device__ __forceinline__ float pair_swap(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
@@ -188,11 +203,11 @@ __device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restri
   if (j >= 0 && j < WBC_NDOF) {
     const float qq = s.q[j], qdv = s.qd[j];
     float sq, cq;
-    sincosf(qq, &sq, &cq);
+    fast_sincosf(qq, &sq, &cq);
     s.sq[j] = sq; s.cq[j] = cq;
     if (HALF) {
       float sh, ch;
-      sincosf(0.5f * qq, &sh, &ch);
+      fast_sincosf(0.5f * qq, &sh, &ch);
       s.viol[j] = sh; s.limd[j] = ch;
       return;
     }
@@ -475,27 +490,23 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       const f3 xc = xk - n * rad;
       st3(s.cn[kc], n); st3(s.cxc[kc], xc);
       s.cvtgt[kc] = (gap >= 0.f) ? -gap * idt : fminf(C->cfg.contact_erp * (-gap) * idt, C->cfg.max_depenetration_vel);
+      // W = J K J^T with J = [-[xc]x  I] (point velocity = v + omega x xc): for any 6-vector (a; l), J-row products are
+      // l + a x xc, so K J^T has rows Kl_r + Ka_r x xc and W's columns are L_c + U_c x xc (54 FMAs instead of 162)
       const float* K = s.IA[b];
-      const float X[9] = {0.f, -xc.z, xc.y, xc.z, 0.f, -xc.x, -xc.y, xc.x, 0.f};
-      float J[18];
+      f3 kj[6];
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 6; ++r) kj[r] = ld3(&K[r * 6 + 3]) + cross(ld3(&K[r * 6]), xc);
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) { J[r * 6 + cc] = -X[r * 3 + cc]; J[r * 6 + 3 + cc] = (r == cc) ? 1.f : 0.f; }
-      float KJt[18];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) KJt[r * 3 + cc] = dot6(&K[r * 6], &J[cc * 6]);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          float acc = 0.f;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) acc += J[r * 6 + j] * KJt[j * 3 + cc];
-          s.cW[kc][r * 3 + cc] = acc + ((r == cc) ? 1e-6f : 0.f);
-        }
+      for (int cc = 0; cc < 3; ++cc) {
+        const f3 up = mk3(cc == 0 ? kj[0].x : (cc == 1 ? kj[0].y : kj[0].z), cc == 0 ? kj[1].x : (cc == 1 ? kj[1].y : kj[1].z),
+                          cc == 0 ? kj[2].x : (cc == 1 ? kj[2].y : kj[2].z));
+        const f3 lo = mk3(cc == 0 ? kj[3].x : (cc == 1 ? kj[3].y : kj[3].z), cc == 0 ? kj[4].x : (cc == 1 ? kj[4].y : kj[4].z),
+                          cc == 0 ? kj[5].x : (cc == 1 ? kj[5].y : kj[5].z));
+        const f3 wc = lo + cross(up, xc);
+        s.cW[kc][0 * 3 + cc] = wc.x + (cc == 0 ? 1e-6f : 0.f);
+        s.cW[kc][1 * 3 + cc] = wc.y + (cc == 1 ? 1e-6f : 0.f);
+        s.cW[kc][2 * 3 + cc] = wc.z + (cc == 2 ? 1e-6f : 0.f);
+      }
       const f3 w = ld3(&s.v[b][0]);
       const f3 vp = ld3(&s.v[b][3]) + cross(w, xc);
       const f3 ab_a = ld3(&s.a[b][0]);
