@@ -1,0 +1,14 @@
+# HBM traffic of wbc_step_kernel: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (MI355X_MICROARCH.md, HBM section)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_traffic/$c -- python $R/tools/time_step.py 4096 30 base > /dev/null 2>&1
+done
+python - <<'PY'
+import csv, glob, os, statistics
+R=os.environ['GRAFT_REPO_ROOT']
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    f=sorted(glob.glob(f"{R}/gpurun_out/pmc_traffic/{c}/*/*counter_collection.csv"))[-1]
+    v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith('wbc_step_kernel') and r['Counter_Name']==c]
+    print(c, "launches", len(v), "median_KB", statistics.median(v), "mean_KB", sum(v)/len(v))
+PY
