@@ -402,6 +402,14 @@ extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, float* out, void* 
   return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
 }
 
+// internal (wbc_arm_kernel.hip): the tensors the arm-dynamics pre-pass reads
+extern "C" int wbc_sim_internal_arm_inputs(wbc_sim* s, const DevConst** hc, const float** root, const float** dofs, const float** body_params,
+                                           const float** mass_params, int* n) {
+  if (!s) return -1;
+  *hc = &s->hc; *root = s->T.root; *dofs = s->T.dof; *body_params = s->T.body_params; *mass_params = s->T.mass_params; *n = s->n;
+  return 0;
+}
+
 extern "C" int wbc_sim_get_step_counter(wbc_sim* s, int64_t* out) { if (!s || !out) return fail(-1, "null"); *out = s->step_counter; return 0; }
 extern "C" int wbc_sim_set_step_counter(wbc_sim* s, int64_t v) { if (!s) return fail(-1, "null"); s->step_counter = v; return 0; }
 

@@ -23,6 +23,34 @@ from .sim import WbcSim
 from .urdf_model import RobotModel, build_model
 
 
+# isaacgym.torch_utils helpers the operational-space controller uses (quaternions are xyzw)
+def _quat_mul(a, b):
+    x1, y1, z1, w1 = a.unbind(-1)
+    x2, y2, z2, w2 = b.unbind(-1)
+    return torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], dim=-1)
+
+
+def _quat_apply(q, v):
+    xyz = q[:, :3]
+    t = torch.linalg.cross(xyz, v, dim=-1) * 2
+    return v + q[:, 3:] * t + torch.linalg.cross(xyz, t, dim=-1)
+
+
+def _orientation_error(desired, current):                                           # widowGo1.py orientation_error
+    cc = torch.cat([-current[:, :3], current[:, 3:]], dim=-1)
+    q_r = _quat_mul(desired, cc)
+    return q_r[:, 0:3] * torch.sign(q_r[:, 3]).unsqueeze(-1)
+
+
+def _yaw_quat(quat):
+    """Quaternion of the yaw of `quat` alone (base_yaw_quat, WG:878-880)."""
+    x, y, z, w = quat.unbind(-1)
+    yaw = torch.atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
+    zero = torch.zeros_like(yaw)
+    return torch.stack([zero, zero, torch.sin(yaw / 2), torch.cos(yaw / 2)], dim=-1)
+
+
 class BaseTask(VecEnv):
     """Buffer/attribute contract of legged_gym/envs/base/base_task.py:41-131 (viewer omitted: headless)."""
 
@@ -239,6 +267,13 @@ class WidowGo1(LeggedRobot):
         self.dof_pos_limits = torch.tensor(np.stack([m.dof_lower, m.dof_upper], 1), dtype=torch.float, device=dev)   # LR:294-296
         self.dof_vel_limits = torch.tensor(m.dof_velocity, dtype=torch.float, device=dev)
         self.commands_scale = f(tc.commands_scale)
+        # operational-space controller of the torque-supervision path (WG:559-565, 664-670)
+        self.arm_osc_kp = torch.tensor(np.asarray(self.cfg.arm.osc_kp, dtype=np.float64), dtype=torch.float, device=dev)
+        self.arm_osc_kd = torch.tensor(np.asarray(self.cfg.arm.osc_kd, dtype=np.float64), dtype=torch.float, device=dev)
+        self.ee_orn_des = torch.tensor([0, 0.7071068, 0, 0.7071068], device=dev).repeat((self.num_envs, 1))
+        self.z_invariant_offset = torch.full((self.num_envs, 1), float(tc.z_invariant_offset), device=dev)
+        self._arm_link_rb = list(range(m.num_rigid_bodies - 9, m.num_rigid_bodies))
+        self.link_mass = torch.tensor(m.rb_mass[-9:], dtype=torch.float, device=dev).unsqueeze(0).repeat((self.num_envs, 1))
         self.common_step_counter = 0
         self.extras = {"episode": {}}
         self._active_terms = None
@@ -300,12 +335,47 @@ class WidowGo1(LeggedRobot):
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
 
+    # ---- torque supervision (WG:1178-1181, 1201-1242): default off (WGC:173) ------------------------------------
+    def _refresh_arm_dynamics(self):
+        self.mm, self.ee_j_eef, self._g_torque = self.sim.arm_dynamics(self._arm_link_rb, self.robot_model.rb_mass[-9:])
+
+    def get_g_torques(self):                                                        # WG:1201-1207
+        self._refresh_arm_dynamics()
+        return self._g_torque
+
+    def get_arm_mm(self):                                                           # WG:1209-1211
+        self._refresh_arm_dynamics()
+        return self.mm
+
+    def get_ee_jac(self):                                                           # WG:1213-1215
+        self._refresh_arm_dynamics()
+        return self.ee_j_eef
+
+    def get_arm_ee_control_torques(self):
+        """Operational-space control torques of the arm, the supervision target (WG:1217-1242), line by line; the
+        mass matrix, the Jacobian and the gravity torques come from wbc_sim_arm_dynamics instead of Isaac Gym."""
+        self._refresh_arm_dynamics()
+        m_inv = torch.linalg.pinv(self.mm)
+        m_eef = torch.linalg.pinv(self.ee_j_eef @ m_inv @ torch.transpose(self.ee_j_eef, 1, 2))
+        ee_orn_normalized = self.ee_orn / torch.norm(self.ee_orn, dim=-1).unsqueeze(-1)
+        orn_err = _orientation_error(self.ee_orn_des, ee_orn_normalized)
+        yaw = _yaw_quat(self.base_quat)
+        pos_err = (torch.cat([self.root_states[:, :2], self.z_invariant_offset], dim=1) + _quat_apply(yaw, self.curr_ee_goal_cart) - self.ee_pos)
+        dpose = torch.cat([pos_err, orn_err], -1)
+        u = (torch.transpose(self.ee_j_eef, 1, 2) @ m_eef @ (self.arm_osc_kp * dpose - self.arm_osc_kd * self.ee_vel)[:, :6].unsqueeze(-1)).squeeze(-1)
+        return u + self._g_torque
+
     def step(self, actions):
         """WG:1156-1199 as one kernel launch; returns the reference's 6-tuple (views, overwritten by the
         next step)."""
         a = actions.to(self.device, dtype=torch.float32)
         if not a.is_contiguous():
             a = a.contiguous()
+        if self.cfg.control.torque_supervision:                                     # WG:1178-1181: state at t = 0 of the step
+            self.arm_ee_control_torques = self.get_arm_ee_control_torques()
+            self.extras["target_arm_torques"] = self.arm_ee_control_torques
+            self.extras["current_arm_dof_pos"] = self.dof_pos[:, -8:-2].clone()
+            self.extras["current_arm_dof_vel"] = self.dof_vel[:, -8:-2].clone()
         self.sim.step(a)
         self.common_step_counter += 1
         self._fill_extras()

@@ -57,6 +57,7 @@ def lib():
         L.wbc_gae_workspace_doubles.argtypes = [c_int]
         L.wbc_abi_sizes.argtypes = [C.POINTER(c_int)]
         L.wbc_hist_latent.argtypes = [c_void, c_void, c_void, c_int, c_void]
+        L.wbc_sim_arm_dynamics.argtypes = [c_void, c_void, c_void, c_void, c_void, c_void, c_void]
         L.wbc_sim_episode_stats.argtypes = [c_void, C.c_float, c_void, c_void]
         L.wbc_rollout_store.argtypes = [c_void] * 5 + [C.c_float, c_void, c_void, c_int, c_void]
         L.wbc_policy_act.argtypes = [c_void] * 9 + [c_int, c_void]
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "wbc_sim_set_root_state_indexed", "wbc_sim_set_dof_state_indexed", "wbc_sim_refresh_dof_state",
     "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force", "wbc_sim_refresh_force_sensor",
     "wbc_sim_refresh_rigid_body_state", "wbc_sim_get_step_counter", "wbc_sim_set_step_counter", "wbc_gae_compute",
-    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_sim_episode_stats", "wbc_rollout_store", "wbc_hist_latent", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_clip_adam", "wbc_ppo_grad_floats",
+    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_sim_episode_stats", "wbc_rollout_store", "wbc_hist_latent", "wbc_sim_arm_dynamics", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_clip_adam", "wbc_ppo_grad_floats",
     "wbc_ppo_num_splits", "wbc_ppo_workspace_floats"]
 
 

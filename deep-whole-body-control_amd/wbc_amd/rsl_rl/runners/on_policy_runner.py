@@ -50,7 +50,9 @@ class OnPolicyRunner:
         if hasattr(env, "collect_episode_stats"):
             env.collect_episode_stats = log_dir is not None
         env.reset()
-        self.alg.set_arm_default_coeffs(env.p_gains[12:], env.d_gains[12:], env.default_dof_pos[-7:-2])   # sic, OPR:91 (quirk Q7)
+        # OPR:91 passes default_dof_pos[-7:-2] (5 values): arm_fk then fails with a shape error the moment torque
+        # supervision is switched on (quirk Q7: the path is dead in the reference). The 6 arm DoFs are [-8:-2].
+        self.alg.set_arm_default_coeffs(env.p_gains[12:], env.d_gains[12:], env.default_dof_pos[-8:-2])
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         env, alg = self.env, self.alg

@@ -112,6 +112,18 @@ class WbcSim:
     def reset_all(self) -> None:
         check(self.L.wbc_sim_reset_all(self.h, self._stream()), "wbc_sim_reset_all")
 
+    def arm_dynamics(self, link_rb9, link_mass9):
+        """(mm [N,6,6], ee Jacobian [N,6,6], gravity torques [N,6]) of the arm from the current state: what the
+        reference reads from Isaac Gym's mass-matrix / Jacobian tensors (WG:550-558, 1201-1207)."""
+        n = self.num_envs
+        mm = torch.empty(n, 6, 6, dtype=torch.float32, device=self.device)
+        jac = torch.empty(n, 6, 6, dtype=torch.float32, device=self.device)
+        gt = torch.empty(n, 6, dtype=torch.float32, device=self.device)
+        rb = (C.c_int * 9)(*[int(x) for x in link_rb9])
+        ms = (C.c_float * 9)(*[float(x) for x in link_mass9])
+        check(self.L.wbc_sim_arm_dynamics(self.h, rb, ms, mm.data_ptr(), jac.data_ptr(), gt.data_ptr(), self._stream()), "wbc_sim_arm_dynamics")
+        return mm, jac, gt
+
     def episode_stats(self, scale: float) -> torch.Tensor:
         """Means over the envs that reset in the last step of their finished episode's reward sums [NREW] and metric
         sums [NMETRIC], times `scale`, as one fresh device tensor (WG:743-754 without a host sync)."""

@@ -153,6 +153,7 @@ class RobotModel:
     rb_names: List[str]
     rb_body: List[int]              # moving body each rigid body rides on
     rb_offset: np.ndarray           # [nrb,3] rigid-body frame origin in that moving body's frame
+    rb_mass: np.ndarray             # [nrb] mass of each rigid body (its link + the links collapsed into it)
     # un-merged pieces needed for per-env mass randomisation (widowGo1.py:431-456)
     base_piece: dict
     gripper_piece: dict
@@ -180,7 +181,7 @@ class RobotModel:
     def from_json(s: str) -> "RobotModel":
         d = json.loads(s)
         arr = ["joint_xyz", "mass", "com", "inertia", "dof_lower", "dof_upper", "dof_velocity",
-               "dof_effort", "dof_friction", "rb_offset"]
+               "dof_effort", "dof_friction", "rb_offset", "rb_mass"]
         for k in arr:
             d[k] = np.array(d[k], dtype=np.float64)
         for piece in ("base_piece", "gripper_piece"):
@@ -217,6 +218,7 @@ def build_model(urdf_path: str, root_link: str = "base", lock_friction_above: fl
     rb_names: List[str] = []
     rb_body: List[int] = []
     rb_offset: List[np.ndarray] = []
+    rb_mass: List[float] = []
     pieces: Dict[str, dict] = {}
 
     def add_piece(tag, body, lk_mass, lk_com, lk_I):
@@ -227,6 +229,9 @@ def build_model(urdf_path: str, root_link: str = "base", lock_friction_above: fl
         lk = links[link_name]
         m, c, I = comp[body]
         comp[body] = _merge(m, c, I, lk.mass, lk.com + offset, lk.inertia)
+        while len(rb_mass) < len(rb_names):
+            rb_mass.append(0.0)
+        rb_mass[rb_index] += lk.mass
         # rigid-body bookkeeping: a collapsed link adds to rigid body rb_index, which for
         # the two randomised links we keep as separate pieces
         for j in children.get(link_name, []):
@@ -316,7 +321,7 @@ def build_model(urdf_path: str, root_link: str = "base", lock_friction_above: fl
         dof_lower=np.array([j.lower for j in dof_meta]), dof_upper=np.array([j.upper for j in dof_meta]),
         dof_velocity=np.array([j.velocity for j in dof_meta]), dof_effort=np.array([j.effort for j in dof_meta]),
         dof_friction=np.array([j.friction for j in dof_meta]), dof_locked=dof_locked,
-        body_names=body_names, rb_names=rb_names, rb_body=rb_body, rb_offset=np.array(rb_offset),
+        body_names=body_names, rb_names=rb_names, rb_body=rb_body, rb_offset=np.array(rb_offset), rb_mass=np.array(rb_mass),
         base_piece=base_piece, gripper_piece=gripper_piece)
 
 

@@ -321,6 +321,14 @@ int wbc_ppo_grad_floats(void);
 int wbc_ppo_num_splits(void);
 size_t wbc_ppo_workspace_floats(int B);
 
+/* What Isaac Gym's mass-matrix / Jacobian tensors give the torque-supervision path (widowGo1.py:550-558, 1201-1242):
+ * mm f32 [N,6,6] = joint-space inertia block of the 6 arm joints, jac f32 [N,6,6] = world-frame Jacobian of the
+ * end-effector rigid body w.r.t. them (rows linear xyz, angular xyz), gtorque f32 [N,6] = sum over the rigid bodies
+ * link_rb9 (the actor's last 9) of J_body^T (0,0,9.81 m,0,0,0) with the host masses link_mass9 (+ env 0's gripper mass
+ * delta, as the reference reads env 0's properties). Computed from the sim's current root / DoF state. */
+int wbc_sim_arm_dynamics(wbc_sim* sim, const int* link_rb9, const float* link_mass9, float* mm, float* jac,
+                         float* gtorque, void* stream);
+
 /* extras["episode"] of reset_idx (widowGo1.py:743-754): out[0:WBC_NREW] = mean over the envs that reset in the last
  * step of their finished episode's reward sums, out[WBC_NREW:+WBC_NMETRIC] the same for the metric sums, both
  * times `scale` (1 / max_episode_length_s). `out`: device, WBC_NREW + WBC_NMETRIC floats. */
