@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--terrain", choices=["plane", "trimesh"], default="plane",
+                    help="plane = BASELINE.json configs[1] (the bench line); trimesh = the shipped fractal-Perlin terrain (configs[2])")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +139,8 @@ def main():
 
     cfg = WidowGo1RoughCfg()
     cfg.env.num_envs = args.envs_per_gpu
-    cfg.terrain.mesh_type = "plane"                   # BASELINE.json configs[1]: flat terrain (the shipped default is the Perlin trimesh)
+    if args.terrain == "plane":
+        cfg.terrain.mesh_type = "plane"               # BASELINE.json configs[1]: flat terrain (the shipped default is the Perlin trimesh)
     train_cfg = WidowGo1RoughCfgPPO()
     torch.manual_seed(train_cfg.seed)                 # identical replicas; env RNG differs per rank
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)
@@ -199,9 +202,9 @@ def main():
             "metric": "env-steps/sec whole node, widowGo1 4096-env PPO",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (random-init policy, seeded domain randomisation, flat terrain)",
-            "config": {"workload": f"widowGo1 flat terrain, {args.envs_per_gpu} envs per GPU, PPO fp32 "
-                                   f"(BASELINE.json configs[1]); T={T} steps/iteration, 5 epochs x 4 minibatches, "
+            "dtype": "f32", "data": f"synthetic (random-init policy, seeded domain randomisation, {'flat' if args.terrain == 'plane' else 'fractal-Perlin trimesh'} terrain)",
+            "config": {"workload": f"widowGo1 {'flat' if args.terrain == 'plane' else 'trimesh (Perlin)'} terrain, {args.envs_per_gpu} envs per GPU, PPO fp32 "
+                                   f"(BASELINE.json configs[{1 if args.terrain == 'plane' else 2}]); T={T} steps/iteration, 5 epochs x 4 minibatches, "
                                    f"DAgger every 20th iteration", "envs_per_gpu": args.envs_per_gpu,
                        "global_envs": args.envs_per_gpu * world, "steps_per_env": T,
                        "parallelism": f"env-shard x{world}, 1 grad all-reduce/minibatch" if world > 1 else "single GPU",
