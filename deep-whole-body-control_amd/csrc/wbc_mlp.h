@@ -78,6 +78,7 @@ struct FwdDesc {            // one forward layer: out = act(in * W^T + b)
   int in_off, ldi, out_off, ldo;     // LDS float offsets (out_off includes the column offset) and row strides
   int act, scol;                     // activation; column in the activation stash (-1: not stashed)
   int ksplit;                        // head layers (one 32-column block, K = 128): the 4 waves split K instead of idling
+  int scratch_off;                   // ksplit: LDS offset of an activation buffer that is dead during this layer (partials)
 };
 struct FwdTable { FwdDesc l[NLAYERS]; };
 
@@ -94,7 +95,7 @@ static inline FwdTable make_fwd_table(const int* stash_cols /* NLAYERS entries o
                             ACT_ELU, ACT_ELU, ACT_NONE};
   for (int l = 0; l < NLAYERS; ++l)
     t.l[l] = FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off[l], ldi[l], out_off[l], ldo[l],
-                     act[l], stash_cols ? stash_cols[l] : -1, (layer_nblk(l) == 1 && layer_in(l) == 128 && in_off[l] == S_A1) ? 1 : 0};
+                     act[l], stash_cols ? stash_cols[l] : -1, (layer_nblk(l) == 1 && layer_in(l) == 128 && in_off[l] == S_A1) ? 1 : 0, S_A0};
   return t;
 }
 
@@ -217,9 +218,15 @@ static __device__ __forceinline__ void fwd_load(float (&w)[65], const FwdDesc& d
 
 // Run forward layer d with its fragments in `w`. smem = LDS base (floats). Outputs go to LDS and, if d.scol >= 0, to
 // stash[(row0+row)*lds + d.scol + col] for valid rows. Ends with a barrier.
-static __device__ __forceinline__ void fwd_run(const float (&w)[65], const FwdDesc& d, float* smem,
-                                               float* __restrict__ stash, int lds, int row0, int num_rows, int dbg_l = 0) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_mfma` runs once this wave's MFMA chain has been issued and `w` is no longer read (single-buffered callers
+// request the next layer's operands there).
+template <typename Hook = NoHook>
+static __device__ __forceinline__ void fwd_run(float (&w)[65], const FwdDesc& d, float* smem,
+                                               float* __restrict__ stash, int lds, int row0, int num_rows, int dbg_l = 0,
+                                               Hook after_mfma = Hook()) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float bias_reg = w[64];
   LSTAMP(dbg_l, 0);
   if (d.ksplit) {
     // each wave: its quarter of K into a partial 32x32 block in a0 (dead at every head layer), then all threads
@@ -227,13 +234,14 @@ static __device__ __forceinline__ void fwd_run(const float (&w)[65], const FwdDe
     const int kq = d.kb >> 2;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5) + 2 * wave * kq, w, kq, acc);
-    float* part = smem + S_A0 + wave * 1024 + (lane & 31) + 4 * (lane >> 5) * 32;
+    after_mfma();
+    float* part = smem + d.scratch_off + wave * 1024 + (lane & 31) + 4 * (lane >> 5) * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
-    if (wave == 0 && lane < 32) smem[S_A0 + 4096 + lane] = w[64];
+    if (wave == 0 && lane < 32) smem[d.scratch_off + 4096 + lane] = bias_reg;
     LSTAMP(dbg_l, 1);
     __syncthreads();
-    const float* p = smem + S_A0;
+    const float* p = smem + d.scratch_off;
     for (int e = threadIdx.x; e < PT_ROWS * d.n; e += PT_THREADS) {
       const int row = e / d.n, col = e - row * d.n;
       const int q = row * 32 + col;
@@ -254,10 +262,11 @@ static __device__ __forceinline__ void fwd_run(const float (&w)[65], const FwdDe
     asm volatile("s_nop 0" :: "v"(acc[0]));      // stamp 1 after the last MFMA has produced its result
 #endif
     LSTAMP(dbg_l, 1);
+    after_mfma();
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int col = wave * 32 + (lane & 31);
     if (col < d.n) {
-      const float bias = w[64];
+      const float bias = bias_reg;
       float v[16];
       if (d.act == ACT_ELU) {
 #pragma unroll
@@ -285,6 +294,8 @@ static __device__ __forceinline__ void fwd_run(const float (&w)[65], const FwdDe
         }
       }
     }
+  } else {
+    after_mfma();
   }
   LSTAMP(dbg_l, 2);
   __syncthreads();

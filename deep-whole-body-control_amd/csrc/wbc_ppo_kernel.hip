@@ -52,8 +52,18 @@ extern "C" void wbc_debug_set_ppo_timing(void* dev_buf) {
 #endif
 }
 
-#define S_G S_END                      // g[32][41]: output grads dmu 18, dv 2, dlat 20
-#define S_PPO_END (S_G + PT_ROWS * 41)
+// LDS plan of the update kernel: x[32][101] (re-used as g[32][41] -- output grads dmu 18, dv 2, dlat 20 -- once the forward
+// is done), TWO activation buffers and outv: 48.6 KB, three workgroups per CU. The third buffer the chain would like (the
+// backbone output feeds two heads) is replaced by a reload from the activation stash (forward) and by keeping the first
+// head's contribution in the accumulator registers until the second head adds to it (backward).
+#define Q_X 0
+#define Q_A0 (PT_ROWS * 101)
+#define Q_A1 (Q_A0 + PT_ROWS * LDA)
+#define Q_OUTV (Q_A1 + PT_ROWS * LDA)
+#define Q_END (Q_OUTV + PT_ROWS * 21)
+#define Q_G Q_X
+static_assert(PT_ROWS * 41 <= PT_ROWS * 101, "g fits in x");
+static_assert(Q_END * 4 * 3 <= 160 * 1024, "three workgroups per CU");
 
 // ---- backward stages ------------------------------------------------------------------------------------
 // stage = [pre-step] ; buf <- buf * act'(A) (also to the DZ stash) ; [out (+)= buf * W on MFMA]
@@ -61,7 +71,8 @@ enum { PRE_NONE = 0, PRE_OUTER_V0, PRE_OUTER_V1, PRE_COPY_LEG, PRE_COPY_ARM, PRE
 struct BwdDesc {
   int pre; const float* wvec; int src_off;       // pre-step; for PRE_OUTER_*: the [128] last-layer weight row; for PRE_LATENT: dA_z buffer
   int buf_off, n, act, acol, dcol;                // activation-derivative pass over buf[32, n]
-  int has_mma, woffT, nblkT, out_dim, in_dim, out_off, accumulate;   // out[32, in_dim] (+)= buf[32, out_dim] * W[out_dim, in_dim] (transposed pack)
+  int has_mma, woffT, nblkT, out_dim, in_dim, out_off;   // out[32, in_dim] = buf[32, out_dim] * W[out_dim, in_dim] (transposed pack)
+  int save_out, add_saved;      // keep the product in the accumulator registers instead of LDS / start from the kept product
 };
 #define NBWD 14
 struct BwdTable { BwdDesc s[NBWD]; };
@@ -69,27 +80,70 @@ struct BwdTable { BwdDesc s[NBWD]; };
 static BwdTable make_bwd_table(const PolicyParams& P) {
   BwdTable t;
   int i = 0;
-  // lw = layer whose weight the stage multiplies by (-1: no GEMM)
-  auto add = [&](int pre, const float* wvec, int src, int buf, int n, int act, int acol, int dcol, int lw, int out, int acc) {
+  // lw = layer whose weight the stage multiplies by (-1: no GEMM); mode: 0 product -> LDS `out`, 1 product kept in registers,
+  // 2 kept product + this product -> LDS `out`
+  auto add = [&](int pre, const float* wvec, int src, int buf, int n, int act, int acol, int dcol, int lw, int out, int mode) {
     t.s[i++] = BwdDesc{pre, wvec, src, buf, n, act, acol, dcol, lw >= 0, lw >= 0 ? layer_packT_off(lw) : 0, lw >= 0 ? layer_nblkT(lw) : 0,
-                       lw >= 0 ? layer_out(lw) : 0, lw >= 0 ? layer_in(lw) : 0, out, acc};
+                       lw >= 0 ? layer_out(lw) : 0, lw >= 0 ? layer_in(lw) : 0, out, mode == 1, mode == 2};
   };
   // critic
-  add(PRE_OUTER_V0, P.cleg4_w, 0, S_A0, 128, ACT_ELU, A_CL2, D_CL2, L_CLEG2, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CL1, D_CL1, L_CLEG0, S_A2, 0);
-  add(PRE_OUTER_V1, P.carm4_w, 0, S_A0, 128, ACT_ELU, A_CA2, D_CA2, L_CARM2, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_CA1, D_CA1, L_CARM0, S_A2, 1);
-  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_CB, D_CB, -1, 0, 0);
+  add(PRE_OUTER_V0, P.cleg4_w, 0, Q_A0, 128, ACT_ELU, A_CL2, D_CL2, L_CLEG2, Q_A1, 0);
+  add(PRE_NONE, nullptr, 0, Q_A1, 128, ACT_ELU, A_CL1, D_CL1, L_CLEG0, 0, 1);
+  add(PRE_OUTER_V1, P.carm4_w, 0, Q_A0, 128, ACT_ELU, A_CA2, D_CA2, L_CARM2, Q_A1, 0);
+  add(PRE_NONE, nullptr, 0, Q_A1, 128, ACT_ELU, A_CA1, D_CA1, L_CARM0, Q_A0, 2);
+  add(PRE_NONE, nullptr, 0, Q_A0, 128, ACT_ELU, A_CB, D_CB, -1, 0, 0);
   // actor
-  add(PRE_COPY_LEG, nullptr, 0, S_A0, PT_NLEG, ACT_TANH, A_LEG, D_LEG, L_LEG4, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_L2, D_L2, L_LEG2, S_A0, 0);
-  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_L1, D_L1, L_LEG0, S_A2, 0);
-  add(PRE_COPY_ARM, nullptr, 0, S_A0, PT_NARM, ACT_TANH, A_ARM, D_ARM, L_ARM4, S_A1, 0);
-  add(PRE_NONE, nullptr, 0, S_A1, 128, ACT_ELU, A_A2, D_A2, L_ARM2, S_A0, 0);
-  add(PRE_NONE, nullptr, 0, S_A0, 128, ACT_ELU, A_A1, D_A1, L_ARM0, S_A2, 1);
-  add(PRE_NONE, nullptr, 0, S_A2, 128, ACT_ELU, A_BB, D_BB, L_BB, S_A0, 0);
-  add(PRE_LATENT, nullptr, S_A0, S_A1, 20, ACT_ELU, A_LAT, D_LAT, L_PRIV2, S_A0, 0);
-  add(PRE_NONE, nullptr, 0, S_A0, 64, ACT_ELU, A_H1, D_H1, -1, 0, 0);
+  add(PRE_COPY_LEG, nullptr, 0, Q_A0, PT_NLEG, ACT_TANH, A_LEG, D_LEG, L_LEG4, Q_A1, 0);
+  add(PRE_NONE, nullptr, 0, Q_A1, 128, ACT_ELU, A_L2, D_L2, L_LEG2, Q_A0, 0);
+  add(PRE_NONE, nullptr, 0, Q_A0, 128, ACT_ELU, A_L1, D_L1, L_LEG0, 0, 1);
+  add(PRE_COPY_ARM, nullptr, 0, Q_A0, PT_NARM, ACT_TANH, A_ARM, D_ARM, L_ARM4, Q_A1, 0);
+  add(PRE_NONE, nullptr, 0, Q_A1, 128, ACT_ELU, A_A2, D_A2, L_ARM2, Q_A0, 0);
+  add(PRE_NONE, nullptr, 0, Q_A0, 128, ACT_ELU, A_A1, D_A1, L_ARM0, Q_A1, 2);
+  add(PRE_NONE, nullptr, 0, Q_A1, 128, ACT_ELU, A_BB, D_BB, L_BB, Q_A0, 0);
+  add(PRE_LATENT, nullptr, Q_A0, Q_A1, 20, ACT_ELU, A_LAT, D_LAT, L_PRIV2, Q_A0, 0);
+  add(PRE_NONE, nullptr, 0, Q_A0, 64, ACT_ELU, A_H1, D_H1, -1, 0, 0);
+  return t;
+}
+
+// ---- forward op list: layers in an order that needs two activation buffers (critic first, x stays alive for both
+// backbones), stash reloads of the backbone outputs for their second head, the proprio copy next to the latent
+enum { FOP_LAYER = 0, FOP_RELOAD, FOP_COPY_PROP };
+struct FOp { int type, next_layer; FwdDesc d; int rcol, rdst; };
+#define NFOPS 19
+struct FOpTable { FOp op[NFOPS]; };
+
+static FOpTable make_fop_table(const int* stash_cols) {
+  FOpTable t;
+  int i = 0;
+  auto layer = [&](int l, int in_off, int ldi, int out_off, int ldo, int scratch) {
+    const int act = (l == L_LEG4 || l == L_ARM4) ? ACT_TANH : ((l == L_CLEG4 || l == L_CARM4) ? ACT_NONE : ACT_ELU);
+    t.op[i++] = FOp{FOP_LAYER, -1, FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off, ldi, out_off, ldo,
+                                           act, stash_cols[l], (layer_nblk(l) == 1 && layer_in(l) == 128) ? 1 : 0, scratch}, 0, 0};
+  };
+  auto reload = [&](int col, int dst) { t.op[i] = FOp{}; t.op[i].type = FOP_RELOAD; t.op[i].next_layer = -1; t.op[i].rcol = col; t.op[i].rdst = dst; ++i; };
+  layer(L_CBB, Q_X, 101, Q_A0, LDA, 0);
+  layer(L_CLEG0, Q_A0, LDA, Q_A1, LDA, 0);
+  layer(L_CLEG2, Q_A1, LDA, Q_A0, LDA, 0);
+  layer(L_CLEG4, Q_A0, LDA, Q_OUTV + 18, 21, Q_A1);
+  reload(A_CB, Q_A0);
+  layer(L_CARM0, Q_A0, LDA, Q_A1, LDA, 0);
+  layer(L_CARM2, Q_A1, LDA, Q_A0, LDA, 0);
+  layer(L_CARM4, Q_A0, LDA, Q_OUTV + 19, 21, Q_A1);
+  t.op[i] = FOp{}; t.op[i].type = FOP_COPY_PROP; t.op[i].next_layer = -1; ++i;
+  layer(L_PRIV0, Q_X + PT_NPROP, 101, Q_A0, LDA, 0);
+  layer(L_PRIV2, Q_A0, LDA, Q_A1 + PT_NPROP, LDA, 0);
+  layer(L_BB, Q_A1, LDA, Q_A0, LDA, 0);
+  layer(L_LEG0, Q_A0, LDA, Q_A1, LDA, 0);
+  layer(L_LEG2, Q_A1, LDA, Q_A0, LDA, 0);
+  layer(L_LEG4, Q_A0, LDA, Q_OUTV, 21, Q_A1);
+  reload(A_BB, Q_A0);
+  layer(L_ARM0, Q_A0, LDA, Q_A1, LDA, 0);
+  layer(L_ARM2, Q_A1, LDA, Q_A0, LDA, 0);
+  layer(L_ARM4, Q_A0, LDA, Q_OUTV + PT_NLEG, 21, Q_A1);
+  for (int a = 0; a < NFOPS; ++a) {            // the next LAYER op after each op (operand prefetch target)
+    t.op[a].next_layer = -1;
+    for (int b2 = a + 1; b2 < NFOPS; ++b2) if (t.op[b2].type == FOP_LAYER) { t.op[a].next_layer = b2; break; }
+  }
   return t;
 }
 
@@ -127,7 +181,7 @@ static __device__ __forceinline__ void bwd_pre_act(const BwdDesc& d, const BwdFe
                                                    int row0, int num_rows) {
   const int tid = threadIdx.x;
   float* buf = smem + d.buf_off;
-  const float* g = smem + S_G;
+  const float* g = smem + Q_G;
   // pre-step
   if (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) {          // dA = dZ_v (x) W_last (1 x 128)
     const int gi = (d.pre == PRE_OUTER_V0) ? 18 : 19;
@@ -163,54 +217,68 @@ static __device__ __forceinline__ void bwd_pre_act(const BwdDesc& d, const BwdFe
   }
 }
 
-// Second half: out (+)= buf * W on the MFMA.
-static __device__ __forceinline__ void bwd_mma(const float (&w)[64], const BwdDesc& d, float* smem) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* buf = smem + d.buf_off;
-  if (d.has_mma) {
-    if (wave < d.nblkT) {
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      mfma_chain(buf + (lane & 31) * LDA + (lane >> 5), w, (d.out_dim + 1) / 2, acc);
-      const int col = wave * 32 + (lane & 31);
-      if (col < d.in_dim) {
-        float* out = smem + d.out_off + col;
+// [32 x 128] tile of the activation stash back into an LDS activation buffer (rows past the end: zeros)
+static __device__ __forceinline__ void reload_tile(float* dst, const float* __restrict__ stash, int col, int row0, int num_rows) {
+  const int tid = threadIdx.x;
+  float4 v[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          out[row * LDA] = d.accumulate ? out[row * LDA] + acc[r] : acc[r];
-        }
-      }
-    }
-    __syncthreads();
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
+    v[j] = (row0 + r < num_rows) ? *reinterpret_cast<const float4*>(stash + (size_t)(row0 + r) * A_LD + col + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
+    float* d = dst + r * LDA + c;
+    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
   }
 }
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS, 2) ppo_fwd_bwd_kernel(PolicyParams P, FwdTable FT, BwdTable BT, const float* __restrict__ wpack,
+extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(PolicyParams P, FOpTable FT, BwdTable BT, const float* __restrict__ wpack,
                                                                            PpoBatch Bt, float* __restrict__ act_stash,
                                                                            float* __restrict__ dz_stash, float* __restrict__ dstd_partial,
                                                                            float* __restrict__ loss_partial) {
-  __shared__ float smem[S_PPO_END];
+  __shared__ float smem[Q_END];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
   PSTAMP(0);
   // gather obs[idx, :100] (float4 loads, all in flight); stash it (input of priv0 / critic backbone) and copy the proprio
   // block to a1[:, :76], next to where priv2 will put the latent
-  load_x_tile(smem + S_X, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
+  load_x_tile(smem + Q_X, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
   __syncthreads();
   for (int e = tid; e < PT_ROWS * 25; e += PT_THREADS) {
     const int r = e / 25, c = (e - r * 25) * 4;
     if (row0 + r < B) {
-      const float* xp = smem + S_X + r * 101 + c;
+      const float* xp = smem + Q_X + r * 101 + c;
       *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_X + c) = make_float4(xp[0], xp[1], xp[2], xp[3]);
     }
   }
-  for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
-    const int r = e / PT_NPROP, c = e - r * PT_NPROP;
-    smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
-  }
   PSTAMP(1);
-  // ---------------- forward (table-driven, wbc_mlp.h), post-activations stashed
-  fwd_chain(FT, smem, wpack, act_stash, A_LD, row0, B);
+  // ---------------- forward: op list (layers, stash reloads, the proprio copy), post-activations stashed. One operand
+  // set: the next layer's fragments are requested as soon as this layer's MFMA chain has consumed the current ones.
+  {
+    float w[65];
+    fwd_load(w, FT.op[0].d, wpack);
+#pragma unroll 1
+    for (int i = 0; i < NFOPS; ++i) {
+      const FOp& o = FT.op[i];
+      if (o.type == FOP_RELOAD) {
+        __threadfence_block();
+        __syncthreads();
+        reload_tile(smem + o.rdst, act_stash, o.rcol, row0, B);
+        __syncthreads();
+      } else if (o.type == FOP_COPY_PROP) {
+        for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
+          const int r = e / PT_NPROP, c = e - r * PT_NPROP;
+          smem[Q_A1 + r * LDA + c] = smem[Q_X + r * 101 + c];
+        }
+        __syncthreads();
+      } else {
+        const int nx = o.next_layer;
+        fwd_run(w, o.d, smem, act_stash, A_LD, row0, B, i, [&]() { if (nx >= 0) fwd_load(w, FT.op[nx].d, wpack); });
+      }
+    }
+  }
   PSTAMP(2);
   __threadfence_block();
   __syncthreads();
@@ -219,13 +287,14 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 2) ppo_fwd_bwd_kernel(P
     const int r = e / 24, c = (e - r * 24) * 4;
     if (row0 + r < B) {
       float4 v;
-      if (c < PT_NPROP) { const float* xp = smem + S_X + r * 101 + c; v = make_float4(xp[0], xp[1], xp[2], xp[3]); }
+      if (c < PT_NPROP) { const float* xp = smem + Q_X + r * 101 + c; v = make_float4(xp[0], xp[1], xp[2], xp[3]); }
       else v = *reinterpret_cast<const float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_LAT + (c - PT_NPROP));
       *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_Z + c) = v;
     }
   }
-  const float* outv = smem + S_OUTV;
-  float* gbuf = smem + S_G;
+  __syncthreads();                      // g re-uses x: every read of x is done
+  const float* outv = smem + Q_OUTV;
+  float* gbuf = smem + Q_G;
   PSTAMP(3);
   // ---------------- losses and output gradients: one row per lane of wave 0
   if (tid < 64) {
@@ -317,24 +386,37 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 2) ppo_fwd_bwd_kernel(P
     dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = gbuf[tid * 41 + 19];
   }
   {
-    // per stage: act' pass with the stash values fetched during the previous stage's GEMM, then request the next stage's
-    // operands and stash values, then this stage's GEMM: every global latency sits behind an MFMA chain
-    float wa[64], wb[64];
+    // per stage: pre-step + act' pass (stash values fetched during the previous stage's GEMM), this stage's GEMM, then --
+    // its operands consumed -- the next stage's operands and stash values are requested before the product is written out
+    float w[64];
     BwdFetch f;
+    f32x16 saved = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     PSTAMP(4);
-    bwd_load(wa, BT.s[0], wpack);
+    bwd_load(w, BT.s[0], wpack);
     bwd_fetch(f, BT.s[0], act_stash, row0, B);
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll 1
-    for (int st = 0; st < NBWD; st += 2) {
-      bwd_pre_act(BT.s[st], f, smem, dz_stash, row0, B);
-      bwd_load(wb, BT.s[st + 1], wpack);
-      bwd_fetch(f, BT.s[st + 1], act_stash, row0, B);
-      bwd_mma(wa, BT.s[st], smem);
+    for (int st = 0; st < NBWD; ++st) {
+      const BwdDesc& d = BT.s[st];
+      bwd_pre_act(d, f, smem, dz_stash, row0, B);
+      const bool mma = d.has_mma && wave < d.nblkT;
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (d.add_saved) acc = saved;
+      if (mma) mfma_chain(smem + d.buf_off + (lane & 31) * LDA + (lane >> 5), w, (d.out_dim + 1) / 2, acc);
+      if (st + 1 < NBWD) { bwd_load(w, BT.s[st + 1], wpack); bwd_fetch(f, BT.s[st + 1], act_stash, row0, B); }
+      if (mma) {
+        if (d.save_out) saved = acc;
+        else {
+          const int col = wave * 32 + (lane & 31);
+          if (col < d.in_dim) {
+            float* out = smem + d.out_off + col + 4 * (lane >> 5) * LDA;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * LDA] = acc[r];
+          }
+        }
+      }
+      if (d.has_mma) __syncthreads();
       PSTAMP(5 + st);
-      bwd_pre_act(BT.s[st + 1], f, smem, dz_stash, row0, B);
-      if (st + 2 < NBWD) { bwd_load(wa, BT.s[st + 2], wpack); bwd_fetch(f, BT.s[st + 2], act_stash, row0, B); }
-      bwd_mma(wb, BT.s[st + 1], smem);
-      PSTAMP(6 + st);
     }
   }
 }
@@ -559,7 +641,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, make_pack_table(), wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
-  const FwdTable FT = make_fwd_table(kStashCols);
+  const FOpTable FT = make_fop_table(kStashCols);
   const BwdTable BT = make_bwd_table(P);
   hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, FT, BT, wpack, Bt, act_stash, dz_stash, dstd_partial, loss_partial);
   WgradTable tab;
