@@ -79,6 +79,7 @@ struct FwdDesc {            // one forward layer: out = act(in * W^T + b)
   int act, scol;                     // activation; column in the activation stash (-1: not stashed)
   int ksplit;                        // head layers (one 32-column block, K = 128): the 4 waves split K instead of idling
   int scratch_off;                   // ksplit: LDS offset of an activation buffer that is dead during this layer (partials)
+  int sw;                            // stash slab width: the stash is slab-major, element (row, scol + c) lives at scol * rows + row * sw + c
 };
 struct FwdTable { FwdDesc l[NLAYERS]; };
 
@@ -95,7 +96,7 @@ static inline FwdTable make_fwd_table(const int* stash_cols /* NLAYERS entries o
                             ACT_ELU, ACT_ELU, ACT_NONE};
   for (int l = 0; l < NLAYERS; ++l)
     t.l[l] = FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off[l], ldi[l], out_off[l], ldo[l],
-                     act[l], stash_cols ? stash_cols[l] : -1, (layer_nblk(l) == 1 && layer_in(l) == 128 && in_off[l] == S_A1) ? 1 : 0, S_A0};
+                     act[l], stash_cols ? stash_cols[l] : -1, (layer_nblk(l) == 1 && layer_in(l) == 128 && in_off[l] == S_A1) ? 1 : 0, S_A0, 0};
   return t;
 }
 
@@ -217,7 +218,7 @@ static __device__ __forceinline__ void fwd_load(float (&w)[65], const FwdDesc& d
 }
 
 // Run forward layer d with its fragments in `w`. smem = LDS base (floats). Outputs go to LDS and, if d.scol >= 0, to
-// stash[(row0+row)*lds + d.scol + col] for valid rows. Ends with a barrier.
+// the slab-major stash (see FwdDesc::sw; `num_rows` = total rows of the stash) for valid rows. Ends with a barrier.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_mfma` runs once this wave's MFMA chain has been issued and `w` is no longer read (single-buffered callers
 // request the next layer's operands there).
@@ -248,7 +249,7 @@ static __device__ __forceinline__ void fwd_run(float (&w)[65], const FwdDesc& d,
       const float x = ((p[q] + p[1024 + q]) + (p[2048 + q] + p[3072 + q])) + p[4096 + col];
       const float v = d.act == ACT_TANH ? tanhf(x) : (d.act == ACT_ELU ? (x > 0.f ? x : __expf(x) - 1.f) : x);
       smem[d.out_off + row * d.ldo + col] = v;
-      if (stash != nullptr && d.scol >= 0 && row0 + row < num_rows) stash[(size_t)(row0 + row) * lds + d.scol + col] = v;
+      if (stash != nullptr && d.scol >= 0 && row0 + row < num_rows) stash[(size_t)d.scol * num_rows + (size_t)(row0 + row) * d.sw + col] = v;
     }
     LSTAMP(dbg_l, 2);
     __syncthreads();
@@ -283,14 +284,14 @@ static __device__ __forceinline__ void fwd_run(float (&w)[65], const FwdDesc& d,
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * d.ldo] = v[r];
       if (stash != nullptr && d.scol >= 0) {
-        float* sp = stash + (size_t)(row0 + rbase) * lds + d.scol + col;
+        float* sp = stash + (size_t)d.scol * num_rows + (size_t)(row0 + rbase) * d.sw + col;
         if (row0 + PT_ROWS <= num_rows) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * lds] = v[r];
+          for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * d.sw] = v[r];
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (row0 + rbase + (r & 3) + 8 * (r >> 2) < num_rows) sp[((r & 3) + 8 * (r >> 2)) * lds] = v[r];
+            if (row0 + rbase + (r & 3) + 8 * (r >> 2) < num_rows) sp[((r & 3) + 8 * (r >> 2)) * d.sw] = v[r];
         }
       }
     }

@@ -23,6 +23,19 @@ enum { A_X = 0, A_H1 = 100, A_LAT = 164, A_BB = 184, A_L1 = 312, A_L2 = 440, A_L
 enum { D_H1 = 0, D_LAT = 64, D_BB = 84, D_L1 = 212, D_L2 = 340, D_LEG = 468, D_A1 = 480, D_A2 = 608, D_ARM = 736, D_CB = 744,
        D_CL1 = 872, D_CL2 = 1000, D_VLEG = 1128, D_CA1 = 1132, D_CA2 = 1260, D_VARM = 1388, D_LD = 1392 };
 
+// The stashes are SLAB-MAJOR: the columns [c0, c0 + w) that one layer produces / consumes form a contiguous [B, w] block
+// at offset c0 * B (element (row, c0 + c) at c0 * B + row * w + c). A wave of the weight-gradient kernel then streams a
+// contiguous block instead of 128-byte pieces 6 KB apart, and a tile's epilogue writes 32 adjacent rows.
+static const int kAslabs[] = {A_X, A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, A_CA1, A_CA2, A_Z, A_LD};
+static const int kDslabs[] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM, D_LD};
+static int slab_w(const int* slabs, int n, int c0) {
+  for (int i = 0; i + 1 < n; ++i) if (slabs[i] == c0) return slabs[i + 1] - c0;
+  return -1;
+}
+static int a_slab_w(int c0) { return slab_w(kAslabs, 17, c0); }
+static int d_slab_w(int c0) { return slab_w(kDslabs, 17, c0); }
+static __device__ __forceinline__ size_t sidx(int B, int c0, int w, int row, int c) { return (size_t)c0 * B + (size_t)row * w + c; }
+
 struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minibatch's row indices
   const float* obs;               // [TN, 860]
   const float* actions;           // [TN, 18]
@@ -70,7 +83,7 @@ static_assert(Q_END * 4 * 3 <= 160 * 1024, "three workgroups per CU");
 enum { PRE_NONE = 0, PRE_OUTER_V0, PRE_OUTER_V1, PRE_COPY_LEG, PRE_COPY_ARM, PRE_LATENT };
 struct BwdDesc {
   int pre; const float* wvec; int src_off;       // pre-step; for PRE_OUTER_*: the [128] last-layer weight row; for PRE_LATENT: dA_z buffer
-  int buf_off, n, act, acol, dcol;                // activation-derivative pass over buf[32, n]
+  int buf_off, n, act, acol, dcol, aw, dw;        // activation-derivative pass over buf[32, n]; stash slabs (start, width)
   int has_mma, woffT, nblkT, out_dim, in_dim, out_off;   // out[32, in_dim] = buf[32, out_dim] * W[out_dim, in_dim] (transposed pack)
   int save_out, add_saved;      // keep the product in the accumulator registers instead of LDS / start from the kept product
 };
@@ -83,7 +96,7 @@ static BwdTable make_bwd_table(const PolicyParams& P) {
   // lw = layer whose weight the stage multiplies by (-1: no GEMM); mode: 0 product -> LDS `out`, 1 product kept in registers,
   // 2 kept product + this product -> LDS `out`
   auto add = [&](int pre, const float* wvec, int src, int buf, int n, int act, int acol, int dcol, int lw, int out, int mode) {
-    t.s[i++] = BwdDesc{pre, wvec, src, buf, n, act, acol, dcol, lw >= 0, lw >= 0 ? layer_packT_off(lw) : 0, lw >= 0 ? layer_nblkT(lw) : 0,
+    t.s[i++] = BwdDesc{pre, wvec, src, buf, n, act, acol, dcol, a_slab_w(acol), d_slab_w(dcol), lw >= 0, lw >= 0 ? layer_packT_off(lw) : 0, lw >= 0 ? layer_nblkT(lw) : 0,
                        lw >= 0 ? layer_out(lw) : 0, lw >= 0 ? layer_in(lw) : 0, out, mode == 1, mode == 2};
   };
   // critic
@@ -118,7 +131,8 @@ static FOpTable make_fop_table(const int* stash_cols) {
   auto layer = [&](int l, int in_off, int ldi, int out_off, int ldo, int scratch) {
     const int act = (l == L_LEG4 || l == L_ARM4) ? ACT_TANH : ((l == L_CLEG4 || l == L_CARM4) ? ACT_NONE : ACT_ELU);
     t.op[i++] = FOp{FOP_LAYER, -1, FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off, ldi, out_off, ldo,
-                                           act, stash_cols[l], (layer_nblk(l) == 1 && layer_in(l) == 128) ? 1 : 0, scratch}, 0, 0};
+                                           act, stash_cols[l], (layer_nblk(l) == 1 && layer_in(l) == 128) ? 1 : 0, scratch,
+                                           stash_cols[l] >= 0 ? a_slab_w(stash_cols[l]) : 0}, 0, 0};
   };
   auto reload = [&](int col, int dst) { t.op[i] = FOp{}; t.op[i].type = FOP_RELOAD; t.op[i].next_layer = -1; t.op[i].rcol = col; t.op[i].rdst = dst; ++i; };
   layer(L_CBB, Q_X, 101, Q_A0, LDA, 0);
@@ -162,14 +176,17 @@ static __device__ __forceinline__ float act_deriv(float a) {
 // This stage's activation-stash values (8 float2 per thread) and, for the critic-head stages, this thread's element of
 // the head's weight row: requested BEFORE the next stage's operand prefetch so that waiting for them leaves it in flight.
 struct BwdFetch { float2 a[8]; float wv; };
+// Fixed thread -> element mapping of the activation-derivative pass, independent of the stage's width n (no run-time
+// divisions, constant column per thread): thread t owns columns c, c+1 with c = 2 (t & 63) of rows (t >> 6) + 4 j, j < 8.
 static __device__ __forceinline__ void bwd_fetch(BwdFetch& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows) {
   const int tid = threadIdx.x;
-  const int q = d.n >> 1, tot = PT_ROWS * q;
+  const int c = (tid & 63) * 2, rb = tid >> 6;
+  const bool c_ok = c < d.n;
+  const float* base = act_stash + sidx(num_rows, d.acol, d.aw, row0 + rb, c_ok ? c : 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
-    const bool ok = e < tot && row0 + r < num_rows;
-    const float2 v = *reinterpret_cast<const float2*>(act_stash + (size_t)(ok ? row0 + r : row0) * A_LD + d.acol + (ok ? c : 0));   // unconditional
+    const bool ok = c_ok && row0 + rb + 4 * j < num_rows;
+    const float2 v = *reinterpret_cast<const float2*>(ok ? base + (size_t)(4 * j) * d.aw : act_stash);   // unconditional load
     f.a[j] = ok ? v : make_float2(1.f, 1.f);
   }
   const float* wv = (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) ? d.wvec : act_stash;
@@ -189,28 +206,31 @@ static __device__ __forceinline__ void bwd_pre_act(const BwdDesc& d, const BwdFe
     __syncthreads();
   } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
     const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
-    for (int e = tid; e < PT_ROWS * n; e += PT_THREADS) { const int r = e / n, c = e - r * n; buf[r * LDA + c] = g[r * 41 + go + c]; }
+    const int r = tid >> 3, c0 = tid & 7;                          // 8 threads per row
+    for (int c = c0; c < n; c += 8) buf[r * LDA + c] = g[r * 41 + go + c];
     __syncthreads();
   } else if (d.pre == PRE_LATENT) {                                // d latent = dA_z[:, 76:96] + ROA gradient
     const float* src = smem + d.src_off;
-    for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) { const int r = e / 20, c = e - r * 20; buf[r * LDA + c] = src[r * LDA + PT_NPROP + c] + g[r * 41 + 20 + c]; }
+    const int r = tid >> 3, c0 = tid & 7;
+    for (int c = c0; c < 20; c += 8) buf[r * LDA + c] = src[r * LDA + PT_NPROP + c] + g[r * 41 + 20 + c];
     __syncthreads();
   }
   // buf <- buf * act'(A) with A the stashed post-activation (fetched by bwd_fetch)
   {
-    const int q = d.n >> 1, tot = PT_ROWS * q;
+    const int c = (tid & 63) * 2, rb = tid >> 6;
+    if (c < d.n) {
+      float* bp = buf + rb * LDA + c;
+      float* dzp = dz_stash + sidx(num_rows, d.dcol, d.dw, row0 + rb, c);
+      const bool elu = d.act == ACT_ELU;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + j * PT_THREADS, r = e / q, c = (e - r * q) * 2;
-      if (e < tot) {
-        float* bp = buf + r * LDA + c;
-        const bool ok = row0 + r < num_rows;
-        float2 v;
-        if (d.act == ACT_ELU) { v.x = bp[0] * act_deriv<ACT_ELU>(f.a[j].x); v.y = bp[1] * act_deriv<ACT_ELU>(f.a[j].y); }
-        else { v.x = bp[0] * act_deriv<ACT_TANH>(f.a[j].x); v.y = bp[1] * act_deriv<ACT_TANH>(f.a[j].y); }
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = row0 + rb + 4 * j < num_rows;
+        const float dx = elu ? act_deriv<ACT_ELU>(f.a[j].x) : act_deriv<ACT_TANH>(f.a[j].x);
+        const float dy = elu ? act_deriv<ACT_ELU>(f.a[j].y) : act_deriv<ACT_TANH>(f.a[j].y);
+        float2 v = make_float2(bp[4 * j * LDA] * dx, bp[4 * j * LDA + 1] * dy);
         if (!ok) v = make_float2(0.f, 0.f);
-        bp[0] = v.x; bp[1] = v.y;
-        if (ok) *reinterpret_cast<float2*>(dz_stash + (size_t)(row0 + r) * D_LD + d.dcol + c) = v;
+        bp[4 * j * LDA] = v.x; bp[4 * j * LDA + 1] = v.y;
+        if (ok) *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;
       }
     }
     __syncthreads();
@@ -224,7 +244,7 @@ static __device__ __forceinline__ void reload_tile(float* dst, const float* __re
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
-    v[j] = (row0 + r < num_rows) ? *reinterpret_cast<const float4*>(stash + (size_t)(row0 + r) * A_LD + col + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[j] = (row0 + r < num_rows) ? *reinterpret_cast<const float4*>(stash + sidx(num_rows, col, 128, row0 + r, c)) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -250,7 +270,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
     const int r = e / 25, c = (e - r * 25) * 4;
     if (row0 + r < B) {
       const float* xp = smem + Q_X + r * 101 + c;
-      *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_X + c) = make_float4(xp[0], xp[1], xp[2], xp[3]);
+      *reinterpret_cast<float4*>(act_stash + sidx(B, A_X, 100, row0 + r, c)) = make_float4(xp[0], xp[1], xp[2], xp[3]);
     }
   }
   PSTAMP(1);
@@ -288,8 +308,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
     if (row0 + r < B) {
       float4 v;
       if (c < PT_NPROP) { const float* xp = smem + Q_X + r * 101 + c; v = make_float4(xp[0], xp[1], xp[2], xp[3]); }
-      else v = *reinterpret_cast<const float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_LAT + (c - PT_NPROP));
-      *reinterpret_cast<float4*>(act_stash + (size_t)(row0 + r) * A_LD + A_Z + c) = v;
+      else v = *reinterpret_cast<const float4*>(act_stash + sidx(B, A_LAT, 20, row0 + r, c - PT_NPROP));
+      *reinterpret_cast<float4*>(act_stash + sidx(B, A_Z, 100, row0 + r, c)) = v;
     }
   }
   __syncthreads();                      // g re-uses x: every read of x is done
@@ -355,7 +375,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
       float dl[20], nrm = 0.f;
 #pragma unroll
       for (int k = 0; k < 20; ++k) {
-        dl[k] = act_stash[(size_t)(row0 + r) * A_LD + A_LAT + k] - Bt.hist_latent[src * 20 + k];
+        dl[k] = act_stash[sidx(B, A_LAT, 20, row0 + r, k)] - Bt.hist_latent[src * 20 + k];
         nrm += dl[k] * dl[k];
       }
       nrm = sqrtf(nrm);
@@ -382,8 +402,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
   __syncthreads();
   // ---------------- backward: 14 table-driven stages, the next stage's weight rows in flight during the current one
   if (tid < PT_ROWS && row0 + tid < B) {
-    dz_stash[(size_t)(row0 + tid) * D_LD + D_VLEG] = gbuf[tid * 41 + 18];
-    dz_stash[(size_t)(row0 + tid) * D_LD + D_VARM] = gbuf[tid * 41 + 19];
+    dz_stash[sidx(B, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
+    dz_stash[sidx(B, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
   }
   {
     // per stage: pre-step + act' pass (stash values fetched during the previous stage's GEMM), this stage's GEMM, then --
@@ -426,12 +446,12 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 // a workgroup owns a row range of one layer, wave w the output rows [32w, 32w+32). Both MFMA operands are read
 // straight from the stashes (a fragment = two runs of 32 consecutive floats: coalesced as stored), the bias
 // gradient falls out of one extra MFMA block whose B operand is the constant 1. No LDS, no atomics.
-struct WgradLayer { int out, in, dcol, acol, goff; };   // goff: offset of this layer's weight gradient in the flat buffer
+struct WgradLayer { int out, in, dcol, dw, acol, aw, aoff, goff; };   // dZ slab (start, width), A slab (start, width, first column in it); goff: offset of this layer's weight gradient in the flat buffer
 struct WgradTable { WgradLayer l[NLAYERS]; };
 
 template <int NIB>
 static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const float* __restrict__ act_stash, const float* __restrict__ dz_stash,
-                                                  float* __restrict__ dst, int r_begin, int r_end) {
+                                                  float* __restrict__ dst, int r_begin, int r_end, int B) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
   f32x16 acc[NIB];
 #pragma unroll
@@ -439,42 +459,66 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   float bsum = 0.f;        // bias gradient: this lane's column of dZ summed over its rows (even rows on lanes 0..31, odd on 32..63)
   const int o = wave * 32 + (lane & 31);
   const bool o_ok = o < L.out;
-  const float* ap = dz_stash + L.dcol + (o_ok ? o : 0);          // clamped address + select: loads stay unconditional
+  const float* ap = dz_stash + (size_t)L.dcol * B + (o_ok ? o : 0);          // clamped address + select: loads stay unconditional
+  const size_t dstr = (size_t)L.dw, astr = (size_t)L.aw;
   const float* bp[NIB];
   bool c_ok[NIB];
 #pragma unroll
   for (int b = 0; b < NIB; ++b) {
     const int c = b * 32 + (lane & 31);
     c_ok[b] = c < L.in;
-    bp[b] = act_stash + L.acol + (c_ok[b] ? c : 0);
+    bp[b] = act_stash + (size_t)L.acol * B + L.aoff + (c_ok[b] ? c : 0);
   }
-  constexpr int U = 4;                                             // k-steps (row pairs) per unrolled iteration
-  int r = r_begin;
-  for (; r + 2 * U <= r_end; r += 2 * U) {
-    float av[U], bv[U][NIB];
+  constexpr int U = 4;                                             // k-steps (row pairs) per batch of loads
+  // Software pipeline: two operand sets; the loads of batch i+1 are issued (unconditionally: past the end they re-read
+  // the first rows and are ignored) before the MFMAs of batch i, so every global latency sits behind 16-20 MFMAs.
+  struct Ops { float av[U], bv[U][NIB]; };
+  auto issue = [&](Ops& o, int r0) {
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-      const size_t row = (size_t)(r + 2 * t + half);
-      av[t] = ap[row * D_LD];
+      const size_t row = (size_t)(r0 + 2 * t + half);
+      o.av[t] = ap[row * dstr];
 #pragma unroll
-      for (int b = 0; b < NIB; ++b) bv[t][b] = bp[b][row * A_LD];
+      for (int b = 0; b < NIB; ++b) o.bv[t][b] = bp[b][row * astr];
     }
+  };
+  auto compute = [&](const Ops& o) {
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-      const float a = o_ok ? av[t] : 0.f;
+      const float a = o_ok ? o.av[t] : 0.f;
 #pragma unroll
-      for (int b = 0; b < NIB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c_ok[b] ? bv[t][b] : 0.f, acc[b], 0, 0, 0);
+      for (int b = 0; b < NIB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c_ok[b] ? o.bv[t][b] : 0.f, acc[b], 0, 0, 0);
       bsum += a;
     }
+  };
+  int r = r_begin;
+  const int nfull = (r_end - r_begin) / (2 * U);                   // full batches
+  if (nfull > 0) {
+    Ops A, Bq;
+    issue(A, r);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 <= nfull; i += 2) {
+      issue(Bq, r + 2 * U);
+      __builtin_amdgcn_sched_barrier(0);        // keep the loads ahead of the MFMAs (the scheduler sinks them to their uses otherwise)
+      compute(A);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(A, (i + 2 < nfull) ? r + 4 * U : r_begin);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(Bq);
+      __builtin_amdgcn_sched_barrier(0);
+      r += 4 * U;
+    }
+    if (i < nfull) { compute(A); r += 2 * U; }
   }
   for (; r < r_end; r += 2) {                                      // ragged tail
     const int row = r + half;
     const bool r_ok = row < r_end;
     const size_t rc = (size_t)(r_ok ? row : r);
-    const float a = (o_ok && r_ok) ? ap[rc * D_LD] : 0.f;
+    const float a = (o_ok && r_ok) ? ap[rc * dstr] : 0.f;
 #pragma unroll
     for (int b = 0; b < NIB; ++b) {
-      const float v = bp[b][rc * A_LD];
+      const float v = bp[b][rc * astr];
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, (c_ok[b] && r_ok) ? v : 0.f, acc[b], 0, 0, 0);
     }
     bsum += a;
@@ -503,10 +547,10 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradT
   const int r_begin = blockIdx.x * rows_per_split, r_end = min(B, r_begin + rows_per_split);
   float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
   const int nib = (L.in + 31) / 32;                                // uniform per workgroup
-  if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end);
-  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end);
-  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end);
-  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end);
+  if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
+  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
+  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
+  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
 }
 
 // grad[p] = sum_s part[s][p] in a fixed order; `stride` floats between consecutive partials
@@ -647,7 +691,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   WgradTable tab;
   int off = 0;
   for (int l = 0; l < NLAYERS; ++l) {
-    tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], kAcol[l], off};
+    const int aslab = (l == L_PRIV0) ? A_X : kAcol[l];                    // priv0 reads columns 76.. of the x slab
+    tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab, off};
     off += layer_out(l) * layer_in(l) + layer_out(l);
   }
   int rows_per_split = (B + PPO_NSPLIT - 1) / PPO_NSPLIT;
