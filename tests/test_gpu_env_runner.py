@@ -99,7 +99,11 @@ def test_runner_with_rccl_process_group_single_rank():
     fused and the DAgger update) on device tensors; with one rank the results must equal the group-less run."""
     import torch.distributed as dist
     if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        import socket
+        with socket.socket() as sk:                     # any free port: the suite may run next to other jobs
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         outs = []
         for group in (None, dist.group.WORLD):
