@@ -138,9 +138,26 @@ __device__ __forceinline__ f3 euler_from_quat(const float* q) {
   sp = fminf(fmaxf(sp, -1.f), 1.f);
   return mk3(atan2f(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)), asinf(sp), atan2f(2 * (w * z + x * y), 1 - 2 * (y * y + z * z)));
 }
+// sin and cos with Cody-Waite reduction by pi/2 and the cephes single-precision polynomials: ~1 ulp for |x| < 1e3
+// (joint angles, goal angles), 25 instructions instead of libm's ~150 (its large-argument path is inlined everywhere)
+__device__ __forceinline__ void fast_sincosf(float x, float* sp, float* cp) {
+  const float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-k, 1.5703125f, x);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188e-8f, r);
+  const float z = r * r;
+  const float sn = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float cs = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.f));
+  const int q = (int)k;
+  const float s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+  *sp = (q & 2) ? -s0 : s0;
+  *cp = ((q + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ f3 sphere2cart(f3 s) {
-  float cp = cosf(s.y);
-  return mk3(s.x * cp * cosf(s.z), s.x * cp * sinf(s.z), s.x * sinf(s.y));
+  float sy, cy, sz, cz;
+  fast_sincosf(s.y, &sy, &cy);
+  fast_sincosf(s.z, &sz, &cz);
+  return mk3(s.x * cy * cz, s.x * cy * sz, s.x * sy);
 }
 __device__ __forceinline__ f3 cart2sphere(f3 c) {
   float l = sqrtf(dot(c, c));

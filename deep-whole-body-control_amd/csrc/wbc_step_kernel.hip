@@ -31,21 +31,6 @@ __device__ long long* g_step_dbg = nullptr;
                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division sequence on the dependent chains
 __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
-// sin and cos with Cody-Waite reduction by pi/2 and the cephes single-precision polynomials: ~1 ulp for |x| < 1e3
-// (joint angles), 25 instructions instead of libm's ~150 (its large-argument path is inlined everywhere)
-__device__ __forceinline__ void fast_sincosf(float x, float* sp, float* cp) {
-  const float k = rintf(x * 0.63661977236758134308f);
-  float r = fmaf(-k, 1.5703125f, x);
-  r = fmaf(-k, 4.837512969970703125e-4f, r);
-  r = fmaf(-k, 7.54978995489188e-8f, r);
-  const float z = r * r;
-  const float sn = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-  const float cs = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.f));
-  const int q = (int)k;
-  const float s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
-  *sp = (q & 2) ? -s0 : s0;
-  *cp = ((q + 1) & 2) ? -c0 : c0;
-}
 // value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], VALU speed, no LDS
 __device__ __forceinline__ float pair_swap(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
@@ -55,6 +40,7 @@ struct PostBuf {                  // post-physics staging; shares LDS with IA (d
   float out_rb[WBC_NRB_ENV][13];
   float quatB[WBC_NB][4], omB[WBC_NB][3], voB[WBC_NB][3];
   float o76[WBC_NPROP];
+  float term[WBC_NREW], msrc[WBC_NREW];      // raw reward terms / metric sources of this step (lane 0 -> lanes t)
 };
 
 struct __align__(16) Smem {
@@ -247,13 +233,14 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(1);
   // joint screws S for all 18 joints: 108 entries
   for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
+    // component m of the axis (kk < 3) or of pos x axis (kk >= 3): only the operands of that component are read
     const int i = 1 + t / 6, kk = t % 6;
+    const int m = kk < 3 ? kk : kk - 3, a = (m == 2) ? 0 : m + 1, b = (m == 0) ? 2 : m - 1;
     const int ax = s.k_body[i] & 3;
-    const f3 sv = mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax]);
-    float val;
-    if (kk < 3) val = (kk == 0) ? sv.x : ((kk == 1) ? sv.y : sv.z);
-    else { const f3 l = cross(ld3(s.pos[i]), sv); val = (kk == 3) ? l.x : ((kk == 4) ? l.y : l.z); }
-    s.S[i][kk] = val;
+    const float* Ei = s.E[i] + ax;
+    const float sm = Ei[3 * m], sa = Ei[3 * a], sb = Ei[3 * b];
+    const float lin = s.pos[i][a] * sb - s.pos[i][b] * sa;
+    s.S[i][kk] = kk < 3 ? sm : lin;
   }
   if (lane < 6) { s.v[0][lane] = (lane < 3) ? s.wb[lane] : s.vb[lane - 3]; s.S[0][lane] = 0.f; s.c[0][lane] = 0.f; }
   WSYNC();
@@ -269,14 +256,16 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   WSYNC();
   // velocity-product accelerations c: 108 entries
   for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
+    // component m of w x ja (kk < 3) or of w x jl + vl x ja (kk >= 3), ja / jl = angular / linear part of S qd
     const int i = 1 + t / 6, kk = t % 6;
+    const int m = kk < 3 ? kk : kk - 3, a = (m == 2) ? 0 : m + 1, b = (m == 0) ? 2 : m - 1;
     const float qd = s.qd[(s.k_body[i] >> 2) & 31];
-    const f3 w = ld3(&s.v[i][0]), vl = ld3(&s.v[i][3]);
-    const f3 ja = ld3(&s.S[i][0]) * qd, jl = ld3(&s.S[i][3]) * qd;
-    float val;
-    if (kk < 3) { const f3 t1 = cross(w, ja); val = (kk == 0) ? t1.x : ((kk == 1) ? t1.y : t1.z); }
-    else { const f3 t2 = cross(w, jl) + cross(vl, ja); val = (kk == 3) ? t2.x : ((kk == 4) ? t2.y : t2.z); }
-    s.c[i][kk] = val;
+    const float* vi = s.v[i];
+    const float* Si = s.S[i];
+    const float wa = vi[a], wb2 = vi[b], jaa = Si[a] * qd, jab = Si[b] * qd;
+    const float ang = wa * jab - wb2 * jaa;
+    const float lin = (wa * (Si[3 + b] * qd) - wb2 * (Si[3 + a] * qd)) + (vi[3 + a] * jab - vi[3 + b] * jaa);
+    s.c[i][kk] = kk < 3 ? ang : lin;
   }
   STAMP(2);
   // spatial inertias in frame F and bias forces: one body per lane
@@ -298,33 +287,38 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     const float* E = s.E[i];
     const f3 Cc = ld3(s.pos[i]) + mat_mul(E, mk3(com[0], com[1], com[2]));
     const float Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
-    float EI[9], Ibar[9];
+    float EI[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) EI[r * 3 + cc] = E[r * 3] * Ib[cc] + E[r * 3 + 1] * Ib[3 + cc] + E[r * 3 + 2] * Ib[6 + cc];
+    // rotational block about F's origin (symmetric: upper triangle computed, mirrored on store):
+    // E Ib E^T + m (|C|^2 1 - C C^T); coupling blocks +-[h]x with h = m C; lower-right m 1
+    const float CC = dot(Cc, Cc);
+    const float Cv[3] = {Cc.x, Cc.y, Cc.z};
+    float Ir[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) Ibar[r * 3 + cc] = EI[r * 3] * E[cc * 3] + EI[r * 3 + 1] * E[cc * 3 + 1] + EI[r * 3 + 2] * E[cc * 3 + 2];
-    const float CC = dot(Cc, Cc);
-    const float Cv[3] = {Cc.x, Cc.y, Cc.z};
-    const float Cx[9] = {0.f, -Cc.z, Cc.y, Cc.z, 0.f, -Cc.x, -Cc.y, Cc.x, 0.f};
+      for (int cc = r; cc < 3; ++cc) {
+        const float v = (EI[r * 3] * E[cc * 3] + EI[r * 3 + 1] * E[cc * 3 + 1] + EI[r * 3 + 2] * E[cc * 3 + 2]) + m * ((r == cc ? CC : 0.f) - Cv[r] * Cv[cc]);
+        Ir[r * 3 + cc] = v; Ir[cc * 3 + r] = v;
+      }
+    const f3 h = Cc * m;
+    const float Hx[9] = {0.f, -h.z, h.y, h.z, 0.f, -h.x, -h.y, h.x, 0.f};
     float* I = s.IA[i];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
-        I[r * 6 + cc] = Ibar[r * 3 + cc] + m * ((r == cc ? CC : 0.f) - Cv[r] * Cv[cc]);
-        I[r * 6 + 3 + cc] = m * Cx[r * 3 + cc];
-        I[(3 + r) * 6 + cc] = m * Cx[cc * 3 + r];
+        I[r * 6 + cc] = Ir[r * 3 + cc];
+        I[r * 6 + 3 + cc] = Hx[r * 3 + cc];
+        I[(3 + r) * 6 + cc] = Hx[cc * 3 + r];
         I[(3 + r) * 6 + 3 + cc] = (r == cc) ? m : 0.f;
       }
-    float Iv[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) Iv[r] = dot6(&I[r * 6], s.v[i]);
+    // bias force v x* (I v) from the blocks: n = Irot w + h x vl, f = m vl - h x w
     const f3 w = ld3(&s.v[i][0]), vl = ld3(&s.v[i][3]);
-    const f3 nn = ld3(&Iv[0]), ff = ld3(&Iv[3]);
+    const f3 nn = mat_mul(Ir, w) + cross(h, vl), ff = vl * m - cross(h, w);
     st3(&s.pA[i][0], cross(w, nn) + cross(vl, ff));
     st3(&s.pA[i][3], cross(w, ff));
   }
@@ -791,6 +785,18 @@ __device__ void resample_ee_goal(Smem& s, const DevConst* __restrict__ C, uint64
 }
 
 __device__ const int8_t POLICY_PERM[WBC_NDOF] = {3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19};
+// terms feeding each metric slot (inverse of MET_OF below, -1 padded, ascending): a metric slot is owned by one lane
+__device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
+    /* LEG_ENERGY_ABS_SUM */ {WBC_REW_LEG_ENERGY_ABS_SUM, -1},
+    /* TRACKING_LIN_VEL_X_L1 */ {WBC_REW_TRACKING_LIN_VEL_X_L1, WBC_REW_TRACKING_LIN_VEL_X_EXP},
+    /* TRACKING_ANG_VEL_YAW_EXP */ {WBC_REW_TRACKING_ANG_VEL_YAW_EXP, -1},
+    /* TRACKING_EE_CART */ {WBC_REW_TRACKING_EE_CART, -1},
+    /* TRACKING_EE_SPHERE */ {WBC_REW_TRACKING_EE_SPHERE, -1},
+    /* TRACKING_EE_ORN */ {WBC_REW_TRACKING_EE_ORN_RY, -1},
+    /* LEG_ACTION_L2 */ {WBC_REW_HIP_ACTION_L2, WBC_REW_LEG_ACTION_L2},
+    /* TORQUE */ {WBC_REW_TORQUES, -1},
+    /* ENERGY_SQUARE */ {WBC_REW_ENERGY_SQUARE, -1},
+    /* FOOT_CONTACTS_Z */ {WBC_REW_FOOT_CONTACTS_Z, -1}};
 __device__ const int8_t MET_OF[WBC_NREW] = {
     WBC_MET_ENERGY_SQUARE, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, WBC_MET_TRACKING_ANG_VEL_YAW_EXP, WBC_MET_LEG_ACTION_L2,
     WBC_MET_FOOT_CONTACTS_Z, WBC_MET_TRACKING_EE_SPHERE, -1, WBC_MET_TRACKING_EE_CART, -1, WBC_MET_TRACKING_EE_ORN,
@@ -799,6 +805,7 @@ __device__ const int8_t MET_OF[WBC_NREW] = {
 // compute_reward of the oracle, executed by lane 0 on LDS state
 __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq) {
   const wbc_task_cfg& cf = C->cfg;
+  const float inv_sig = 1.f / cf.tracking_sigma, inv_ee_sig = 1.f / cf.tracking_ee_sigma;
   float term[WBC_NREW], met_src[WBC_NREW];
 #pragma unroll
   for (int t = 0; t < WBC_NREW; ++t) met_src[t] = 0.f;
@@ -815,9 +822,9 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   term[WBC_REW_SURVIVE] = 1.f;
   const float ex = fabsf(s.cmd[0] - s.blv[0]);
   term[WBC_REW_TRACKING_LIN_VEL_X_L1] = -ex + fabsf(s.cmd[0]);
-  term[WBC_REW_TRACKING_LIN_VEL_X_EXP] = expf(-ex / cf.tracking_sigma);
+  term[WBC_REW_TRACKING_LIN_VEL_X_EXP] = expf(-ex * inv_sig);
   const float eyaw = fabsf(s.cmd[2] - s.bav[2]);
-  term[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = expf(-eyaw / cf.tracking_sigma);
+  term[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = expf(-eyaw * inv_sig);
   term[WBC_REW_TRACKING_ANG_VEL_YAW_L1] = -eyaw + fabsf(s.cmd[2]);
   const float hip = s.act[0] * s.act[0] + s.act[3] * s.act[3] + s.act[6] * s.act[6] + s.act[9] * s.act[9];
   term[WBC_REW_HIP_ACTION_L2] = hip;
@@ -829,11 +836,11 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   const f3 sph = cart2sphere(loc);
   const float es = fabsf(sph.x - s.goal[G_CURR]) * cf.sphere_error_scale[0] + fabsf(sph.y - s.goal[G_CURR + 1]) * cf.sphere_error_scale[1] +
                    fabsf(sph.z - s.goal[G_CURR + 2]) * cf.sphere_error_scale[2];
-  term[WBC_REW_TRACKING_EE_SPHERE] = expf(-es / cf.tracking_ee_sigma);
+  term[WBC_REW_TRACKING_EE_SPHERE] = expf(-es * inv_ee_sig);
   const float yq_inv[4] = {-yq[0], -yq[1], -yq[2], yq[3]};
   const f3 tw = quat_rotate_inverse(yq_inv, ld3(&s.goal[G_CURR_CART]));
   const float ec = fabsf(ee_pos[0] - (s.root[0] + tw.x)) + fabsf(ee_pos[1] - (s.root[1] + tw.y)) + fabsf(ee_pos[2] - (cf.z_invariant_offset + tw.z));
-  term[WBC_REW_TRACKING_EE_CART] = expf(-ec / cf.tracking_ee_sigma);
+  term[WBC_REW_TRACKING_EE_CART] = expf(-ec * inv_ee_sig);
   const f3 eul = euler_from_quat(ee_orn);
   const float eu[3] = {eul.x, eul.y, eul.z};
   float eo = 0.f, eo_ry = 0.f;
@@ -843,15 +850,15 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
     eo += fabsf(d) * cf.orn_error_scale[j];
     if (j != 1) eo_ry += fabsf(d * cf.orn_error_scale[j]);
   }
-  term[WBC_REW_TRACKING_EE_ORN] = expf(-eo / cf.tracking_ee_sigma);
-  term[WBC_REW_TRACKING_EE_ORN_RY] = expf(-eo_ry / cf.tracking_ee_sigma);
+  term[WBC_REW_TRACKING_EE_ORN] = expf(-eo * inv_ee_sig);
+  term[WBC_REW_TRACKING_EE_ORN_RY] = expf(-eo_ry * inv_ee_sig);
   term[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum;
   term[WBC_REW_LEG_ENERGY_SUM_ABS] = fabsf(sum);
   term[WBC_REW_LEG_ACTION_L2] = act_leg;
   term[WBC_REW_LEG_ENERGY] = sum;
   term[WBC_REW_ARM_ENERGY_ABS_SUM] = arm_abs;
   const float dx = s.cmd[0] - s.blv[0], dy = s.cmd[1] - s.blv[1], dz = s.cmd[2] - s.blv[2];
-  term[WBC_REW_TRACKING_LIN_VEL] = expf(-(dx * dx + dy * dy) / cf.tracking_sigma);
+  term[WBC_REW_TRACKING_LIN_VEL] = expf(-(dx * dx + dy * dy) * inv_sig);
   term[WBC_REW_TRACKING_LIN_VEL_Y_L2] = dy * dy;
   term[WBC_REW_TRACKING_LIN_VEL_Z_L2] = dz * dz;
   term[WBC_REW_TORQUES] = tq2;
@@ -859,29 +866,48 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   met_src[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = eyaw; met_src[WBC_REW_HIP_ACTION_L2] = hip; met_src[WBC_REW_LEG_ACTION_L2] = act_leg;
   met_src[WBC_REW_FOOT_CONTACTS_Z] = fz; met_src[WBC_REW_TRACKING_EE_SPHERE] = es; met_src[WBC_REW_TRACKING_EE_CART] = ec;
   met_src[WBC_REW_TRACKING_EE_ORN_RY] = eo_ry; met_src[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum; met_src[WBC_REW_TORQUES] = tq2;
-  float r = 0.f, ra = 0.f;
+  // the per-term scaling / episode sums / metrics are done by lanes t < 21 (reward_accumulate)
 #pragma unroll
-  for (int t = 0; t < WBC_NREW; ++t) {
-    const float sc = C->cur.leg_reward_scale[t];
-    if (sc != 0.f) {
-      const float v = term[t] * sc;
-      r += v; s.ep_sums[t] += v;
-      if (MET_OF[t] >= 0) s.met_sums[MET_OF[t]] += met_src[t];
-    }
+  for (int t = 0; t < WBC_NREW; ++t) { s.post.term[t] = term[t]; s.post.msrc[t] = met_src[t]; }
+}
+
+// rew_buf / arm_rew_buf, episode sums and metric sums from the raw terms: lane t owns term t, lane m metric slot m.
+// lsc / asc = this lane's leg / arm reward scale (lanes >= 21: 0). Per slot the order of additions is the reference's
+// (leg channel then arm channel, terms ascending); the two reward totals are butterfly sums over the wavefront.
+__device__ __forceinline__ void reward_accumulate(Smem& s, const DevConst* __restrict__ C, float lsc, float asc) {
+  const int lane = threadIdx.x;
+  float vl = 0.f, va = 0.f;
+  if (lane < WBC_NREW) {
+    const float tm = s.post.term[lane];
+    float e = s.ep_sums[lane];
+    if (lsc != 0.f) { vl = tm * lsc; e += vl; }
+    if (asc != 0.f) { va = tm * asc; e += va; }
+    s.ep_sums[lane] = e;
   }
-  if (cf.only_positive_rewards && r < 0.f) r = 0.f;
-  s.rew = r / 100.f;
+  // which terms are active per channel, as bit masks every lane can test
+  const uint64_t lmask = __ballot(lsc != 0.f), amask = __ballot(asc != 0.f);
+  if (lane < WBC_NMETRIC) {
+    float mt = s.met_sums[lane];
 #pragma unroll
-  for (int t = 0; t < WBC_NREW; ++t) {
-    const float sc = C->cur.arm_reward_scale[t];
-    if (sc != 0.f) {
-      const float v = term[t] * sc;
-      ra += v; s.ep_sums[t] += v;
-      if (MET_OF[t] >= 0) s.met_sums[MET_OF[t]] += met_src[t];
+    for (int ch = 0; ch < 2; ++ch) {
+      const uint64_t mask = ch == 0 ? lmask : amask;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = MET_TERMS[lane][j];
+        if (t >= 0 && ((mask >> t) & 1)) mt += s.post.msrc[t];
+      }
     }
+    s.met_sums[lane] = mt;
   }
-  if (cf.only_positive_rewards && ra < 0.f) ra = 0.f;
-  s.arm_rew = ra / 100.f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { vl += __shfl_xor(vl, off); va += __shfl_xor(va, off); }
+  if (lane == 0) {
+    float r = vl, ra = va;
+    if (C->cfg.only_positive_rewards && r < 0.f) r = 0.f;
+    if (C->cfg.only_positive_rewards && ra < 0.f) ra = 0.f;
+    s.rew = r / 100.f;
+    s.arm_rew = ra / 100.f;
+  }
 }
 
 // Load one env's state from HBM into LDS (consecutive lanes read consecutive words).
@@ -1079,6 +1105,8 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   }
   STAMP(13);
   // post_physics_step (WG:865-915)
+  float rsc_leg = 0.f, rsc_arm = 0.f;             // this lane's reward scales (consumed after the lane-0 task logic)
+  if (lane < WBC_NREW) { rsc_leg = C->cur.leg_reward_scale[lane]; rsc_arm = C->cur.arm_reward_scale[lane]; }
   rigid_body_pass(s, C, cr, chain, k);
   STAMP(14);
   float base_yaw = 0.f;
@@ -1090,7 +1118,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     base_yaw = rpy.z;
     s.base_yaw = base_yaw;
     float sy, cy;
-    sincosf(0.5f * base_yaw, &sy, &cy);
+    fast_sincosf(0.5f * base_yaw, &sy, &cy);
     const float yq[4] = {0.f, 0.f, sy, cy};
     // update_curr_ee_goal
     const float tt = clampf(s.goal[G_TIMER] / s.goal[G_TRAJ], 0.f, 1.f);
@@ -1113,6 +1141,8 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     s.reset_flag = r_term | p_term | z_term | s.time_out;
     compute_reward(s, C, yq);
   }
+  WSYNC();
+  reward_accumulate(s, C, rsc_leg, rsc_arm);
   WSYNC();
   STAMP(15);
   const bool do_reset = s.reset_flag != 0;
