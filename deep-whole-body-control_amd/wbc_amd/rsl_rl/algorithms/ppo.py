@@ -370,15 +370,20 @@ class PPO:
         ac = self.actor_critic
         total = torch.zeros((), device=self.device)
         hist_params = list(ac.actor.history_encoder.parameters())
-        for (obs_b, *_rest, hid_b, masks_b) in self._generator():
+        if self.fused_rollout and self.storage.observations.is_cuda and self.storage.privileged_observations is None:
+            batches = self._dagger_batches_light()
+        else:
+            batches = ((obs_b, None) for (obs_b, *_rest) in self._generator())
+        for obs_b, priv_latent in batches:
             with torch.inference_mode():
                 if self.fused_rollout and obs_b.is_cuda:
                     # the reference's act() here only samples and discards (quirk L1): keep the generator advancing by one
                     # [mb, 18] normal draw, skip the 17 launches of the unused forward
                     torch.empty(obs_b.shape[0], ac.std.shape[0], device=obs_b.device).normal_()
                 else:
-                    ac.act(obs_b, hist_encoding=True, masks=masks_b, hidden_states=hid_b[0])
-                priv_latent = ac.actor.infer_priv_latent(obs_b)
+                    ac.act(obs_b, hist_encoding=True, masks=None, hidden_states=None)
+                if priv_latent is None:
+                    priv_latent = ac.actor.infer_priv_latent(obs_b)
             hist_latent = ac.actor.infer_hist_latent(obs_b)
             loss = (priv_latent.detach() - hist_latent).norm(p=2, dim=1).mean()
             self.hist_encoder_optimizer.zero_grad()
@@ -392,6 +397,22 @@ class PPO:
         self.update_counter()
         ac.mark_params_changed()
         return (total / num_updates).item()
+
+    def _dagger_batches_light(self):
+        """The minibatches update_dagger needs -- observations and the (constant: only the history encoder is trained)
+        privileged latent -- with the generator's permutation (one randperm per update, RS:163) but without gathering the
+        ten rollout tensors it does not read; the privileged latent of every stored row is computed once."""
+        st = self.storage
+        batch = st.num_envs * st.num_transitions_per_env
+        mb = batch // self.num_mini_batches
+        indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=st.observations.device)
+        obs = st.observations.flatten(0, 1)
+        with torch.inference_mode():
+            priv_all = self.actor_critic.actor.infer_priv_latent(obs)
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                idx = indices[i * mb:(i + 1) * mb]
+                yield obs[idx], priv_all[idx]
 
     def enforce_min_std(self):
         with torch.no_grad():           # in place: kernels hold the parameter's address

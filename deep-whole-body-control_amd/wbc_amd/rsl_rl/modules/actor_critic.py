@@ -46,6 +46,8 @@ class _SplitKLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gy @ weight
         b, s = x.shape[0], _SplitKLinearFn.SPLIT_K
+        while b // s > 2048 and b % (2 * s) == 0:       # longer reductions (history-encoder rows: batch x 10): more splits, ~1-2 k rows each
+            s *= 2
         if ctx.needs_input_grad[1]:
             gyc, xc = gy.contiguous(), x.contiguous()
             gw = torch.bmm(gyc.view(s, b // s, -1).transpose(1, 2), xc.view(s, b // s, -1)).sum(0)
