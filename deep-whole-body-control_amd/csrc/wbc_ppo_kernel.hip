@@ -446,64 +446,83 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 // a workgroup owns a row range of one layer, wave w the output rows [32w, 32w+32). Both MFMA operands are read
 // straight from the stashes (a fragment = two runs of 32 consecutive floats: coalesced as stored), the bias
 // gradient falls out of one extra MFMA block whose B operand is the constant 1. No LDS, no atomics.
-struct WgradLayer { int out, in, dcol, dw, acol, aw, aoff, goff; };   // dZ slab (start, width), A slab (start, width, first column in it); goff: offset of this layer's weight gradient in the flat buffer
+struct WgradLayer { int out, in, dcol, dw, acol, aw, aoff, goff, nsplit, rows; };   // nsplit row ranges of `rows` rows: proportional to the layer's MFMAs per row pair, so every wave has the same work   // dZ slab (start, width), A slab (start, width, first column in it); goff: offset of this layer's weight gradient in the flat buffer
 struct WgradTable { WgradLayer l[NLAYERS]; };
+#ifndef WG_U
+#define WG_U 4               // row pairs per batch of operand loads (two batches in flight per wave)
+#endif
 
-template <int NIB>
+// NIB = 32-column blocks of the layer's input. IL (NIB == 4 only): block b holds the input columns 4 j + b (j = lane & 31)
+// instead of 32 b + j, so that ONE 16-byte load per lane and row pair feeds all four MFMAs. `wave` = 32-row block of the
+// layer's outputs this wave accumulates.
+template <int NIB, bool IL = false>
 static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const float* __restrict__ act_stash, const float* __restrict__ dz_stash,
-                                                  float* __restrict__ dst, int r_begin, int r_end, int B) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+                                                  float* __restrict__ dst, int r_begin, int r_end, int B, int wave) {
+  const int lane = threadIdx.x & 63, half = lane >> 5;
   f32x16 acc[NIB];
 #pragma unroll
   for (int b = 0; b < NIB; ++b) acc[b] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;        // bias gradient: this lane's column of dZ summed over its rows (even rows on lanes 0..31, odd on 32..63)
   const int o = wave * 32 + (lane & 31);
   const bool o_ok = o < L.out;
-  const float* ap = dz_stash + (size_t)L.dcol * B + (o_ok ? o : 0);          // clamped address + select: loads stay unconditional
+  const float* ap = dz_stash + (size_t)L.dcol * B + (o_ok ? o : 0);          // (ragged tail) clamped address + select
   const size_t dstr = (size_t)L.dw, astr = (size_t)L.aw;
   const float* bp[NIB];
   bool c_ok[NIB];
 #pragma unroll
   for (int b = 0; b < NIB; ++b) {
-    const int c = b * 32 + (lane & 31);
+    const int c = IL ? 4 * (lane & 31) + b : b * 32 + (lane & 31);
     c_ok[b] = c < L.in;
     bp[b] = act_stash + (size_t)L.acol * B + L.aoff + (c_ok[b] ? c : 0);
   }
-  constexpr int U = 4;                                             // k-steps (row pairs) per batch of loads
-  // Software pipeline: two operand sets; the loads of batch i+1 are issued (unconditionally: past the end they re-read
-  // the first rows and are ignored) before the MFMAs of batch i, so every global latency sits behind 16-20 MFMAs.
+  constexpr int U = WG_U;
+  // Main loop. On this GPU vector-ALU instructions do not overlap the MFMAs of other waves on the same SIMD (measured: the
+  // kernel took the same 240 us with every operand load removed, and for 1..9 workgroups per CU), so everything that is
+  // not an MFMA is paid in full: no per-operand selects (columns / output rows past the layer's width read finite
+  // neighbours inside the workspace and only feed accumulator entries that are never stored), uniform base + 32-bit lane
+  // offset addressing, one offset add per batch. Two operand sets: the loads of batch i+1 are issued before the MFMAs of
+  // batch i (2 x U row pairs in flight: this wave is alone on its SIMD, nothing else hides the memory latency).
+  const char* dbase = reinterpret_cast<const char*>(dz_stash + (size_t)L.dcol * B);
+  const char* abase = reinterpret_cast<const char*>(act_stash + (size_t)L.acol * B + L.aoff);
+  uint32_t doff = (uint32_t)(((r_begin + half) * L.dw + o) * 4);
+  uint32_t aoff = (uint32_t)(((r_begin + half) * L.aw + (IL ? 4 * (lane & 31) : (lane & 31))) * 4);
+  const uint32_t dstep = 2u * (uint32_t)L.dw * 4u, astep = 2u * (uint32_t)L.aw * 4u;      // bytes per row pair
   struct Ops { float av[U], bv[U][NIB]; };
-  auto issue = [&](Ops& o, int r0) {
+  auto issue = [&](Ops& q) {
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-      const size_t row = (size_t)(r0 + 2 * t + half);
-      o.av[t] = ap[row * dstr];
+      q.av[t] = *reinterpret_cast<const float*>(dbase + (doff + t * dstep));
+      if (IL) {
+        const float4 v = *reinterpret_cast<const float4*>(abase + (aoff + t * astep));
+        q.bv[t][0] = v.x; q.bv[t][1 % NIB] = v.y; q.bv[t][2 % NIB] = v.z; q.bv[t][3 % NIB] = v.w;
+      } else {
 #pragma unroll
-      for (int b = 0; b < NIB; ++b) o.bv[t][b] = bp[b][row * astr];
+        for (int b = 0; b < NIB; ++b) q.bv[t][b] = *reinterpret_cast<const float*>(abase + (aoff + t * astep) + b * 128);
+      }
     }
+    doff += U * dstep; aoff += U * astep;
   };
-  auto compute = [&](const Ops& o) {
+  auto compute = [&](const Ops& q) {
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-      const float a = o_ok ? o.av[t] : 0.f;
 #pragma unroll
-      for (int b = 0; b < NIB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, c_ok[b] ? o.bv[t][b] : 0.f, acc[b], 0, 0, 0);
-      bsum += a;
+      for (int b = 0; b < NIB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(q.av[t], q.bv[t][b], acc[b], 0, 0, 0);
+      bsum += q.av[t];
     }
   };
   int r = r_begin;
   const int nfull = (r_end - r_begin) / (2 * U);                   // full batches
   if (nfull > 0) {
     Ops A, Bq;
-    issue(A, r);
+    issue(A);
     int i = 0;
 #pragma unroll 1
     for (; i + 2 <= nfull; i += 2) {
-      issue(Bq, r + 2 * U);
+      issue(Bq);
       __builtin_amdgcn_sched_barrier(0);        // keep the loads ahead of the MFMAs (the scheduler sinks them to their uses otherwise)
       compute(A);
       __builtin_amdgcn_sched_barrier(0);
-      issue(A, (i + 2 < nfull) ? r + 4 * U : r_begin);
+      issue(A);                                 // past the last batch this reads the following rows (inside the workspace), unused
       __builtin_amdgcn_sched_barrier(0);
       compute(Bq);
       __builtin_amdgcn_sched_barrier(0);
@@ -525,7 +544,7 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   }
 #pragma unroll
   for (int b = 0; b < NIB; ++b) {
-    const int col = b * 32 + (lane & 31);
+    const int col = IL ? 4 * (lane & 31) + b : b * 32 + (lane & 31);
     if (col < L.in) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -538,19 +557,43 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   if (lane < 32 && o_ok) dst[(size_t)L.out * L.in + o] = bsum;
 }
 
+// Grid = (row ranges, layers), 4 waves per workgroup = the layer's four 32-row output blocks. About three workgroups per
+// CU: co-resident waves do not overlap each other's vector-ALU work with MFMAs, but they do hide each other's memory latency
+// (one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
 extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
-                                                                         int B, int rows_per_split, int nparams) {
+                                                                         int B, int nparams) {
   const WgradLayer L = tab.l[blockIdx.y];
   const int wave = threadIdx.x >> 6;
-  if (wave * 32 >= L.out) return;
-  const int r_begin = blockIdx.x * rows_per_split, r_end = min(B, r_begin + rows_per_split);
+  if (wave * 32 >= L.out || (int)blockIdx.x >= L.nsplit) return;
+  const int r_begin = blockIdx.x * L.rows, r_end = min(B, r_begin + L.rows);
   float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
-  const int nib = (L.in + 31) / 32;                                // uniform per workgroup
-  if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
-  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
-  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
-  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, B);
+  const int nib = (L.in + 31) / 32;
+  if (nib == 4 && ((L.aw | L.aoff) & 3) == 0) wgrad_body<4, true>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);   // 16-byte aligned rows
+  else if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
+  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
+  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
+  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
+}
+
+// grad[L.goff + i] = sum_{s < L.nsplit} part[s][L.goff + i] in a fixed order, one grid row per layer
+extern "C" __global__ void __launch_bounds__(256) ppo_layer_reduce_kernel(WgradTable tab, const float* __restrict__ part, int stride,
+                                                                         float* __restrict__ grad) {
+  const WgradLayer L = tab.l[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L.out * L.in + L.out) return;
+  const int p = L.goff + i;
+  float acc = 0.f;
+  int s2 = 0;
+  for (; s2 + 8 <= L.nsplit; s2 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s2 + j) * stride + p];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; s2 < L.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
+  grad[p] = acc;
 }
 
 // grad[p] = sum_s part[s][p] in a fixed order; `stride` floats between consecutive partials
@@ -692,13 +735,14 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   int off = 0;
   for (int l = 0; l < NLAYERS; ++l) {
     const int aslab = (l == L_PRIV0) ? A_X : kAcol[l];                    // priv0 reads columns 76.. of the x slab
-    tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab, off};
+    int nsplit = PPO_NSPLIT;
+    int rows = (B + nsplit - 1) / nsplit;
+    rows = (rows + 7) / 8 * 8;
+    tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab, off, nsplit, rows};
     off += layer_out(l) * layer_in(l) + layer_out(l);
   }
-  int rows_per_split = (B + PPO_NSPLIT - 1) / PPO_NSPLIT;
-  rows_per_split = (rows_per_split + 7) / 8 * 8;
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, rows_per_split, ng);
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3((off + 255) / 256), dim3(256), 0, st, wpart, PPO_NSPLIT, ng, off, grad);
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, ng);
+  hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, tab, wpart, ng, grad);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(3), dim3(256), 0, st, loss_partial, tiles, 3, grad + off + 18);
   return hipGetLastError() == hipSuccess ? 0 : -2;
