@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the RCCL process group even for one rank (exercises the multi-GPU code path on one GPU)")
     ap.add_argument("--terrain", choices=["plane", "trimesh"], default="plane",
                     help="plane = BASELINE.json configs[1] (the bench line); trimesh = the shipped fractal-Perlin terrain (configs[2])")
     args = ap.parse_args()
@@ -123,15 +125,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     group = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
         group = dist.group.WORLD
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from wbc_amd.config import WidowGo1RoughCfg, WidowGo1RoughCfgPPO, class_to_dict
     from wbc_amd.envs import WidowGo1
@@ -167,7 +171,7 @@ def main():
     env.sim.step = timed_step
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +183,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timing_on["v"] = False
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -217,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
