@@ -65,6 +65,7 @@ struct __align__(16) Smem {
   float act_last[WBC_NACT];      // newest (undelayed) action, sim order
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
   float rew, arm_rew, base_yaw, mu, friction;
+  float rp[2];                   // base roll / pitch of the state the observation is built from (post-physics, or post-reset)
   int reset_flag, time_out, ep_len;
   float sq[WBC_NDOF], cq[WBC_NDOF];      // sin/cos of the joint angles of this substep
   float viol[WBC_NDOF], limd[WBC_NDOF];  // joint-limit violation and (if moving further out) the joint velocity
@@ -979,6 +980,7 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
     s.box[1] = s.root[1] + T.box_dy[env];
     s.box[2] = C->cfg.box_origin_z;
     for (int j = 0; j < 6; ++j) s.root[7 + j] = rng_range(-C->cfg.init_vel_perturb_range, C->cfg.init_vel_perturb_range, seed, env, step, SLOT_RESET_VEL + j);
+    { const f3 e = euler_from_quat(&s.root[3]); s.rp[0] = e.x; s.rp[1] = e.y; }      // the observation of a reset env shows the new pose
     if (start || s.time_out) resample_commands(s, C, seed, env, step, SLOT_RESET_CMD);
     resample_ee_goal(s, C, seed, env, step, SLOT_RESET_GOAL_ORN, SLOT_RESET_GOAL_SPHERE, base_yaw);
     s.ep_len = 0;
@@ -995,7 +997,7 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   // proprio vector o76, one or two entries per lane
   for (int e = lane; e < WBC_NPROP; e += LANES) {
     float val;
-    if (e < 2) { const f3 rpy = euler_from_quat(&s.root[3]); val = (e == 0) ? rpy.x : rpy.y; }
+    if (e < 2) val = s.rp[e];
     else if (e < 5) val = s.bav[e - 2] * cf.obs_scale_ang_vel;
     else if (e < 25) {
       const int sj = POLICY_PERM[e - 5];
@@ -1117,6 +1119,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     const f3 rpy = euler_from_quat(&s.root[3]);
     base_yaw = rpy.z;
     s.base_yaw = base_yaw;
+    s.rp[0] = rpy.x; s.rp[1] = rpy.y;
     float sy, cy;
     fast_sincosf(0.5f * base_yaw, &sy, &cy);
     const float yq[4] = {0.f, 0.f, sy, cy};
