@@ -75,7 +75,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
 #undef DBG_STAMP
 }
 
-// ==== 16-row tiles (v_mfma_f32_16x16x4_f32) for rollout-sized batches ========================================
+// ==== 16-row tiles (v_mfma_f32_16x16x4_f32): the default path ================================================
 // 4096 envs are only 128 tiles of 32 rows: one workgroup per CU, one wave per SIMD, nothing to hide the LDS / barrier /
 // operand latencies of the 9-layer chain behind. With 16-row tiles the same batch gives 512 workgroups (two per CU), each
 // layer costs a wave 64 MFMAs of 32 cycles instead of 64 cycles, and the epilogue handles 8 outputs per lane instead of 16.
@@ -288,7 +288,10 @@ extern "C" int wbc_policy_act(const void* const* params, const float* wpack, con
                               float* actions, float* mean, float* logp, float* values, int num_rows, void* stream) {
   PolicyParams P;
   if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
-  if (num_rows <= 8192 && !g_policy_dbg) {       // rollout-sized batch: 16-row tiles
+#ifndef ACT16_MAX_ROWS
+#define ACT16_MAX_ROWS 0x7fffffff      // measured faster at every batch size (4096: 33 vs 51 us, 40960: 211 vs 281 us); 32-row path kept for A/B runs
+#endif
+  if (num_rows <= ACT16_MAX_ROWS && !g_policy_dbg) {       // rollout-sized batch: 16-row tiles
     static const Tab16 T16 = make_tab16();
     hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3((num_rows + P16_ROWS - 1) / P16_ROWS, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
                        wpack + WPACK16_OFF, wpack + WPACK_WEIGHT_FLOATS, obs, latent, eps, actions, mean, logp, values, num_rows);

@@ -6,7 +6,7 @@ import golden_procedure as gp
 from wbc_amd.rsl_rl.modules import ActorCritic
 torch.manual_seed(0)
 ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
-for n in (4096, 40960):
+for n in (4096, 8192, 16384, 40960):
     obs = torch.randn(n, 860, device="cuda"); eps = torch.randn(n, 18, device="cuda")
     with torch.inference_mode():
         for _ in range(5): ac.fused_act(obs, eps)
