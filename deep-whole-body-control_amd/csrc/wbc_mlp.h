@@ -320,3 +320,145 @@ static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem,
     }
   }
 }
+
+// ==== 16-row tiles: v_mfma_f32_16x16x4_f32 ===================================================================================
+// A: lane L supplies A[row = L & 15][k = L >> 4]; B: B[k = L >> 4][col = L & 15]; C/D: 4 registers, D[row = 4 (L >> 4) + r][col = L & 15].
+// A wave owns 32 output columns as two 16-column halves h. Pack ("pack16"): lane L's float4 for k-step pair kp holds
+// W[cb*32 + 16h + (L&15)][4 ks + (L>>4)] for (ks, h) = (2kp,0), (2kp,1), (2kp+1,0), (2kp+1,1); the transposed pack ("packT16",
+// dgrad: k over the layer's outputs, columns over its inputs) holds W[4 ks + (L>>4)][cb*32 + 16h + (L&15)]. Blob layout:
+// [pack16 of all layers | packT16 of all layers | biases].
+#define R16 16
+#define LD16 132              // LDS row stride: (4 row + k) mod 64 is conflict-free for the 16 x 4 operand read
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// k is zero-padded to chunks of 8 k-steps (32 values = 4 k-step pairs): the MFMA chain branches once per chunk, not per k-step
+__host__ __device__ constexpr int l16_floats(int l) { return (layer_in(l) + 31) / 32 * 4 * layer_nblk(l) * 256; }
+__host__ __device__ constexpr int l16T_floats(int l) { return (layer_out(l) + 31) / 32 * 4 * layer_nblkT(l) * 256; }
+__host__ __device__ constexpr int l16_sum(int l) { return l < 0 ? 0 : l16_sum(l - 1) + l16_floats(l); }
+__host__ __device__ constexpr int l16T_sum(int l) { return l < 0 ? 0 : l16T_sum(l - 1) + l16T_floats(l); }
+constexpr int kWpack16Fwd = l16_sum(NLAYERS - 1);            // constexpr variables: a constexpr recursion evaluated in device code
+constexpr int kWpack16Bias = kWpack16Fwd + l16T_sum(NLAYERS - 1);   // would be compiled as a recursive call
+#define WPACK16_FWD_FLOATS kWpack16Fwd
+#define WPACK16_BIAS_OFF kWpack16Bias
+#define WPACK16_FLOATS (WPACK16_BIAS_OFF + WPACK_BIAS_FLOATS)
+#define WPACK16_OFF ((WPACK_FLOATS + 3) / 4 * 4)          // where the 16-row blob sits inside a wbc_policy_pack buffer
+
+struct Desc16 {               // one forward layer on a 16-row tile
+  int woff, boff, nch, nblk, n, in_off, out_off, ldo, act;      // pack16 offset, bias offset, k chunks (of 32 inputs; the LDS columns up to
+                                                                 // 32 nch must be finite), 32-col blocks, outputs, LDS offsets
+  int scol, sw;                                                  // stash slab (start column, width) or scol < 0
+};
+struct Tab16 { Desc16 l[NLAYERS]; };
+struct Pack16Table { int n[NLAYERS], k[NLAYERS], off[NLAYERS], offT[NLAYERS], boff[NLAYERS]; };
+
+static inline Desc16 make_desc16(int l, int in_off, int out_off, int scol, int sw = 0) {
+  const int act = (l == L_LEG4 || l == L_ARM4) ? ACT_TANH : ((l == L_CLEG4 || l == L_CARM4) ? ACT_NONE : ACT_ELU);
+  const bool head = (l == L_LEG4 || l == L_ARM4 || l == L_CLEG4 || l == L_CARM4);       // heads write outv[., 21]
+  return Desc16{l16_sum(l - 1), layer_bias_off(l), (layer_in(l) + 31) / 32, layer_nblk(l), layer_out(l), in_off, out_off, head ? 21 : LD16, act, scol, sw};
+}
+static inline Pack16Table make_pack16_table() {
+  Pack16Table t;
+  for (int l = 0; l < NLAYERS; ++l) {
+    t.n[l] = layer_out(l); t.k[l] = layer_in(l); t.off[l] = l16_sum(l - 1); t.offT[l] = WPACK16_FWD_FLOATS + l16T_sum(l - 1); t.boff[l] = layer_bias_off(l);
+  }
+  return t;
+}
+
+// grid = (blocks, NLAYERS, 1 or 2): z = 0 forward pack (+ biases), z = 1 transposed pack. `blob` 16-byte aligned.
+static __global__ void wbc_pack16_kernel(PolicyParams P, Pack16Table T, float* __restrict__ blob) {
+  const int l = blockIdx.y;
+  const bool tr = blockIdx.z != 0;
+  const float* W = reinterpret_cast<const float* const*>(&P)[2 * l];
+  const float* bsrc = reinterpret_cast<const float* const*>(&P)[2 * l + 1];
+  const int N = T.n[l], K = T.k[l];
+  const int kdim = tr ? N : K, cdim = tr ? K : N;                // k runs over kdim, columns over cdim
+  const int nblk = (cdim + 31) / 32, nkp = (kdim + 31) / 32 * 4;
+  const int off = tr ? T.offT[l] : T.off[l], total = nkp * nblk * 256;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int j = e & 3, lane = (e >> 2) & 63, frag = e >> 8;
+    const int cb = frag % nblk, kp = frag / nblk;
+    const int ks = 2 * kp + (j >> 1), h = j & 1;
+    const int c = cb * 32 + 16 * h + (lane & 15), k = 4 * ks + (lane >> 4);
+    float v = 0.f;
+    if (c < cdim && k < kdim) v = tr ? W[(size_t)k * K + c] : W[(size_t)c * K + k];
+    blob[off + e] = v;
+  }
+  if (blockIdx.x == 0 && !tr)
+    for (int e = threadIdx.x; e < N; e += blockDim.x) blob[WPACK16_BIAS_OFF + T.boff[l] + e] = bsrc[e];
+}
+
+// 16 float4 of one operand set: `ub` = the layer's pack (uniform), fragment stride `nblk * 64` float4 per k-step pair
+static __device__ __forceinline__ void load_ops16(float (&w)[66], const float4* __restrict__ ub, int nblk, int nch, int cb) {
+  const int lane = threadIdx.x & 63;
+  const int nkp = nch * 4;
+#pragma unroll
+  for (int kp = 0; kp < 16; ++kp) {
+    const float4 v = (ub + (kp < nkp ? kp : 0) * (nblk * 64))[cb * 64 + lane];      // unconditional (see load_operands)
+    w[4 * kp] = v.x; w[4 * kp + 1] = v.y; w[4 * kp + 2] = v.z; w[4 * kp + 3] = v.w;
+  }
+}
+
+// operands of forward layer d for this wave + the two bias values of its column halves (w[64], w[65])
+static __device__ __forceinline__ void load16(float (&w)[66], const Desc16& d, const float* __restrict__ pack16, const float* __restrict__ bias) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_ops16(w, reinterpret_cast<const float4*>(pack16 + d.woff), d.nblk, d.nch, wave < d.nblk ? wave : 0);
+  const int c0 = wave * 32 + (lane & 15);
+  w[64] = bias[d.boff + (c0 < d.n ? c0 : 0)];
+  w[65] = bias[d.boff + (c0 + 16 < d.n ? c0 + 16 : 0)];
+}
+
+// acc_h += sum_{ks < 8 nch} A[.., 4 ks + (L>>4)] * w[2 ks + h] for both column halves; A from LDS (ap = this lane's row / k
+// offset). One uniform branch per chunk of 8 k-steps: a branch per MFMA costs about as much as the 8-pass MFMA itself.
+static __device__ __forceinline__ void mfma_chain16(const float* ap, const float (&w)[66], int nch, f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < nch) {
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = ap[4 * (c * 8 + j)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * (c * 8 + j)], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * (c * 8 + j) + 1], acc1, 0, 0, 0);
+      }
+    }
+  }
+}
+
+static __device__ __forceinline__ float act16(float x, int act) {
+  if (act == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;     // abs error <= 1 ulp(1.0); the derivative uses the stored value
+  if (act == ACT_TANH) return tanhf(x);
+  return x;
+}
+
+// Forward layer d on a 16-row tile: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the slab-major
+// stash (`num_rows` = its total rows). `after_mfma` runs once `w` is no longer read. Ends with a barrier.
+template <typename Hook = NoHook>
+static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int num_rows,
+                                             Hook after_mfma = Hook()) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float b0 = w[64], b1 = w[65];
+  if (wave < d.nblk) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    mfma_chain16(smem + d.in_off + (lane & 15) * LD16 + (lane >> 4), w, d.nch, acc0, acc1);
+    after_mfma();
+    const int c0 = wave * 32 + (lane & 15), rb = 4 * (lane >> 4);
+    const bool st = stash != nullptr && d.scol >= 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = c0 + 16 * h;
+      if (col < d.n) {
+        float* sp = st ? stash + (size_t)d.scol * num_rows + (size_t)(row0 + rb) * d.sw + col : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = act16((h ? acc1[r] : acc0[r]) + (h ? b1 : b0), d.act);
+          smem[d.out_off + (rb + r) * d.ldo + col] = v;
+          if (st && row0 + rb + r < num_rows) sp[r * d.sw] = v;
+        }
+      }
+    }
+  } else {
+    after_mfma();
+  }
+  __syncthreads();
+}

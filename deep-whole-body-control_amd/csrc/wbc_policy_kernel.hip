@@ -77,114 +77,23 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(P
 
 // ==== 16-row tiles (v_mfma_f32_16x16x4_f32): the default path ================================================
 // 4096 envs are only 128 tiles of 32 rows: one workgroup per CU, one wave per SIMD, nothing to hide the LDS / barrier /
-// operand latencies of the 9-layer chain behind. With 16-row tiles the same batch gives 512 workgroups (two per CU), each
-// layer costs a wave 64 MFMAs of 32 cycles instead of 64 cycles, and the epilogue handles 8 outputs per lane instead of 16.
-// A wave still owns 32 output columns (two 16-column halves h); its B operands come from a third pack: lane L's float4 for
-// k-step pair kp holds W[cb*32 + 16h + (L&15)][4 ks + (L>>4)] for (ks, h) = (2kp,0), (2kp,1), (2kp+1,0), (2kp+1,1).
-#define P16_ROWS 16
-#define LD16 132              // row stride: (4 row + k) mod 64 is conflict-free for the 16 x 4 operand read
+// operand latencies of the 9-layer chain behind. With 16-row tiles the same batch gives 512 workgroups, each layer costs a
+// wave 64 MFMAs of 32 cycles instead of 64 cycles and the epilogue handles 8 outputs per lane instead of 16 (helpers in
+// wbc_mlp.h). Measured faster at every batch size (4096 rows: 33 vs 51 us, 40960: 211 vs 281 us).
 #define T_X 0
-#define T_A0 (P16_ROWS * LD16)
-#define T_A1 (T_A0 + P16_ROWS * LD16)
-#define T_A2 (T_A1 + P16_ROWS * LD16)
-#define T_OUTV (T_A2 + P16_ROWS * LD16)
-#define T_END (T_OUTV + P16_ROWS * 21)
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-struct Desc16 { int woff, boff, nks, nblk, n, in_off, out_off, ldo, act; };
-struct Tab16 { Desc16 l[NLAYERS]; };
-static int pack16_floats(int l) { return ((layer_in(l) + 3) / 4 + 1) / 2 * layer_nblk(l) * 256; }
-static int pack16_total() { int t = 0; for (int l = 0; l < NLAYERS; ++l) t += pack16_floats(l); return t; }
-#define WPACK16_OFF ((WPACK_FLOATS + 3) / 4 * 4)
+#define T_A0 (R16 * LD16)
+#define T_A1 (T_A0 + R16 * LD16)
+#define T_A2 (T_A1 + R16 * LD16)
+#define T_OUTV (T_A2 + R16 * LD16)
+#define T_END (T_OUTV + R16 * 21)
 
 static Tab16 make_tab16() {
   Tab16 t;
   const int in_off[NLAYERS] = {T_X + PT_NPROP, T_A0, T_A1, T_A2, T_A0, T_A1, T_A2, T_A0, T_A1, T_X, T_A2, T_A0, T_A1, T_A2, T_A0, T_A1};
   const int out_off[NLAYERS] = {T_A0, T_A1 + PT_NPROP, T_A2, T_A0, T_A1, T_OUTV, T_A0, T_A1, T_OUTV + PT_NLEG, T_A2, T_A0, T_A1, T_OUTV + 18,
                                 T_A0, T_A1, T_OUTV + 19};
-  const int act[NLAYERS] = {ACT_ELU, ACT_ELU, ACT_ELU, ACT_ELU, ACT_ELU, ACT_TANH, ACT_ELU, ACT_ELU, ACT_TANH, ACT_ELU, ACT_ELU, ACT_ELU, ACT_NONE,
-                            ACT_ELU, ACT_ELU, ACT_NONE};
-  int off = 0;
-  for (int l = 0; l < NLAYERS; ++l) {
-    const bool head = layer_out(l) < 32 && l != L_PRIV2;
-    t.l[l] = Desc16{off, layer_bias_off(l), (layer_in(l) + 3) / 4, layer_nblk(l), layer_out(l), in_off[l], out_off[l], head ? 21 : LD16, act[l]};
-    off += pack16_floats(l);
-  }
+  for (int l = 0; l < NLAYERS; ++l) t.l[l] = make_desc16(l, in_off[l], out_off[l], -1);
   return t;
-}
-
-static __global__ void wbc_pack16_kernel(PolicyParams P, Tab16 T, float* __restrict__ wpack16) {
-  const int l = blockIdx.y;
-  const float* W = reinterpret_cast<const float* const*>(&P)[2 * l];
-  const Desc16 d = T.l[l];
-  const int N = d.n;
-  const int Kin = (l == L_PRIV0 ? 24 : l == L_PRIV2 ? 64 : l == L_BB ? 96 : l == L_CBB ? 100 : 128);
-  const int total = (d.nks + 1) / 2 * d.nblk * 256;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int j = e & 3, lane = (e >> 2) & 63, frag = e >> 8;
-    const int cb = frag % d.nblk, kp = frag / d.nblk;
-    const int ks = 2 * kp + (j >> 1), h = j & 1;
-    const int c = cb * 32 + 16 * h + (lane & 15), k = 4 * ks + (lane >> 4);
-    wpack16[d.woff + e] = (c < N && k < Kin) ? W[(size_t)c * Kin + k] : 0.f;
-  }
-}
-
-// operands of layer d for this wave (16 float4) + the two bias values of its column halves (w[64], w[65])
-static __device__ __forceinline__ void load16(float (&w)[66], const Desc16& d, const float* __restrict__ wpack16, const float* __restrict__ bias) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cb = wave < d.nblk ? wave : 0;
-  const int nkp = (d.nks + 1) >> 1;
-  const float4* ub = reinterpret_cast<const float4*>(wpack16 + d.woff);
-#pragma unroll
-  for (int kp = 0; kp < 16; ++kp) {
-    const float4 v = (ub + (kp < nkp ? kp : 0) * (d.nblk * 64))[cb * 64 + lane];
-    w[4 * kp] = v.x; w[4 * kp + 1] = v.y; w[4 * kp + 2] = v.z; w[4 * kp + 3] = v.w;
-  }
-  const int c0 = wave * 32 + (lane & 15);
-  w[64] = bias[d.boff + (c0 < d.n ? c0 : 0)];
-  w[65] = bias[d.boff + (c0 + 16 < d.n ? c0 + 16 : 0)];
-}
-
-static __device__ __forceinline__ float act16(float x, int act) {
-  if (act == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;
-  if (act == ACT_TANH) return tanhf(x);
-  return x;
-}
-
-static __device__ __forceinline__ void run16(const float (&w)[66], const Desc16& d, float* smem) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < d.nblk) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const bool two = d.n > wave * 32 + 16;                       // second 16-column half exists
-    const float* ap = smem + d.in_off + (lane & 15) * LD16 + (lane >> 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c * 8 < d.nks) {
-        float a[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = ap[4 * (c * 8 + j)];          // reads past the row's k range stay inside LDS
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ks = c * 8 + j;
-          if (ks < d.nks) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * ks], acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * ks + 1], acc1, 0, 0, 0);
-          }
-        }
-      }
-    }
-    // C/D layout of 16x16: col = lane & 15, row = 4 * (lane >> 4) + reg
-    const int c0 = wave * 32 + (lane & 15), rb = 4 * (lane >> 4);
-    if (c0 < d.n) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) smem[d.out_off + (rb + r) * d.ldo + c0] = act16(acc0[r] + w[64], d.act);
-    }
-    if (c0 + 16 < d.n) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) smem[d.out_off + (rb + r) * d.ldo + c0 + 16] = act16(acc1[r] + w[65], d.act);
-    }
-  }
-  __syncthreads();
 }
 
 extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act16_kernel(PolicyParams P, Tab16 T, const float* __restrict__ wpack16,
@@ -194,24 +103,24 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act16_kernel
                                                                                 float* __restrict__ logp_out, float* __restrict__ value_out, int num_rows) {
   __shared__ float smem[T_END];
   const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * P16_ROWS;
+  const int row0 = blockIdx.x * R16;
   const bool critic = blockIdx.y != 0;
-  // x[16][100] <- obs[:, :100] (float4 loads), rows past the end zero
-  for (int e4 = tid; e4 < P16_ROWS * 25; e4 += PT_THREADS) {
-    const int r = e4 / 25, c = (e4 - r * 25) * 4;
+  // x[16][128] <- obs[:, :100] (float4 loads); rows past the end and the columns 100..127 (k padding of the first layers) zero
+  for (int e4 = tid; e4 < R16 * 32; e4 += PT_THREADS) {
+    const int r = e4 >> 5, c = (e4 & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < num_rows) v = *reinterpret_cast<const float4*>(obs + (size_t)(row0 + r) * PT_NOBS + c);
+    if (row0 + r < num_rows && c < 100) v = *reinterpret_cast<const float4*>(obs + (size_t)(row0 + r) * PT_NOBS + c);
     float* dst = smem + T_X + r * LD16 + c;
     dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
   }
   __syncthreads();
   if (!critic) {
-    for (int e = tid; e < P16_ROWS * PT_NPROP; e += PT_THREADS) {
+    for (int e = tid; e < R16 * PT_NPROP; e += PT_THREADS) {
       const int r = e / PT_NPROP, c = e - r * PT_NPROP;
       smem[T_A1 + r * LD16 + c] = smem[T_X + r * LD16 + c];
     }
     if (latent)
-      for (int e = tid; e < P16_ROWS * 20; e += PT_THREADS) {
+      for (int e = tid; e < R16 * 20; e += PT_THREADS) {
         const int r = e / 20, c = e - r * 20;
         smem[T_A1 + r * LD16 + PT_NPROP + c] = (row0 + r < num_rows) ? latent[(size_t)(row0 + r) * 20 + c] : 0.f;
       }
@@ -225,22 +134,22 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act16_kernel
     for (int l = lbeg; l < lend; l += 2) {
       const bool two = l + 1 < lend;
       if (two) load16(wb, T.l[l + 1], wpack16, bias);
-      run16(wa, T.l[l], smem);
+      run16(wa, T.l[l], smem, nullptr, row0, num_rows);
       if (two) {
         if (l + 2 < lend) load16(wa, T.l[l + 2], wpack16, bias);
-        run16(wb, T.l[l + 1], smem);
+        run16(wb, T.l[l + 1], smem, nullptr, row0, num_rows);
       }
     }
   }
   const float* outv = smem + T_OUTV;
   if (critic) {
-    if (tid < P16_ROWS && row0 + tid < num_rows) {
+    if (tid < R16 && row0 + tid < num_rows) {
       const size_t g = (size_t)(row0 + tid);
       value_out[g * 2] = outv[tid * 21 + 18]; value_out[g * 2 + 1] = outv[tid * 21 + 19];
     }
     return;
   }
-  if (tid < P16_ROWS && row0 + tid < num_rows) {
+  if (tid < R16 && row0 + tid < num_rows) {
     const int r = tid;
     const size_t g = (size_t)(row0 + r);
     float lp_leg = 0.f, lp_arm = 0.f;
@@ -273,14 +182,14 @@ static int fill_params(const void* const* params, PolicyParams* P) {
 }
 
 // C-ABI. params: 33 device pointers in the order of struct PolicyParams; wpack: wbc_policy_pack_floats() floats.
-extern "C" int wbc_policy_pack_floats(void) { return WPACK16_OFF + pack16_total(); }
+extern "C" int wbc_policy_pack_floats(void) { return WPACK16_OFF + WPACK16_FLOATS; }
 
 // Re-pack the weights into MFMA fragment order (call after the parameters changed).
 extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* stream) {
   PolicyParams P;
   if (!params || !wpack || (reinterpret_cast<uintptr_t>(wpack) & 15) || fill_params(params, &P)) return -1;
   hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, (hipStream_t)stream, P, make_pack_table(), wpack);
-  hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS), dim3(256), 0, (hipStream_t)stream, P, make_tab16(), wpack + WPACK16_OFF);
+  hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 1), dim3(256), 0, (hipStream_t)stream, P, make_pack16_table(), wpack + WPACK16_OFF);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -293,8 +202,8 @@ extern "C" int wbc_policy_act(const void* const* params, const float* wpack, con
 #endif
   if (num_rows <= ACT16_MAX_ROWS && !g_policy_dbg) {       // rollout-sized batch: 16-row tiles
     static const Tab16 T16 = make_tab16();
-    hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3((num_rows + P16_ROWS - 1) / P16_ROWS, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
-                       wpack + WPACK16_OFF, wpack + WPACK_WEIGHT_FLOATS, obs, latent, eps, actions, mean, logp, values, num_rows);
+    hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3((num_rows + R16 - 1) / R16, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
+                       wpack + WPACK16_OFF, wpack + WPACK16_OFF + WPACK16_BIAS_OFF, obs, latent, eps, actions, mean, logp, values, num_rows);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   const int blocks = (num_rows + PT_ROWS - 1) / PT_ROWS;

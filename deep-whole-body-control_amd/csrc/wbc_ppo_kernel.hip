@@ -441,6 +441,335 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
   }
 }
 
+// ==== 16-row tiles =======================================================================================================
+// The same kernel on v_mfma_f32_16x16x4_f32 tiles (wbc_mlp.h): twice the workgroups, a 26.7 KB LDS plan (x / g, two
+// activation buffers, outv) and half the accumulator / epilogue registers per wave, so more workgroups share a CU and hide
+// each other's barriers and stash traffic. Stash layouts, loss phase and stage order are those of the 32-row kernel.
+#define H_X 0
+#define H_A0 (R16 * LD16)
+#define H_A1 (H_A0 + R16 * LD16)
+#define H_OUTV (H_A1 + R16 * LD16)
+#define H_END (H_OUTV + R16 * 21)
+#define H_G H_X
+#ifndef PPO16_OCC
+#define PPO16_OCC 3
+#endif
+static_assert(R16 * 41 <= R16 * LD16, "g fits in x");
+
+struct FOp16 { int type, next_layer; Desc16 d; int rcol, rdst; };
+struct FOpTable16 { FOp16 op[NFOPS]; };
+static FOpTable16 make_fop_table16(const int* stash_cols) {
+  FOpTable16 t;
+  int i = 0;
+  auto layer = [&](int l, int in_off, int out_off) {
+    t.op[i] = FOp16{FOP_LAYER, -1, make_desc16(l, in_off, out_off, stash_cols[l], stash_cols[l] >= 0 ? a_slab_w(stash_cols[l]) : 0), 0, 0};
+    ++i;
+  };
+  auto other = [&](int type, int col, int dst) { t.op[i] = FOp16{}; t.op[i].type = type; t.op[i].rcol = col; t.op[i].rdst = dst; ++i; };
+  layer(L_CBB, H_X, H_A0);
+  layer(L_CLEG0, H_A0, H_A1);
+  layer(L_CLEG2, H_A1, H_A0);
+  layer(L_CLEG4, H_A0, H_OUTV + 18);
+  other(FOP_RELOAD, A_CB, H_A0);
+  layer(L_CARM0, H_A0, H_A1);
+  layer(L_CARM2, H_A1, H_A0);
+  layer(L_CARM4, H_A0, H_OUTV + 19);
+  other(FOP_COPY_PROP, 0, 0);
+  layer(L_PRIV0, H_X + PT_NPROP, H_A0);
+  layer(L_PRIV2, H_A0, H_A1 + PT_NPROP);
+  layer(L_BB, H_A1, H_A0);
+  layer(L_LEG0, H_A0, H_A1);
+  layer(L_LEG2, H_A1, H_A0);
+  layer(L_LEG4, H_A0, H_OUTV);
+  other(FOP_RELOAD, A_BB, H_A0);
+  layer(L_ARM0, H_A0, H_A1);
+  layer(L_ARM2, H_A1, H_A0);
+  layer(L_ARM4, H_A0, H_OUTV + PT_NLEG);
+  for (int a = 0; a < NFOPS; ++a) {
+    t.op[a].next_layer = -1;
+    for (int b2 = a + 1; b2 < NFOPS; ++b2) if (t.op[b2].type == FOP_LAYER) { t.op[a].next_layer = b2; break; }
+  }
+  return t;
+}
+
+// the 32-row stage table with the 16-row LDS offsets and transposed-pack16 offsets
+static BwdTable make_bwd_table16(const PolicyParams& P) {
+  BwdTable t = make_bwd_table(P);
+  for (int i = 0; i < NBWD; ++i) {
+    BwdDesc& d = t.s[i];
+    auto map = [](int q) { return q == Q_A0 ? H_A0 : (q == Q_A1 ? H_A1 : q); };
+    d.buf_off = map(d.buf_off); d.out_off = map(d.out_off); d.src_off = map(d.src_off);
+  }
+  const int lw[NBWD] = {L_CLEG2, L_CLEG0, L_CARM2, L_CARM0, -1, L_LEG4, L_LEG2, L_LEG0, L_ARM4, L_ARM2, L_ARM0, L_BB, L_PRIV2, -1};
+  for (int i = 0; i < NBWD; ++i) t.s[i].woffT = lw[i] >= 0 ? WPACK16_FWD_FLOATS + l16T_sum(lw[i] - 1) : WPACK16_FWD_FLOATS;
+  return t;
+}
+
+static __device__ __forceinline__ void bwd_load16(float (&w)[66], const BwdDesc& d, const float* __restrict__ blob) {
+  const int wave = threadIdx.x >> 6;
+  const int nblk = d.has_mma ? d.nblkT : 1;
+  load_ops16(w, reinterpret_cast<const float4*>(blob + d.woffT), nblk, (d.out_dim + 31) >> 5, wave < nblk ? wave : 0);
+}
+
+// thread t owns columns c, c+1 with c = 2 (t & 63) of rows (t >> 6) + 4 j, j < 4
+struct BwdFetch16 { float2 a[4]; float wv; };
+static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows) {
+  const int tid = threadIdx.x;
+  const int c = (tid & 63) * 2, rb = tid >> 6;
+  const bool c_ok = c < d.n;
+  const float* base = act_stash + sidx(num_rows, d.acol, d.aw, row0 + rb, c_ok ? c : 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = c_ok && row0 + rb + 4 * j < num_rows;
+    const float2 v = *reinterpret_cast<const float2*>(ok ? base + (size_t)(4 * j) * d.aw : act_stash);
+    f.a[j] = ok ? v : make_float2(1.f, 1.f);
+  }
+  const float* wv = (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) ? d.wvec : act_stash;
+  f.wv = wv[tid & 127];
+}
+
+static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const BwdFetch16& f, float* smem, float* __restrict__ dz_stash,
+                                                     int row0, int num_rows) {
+  const int tid = threadIdx.x;
+  float* buf = smem + d.buf_off;
+  const float* g = smem + H_G;
+  if (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) {
+    const int gi = (d.pre == PRE_OUTER_V0) ? 18 : 19;
+    const int c = tid & 127, r0 = tid >> 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) buf[(r0 + 2 * k) * LD16 + c] = g[(r0 + 2 * k) * 41 + gi] * f.wv;
+    __syncthreads();
+  } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
+    // the GEMM's k runs over the head's outputs in chunks of 32: the columns up to 32 must be finite (zeros)
+    const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
+    const int r = tid >> 4, c = tid & 15;                            // 16 threads per row, n <= 12
+    buf[r * LD16 + c] = c < n ? g[r * 41 + go + c] : 0.f;
+    buf[r * LD16 + 16 + c] = 0.f;
+    __syncthreads();
+  } else if (d.pre == PRE_LATENT) {
+    const float* src = smem + d.src_off;
+    const int r = tid >> 4, c = tid & 15;
+    buf[r * LD16 + c] = src[r * LD16 + PT_NPROP + c] + g[r * 41 + 20 + c];
+    buf[r * LD16 + 16 + c] = c < 4 ? src[r * LD16 + PT_NPROP + 16 + c] + g[r * 41 + 36 + c] : 0.f;      // k padding: zeros up to column 32
+    __syncthreads();
+  }
+  {
+    const int c = (tid & 63) * 2, rb = tid >> 6;
+    if (c < d.n) {
+      float* bp = buf + rb * LD16 + c;
+      float* dzp = dz_stash + sidx(num_rows, d.dcol, d.dw, row0 + rb, c);
+      const bool elu = d.act == ACT_ELU;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = row0 + rb + 4 * j < num_rows;
+        const float dx = elu ? act_deriv<ACT_ELU>(f.a[j].x) : act_deriv<ACT_TANH>(f.a[j].x);
+        const float dy = elu ? act_deriv<ACT_ELU>(f.a[j].y) : act_deriv<ACT_TANH>(f.a[j].y);
+        float2 v = *reinterpret_cast<const float2*>(bp + 4 * j * LD16);
+        v.x *= dx; v.y *= dy;
+        if (!ok) v = make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(bp + 4 * j * LD16) = v;
+        if (ok) *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd16_kernel(PolicyParams P, FOpTable16 FT, BwdTable BT,
+                                                                                       const float* __restrict__ blob, PpoBatch Bt,
+                                                                                       float* __restrict__ act_stash, float* __restrict__ dz_stash,
+                                                                                       float* __restrict__ dstd_partial, float* __restrict__ loss_partial) {
+  __shared__ __attribute__((aligned(16))) float smem[H_END];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, row0 = tile * R16, B = Bt.B;
+  const float* bias = blob + WPACK16_BIAS_OFF;
+  PSTAMP(0);
+  // gather obs[idx, :100] into x (and the x slab of the stash); the columns 100..127 (k padding of the first layers) zero
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e4 = tid + k * PT_THREADS;
+    const int r = e4 >> 5, c = (e4 & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < B && c < 100) {
+      v = *reinterpret_cast<const float4*>(Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS + c);
+      *reinterpret_cast<float4*>(act_stash + sidx(B, A_X, 100, row0 + r, c)) = v;
+    }
+    *reinterpret_cast<float4*>(smem + H_X + r * LD16 + c) = v;
+  }
+  __syncthreads();
+  PSTAMP(1);
+  {
+    float w[66];
+    load16(w, FT.op[0].d, blob, bias);
+#pragma unroll 1
+    for (int i = 0; i < NFOPS; ++i) {
+      const FOp16& o = FT.op[i];
+      if (o.type == FOP_RELOAD) {
+        __threadfence_block();
+        __syncthreads();
+        float4 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
+          v[j] = (row0 + r < B) ? *reinterpret_cast<const float4*>(act_stash + sidx(B, o.rcol, 128, row0 + r, c)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
+          *reinterpret_cast<float4*>(smem + o.rdst + r * LD16 + c) = v[j];
+        }
+        __syncthreads();
+      } else if (o.type == FOP_COPY_PROP) {
+        for (int e = tid; e < R16 * (PT_NPROP / 4); e += PT_THREADS) {
+          const int r = e / (PT_NPROP / 4), c = (e - r * (PT_NPROP / 4)) * 4;
+          *reinterpret_cast<float4*>(smem + H_A1 + r * LD16 + c) = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
+        }
+        __syncthreads();
+      } else {
+        const int nx = o.next_layer;
+        run16(w, o.d, smem, act_stash, row0, B, [&]() { if (nx >= 0) load16(w, FT.op[nx].d, blob, bias); });
+      }
+    }
+  }
+  PSTAMP(2);
+  __threadfence_block();
+  __syncthreads();
+  // z = [prop, latent] slab (the backbone's input, for its weight gradient)
+  for (int e = tid; e < R16 * 24; e += PT_THREADS) {
+    const int r = e / 24, c = (e - r * 24) * 4;
+    if (row0 + r < B) {
+      float4 v;
+      if (c < PT_NPROP) v = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
+      else v = *reinterpret_cast<const float4*>(act_stash + sidx(B, A_LAT, 20, row0 + r, c - PT_NPROP));
+      *reinterpret_cast<float4*>(act_stash + sidx(B, A_Z, 100, row0 + r, c)) = v;
+    }
+  }
+  __syncthreads();
+  const float* outv = smem + H_OUTV;
+  float* gbuf = smem + H_G;
+  PSTAMP(3);
+  if (tid < 64) {
+    const int r = tid & 15;
+    const bool valid = (tid < R16) && (row0 + r < B);
+    float surr = 0.f, vls = 0.f, preg = 0.f;
+    float dsd[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dsd[j] = 0.f;
+    if (valid) {
+      const size_t src = (size_t)Bt.idx[row0 + r];
+      const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
+      float lp[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const float mu = outv[r * 21 + j], sd = P.std[j];
+        const float d = Bt.actions[src * 18 + j] - mu;
+        lp[j < PT_NLEG ? 0 : 1] += -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+      }
+      const float adv0 = Bt.advantages[src * 2], adv1 = Bt.advantages[src * 2 + 1];
+      const float mixed[2] = {adv0 + Bt.mixing * adv1, adv1 + Bt.mixing * adv0};               // PPO:199-201
+      float dlp[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float ratio = expf(lp[c] - Bt.old_logp[src * 2 + c]);                               // PPO:202
+        const float rc = fminf(fmaxf(ratio, 1.f - Bt.clip), 1.f + Bt.clip);
+        const float s1 = -mixed[c] * ratio, s2 = -mixed[c] * rc;                                  // PPO:203-205
+        surr += fmaxf(s1, s2);
+        const bool inside = (ratio >= 1.f - Bt.clip) && (ratio <= 1.f + Bt.clip);
+        const float dr = (inside || s1 > s2) ? -mixed[c] : 0.f;
+        dlp[c] = inv2B * dr * ratio;
+        const float v = outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];    // PPO:209-216
+        float dv;
+        if (Bt.use_clipped_value_loss) {
+          const float dlt = v - ov;
+          const float vc = ov + fminf(fmaxf(dlt, -Bt.clip), Bt.clip);
+          const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+          vls += fmaxf(l1, l2);
+          const float m = (dlt >= -Bt.clip && dlt <= Bt.clip) ? 1.f : 0.f;
+          const float g1 = 2.f * (v - R), g2 = 2.f * (vc - R) * m;
+          dv = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+        } else {
+          vls += (R - v) * (R - v);
+          dv = 2.f * (v - R);
+        }
+        gbuf[r * 41 + 18 + c] = Bt.value_coef * inv2B * dv;
+      }
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const float mu = outv[r * 21 + j], sd = P.std[j];
+        const float d = Bt.actions[src * 18 + j] - mu;
+        const float gl = dlp[j < PT_NLEG ? 0 : 1];
+        gbuf[r * 41 + j] = gl * d / (sd * sd);
+        dsd[j] = gl * (d * d / (sd * sd * sd) - 1.f / sd);
+      }
+      float dl[20], nrm = 0.f;                                                                    // ROA regulariser PPO:174-179
+#pragma unroll
+      for (int k = 0; k < 20; ++k) {
+        dl[k] = act_stash[sidx(B, A_LAT, 20, row0 + r, k)] - Bt.hist_latent[src * 20 + k];
+        nrm += dl[k] * dl[k];
+      }
+      nrm = sqrtf(nrm);
+      preg = nrm;
+      const float sc = (nrm > 0.f) ? Bt.roa_coef * invB / nrm : 0.f;
+#pragma unroll
+      for (int k = 0; k < 20; ++k) gbuf[r * 41 + 20 + k] = sc * dl[k];
+    } else if (tid < R16) {
+      for (int k = 0; k < 40; ++k) gbuf[r * 41 + k] = 0.f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      surr += __shfl_xor(surr, off); vls += __shfl_xor(vls, off); preg += __shfl_xor(preg, off);
+#pragma unroll
+      for (int j = 0; j < 18; ++j) dsd[j] += __shfl_xor(dsd[j], off);
+    }
+    if (tid == 0) {
+      loss_partial[tile * 3 + 0] = surr; loss_partial[tile * 3 + 1] = vls; loss_partial[tile * 3 + 2] = preg;
+#pragma unroll
+      for (int j = 0; j < 18; ++j) dstd_partial[tile * 18 + j] = dsd[j];
+    }
+  }
+  __syncthreads();
+  if (tid < R16 && row0 + tid < B) {
+    dz_stash[sidx(B, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
+    dz_stash[sidx(B, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
+  }
+  {
+    float w[66];
+    BwdFetch16 f;
+    f32x4 saved0 = {0.f, 0.f, 0.f, 0.f}, saved1 = {0.f, 0.f, 0.f, 0.f};
+    PSTAMP(4);
+    bwd_load16(w, BT.s[0], blob);
+    bwd_fetch16(f, BT.s[0], act_stash, row0, B);
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
+    for (int st = 0; st < NBWD; ++st) {
+      const BwdDesc& d = BT.s[st];
+      bwd_pre_act16(d, f, smem, dz_stash, row0, B);
+      const bool mma = d.has_mma && wave < d.nblkT;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      if (d.add_saved) { acc0 = saved0; acc1 = saved1; }
+      if (mma) mfma_chain16(smem + d.buf_off + (lane & 15) * LD16 + (lane >> 4), w, (d.out_dim + 31) >> 5, acc0, acc1);
+      if (st + 1 < NBWD) { bwd_load16(w, BT.s[st + 1], blob); bwd_fetch16(f, BT.s[st + 1], act_stash, row0, B); }
+      if (mma) {
+        if (d.save_out) { saved0 = acc0; saved1 = acc1; }
+        else {
+          const int col = wave * 32 + (lane & 15);
+          float* out = smem + d.out_off + 4 * (lane >> 4) * LD16 + col;
+          if (col < d.in_dim) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r * LD16] = acc0[r];
+          }
+          if (col + 16 < d.in_dim) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r * LD16 + 16] = acc1[r];
+          }
+        }
+      }
+      if (d.has_mma) __syncthreads();
+      PSTAMP(5 + st);
+    }
+  }
+}
+
 // ---- weight and bias gradients -------------------------------------------------------------------
 // dW_l[o][i] = sum_rows dZ_l[row][o] * A_{l-1}[row][i], db_l[o] = sum_rows dZ_l[row][o]. grid = (splits, layers);
 // a workgroup owns a row range of one layer, wave w the output rows [32w, 32w+32). Both MFMA operands are read
@@ -684,6 +1013,10 @@ static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, 
 #ifndef PPO_NSPLIT
 #define PPO_NSPLIT 48
 #endif
+#ifndef PPO_TILE16
+#define PPO_TILE16 1        // 16-row tiles (ppo_fwd_bwd16_kernel); 0: the 32-row kernel, kept for A/B runs
+#endif
+#define PPO_WPACK_FLOATS (WPACK_FLOATS > WPACK16_FLOATS ? WPACK_FLOATS : WPACK16_FLOATS)
 
 extern "C" int wbc_ppo_grad_floats(void) {
   int n = 0;
@@ -693,8 +1026,8 @@ extern "C" int wbc_ppo_grad_floats(void) {
 extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
-  const size_t tiles = (size_t)(B + PT_ROWS - 1) / PT_ROWS;
-  return (size_t)B * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)WPACK_FLOATS + 4;
+  const size_t tiles = (size_t)(B + R16 - 1) / R16;
+  return (size_t)B * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
 }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
@@ -717,7 +1050,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
       B <= 0 || fill_params(params, &P))
     return -1;
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = (B + PT_ROWS - 1) / PT_ROWS;
+  const int tile_rows = PPO_TILE16 ? R16 : PT_ROWS;
+  const int tiles = (B + tile_rows - 1) / tile_rows;
   const int ng = wbc_ppo_grad_floats();
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)B * A_LD;
@@ -725,12 +1059,17 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   float* loss_partial = dstd_partial + (size_t)tiles * 18;
   float* wpart = loss_partial + (size_t)tiles * 3;
   float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
-  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, make_pack_table(), wpack);
+  if (PPO_TILE16) hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 2), dim3(256), 0, st, P, make_pack16_table(), wpack);
+  else hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, make_pack_table(), wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
-  const FOpTable FT = make_fop_table(kStashCols);
-  const BwdTable BT = make_bwd_table(P);
-  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, FT, BT, wpack, Bt, act_stash, dz_stash, dstd_partial, loss_partial);
+  if (PPO_TILE16) {
+    hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fop_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
+                       act_stash, dz_stash, dstd_partial, loss_partial);
+  } else {
+    hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fop_table(kStashCols), make_bwd_table(P), wpack, Bt, act_stash,
+                       dz_stash, dstd_partial, loss_partial);
+  }
   WgradTable tab;
   int off = 0;
   for (int l = 0; l < NLAYERS; ++l) {
