@@ -322,16 +322,31 @@ static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem,
 }
 
 // ==== 16-row tiles: v_mfma_f32_16x16x4_f32 ===================================================================================
-// A: lane L supplies A[row = L & 15][k = L >> 4]; B: B[k = L >> 4][col = L & 15]; C/D: 4 registers, D[row = 4 (L >> 4) + r][col = L & 15].
-// A wave owns 32 output columns as two 16-column halves h. Pack ("pack16"): lane L's float4 for k-step pair kp holds
-// W[cb*32 + 16h + (L&15)][4 ks + (L>>4)] for (ks, h) = (2kp,0), (2kp,1), (2kp+1,0), (2kp+1,1); the transposed pack ("packT16",
-// dgrad: k over the layer's outputs, columns over its inputs) holds W[4 ks + (L>>4)][cb*32 + 16h + (L&15)]. Blob layout:
-// [pack16 of all layers | packT16 of all layers | biases].
+// A: lane L supplies A[row = L & 15][k-slot g = L >> 4]; B: B[g][col = L & 15]; C/D: 4 registers, D[row = 4 g + r][col = L & 15].
+// A wave owns 32 output columns as two 16-column halves h. The reduction index is cut into chunks of 32 (zero-padded): in
+// chunk c, k-step j (0..7) and slot g stand for k = 32 c + 8 g + j, so that a lane's 8 A operands of a chunk are 8 consecutive
+// LDS floats (two ds_read_b128, conflict-free at row stride 132). Pack ("pack16"), per 32-column block cb contiguous:
+// float4 [cb][kp][lane] = W[cb*32 + 16h + (L&15)][k(ks, g)] for (ks, h) = (2kp,0), (2kp,1), (2kp+1,0), (2kp+1,1); the transposed
+// pack ("packT16", dgrad: k over the layer's outputs, columns over its inputs) holds W[k(ks, g)][cb*32 + 16h + (L&15)].
+// Blob layout: [pack16 of all layers | packT16 of all layers | biases].
 #define R16 16
-#define LD16 132              // LDS row stride: (4 row + k) mod 64 is conflict-free for the 16 x 4 operand read
+#define LD16 132
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also waits for every outstanding global access
+// (s_waitcnt vmcnt(0)): at each layer that drained the operand prefetch and stalled on the acknowledgement of the stash
+// stores (measured: ~8 k cycles per 128x128 layer against a 2 k-cycle MFMA chain). Use __syncthreads() wherever another
+// wave's GLOBAL writes are read back.
+// Which 32-column block a wave works on. Narrow layers (heads, latent) only occupy the first blocks; with WBC_ROLE_ROT the
+// block -> wave assignment rotates with the workgroup's dispatch round so that this extra work is not always on the same SIMD.
+static __device__ __forceinline__ int wave_role() {
+#ifdef WBC_ROLE_ROT
+  return ((threadIdx.x >> 6) + (blockIdx.x >> 8)) & 3;
+#else
+  return threadIdx.x >> 6;
+#endif
+}
+#define LBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// k is zero-padded to chunks of 8 k-steps (32 values = 4 k-step pairs): the MFMA chain branches once per chunk, not per k-step
 __host__ __device__ constexpr int l16_floats(int l) { return (layer_in(l) + 31) / 32 * 4 * layer_nblk(l) * 256; }
 __host__ __device__ constexpr int l16T_floats(int l) { return (layer_out(l) + 31) / 32 * 4 * layer_nblkT(l) * 256; }
 __host__ __device__ constexpr int l16_sum(int l) { return l < 0 ? 0 : l16_sum(l - 1) + l16_floats(l); }
@@ -345,7 +360,7 @@ constexpr int kWpack16Bias = kWpack16Fwd + l16T_sum(NLAYERS - 1);   // would be 
 
 struct Desc16 {               // one forward layer on a 16-row tile
   int woff, boff, nch, nblk, n, in_off, out_off, ldo, act;      // pack16 offset, bias offset, k chunks (of 32 inputs; the LDS columns up to
-                                                                 // 32 nch must be finite), 32-col blocks, outputs, LDS offsets
+                                                                 // 32 nch must be finite), 32-col blocks, outputs, LDS offsets (in_off % 4 == 0)
   int scol, sw;                                                  // stash slab (start column, width) or scol < 0
 };
 struct Tab16 { Desc16 l[NLAYERS]; };
@@ -376,9 +391,9 @@ static __global__ void wbc_pack16_kernel(PolicyParams P, Pack16Table T, float* _
   const int off = tr ? T.offT[l] : T.off[l], total = nkp * nblk * 256;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int j = e & 3, lane = (e >> 2) & 63, frag = e >> 8;
-    const int cb = frag % nblk, kp = frag / nblk;
+    const int kp = frag % nkp, cb = frag / nkp;
     const int ks = 2 * kp + (j >> 1), h = j & 1;
-    const int c = cb * 32 + 16 * h + (lane & 15), k = 4 * ks + (lane >> 4);
+    const int c = cb * 32 + 16 * h + (lane & 15), k = 32 * (ks >> 3) + 8 * (lane >> 4) + (ks & 7);
     float v = 0.f;
     if (c < cdim && k < kdim) v = tr ? W[(size_t)k * K + c] : W[(size_t)c * K + k];
     blob[off + e] = v;
@@ -387,78 +402,119 @@ static __global__ void wbc_pack16_kernel(PolicyParams P, Pack16Table T, float* _
     for (int e = threadIdx.x; e < N; e += blockDim.x) blob[WPACK16_BIAS_OFF + T.boff[l] + e] = bsrc[e];
 }
 
-// 16 float4 of one operand set: `ub` = the layer's pack (uniform), fragment stride `nblk * 64` float4 per k-step pair
-static __device__ __forceinline__ void load_ops16(float (&w)[66], const float4* __restrict__ ub, int nblk, int nch, int cb) {
+// 16 float4 of one operand set for column block `cb` (wave-uniform) of a pack with `nch` chunks: scalar base + lane offset
+// addressing, all 16 loads unconditional (chunks past nch re-read chunk 0; see load_operands)
+static __device__ __forceinline__ void load_ops16(float (&w)[66], const float* __restrict__ pack, int nch, int cb) {
   const int lane = threadIdx.x & 63;
   const int nkp = nch * 4;
+  const float4* base = reinterpret_cast<const float4*>(pack) + __builtin_amdgcn_readfirstlane(cb * nkp * 64);
 #pragma unroll
   for (int kp = 0; kp < 16; ++kp) {
-    const float4 v = (ub + (kp < nkp ? kp : 0) * (nblk * 64))[cb * 64 + lane];      // unconditional (see load_operands)
+    const float4 v = (base + (kp < nkp ? kp * 64 : 0))[lane];
     w[4 * kp] = v.x; w[4 * kp + 1] = v.y; w[4 * kp + 2] = v.z; w[4 * kp + 3] = v.w;
   }
 }
 
 // operands of forward layer d for this wave + the two bias values of its column halves (w[64], w[65])
 static __device__ __forceinline__ void load16(float (&w)[66], const Desc16& d, const float* __restrict__ pack16, const float* __restrict__ bias) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_ops16(w, reinterpret_cast<const float4*>(pack16 + d.woff), d.nblk, d.nch, wave < d.nblk ? wave : 0);
+  const int lane = threadIdx.x & 63, wave = wave_role();
+  load_ops16(w, pack16 + d.woff, d.nch, wave < d.nblk ? wave : 0);
   const int c0 = wave * 32 + (lane & 15);
   w[64] = bias[d.boff + (c0 < d.n ? c0 : 0)];
   w[65] = bias[d.boff + (c0 + 16 < d.n ? c0 + 16 : 0)];
 }
 
-// acc_h += sum_{ks < 8 nch} A[.., 4 ks + (L>>4)] * w[2 ks + h] for both column halves; A from LDS (ap = this lane's row / k
-// offset). One uniform branch per chunk of 8 k-steps: a branch per MFMA costs about as much as the 8-pass MFMA itself.
+// acc_h += sum over nch chunks of A * w for both column halves. ap = in + (L & 15) * LD16 + 8 (L >> 4) (16-byte aligned).
+// The next chunk's A operands are read before this chunk's 16 MFMAs are issued (a chunk past the end re-reads the last one).
 static __device__ __forceinline__ void mfma_chain16(const float* ap, const float (&w)[66], int nch, f32x4& acc0, f32x4& acc1) {
+  float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c < nch) {
-      float a[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = ap[4 * (c * 8 + j)];
+      const float* np = ap + 32 * (c + 1 < nch ? c + 1 : c);
+      const float4 n0 = *reinterpret_cast<const float4*>(np), n1 = *reinterpret_cast<const float4*>(np + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * (c * 8 + j)], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * (c * 8 + j) + 1], acc1, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = n0; a1 = n1;
     }
   }
 }
 
-static __device__ __forceinline__ float act16(float x, int act) {
-  if (act == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;     // abs error <= 1 ulp(1.0); the derivative uses the stored value
-  if (act == ACT_TANH) return tanhf(x);
+template <int ACT>
+static __device__ __forceinline__ float act16(float x) {
+  if (ACT == ACT_ELU) {          // branch-free; exp via v_exp_f32 (abs error <= 1 ulp(1.0); the derivative uses the stored value)
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f) - 1.f;
+    return x > 0.f ? x : e;
+  }
+  if (ACT == ACT_TANH) return tanhf(x);
   return x;
 }
 
-// Forward layer d on a 16-row tile: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the slab-major
-// stash (`num_rows` = its total rows). `after_mfma` runs once `w` is no longer read. Ends with a barrier.
-template <typename Hook = NoHook>
-static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int num_rows,
-                                             Hook after_mfma = Hook()) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float b0 = w[64], b1 = w[65];
-  if (wave < d.nblk) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    mfma_chain16(smem + d.in_off + (lane & 15) * LD16 + (lane >> 4), w, d.nch, acc0, acc1);
-    after_mfma();
-    const int c0 = wave * 32 + (lane & 15), rb = 4 * (lane >> 4);
-    const bool st = stash != nullptr && d.scol >= 0;
+// Addresses of a lane's outputs, computed BEFORE the operand prefetch is issued: address arithmetic after it (the compiler
+// uses 64-bit multiply-adds whose unused high half may alias a register that a prefetch load is still writing) made the
+// epilogue wait for every outstanding load.
+struct Epi16 { uint32_t lds[4], st[4]; };
+static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d, int row0) {
+  const int lane = threadIdx.x & 63, wave = wave_role();
+  const int c0 = wave * 32 + (lane & 15), rb = 4 * (lane >> 4);
+  Epi16 e;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int col = c0 + 16 * h;
-      if (col < d.n) {
-        float* sp = st ? stash + (size_t)d.scol * num_rows + (size_t)(row0 + rb) * d.sw + col : nullptr;
+  for (int r = 0; r < 4; ++r) {
+    e.lds[r] = (uint32_t)(d.out_off + (rb + r) * d.ldo + c0);
+    e.st[r] = (uint32_t)((row0 + rb + r) * d.sw + c0);
+  }
+  return e;
+}
+
+// epilogue of one layer: act(acc + bias) to LDS and, when `sbase` != nullptr, to the stash slab (element (row, col) at
+// sbase[row * sw + col]; slabs are padded to whole tiles and every tile row is stored: a predicated store would make every
+// later s_waitcnt vmcnt conservative)
+template <int ACT>
+static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4& acc0, const f32x4& acc1, float b0, float b1,
+                                                  float* smem, float* __restrict__ sbase) {
+  const int lane = threadIdx.x & 63, wave = wave_role();
+  const int c0 = wave * 32 + (lane & 15);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = act16((h ? acc1[r] : acc0[r]) + (h ? b1 : b0), d.act);
-          smem[d.out_off + (rb + r) * d.ldo + col] = v;
-          if (st && row0 + rb + r < num_rows) sp[r * d.sw] = v;
-        }
+  for (int h = 0; h < 2; ++h) {
+    if (c0 + 16 * h < d.n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = act16<ACT>((h ? acc1[r] : acc0[r]) + (h ? b1 : b0));
+        smem[e.lds[r] + 16 * h] = v;
+        if (sbase) sbase[e.st[r] + 16 * h] = v;
       }
     }
-  } else {
-    after_mfma();
   }
-  __syncthreads();
+}
+
+// Forward layer d on a 16-row tile: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the slab-major
+// stash whose slabs have `slab_rows` rows. `after_mfma` runs once `w` is no longer read (one call site: the operand
+// registers it refills keep their place). Ends with a barrier.
+template <typename Hook = NoHook>
+static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int num_rows,
+                                             int slab_rows, Hook after_mfma = Hook(), int dbg_l = 0) {
+  const int lane = threadIdx.x & 63, wave = wave_role();
+  const bool active = wave < d.nblk;
+  LSTAMP(dbg_l, 0);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if (active) mfma_chain16(smem + d.in_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, d.nch, acc0, acc1);
+  const float b0 = w[64], b1 = w[65];
+  const Epi16 e = epilogue16_offsets(d, row0);
+  float* sbase = (stash != nullptr && d.scol >= 0) ? stash + (size_t)d.scol * slab_rows : nullptr;
+  LSTAMP(dbg_l, 1);
+  after_mfma();
+  if (active) {
+    if (d.act == ACT_ELU) epilogue16<ACT_ELU>(d, e, acc0, acc1, b0, b1, smem, sbase);
+    else if (d.act == ACT_TANH) epilogue16<ACT_TANH>(d, e, acc0, acc1, b0, b1, smem, sbase);
+    else epilogue16<ACT_NONE>(d, e, acc0, acc1, b0, b1, smem, sbase);
+  }
+  LSTAMP(dbg_l, 2);
+  LBAR();
+  LSTAMP(dbg_l, 3);
 }

@@ -46,6 +46,7 @@ struct PpoBatch {                 // flat [T*N, ...] rollout tensors + the minib
   const float* hist_latent;       // [TN, 20]  history-encoder latent of every stored row
   const int64_t* idx;             // [B]
   int B;
+  int Bs;                         // rows of a stash slab (>= B; the 16-row kernel pads to whole tiles and stores every tile row)
   float clip, value_coef, mixing, roa_coef;
   int use_clipped_value_loss;
 };
@@ -448,7 +449,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 #define H_X 0
 #define H_A0 (R16 * LD16)
 #define H_A1 (H_A0 + R16 * LD16)
-#define H_OUTV (H_A1 + R16 * LD16)
+#define H_A2 (H_A1 + R16 * LD16)
+#define H_OUTV (H_A2 + R16 * LD16)
 #define H_END (H_OUTV + R16 * 21)
 #define H_G H_X
 #ifndef PPO16_OCC
@@ -456,39 +458,31 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 #endif
 static_assert(R16 * 41 <= R16 * LD16, "g fits in x");
 
-struct FOp16 { int type, next_layer; Desc16 d; int rcol, rdst; };
-struct FOpTable16 { FOp16 op[NFOPS]; };
-static FOpTable16 make_fop_table16(const int* stash_cols) {
-  FOpTable16 t;
+// Forward order: the 35 KB plan has three activation buffers, so both backbone outputs stay in LDS for their second head (no
+// stash reload) and the forward is a plain loop over the 16 layers; the proprio block is copied next to where priv2 puts the
+// latent while x is loaded.
+static Tab16 make_fwd_table16(const int* stash_cols) {
+  Tab16 t;
   int i = 0;
   auto layer = [&](int l, int in_off, int out_off) {
-    t.op[i] = FOp16{FOP_LAYER, -1, make_desc16(l, in_off, out_off, stash_cols[l], stash_cols[l] >= 0 ? a_slab_w(stash_cols[l]) : 0), 0, 0};
-    ++i;
+    t.l[i++] = make_desc16(l, in_off, out_off, stash_cols[l], stash_cols[l] >= 0 ? a_slab_w(stash_cols[l]) : 0);
   };
-  auto other = [&](int type, int col, int dst) { t.op[i] = FOp16{}; t.op[i].type = type; t.op[i].rcol = col; t.op[i].rdst = dst; ++i; };
-  layer(L_CBB, H_X, H_A0);
-  layer(L_CLEG0, H_A0, H_A1);
-  layer(L_CLEG2, H_A1, H_A0);
-  layer(L_CLEG4, H_A0, H_OUTV + 18);
-  other(FOP_RELOAD, A_CB, H_A0);
-  layer(L_CARM0, H_A0, H_A1);
-  layer(L_CARM2, H_A1, H_A0);
-  layer(L_CARM4, H_A0, H_OUTV + 19);
-  other(FOP_COPY_PROP, 0, 0);
   layer(L_PRIV0, H_X + PT_NPROP, H_A0);
   layer(L_PRIV2, H_A0, H_A1 + PT_NPROP);
   layer(L_BB, H_A1, H_A0);
   layer(L_LEG0, H_A0, H_A1);
-  layer(L_LEG2, H_A1, H_A0);
-  layer(L_LEG4, H_A0, H_OUTV);
-  other(FOP_RELOAD, A_BB, H_A0);
+  layer(L_LEG2, H_A1, H_A2);
+  layer(L_LEG4, H_A2, H_OUTV);
   layer(L_ARM0, H_A0, H_A1);
-  layer(L_ARM2, H_A1, H_A0);
-  layer(L_ARM4, H_A0, H_OUTV + PT_NLEG);
-  for (int a = 0; a < NFOPS; ++a) {
-    t.op[a].next_layer = -1;
-    for (int b2 = a + 1; b2 < NFOPS; ++b2) if (t.op[b2].type == FOP_LAYER) { t.op[a].next_layer = b2; break; }
-  }
+  layer(L_ARM2, H_A1, H_A2);
+  layer(L_ARM4, H_A2, H_OUTV + PT_NLEG);
+  layer(L_CBB, H_X, H_A0);
+  layer(L_CLEG0, H_A0, H_A1);
+  layer(L_CLEG2, H_A1, H_A2);
+  layer(L_CLEG4, H_A2, H_OUTV + 18);
+  layer(L_CARM0, H_A0, H_A1);
+  layer(L_CARM2, H_A1, H_A2);
+  layer(L_CARM4, H_A2, H_OUTV + 19);
   return t;
 }
 
@@ -506,18 +500,19 @@ static BwdTable make_bwd_table16(const PolicyParams& P) {
 }
 
 static __device__ __forceinline__ void bwd_load16(float (&w)[66], const BwdDesc& d, const float* __restrict__ blob) {
-  const int wave = threadIdx.x >> 6;
+  const int wave = wave_role();
   const int nblk = d.has_mma ? d.nblkT : 1;
-  load_ops16(w, reinterpret_cast<const float4*>(blob + d.woffT), nblk, (d.out_dim + 31) >> 5, wave < nblk ? wave : 0);
+  load_ops16(w, blob + d.woffT, (d.out_dim + 31) >> 5, wave < nblk ? wave : 0);
 }
 
 // thread t owns columns c, c+1 with c = 2 (t & 63) of rows (t >> 6) + 4 j, j < 4
 struct BwdFetch16 { float2 a[4]; float wv; };
-static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows) {
+static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows,
+                                                   int Bs) {
   const int tid = threadIdx.x;
   const int c = (tid & 63) * 2, rb = tid >> 6;
   const bool c_ok = c < d.n;
-  const float* base = act_stash + sidx(num_rows, d.acol, d.aw, row0 + rb, c_ok ? c : 0);
+  const float* base = act_stash + sidx(Bs, d.acol, d.aw, row0 + rb, c_ok ? c : 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const bool ok = c_ok && row0 + rb + 4 * j < num_rows;
@@ -529,7 +524,7 @@ static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc&
 }
 
 static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const BwdFetch16& f, float* smem, float* __restrict__ dz_stash,
-                                                     int row0, int num_rows) {
+                                                     int row0, int num_rows, int Bs) {
   const int tid = threadIdx.x;
   float* buf = smem + d.buf_off;
   const float* g = smem + H_G;
@@ -538,26 +533,26 @@ static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const Bwd
     const int c = tid & 127, r0 = tid >> 7;
 #pragma unroll
     for (int k = 0; k < 8; ++k) buf[(r0 + 2 * k) * LD16 + c] = g[(r0 + 2 * k) * 41 + gi] * f.wv;
-    __syncthreads();
+    LBAR();
   } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
     // the GEMM's k runs over the head's outputs in chunks of 32: the columns up to 32 must be finite (zeros)
     const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
     const int r = tid >> 4, c = tid & 15;                            // 16 threads per row, n <= 12
     buf[r * LD16 + c] = c < n ? g[r * 41 + go + c] : 0.f;
     buf[r * LD16 + 16 + c] = 0.f;
-    __syncthreads();
+    LBAR();
   } else if (d.pre == PRE_LATENT) {
     const float* src = smem + d.src_off;
     const int r = tid >> 4, c = tid & 15;
     buf[r * LD16 + c] = src[r * LD16 + PT_NPROP + c] + g[r * 41 + 20 + c];
     buf[r * LD16 + 16 + c] = c < 4 ? src[r * LD16 + PT_NPROP + 16 + c] + g[r * 41 + 36 + c] : 0.f;      // k padding: zeros up to column 32
-    __syncthreads();
+    LBAR();
   }
   {
     const int c = (tid & 63) * 2, rb = tid >> 6;
     if (c < d.n) {
       float* bp = buf + rb * LD16 + c;
-      float* dzp = dz_stash + sidx(num_rows, d.dcol, d.dw, row0 + rb, c);
+      float* dzp = dz_stash + sidx(Bs, d.dcol, d.dw, row0 + rb, c);
       const bool elu = d.act == ACT_ELU;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -568,20 +563,21 @@ static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const Bwd
         v.x *= dx; v.y *= dy;
         if (!ok) v = make_float2(0.f, 0.f);
         *reinterpret_cast<float2*>(bp + 4 * j * LD16) = v;
-        if (ok) *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;
+        *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;       // unconditional (padded slabs): a predicated store would make
+                                                                            // every later s_waitcnt vmcnt conservative
       }
     }
-    __syncthreads();
+    LBAR();
   }
 }
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd16_kernel(PolicyParams P, FOpTable16 FT, BwdTable BT,
+extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd16_kernel(PolicyParams P, Tab16 FT, BwdTable BT,
                                                                                        const float* __restrict__ blob, PpoBatch Bt,
                                                                                        float* __restrict__ act_stash, float* __restrict__ dz_stash,
                                                                                        float* __restrict__ dstd_partial, float* __restrict__ loss_partial) {
   __shared__ __attribute__((aligned(16))) float smem[H_END];
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x, row0 = tile * R16, B = Bt.B;
+  const int tile = blockIdx.x, row0 = tile * R16, B = Bt.B, Bs = Bt.Bs;
   const float* bias = blob + WPACK16_BIAS_OFF;
   PSTAMP(0);
   // gather obs[idx, :100] into x (and the x slab of the stash); the columns 100..127 (k padding of the first layers) zero
@@ -590,61 +586,51 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
     const int e4 = tid + k * PT_THREADS;
     const int r = e4 >> 5, c = (e4 & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < B && c < 100) {
-      v = *reinterpret_cast<const float4*>(Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS + c);
-      *reinterpret_cast<float4*>(act_stash + sidx(B, A_X, 100, row0 + r, c)) = v;
+    if (c < 100) {
+      v = *reinterpret_cast<const float4*>(Bt.obs + (size_t)Bt.idx[min(row0 + r, B - 1)] * PT_NOBS + c);
+      if (row0 + r >= B) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_X, 100, row0 + r, c)) = v;
     }
     *reinterpret_cast<float4*>(smem + H_X + r * LD16 + c) = v;
+    if (c < PT_NPROP) *reinterpret_cast<float4*>(smem + H_A1 + r * LD16 + c) = v;      // proprio block of the backbone's input
   }
-  __syncthreads();
+  LBAR();
   PSTAMP(1);
+#ifdef PPO16_TWO_SETS
   {
-    float w[66];
-    load16(w, FT.op[0].d, blob, bias);
+    float wa[66], wb[66];
+    load16(wa, FT.l[0], blob, bias);
 #pragma unroll 1
-    for (int i = 0; i < NFOPS; ++i) {
-      const FOp16& o = FT.op[i];
-      if (o.type == FOP_RELOAD) {
-        __threadfence_block();
-        __syncthreads();
-        float4 v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
-          v[j] = (row0 + r < B) ? *reinterpret_cast<const float4*>(act_stash + sidx(B, o.rcol, 128, row0 + r, c)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
-          *reinterpret_cast<float4*>(smem + o.rdst + r * LD16 + c) = v[j];
-        }
-        __syncthreads();
-      } else if (o.type == FOP_COPY_PROP) {
-        for (int e = tid; e < R16 * (PT_NPROP / 4); e += PT_THREADS) {
-          const int r = e / (PT_NPROP / 4), c = (e - r * (PT_NPROP / 4)) * 4;
-          *reinterpret_cast<float4*>(smem + H_A1 + r * LD16 + c) = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
-        }
-        __syncthreads();
-      } else {
-        const int nx = o.next_layer;
-        run16(w, o.d, smem, act_stash, row0, B, [&]() { if (nx >= 0) load16(w, FT.op[nx].d, blob, bias); });
-      }
+    for (int i = 0; i < NLAYERS; i += 2) {
+      load16(wb, FT.l[i + 1], blob, bias);
+      run16(wa, FT.l[i], smem, act_stash, row0, B, Bs, NoHook(), i);
+      load16(wa, FT.l[i + 2 < NLAYERS ? i + 2 : i], blob, bias);
+      run16(wb, FT.l[i + 1], smem, act_stash, row0, B, Bs, NoHook(), i + 1);
     }
   }
+#else
+  {
+    float w[66];
+    load16(w, FT.l[0], blob, bias);
+#pragma unroll 1
+    for (int i = 0; i < NLAYERS; ++i) {
+      const int nx = i + 1 < NLAYERS ? i + 1 : i;        // (the last layer re-requests its own operands: no conditional refill)
+      run16(w, FT.l[i], smem, act_stash, row0, B, Bs, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
+    }
+  }
+#endif
   PSTAMP(2);
   __threadfence_block();
   __syncthreads();
   // z = [prop, latent] slab (the backbone's input, for its weight gradient)
   for (int e = tid; e < R16 * 24; e += PT_THREADS) {
     const int r = e / 24, c = (e - r * 24) * 4;
-    if (row0 + r < B) {
-      float4 v;
-      if (c < PT_NPROP) v = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
-      else v = *reinterpret_cast<const float4*>(act_stash + sidx(B, A_LAT, 20, row0 + r, c - PT_NPROP));
-      *reinterpret_cast<float4*>(act_stash + sidx(B, A_Z, 100, row0 + r, c)) = v;
-    }
+    float4 v;
+    if (c < PT_NPROP) v = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
+    else v = *reinterpret_cast<const float4*>(act_stash + sidx(Bs, A_LAT, 20, row0 + r, c - PT_NPROP));
+    *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_Z, 100, row0 + r, c)) = v;
   }
-  __syncthreads();
+  LBAR();
   const float* outv = smem + H_OUTV;
   float* gbuf = smem + H_G;
   PSTAMP(3);
@@ -704,7 +690,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
       float dl[20], nrm = 0.f;                                                                    // ROA regulariser PPO:174-179
 #pragma unroll
       for (int k = 0; k < 20; ++k) {
-        dl[k] = act_stash[sidx(B, A_LAT, 20, row0 + r, k)] - Bt.hist_latent[src * 20 + k];
+        dl[k] = act_stash[sidx(Bs, A_LAT, 20, row0 + r, k)] - Bt.hist_latent[src * 20 + k];
         nrm += dl[k] * dl[k];
       }
       nrm = sqrtf(nrm);
@@ -727,28 +713,32 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
       for (int j = 0; j < 18; ++j) dstd_partial[tile * 18 + j] = dsd[j];
     }
   }
-  __syncthreads();
-  if (tid < R16 && row0 + tid < B) {
-    dz_stash[sidx(B, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
-    dz_stash[sidx(B, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
+  LBAR();
+  if (tid < R16) {
+    dz_stash[sidx(Bs, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
+    dz_stash[sidx(Bs, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
   }
   {
     float w[66];
     BwdFetch16 f;
     f32x4 saved0 = {0.f, 0.f, 0.f, 0.f}, saved1 = {0.f, 0.f, 0.f, 0.f};
     PSTAMP(4);
+    bwd_fetch16(f, BT.s[0], act_stash, row0, B, Bs);
     bwd_load16(w, BT.s[0], blob);
-    bwd_fetch16(f, BT.s[0], act_stash, row0, B);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = wave_role();
 #pragma unroll 1
     for (int st = 0; st < NBWD; ++st) {
       const BwdDesc& d = BT.s[st];
-      bwd_pre_act16(d, f, smem, dz_stash, row0, B);
+      bwd_pre_act16(d, f, smem, dz_stash, row0, B, Bs);
       const bool mma = d.has_mma && wave < d.nblkT;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       if (d.add_saved) { acc0 = saved0; acc1 = saved1; }
-      if (mma) mfma_chain16(smem + d.buf_off + (lane & 15) * LD16 + (lane >> 4), w, (d.out_dim + 31) >> 5, acc0, acc1);
-      if (st + 1 < NBWD) { bwd_load16(w, BT.s[st + 1], blob); bwd_fetch16(f, BT.s[st + 1], act_stash, row0, B); }
+      if (mma) mfma_chain16(smem + d.buf_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, (d.out_dim + 31) >> 5, acc0, acc1);
+      {
+        const BwdDesc& dn = BT.s[st + 1 < NBWD ? st + 1 : st];
+        bwd_fetch16(f, dn, act_stash, row0, B, Bs);          // first: loads return in order, and the next stage starts with these
+        bwd_load16(w, dn, blob);
+      }
       if (mma) {
         if (d.save_out) { saved0 = acc0; saved1 = acc1; }
         else {
@@ -764,7 +754,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
           }
         }
       }
-      if (d.has_mma) __syncthreads();
+      if (d.has_mma) LBAR();
       PSTAMP(5 + st);
     }
   }
@@ -786,7 +776,7 @@ struct WgradTable { WgradLayer l[NLAYERS]; };
 // layer's outputs this wave accumulates.
 template <int NIB, bool IL = false>
 static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const float* __restrict__ act_stash, const float* __restrict__ dz_stash,
-                                                  float* __restrict__ dst, int r_begin, int r_end, int B, int wave) {
+                                                  float* __restrict__ dst, int r_begin, int r_end, int B, int wave) {     // B = slab rows
   const int lane = threadIdx.x & 63, half = lane >> 5;
   f32x16 acc[NIB];
 #pragma unroll
@@ -891,18 +881,18 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
 // (one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
 extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
-                                                                         int B, int nparams) {
+                                                                         int B, int Bs, int nparams) {
   const WgradLayer L = tab.l[blockIdx.y];
   const int wave = threadIdx.x >> 6;
   if (wave * 32 >= L.out || (int)blockIdx.x >= L.nsplit) return;
   const int r_begin = blockIdx.x * L.rows, r_end = min(B, r_begin + L.rows);
   float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
   const int nib = (L.in + 31) / 32;
-  if (nib == 4 && ((L.aw | L.aoff) & 3) == 0) wgrad_body<4, true>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);   // 16-byte aligned rows
-  else if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
-  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
-  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
-  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, B, wave);
+  if (nib == 4 && ((L.aw | L.aoff) & 3) == 0) wgrad_body<4, true>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);   // 16-byte aligned rows
+  else if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
+  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
+  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
+  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
 }
 
 // grad[L.goff + i] = sum_{s < L.nsplit} part[s][L.goff + i] in a fixed order, one grid row per layer
@@ -1027,7 +1017,7 @@ extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
   const size_t tiles = (size_t)(B + R16 - 1) / R16;
-  return (size_t)B * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
+  return (size_t)((B + 31) & ~31) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
 }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
@@ -1053,18 +1043,19 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   const int tile_rows = PPO_TILE16 ? R16 : PT_ROWS;
   const int tiles = (B + tile_rows - 1) / tile_rows;
   const int ng = wbc_ppo_grad_floats();
+  const int Bs = PPO_TILE16 ? ((B + 31) & ~31) : B;          // rows per stash slab
   float* act_stash = workspace;
-  float* dz_stash = act_stash + (size_t)B * A_LD;
-  float* dstd_partial = dz_stash + (size_t)B * D_LD;
+  float* dz_stash = act_stash + (size_t)Bs * A_LD;
+  float* dstd_partial = dz_stash + (size_t)Bs * D_LD;
   float* loss_partial = dstd_partial + (size_t)tiles * 18;
   float* wpart = loss_partial + (size_t)tiles * 3;
   float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
   if (PPO_TILE16) hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 2), dim3(256), 0, st, P, make_pack16_table(), wpack);
   else hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, make_pack_table(), wpack);
-  PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
+  PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, Bs, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
   if (PPO_TILE16) {
-    hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fop_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
+    hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fwd_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
                        act_stash, dz_stash, dstd_partial, loss_partial);
   } else {
     hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fop_table(kStashCols), make_bwd_table(P), wpack, Bt, act_stash,
@@ -1080,7 +1071,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
     tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab, off, nsplit, rows};
     off += layer_out(l) * layer_in(l) + layer_out(l);
   }
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, ng);
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, Bs, ng);
   hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, tab, wpart, ng, grad);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(3), dim3(256), 0, st, loss_partial, tiles, 3, grad + off + 18);

@@ -28,9 +28,10 @@ for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): run()
+NIT = int(os.environ.get("WBC_ITERS", "100"))
+for _ in range(NIT): run()
 e1.record(); torch.cuda.synchronize()
-print(f"minibatch B={B}: {e0.elapsed_time(e1)/20*1000:.1f} us per call (pack + fwd_bwd + wgrad + reducers)")
+print(f"minibatch B={B}: {e0.elapsed_time(e1)/NIT*1000:.1f} us per call (pack + fwd_bwd + wgrad + reducers)")
 if os.environ.get("WBC_STAMPS"):
     L.wbc_debug_set_ppo_timing.argtypes = [C.c_void_p]
     buf = torch.zeros(128, dtype=torch.int64, device=dev)
