@@ -424,24 +424,41 @@ static __device__ __forceinline__ void load16(float (&w)[66], const Desc16& d, c
   w[65] = bias[d.boff + (c0 + 16 < d.n ? c0 + 16 : 0)];
 }
 
-// acc_h += sum over nch chunks of A * w for both column halves. ap = in + (L & 15) * LD16 + 8 (L >> 4) (16-byte aligned).
-// The next chunk's A operands are read before this chunk's 16 MFMAs are issued (a chunk past the end re-reads the last one).
-static __device__ __forceinline__ void mfma_chain16(const float* ap, const float (&w)[66], int nch, f32x4& acc0, f32x4& acc1) {
-  float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+// A tile has MB blocks of 16 rows ("M-blocks") that share one operand set: acc[m][h] += sum over nch chunks of A_m * w for
+// both column halves h. ap = in + (L & 15) * LD16 + 8 (L >> 4) (16-byte aligned), M-block m at ap + 16 m LD16. The next
+// chunk's A operands are read before this chunk's MFMAs are issued (a chunk past the end re-reads the last one).
+template <int MB>
+static __device__ __forceinline__ void mfma_chain16(const float* ap, const float (&w)[66], int nch, f32x4 (&acc)[MB][2]) {
+  float4 a[MB][2];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    a[m][0] = *reinterpret_cast<const float4*>(ap + m * 16 * LD16);
+    a[m][1] = *reinterpret_cast<const float4*>(ap + m * 16 * LD16 + 4);
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c < nch) {
       const float* np = ap + 32 * (c + 1 < nch ? c + 1 : c);
-      const float4 n0 = *reinterpret_cast<const float4*>(np), n1 = *reinterpret_cast<const float4*>(np + 4);
-      __builtin_amdgcn_sched_barrier(0);
-      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      float4 n[MB][2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * (c * 8 + j)], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[2 * (c * 8 + j) + 1], acc1, 0, 0, 0);
+      for (int m = 0; m < MB; ++m) {
+        n[m][0] = *reinterpret_cast<const float4*>(np + m * 16 * LD16);
+        n[m][1] = *reinterpret_cast<const float4*>(np + m * 16 * LD16 + 4);
       }
       __builtin_amdgcn_sched_barrier(0);
-      a0 = n0; a1 = n1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          const float4 q = a[m][j >> 2];
+          const float av = (j & 3) == 0 ? q.x : ((j & 3) == 1 ? q.y : ((j & 3) == 2 ? q.z : q.w));
+          acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[2 * (c * 8 + j)], acc[m][0], 0, 0, 0);
+          acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[2 * (c * 8 + j) + 1], acc[m][1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) { a[m][0] = n[m][0]; a[m][1] = n[m][1]; }
     }
   }
 }
@@ -458,8 +475,8 @@ static __device__ __forceinline__ float act16(float x) {
 
 // Addresses of a lane's outputs, computed BEFORE the operand prefetch is issued: address arithmetic after it (the compiler
 // uses 64-bit multiply-adds whose unused high half may alias a register that a prefetch load is still writing) made the
-// epilogue wait for every outstanding load.
-struct Epi16 { uint32_t lds[4], st[4]; };
+// epilogue wait for every outstanding load. lds16 / st16: step between M-blocks.
+struct Epi16 { uint32_t lds[4], st[4], lds16, st16; };
 static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d, int row0) {
   const int lane = threadIdx.x & 63, wave = wave_role();
   const int c0 = wave * 32 + (lane & 15), rb = 4 * (lane >> 4);
@@ -469,14 +486,15 @@ static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d, int 
     e.lds[r] = (uint32_t)(d.out_off + (rb + r) * d.ldo + c0);
     e.st[r] = (uint32_t)((row0 + rb + r) * d.sw + c0);
   }
+  e.lds16 = (uint32_t)(16 * d.ldo); e.st16 = (uint32_t)(16 * d.sw);
   return e;
 }
 
 // epilogue of one layer: act(acc + bias) to LDS and, when `sbase` != nullptr, to the stash slab (element (row, col) at
 // sbase[row * sw + col]; slabs are padded to whole tiles and every tile row is stored: a predicated store would make every
 // later s_waitcnt vmcnt conservative)
-template <int ACT>
-static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4& acc0, const f32x4& acc1, float b0, float b1,
+template <int ACT, int MB>
+static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4 (&acc)[MB][2], float b0, float b1,
                                                   float* smem, float* __restrict__ sbase) {
   const int lane = threadIdx.x & 63, wave = wave_role();
   const int c0 = wave * 32 + (lane & 15);
@@ -484,35 +502,40 @@ static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& 
   for (int h = 0; h < 2; ++h) {
     if (c0 + 16 * h < d.n) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = act16<ACT>((h ? acc1[r] : acc0[r]) + (h ? b1 : b0));
-        smem[e.lds[r] + 16 * h] = v;
-        if (sbase) sbase[e.st[r] + 16 * h] = v;
+      for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = act16<ACT>(acc[m][h][r] + (h ? b1 : b0));
+          smem[e.lds[r] + m * e.lds16 + 16 * h] = v;
+          if (sbase) sbase[e.st[r] + m * e.st16 + 16 * h] = v;
+        }
       }
     }
   }
 }
 
-// Forward layer d on a 16-row tile: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the slab-major
-// stash whose slabs have `slab_rows` rows. `after_mfma` runs once `w` is no longer read (one call site: the operand
-// registers it refills keep their place). Ends with a barrier.
-template <typename Hook = NoHook>
-static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int num_rows,
-                                             int slab_rows, Hook after_mfma = Hook(), int dbg_l = 0) {
+// Forward layer d on a tile of MB x 16 rows: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the
+// slab-major stash whose slabs have `slab_rows` rows. `after_mfma` runs once `w` is no longer read (one call site: the
+// operand registers it refills keep their place). Ends with a barrier.
+template <int MB, typename Hook = NoHook>
+static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int slab_rows,
+                                             Hook after_mfma = Hook(), int dbg_l = 0) {
   const int lane = threadIdx.x & 63, wave = wave_role();
   const bool active = wave < d.nblk;
   LSTAMP(dbg_l, 0);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  if (active) mfma_chain16(smem + d.in_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, d.nch, acc0, acc1);
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  if (active) mfma_chain16<MB>(smem + d.in_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, d.nch, acc);
   const float b0 = w[64], b1 = w[65];
   const Epi16 e = epilogue16_offsets(d, row0);
   float* sbase = (stash != nullptr && d.scol >= 0) ? stash + (size_t)d.scol * slab_rows : nullptr;
   LSTAMP(dbg_l, 1);
   after_mfma();
   if (active) {
-    if (d.act == ACT_ELU) epilogue16<ACT_ELU>(d, e, acc0, acc1, b0, b1, smem, sbase);
-    else if (d.act == ACT_TANH) epilogue16<ACT_TANH>(d, e, acc0, acc1, b0, b1, smem, sbase);
-    else epilogue16<ACT_NONE>(d, e, acc0, acc1, b0, b1, smem, sbase);
+    if (d.act == ACT_ELU) epilogue16<ACT_ELU, MB>(d, e, acc, b0, b1, smem, sbase);
+    else if (d.act == ACT_TANH) epilogue16<ACT_TANH, MB>(d, e, acc, b0, b1, smem, sbase);
+    else epilogue16<ACT_NONE, MB>(d, e, acc, b0, b1, smem, sbase);
   }
   LSTAMP(dbg_l, 2);
   LBAR();

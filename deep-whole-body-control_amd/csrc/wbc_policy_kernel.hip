@@ -96,7 +96,10 @@ static Tab16 make_tab16() {
   return t;
 }
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) wbc_policy_act16_kernel(PolicyParams P, Tab16 T, const float* __restrict__ wpack16,
+#ifndef ACT16_OCC
+#define ACT16_OCC 2
+#endif
+extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_act16_kernel(PolicyParams P, Tab16 T, const float* __restrict__ wpack16,
                                                                                 const float* __restrict__ bias, const float* __restrict__ obs,
                                                                                 const float* __restrict__ latent, const float* __restrict__ eps,
                                                                                 float* __restrict__ actions, float* __restrict__ mean_out,
@@ -134,10 +137,10 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) wbc_policy_act16_ker
     for (int l = lbeg; l < lend; l += 2) {
       const bool two = l + 1 < lend;
       if (two) load16(wb, T.l[l + 1], wpack16, bias);
-      run16(wa, T.l[l], smem, nullptr, row0, num_rows, 0);
+      run16<1>(wa, T.l[l], smem, nullptr, row0, 0);
       if (two) {
         if (l + 2 < lend) load16(wa, T.l[l + 2], wpack16, bias);
-        run16(wb, T.l[l + 1], smem, nullptr, row0, num_rows, 0);
+        run16<1>(wb, T.l[l + 1], smem, nullptr, row0, 0);
       }
     }
   }

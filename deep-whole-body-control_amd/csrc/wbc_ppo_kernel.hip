@@ -443,20 +443,25 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 }
 
 // ==== 16-row tiles =======================================================================================================
-// The same kernel on v_mfma_f32_16x16x4_f32 tiles (wbc_mlp.h): twice the workgroups, a 26.7 KB LDS plan (x / g, two
-// activation buffers, outv) and half the accumulator / epilogue registers per wave, so more workgroups share a CU and hide
-// each other's barriers and stash traffic. Stash layouts, loss phase and stage order are those of the 32-row kernel.
+// The same kernel on v_mfma_f32_16x16x4_f32 tiles (wbc_mlp.h). A workgroup takes PPO_MB blocks of 16 rows that share every
+// operand set (weight traffic from L2, descriptor loads, barriers and address arithmetic are per layer and workgroup, not
+// per row). LDS: x / g, three activation buffers, outv. Stash layouts, loss phase and stage order are those of the 32-row kernel.
+#ifndef PPO_MB
+#define PPO_MB 2
+#endif
+#define HROWS (16 * PPO_MB)
 #define H_X 0
-#define H_A0 (R16 * LD16)
-#define H_A1 (H_A0 + R16 * LD16)
-#define H_A2 (H_A1 + R16 * LD16)
-#define H_OUTV (H_A2 + R16 * LD16)
-#define H_END (H_OUTV + R16 * 21)
+#define H_A0 (HROWS * LD16)
+#define H_A1 (H_A0 + HROWS * LD16)
+#define H_A2 (H_A1 + HROWS * LD16)
+#define H_OUTV (H_A2 + HROWS * LD16)
+#define H_END (H_OUTV + HROWS * 21)
 #define H_G H_X
 #ifndef PPO16_OCC
-#define PPO16_OCC 3
+#define PPO16_OCC (PPO_MB == 1 ? 3 : 2)
 #endif
-static_assert(R16 * 41 <= R16 * LD16, "g fits in x");
+static_assert(HROWS <= 64 && HROWS * 41 <= HROWS * LD16, "g fits in x; the loss phase has one row per lane of wave 0");
+static_assert(H_END * 4 * PPO16_OCC <= 160 * 1024, "LDS");
 
 // Forward order: the 35 KB plan has three activation buffers, so both backbone outputs stay in LDS for their second head (no
 // stash reload) and the forward is a plain loop over the 16 layers; the proprio block is copied next to where priv2 puts the
@@ -505,20 +510,16 @@ static __device__ __forceinline__ void bwd_load16(float (&w)[66], const BwdDesc&
   load_ops16(w, blob + d.woffT, (d.out_dim + 31) >> 5, wave < nblk ? wave : 0);
 }
 
-// thread t owns columns c, c+1 with c = 2 (t & 63) of rows (t >> 6) + 4 j, j < 4
-struct BwdFetch16 { float2 a[4]; float wv; };
-static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows,
-                                                   int Bs) {
+// Thread t owns columns c, c+1 with c = 2 (t & 63) of rows (t >> 6) + 4 j, j < 4 PPO_MB. Lanes past the stage's width n
+// work on its last column pair as well (same wave, same instruction, same values as the owning lane): no lane predicate, so
+// the stash accesses are unconditional and the compiler's s_waitcnt vmcnt counts stay exact.
+struct BwdFetch16 { float2 a[4 * PPO_MB]; float wv; };
+static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int Bs) {
   const int tid = threadIdx.x;
-  const int c = (tid & 63) * 2, rb = tid >> 6;
-  const bool c_ok = c < d.n;
-  const float* base = act_stash + sidx(Bs, d.acol, d.aw, row0 + rb, c_ok ? c : 0);
+  const int c = min((tid & 63) * 2, d.n - 2), rb = tid >> 6;
+  const float* base = act_stash + sidx(Bs, d.acol, d.aw, row0 + rb, c);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool ok = c_ok && row0 + rb + 4 * j < num_rows;
-    const float2 v = *reinterpret_cast<const float2*>(ok ? base + (size_t)(4 * j) * d.aw : act_stash);
-    f.a[j] = ok ? v : make_float2(1.f, 1.f);
-  }
+  for (int j = 0; j < 4 * PPO_MB; ++j) f.a[j] = *reinterpret_cast<const float2*>(base + (size_t)(4 * j) * d.aw);    // padded slabs: every tile row exists
   const float* wv = (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) ? d.wvec : act_stash;
   f.wv = wv[tid & 127];
 }
@@ -532,40 +533,45 @@ static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const Bwd
     const int gi = (d.pre == PRE_OUTER_V0) ? 18 : 19;
     const int c = tid & 127, r0 = tid >> 7;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) buf[(r0 + 2 * k) * LD16 + c] = g[(r0 + 2 * k) * 41 + gi] * f.wv;
+    for (int k = 0; k < 8 * PPO_MB; ++k) buf[(r0 + 2 * k) * LD16 + c] = g[(r0 + 2 * k) * 41 + gi] * f.wv;
     LBAR();
   } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
     // the GEMM's k runs over the head's outputs in chunks of 32: the columns up to 32 must be finite (zeros)
     const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
-    const int r = tid >> 4, c = tid & 15;                            // 16 threads per row, n <= 12
-    buf[r * LD16 + c] = c < n ? g[r * 41 + go + c] : 0.f;
-    buf[r * LD16 + 16 + c] = 0.f;
+    const int c = tid & 15;                                          // 16 threads per row, n <= 12
+#pragma unroll
+    for (int m = 0; m < PPO_MB; ++m) {
+      const int r = (tid >> 4) + 16 * m;
+      buf[r * LD16 + c] = c < n ? g[r * 41 + go + c] : 0.f;
+      buf[r * LD16 + 16 + c] = 0.f;
+    }
     LBAR();
   } else if (d.pre == PRE_LATENT) {
     const float* src = smem + d.src_off;
-    const int r = tid >> 4, c = tid & 15;
-    buf[r * LD16 + c] = src[r * LD16 + PT_NPROP + c] + g[r * 41 + 20 + c];
-    buf[r * LD16 + 16 + c] = c < 4 ? src[r * LD16 + PT_NPROP + 16 + c] + g[r * 41 + 36 + c] : 0.f;      // k padding: zeros up to column 32
+    const int c = tid & 15;
+#pragma unroll
+    for (int m = 0; m < PPO_MB; ++m) {
+      const int r = (tid >> 4) + 16 * m;
+      buf[r * LD16 + c] = src[r * LD16 + PT_NPROP + c] + g[r * 41 + 20 + c];
+      buf[r * LD16 + 16 + c] = c < 4 ? src[r * LD16 + PT_NPROP + 16 + c] + g[r * 41 + 36 + c] : 0.f;      // k padding: zeros up to column 32
+    }
     LBAR();
   }
   {
-    const int c = (tid & 63) * 2, rb = tid >> 6;
-    if (c < d.n) {
-      float* bp = buf + rb * LD16 + c;
-      float* dzp = dz_stash + sidx(Bs, d.dcol, d.dw, row0 + rb, c);
-      const bool elu = d.act == ACT_ELU;
+    const int c = min((tid & 63) * 2, d.n - 2), rb = tid >> 6;
+    float* bp = buf + rb * LD16 + c;
+    float* dzp = dz_stash + sidx(Bs, d.dcol, d.dw, row0 + rb, c);
+    const bool elu = d.act == ACT_ELU;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = row0 + rb + 4 * j < num_rows;
-        const float dx = elu ? act_deriv<ACT_ELU>(f.a[j].x) : act_deriv<ACT_TANH>(f.a[j].x);
-        const float dy = elu ? act_deriv<ACT_ELU>(f.a[j].y) : act_deriv<ACT_TANH>(f.a[j].y);
-        float2 v = *reinterpret_cast<const float2*>(bp + 4 * j * LD16);
-        v.x *= dx; v.y *= dy;
-        if (!ok) v = make_float2(0.f, 0.f);
-        *reinterpret_cast<float2*>(bp + 4 * j * LD16) = v;
-        *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;       // unconditional (padded slabs): a predicated store would make
-                                                                            // every later s_waitcnt vmcnt conservative
-      }
+    for (int j = 0; j < 4 * PPO_MB; ++j) {
+      const bool ok = row0 + rb + 4 * j < num_rows;
+      const float dx = elu ? act_deriv<ACT_ELU>(f.a[j].x) : act_deriv<ACT_TANH>(f.a[j].x);
+      const float dy = elu ? act_deriv<ACT_ELU>(f.a[j].y) : act_deriv<ACT_TANH>(f.a[j].y);
+      float2 v = *reinterpret_cast<const float2*>(bp + 4 * j * LD16);
+      v.x *= dx; v.y *= dy;
+      if (!ok) v = make_float2(0.f, 0.f);
+      *reinterpret_cast<float2*>(bp + 4 * j * LD16) = v;
+      *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;
     }
     LBAR();
   }
@@ -577,12 +583,12 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
                                                                                        float* __restrict__ dstd_partial, float* __restrict__ loss_partial) {
   __shared__ __attribute__((aligned(16))) float smem[H_END];
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x, row0 = tile * R16, B = Bt.B, Bs = Bt.Bs;
+  const int tile = blockIdx.x, row0 = tile * HROWS, B = Bt.B, Bs = Bt.Bs;
   const float* bias = blob + WPACK16_BIAS_OFF;
   PSTAMP(0);
   // gather obs[idx, :100] into x (and the x slab of the stash); the columns 100..127 (k padding of the first layers) zero
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2 * PPO_MB; ++k) {
     const int e4 = tid + k * PT_THREADS;
     const int r = e4 >> 5, c = (e4 & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -603,9 +609,9 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
 #pragma unroll 1
     for (int i = 0; i < NLAYERS; i += 2) {
       load16(wb, FT.l[i + 1], blob, bias);
-      run16(wa, FT.l[i], smem, act_stash, row0, B, Bs, NoHook(), i);
+      run16<PPO_MB>(wa, FT.l[i], smem, act_stash, row0, Bs, NoHook(), i);
       load16(wa, FT.l[i + 2 < NLAYERS ? i + 2 : i], blob, bias);
-      run16(wb, FT.l[i + 1], smem, act_stash, row0, B, Bs, NoHook(), i + 1);
+      run16<PPO_MB>(wb, FT.l[i + 1], smem, act_stash, row0, Bs, NoHook(), i + 1);
     }
   }
 #else
@@ -615,7 +621,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
 #pragma unroll 1
     for (int i = 0; i < NLAYERS; ++i) {
       const int nx = i + 1 < NLAYERS ? i + 1 : i;        // (the last layer re-requests its own operands: no conditional refill)
-      run16(w, FT.l[i], smem, act_stash, row0, B, Bs, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
+      run16<PPO_MB>(w, FT.l[i], smem, act_stash, row0, Bs, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
     }
   }
 #endif
@@ -623,7 +629,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
   __threadfence_block();
   __syncthreads();
   // z = [prop, latent] slab (the backbone's input, for its weight gradient)
-  for (int e = tid; e < R16 * 24; e += PT_THREADS) {
+  for (int e = tid; e < HROWS * 24; e += PT_THREADS) {
     const int r = e / 24, c = (e - r * 24) * 4;
     float4 v;
     if (c < PT_NPROP) v = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
@@ -635,8 +641,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
   float* gbuf = smem + H_G;
   PSTAMP(3);
   if (tid < 64) {
-    const int r = tid & 15;
-    const bool valid = (tid < R16) && (row0 + r < B);
+    const int r = tid & (HROWS - 1);
+    const bool valid = (tid < HROWS) && (row0 + r < B);
     float surr = 0.f, vls = 0.f, preg = 0.f;
     float dsd[18];
 #pragma unroll
@@ -698,7 +704,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
       const float sc = (nrm > 0.f) ? Bt.roa_coef * invB / nrm : 0.f;
 #pragma unroll
       for (int k = 0; k < 20; ++k) gbuf[r * 41 + 20 + k] = sc * dl[k];
-    } else if (tid < R16) {
+    } else if (tid < HROWS) {
       for (int k = 0; k < 40; ++k) gbuf[r * 41 + k] = 0.f;
     }
 #pragma unroll
@@ -714,16 +720,18 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
     }
   }
   LBAR();
-  if (tid < R16) {
+  if (tid < HROWS) {
     dz_stash[sidx(Bs, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
     dz_stash[sidx(Bs, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
   }
   {
     float w[66];
     BwdFetch16 f;
-    f32x4 saved0 = {0.f, 0.f, 0.f, 0.f}, saved1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 saved[PPO_MB][2];
+#pragma unroll
+    for (int m = 0; m < PPO_MB; ++m) { saved[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; saved[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     PSTAMP(4);
-    bwd_fetch16(f, BT.s[0], act_stash, row0, B, Bs);
+    bwd_fetch16(f, BT.s[0], act_stash, row0, Bs);
     bwd_load16(w, BT.s[0], blob);
     const int lane = tid & 63, wave = wave_role();
 #pragma unroll 1
@@ -731,26 +739,35 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
       const BwdDesc& d = BT.s[st];
       bwd_pre_act16(d, f, smem, dz_stash, row0, B, Bs);
       const bool mma = d.has_mma && wave < d.nblkT;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      if (d.add_saved) { acc0 = saved0; acc1 = saved1; }
-      if (mma) mfma_chain16(smem + d.buf_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, (d.out_dim + 31) >> 5, acc0, acc1);
+      f32x4 acc[PPO_MB][2];
+#pragma unroll
+      for (int m = 0; m < PPO_MB; ++m) {
+        acc[m][0] = d.add_saved ? saved[m][0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[m][1] = d.add_saved ? saved[m][1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      if (mma) mfma_chain16<PPO_MB>(smem + d.buf_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, (d.out_dim + 31) >> 5, acc);
       {
         const BwdDesc& dn = BT.s[st + 1 < NBWD ? st + 1 : st];
-        bwd_fetch16(f, dn, act_stash, row0, B, Bs);          // first: loads return in order, and the next stage starts with these
+        bwd_fetch16(f, dn, act_stash, row0, Bs);          // first: loads return in order, and the next stage starts with these
         bwd_load16(w, dn, blob);
       }
       if (mma) {
-        if (d.save_out) { saved0 = acc0; saved1 = acc1; }
-        else {
+        if (d.save_out) {
+#pragma unroll
+          for (int m = 0; m < PPO_MB; ++m) { saved[m][0] = acc[m][0]; saved[m][1] = acc[m][1]; }
+        } else {
           const int col = wave * 32 + (lane & 15);
           float* out = smem + d.out_off + 4 * (lane >> 4) * LD16 + col;
-          if (col < d.in_dim) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r * LD16] = acc0[r];
-          }
-          if (col + 16 < d.in_dim) {
+          for (int m = 0; m < PPO_MB; ++m) {
+            if (col < d.in_dim) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r * LD16 + 16] = acc1[r];
+              for (int r = 0; r < 4; ++r) out[(16 * m + r) * LD16] = acc[m][0][r];
+            }
+            if (col + 16 < d.in_dim) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) out[(16 * m + r) * LD16 + 16] = acc[m][1][r];
+            }
           }
         }
       }
@@ -1017,7 +1034,7 @@ extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
   const size_t tiles = (size_t)(B + R16 - 1) / R16;
-  return (size_t)((B + 31) & ~31) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
+  return (size_t)((B + 63) & ~63) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
 }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
@@ -1040,10 +1057,10 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
       B <= 0 || fill_params(params, &P))
     return -1;
   hipStream_t st = (hipStream_t)stream;
-  const int tile_rows = PPO_TILE16 ? R16 : PT_ROWS;
+  const int tile_rows = PPO_TILE16 ? HROWS : PT_ROWS;
   const int tiles = (B + tile_rows - 1) / tile_rows;
   const int ng = wbc_ppo_grad_floats();
-  const int Bs = PPO_TILE16 ? ((B + 31) & ~31) : B;          // rows per stash slab
+  const int Bs = PPO_TILE16 ? ((B + 63) & ~63) : B;          // rows per stash slab
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)Bs * A_LD;
   float* dstd_partial = dz_stash + (size_t)Bs * D_LD;
