@@ -490,24 +490,43 @@ static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d, int 
   return e;
 }
 
-// epilogue of one layer: act(acc + bias) to LDS and, when `sbase` != nullptr, to the stash slab (element (row, col) at
-// sbase[row * sw + col]; slabs are padded to whole tiles and every tile row is stored: a predicated store would make every
-// later s_waitcnt vmcnt conservative)
+// Stash stores of a layer are issued one layer late (after the next layer's MFMA chain, right before the operand
+// prefetch): a wave's vector-memory operations then always go [stores][loads], so the s_waitcnt vmcnt in front of an MFMA
+// chain counts only loads. Stores issued after the loads are lane-predicated, the compiler has to assume they were not
+// issued, and the chain's last waits turned into waits for the acknowledgement of the previous layer's stores.
+template <int MB>
+struct Pend16 { float v[MB][2][4]; uint32_t st[4], st16; float* sbase; bool ok[2]; };
+template <int MB>
+static __device__ __forceinline__ void pend16_flush(Pend16<MB>& p) {
+  if (p.sbase) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (p.ok[h]) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p.sbase[p.st[r] + m * p.st16 + 16 * h] = p.v[m][h][r];
+        }
+      }
+    }
+  }
+  p.sbase = nullptr;
+}
+
+// epilogue of one layer: act(acc + bias) to LDS; the values stay in `p` for the deferred stash store
 template <int ACT, int MB>
 static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4 (&acc)[MB][2], float b0, float b1,
-                                                  float* smem, float* __restrict__ sbase) {
-  const int lane = threadIdx.x & 63, wave = wave_role();
-  const int c0 = wave * 32 + (lane & 15);
+                                                  float* smem, Pend16<MB>& p) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (c0 + 16 * h < d.n) {
+    if (p.ok[h]) {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = act16<ACT>(acc[m][h][r] + (h ? b1 : b0));
           smem[e.lds[r] + m * e.lds16 + 16 * h] = v;
-          if (sbase) sbase[e.st[r] + m * e.st16 + 16 * h] = v;
+          p.v[m][h][r] = v;
         }
       }
     }
@@ -515,11 +534,12 @@ static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& 
 }
 
 // Forward layer d on a tile of MB x 16 rows: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the
-// slab-major stash whose slabs have `slab_rows` rows. `after_mfma` runs once `w` is no longer read (one call site: the
-// operand registers it refills keep their place). Ends with a barrier.
+// slab-major stash whose slabs have `slab_rows` rows -- the stash store is left pending in `p` (flush it after the last
+// layer). `after_mfma` runs once `w` is no longer read (one call site: the operand registers it refills keep their
+// place). Ends with a barrier.
 template <int MB, typename Hook = NoHook>
 static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int slab_rows,
-                                             Hook after_mfma = Hook(), int dbg_l = 0) {
+                                             Pend16<MB>& p, Hook after_mfma = Hook(), int dbg_l = 0) {
   const int lane = threadIdx.x & 63, wave = wave_role();
   const bool active = wave < d.nblk;
   LSTAMP(dbg_l, 0);
@@ -529,14 +549,20 @@ static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, fl
   if (active) mfma_chain16<MB>(smem + d.in_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, d.nch, acc);
   const float b0 = w[64], b1 = w[65];
   const Epi16 e = epilogue16_offsets(d, row0);
-  float* sbase = (stash != nullptr && d.scol >= 0) ? stash + (size_t)d.scol * slab_rows : nullptr;
+  pend16_flush<MB>(p);                                   // the previous layer's stash stores
   LSTAMP(dbg_l, 1);
   after_mfma();
-  if (active) {
-    if (d.act == ACT_ELU) epilogue16<ACT_ELU, MB>(d, e, acc, b0, b1, smem, sbase);
-    else if (d.act == ACT_TANH) epilogue16<ACT_TANH, MB>(d, e, acc, b0, b1, smem, sbase);
-    else epilogue16<ACT_NONE, MB>(d, e, acc, b0, b1, smem, sbase);
+  {
+    const int c0 = wave * 32 + (lane & 15);
+    p.ok[0] = active && c0 < d.n; p.ok[1] = active && c0 + 16 < d.n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p.st[r] = e.st[r];
+    p.st16 = e.st16;
+    p.sbase = (stash != nullptr && d.scol >= 0) ? stash + (size_t)d.scol * slab_rows : nullptr;
   }
+  if (d.act == ACT_ELU) epilogue16<ACT_ELU, MB>(d, e, acc, b0, b1, smem, p);
+  else if (d.act == ACT_TANH) epilogue16<ACT_TANH, MB>(d, e, acc, b0, b1, smem, p);
+  else epilogue16<ACT_NONE, MB>(d, e, acc, b0, b1, smem, p);
   LSTAMP(dbg_l, 2);
   LBAR();
   LSTAMP(dbg_l, 3);

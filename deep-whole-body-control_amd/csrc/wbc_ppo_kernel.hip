@@ -445,27 +445,30 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 // ==== 16-row tiles =======================================================================================================
 // The same kernel on v_mfma_f32_16x16x4_f32 tiles (wbc_mlp.h). A workgroup takes PPO_MB blocks of 16 rows that share every
 // operand set (weight traffic from L2, descriptor loads, barriers and address arithmetic are per layer and workgroup, not
-// per row). LDS: x / g, three activation buffers, outv. Stash layouts, loss phase and stage order are those of the 32-row kernel.
+// per row). LDS: three activation buffers and outv; x = obs[idx, :100] is gathered into the third buffer for the actor's
+// first layer and gathered again (obs is an input: no synchronisation) for the critic's, and that buffer holds the output
+// gradients g afterwards. Stash layouts, loss phase and stage order are those of the 32-row kernel.
 #ifndef PPO_MB
 #define PPO_MB 2
 #endif
 #define HROWS (16 * PPO_MB)
-#define H_X 0
-#define H_A0 (HROWS * LD16)
+#define H_A0 0
 #define H_A1 (H_A0 + HROWS * LD16)
 #define H_A2 (H_A1 + HROWS * LD16)
 #define H_OUTV (H_A2 + HROWS * LD16)
 #define H_END (H_OUTV + HROWS * 21)
-#define H_G H_X
+#define H_X H_A2
+#define H_G H_A2
 #ifndef PPO16_OCC
-#define PPO16_OCC (PPO_MB == 1 ? 3 : 2)
+#define PPO16_OCC 3
 #endif
+#define PPO16_CBB_POS 9          // position of the critic backbone in the forward order: x is gathered again in front of it
 static_assert(HROWS <= 64 && HROWS * 41 <= HROWS * LD16, "g fits in x; the loss phase has one row per lane of wave 0");
 static_assert(H_END * 4 * PPO16_OCC <= 160 * 1024, "LDS");
 
-// Forward order: the 35 KB plan has three activation buffers, so both backbone outputs stay in LDS for their second head (no
-// stash reload) and the forward is a plain loop over the 16 layers; the proprio block is copied next to where priv2 puts the
-// latent while x is loaded.
+// Forward order: with three activation buffers both backbone outputs stay in LDS for their second head (no stash reload)
+// and the forward is a plain loop over the 16 layers; the proprio block is copied next to where priv2 puts the latent
+// while x is loaded.
 static Tab16 make_fwd_table16(const int* stash_cols) {
   Tab16 t;
   int i = 0;
@@ -586,55 +589,49 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
   const int tile = blockIdx.x, row0 = tile * HROWS, B = Bt.B, Bs = Bt.Bs;
   const float* bias = blob + WPACK16_BIAS_OFF;
   PSTAMP(0);
-  // gather obs[idx, :100] into x (and the x slab of the stash); the columns 100..127 (k padding of the first layers) zero
+  // gather obs[idx, :100] into x (and the x slab and the proprio part of the z slab of the stash); the columns 100..127
+  // (k padding of the first layers) zero; first = false: the second gather, LDS only
+  auto gather_x = [&](bool first) {
 #pragma unroll
-  for (int k = 0; k < 2 * PPO_MB; ++k) {
-    const int e4 = tid + k * PT_THREADS;
-    const int r = e4 >> 5, c = (e4 & 31) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < 100) {
-      v = *reinterpret_cast<const float4*>(Bt.obs + (size_t)Bt.idx[min(row0 + r, B - 1)] * PT_NOBS + c);
-      if (row0 + r >= B) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_X, 100, row0 + r, c)) = v;
+    for (int k = 0; k < 2 * PPO_MB; ++k) {
+      const int e4 = tid + k * PT_THREADS;
+      const int r = e4 >> 5, c = (e4 & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < 100) {
+        v = *reinterpret_cast<const float4*>(Bt.obs + (size_t)Bt.idx[min(row0 + r, B - 1)] * PT_NOBS + c);
+        if (row0 + r >= B) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (first) {
+          *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_X, 100, row0 + r, c)) = v;
+          if (c < PT_NPROP) *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_Z, 100, row0 + r, c)) = v;
+        }
+      }
+      *reinterpret_cast<float4*>(smem + H_X + r * LD16 + c) = v;
+      if (first && c < PT_NPROP) *reinterpret_cast<float4*>(smem + H_A1 + r * LD16 + c) = v;      // proprio block of the backbone's input
     }
-    *reinterpret_cast<float4*>(smem + H_X + r * LD16 + c) = v;
-    if (c < PT_NPROP) *reinterpret_cast<float4*>(smem + H_A1 + r * LD16 + c) = v;      // proprio block of the backbone's input
-  }
-  LBAR();
+    LBAR();
+  };
+  gather_x(true);
   PSTAMP(1);
-#ifdef PPO16_TWO_SETS
-  {
-    float wa[66], wb[66];
-    load16(wa, FT.l[0], blob, bias);
-#pragma unroll 1
-    for (int i = 0; i < NLAYERS; i += 2) {
-      load16(wb, FT.l[i + 1], blob, bias);
-      run16<PPO_MB>(wa, FT.l[i], smem, act_stash, row0, Bs, NoHook(), i);
-      load16(wa, FT.l[i + 2 < NLAYERS ? i + 2 : i], blob, bias);
-      run16<PPO_MB>(wb, FT.l[i + 1], smem, act_stash, row0, Bs, NoHook(), i + 1);
-    }
-  }
-#else
   {
     float w[66];
+    Pend16<PPO_MB> pend; pend.sbase = nullptr;
     load16(w, FT.l[0], blob, bias);
 #pragma unroll 1
     for (int i = 0; i < NLAYERS; ++i) {
       const int nx = i + 1 < NLAYERS ? i + 1 : i;        // (the last layer re-requests its own operands: no conditional refill)
-      run16<PPO_MB>(w, FT.l[i], smem, act_stash, row0, Bs, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
+      if (i == PPO16_CBB_POS) gather_x(false);           // (the previous layer's barrier: nobody reads this buffer any more)
+      run16<PPO_MB>(w, FT.l[i], smem, act_stash, row0, Bs, pend, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
     }
+    pend16_flush<PPO_MB>(pend);
   }
-#endif
   PSTAMP(2);
   __threadfence_block();
   __syncthreads();
-  // z = [prop, latent] slab (the backbone's input, for its weight gradient)
-  for (int e = tid; e < HROWS * 24; e += PT_THREADS) {
-    const int r = e / 24, c = (e - r * 24) * 4;
-    float4 v;
-    if (c < PT_NPROP) v = *reinterpret_cast<const float4*>(smem + H_X + r * LD16 + c);
-    else v = *reinterpret_cast<const float4*>(act_stash + sidx(Bs, A_LAT, 20, row0 + r, c - PT_NPROP));
-    *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_Z, 100, row0 + r, c)) = v;
+  // latent part of the z = [prop, latent] slab (the backbone's input, for its weight gradient)
+  for (int e = tid; e < HROWS * 5; e += PT_THREADS) {
+    const int r = e / 5, c = (e - r * 5) * 4;
+    *reinterpret_cast<float4*>(act_stash + sidx(Bs, A_Z, 100, row0 + r, PT_NPROP + c)) =
+        *reinterpret_cast<const float4*>(act_stash + sidx(Bs, A_LAT, 20, row0 + r, c));
   }
   LBAR();
   const float* outv = smem + H_OUTV;
