@@ -335,15 +335,9 @@ static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem,
 // (s_waitcnt vmcnt(0)): at each layer that drained the operand prefetch and stalled on the acknowledgement of the stash
 // stores (measured: ~8 k cycles per 128x128 layer against a 2 k-cycle MFMA chain). Use __syncthreads() wherever another
 // wave's GLOBAL writes are read back.
-// Which 32-column block a wave works on. Narrow layers (heads, latent) only occupy the first blocks; with WBC_ROLE_ROT the
-// block -> wave assignment rotates with the workgroup's dispatch round so that this extra work is not always on the same SIMD.
-static __device__ __forceinline__ int wave_role() {
-#ifdef WBC_ROLE_ROT
-  return ((threadIdx.x >> 6) + (blockIdx.x >> 8)) & 3;
-#else
-  return threadIdx.x >> 6;
-#endif
-}
+// Which 32-column block a wave works on. (Rotating this assignment with the workgroup's dispatch round, so that the extra
+// work of the narrow layers -- heads, latent -- is not always on wave 0, changed nothing: 586 vs 577 us per minibatch.)
+static __device__ __forceinline__ int wave_role() { return threadIdx.x >> 6; }
 #define LBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -466,7 +460,7 @@ static __device__ __forceinline__ void mfma_chain16(const float* ap, const float
 template <int ACT>
 static __device__ __forceinline__ float act16(float x) {
   if (ACT == ACT_ELU) {          // branch-free; exp via v_exp_f32 (abs error <= 1 ulp(1.0); the derivative uses the stored value)
-    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f) - 1.f;
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.f;     // (+inf for large x: not selected)
     return x > 0.f ? x : e;
   }
   if (ACT == ACT_TANH) return tanhf(x);
@@ -484,9 +478,9 @@ static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d, int 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     e.lds[r] = (uint32_t)(d.out_off + (rb + r) * d.ldo + c0);
-    e.st[r] = (uint32_t)((row0 + rb + r) * d.sw + c0);
+    e.st[r] = (uint32_t)((row0 + rb + r) * d.sw + c0) * 4u;           // bytes: scalar base + 32-bit lane offset addressing
   }
-  e.lds16 = (uint32_t)(16 * d.ldo); e.st16 = (uint32_t)(16 * d.sw);
+  e.lds16 = (uint32_t)(16 * d.ldo); e.st16 = (uint32_t)(16 * d.sw) * 4u;
   return e;
 }
 
@@ -505,7 +499,8 @@ static __device__ __forceinline__ void pend16_flush(Pend16<MB>& p) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p.sbase[p.st[r] + m * p.st16 + 16 * h] = p.v[m][h][r];
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(p.sbase) + (p.st[r] + m * p.st16 + 64u * h)) = p.v[m][h][r];
         }
       }
     }
@@ -513,10 +508,11 @@ static __device__ __forceinline__ void pend16_flush(Pend16<MB>& p) {
   p.sbase = nullptr;
 }
 
-// epilogue of one layer: act(acc + bias) to LDS; the values stay in `p` for the deferred stash store
+// epilogue of one layer: act(acc + bias) to LDS; the values stay in `p` for the deferred stash store. (Starting the
+// accumulators from the bias instead saves the adds but moved the 20-step update test 3e-4 away from the eager path.)
 template <int ACT, int MB>
-static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4 (&acc)[MB][2], float b0, float b1,
-                                                  float* smem, Pend16<MB>& p) {
+static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4 (&acc)[MB][2], float b0, float b1, float* smem,
+                                                  Pend16<MB>& p) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (p.ok[h]) {

@@ -520,9 +520,10 @@ struct BwdFetch16 { float2 a[4 * PPO_MB]; float wv; };
 static __device__ __forceinline__ void bwd_fetch16(BwdFetch16& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int Bs) {
   const int tid = threadIdx.x;
   const int c = min((tid & 63) * 2, d.n - 2), rb = tid >> 6;
-  const float* base = act_stash + sidx(Bs, d.acol, d.aw, row0 + rb, c);
+  const char* base = reinterpret_cast<const char*>(act_stash + (size_t)d.acol * Bs);          // scalar base + 32-bit lane offset (bytes)
+  const uint32_t off = (uint32_t)((row0 + rb) * d.aw + c) * 4u, step = (uint32_t)(16 * d.aw);
 #pragma unroll
-  for (int j = 0; j < 4 * PPO_MB; ++j) f.a[j] = *reinterpret_cast<const float2*>(base + (size_t)(4 * j) * d.aw);    // padded slabs: every tile row exists
+  for (int j = 0; j < 4 * PPO_MB; ++j) f.a[j] = *reinterpret_cast<const float2*>(base + (off + j * step));    // padded slabs: every tile row exists
   const float* wv = (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) ? d.wvec : act_stash;
   f.wv = wv[tid & 127];
 }
@@ -563,7 +564,8 @@ static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const Bwd
   {
     const int c = min((tid & 63) * 2, d.n - 2), rb = tid >> 6;
     float* bp = buf + rb * LD16 + c;
-    float* dzp = dz_stash + sidx(Bs, d.dcol, d.dw, row0 + rb, c);
+    char* dzp = reinterpret_cast<char*>(dz_stash + (size_t)d.dcol * Bs);
+    const uint32_t off = (uint32_t)((row0 + rb) * d.dw + c) * 4u, step = (uint32_t)(16 * d.dw);
     const bool elu = d.act == ACT_ELU;
 #pragma unroll
     for (int j = 0; j < 4 * PPO_MB; ++j) {
@@ -574,7 +576,7 @@ static __device__ __forceinline__ void bwd_pre_act16(const BwdDesc& d, const Bwd
       v.x *= dx; v.y *= dy;
       if (!ok) v = make_float2(0.f, 0.f);
       *reinterpret_cast<float2*>(bp + 4 * j * LD16) = v;
-      *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;
+      *reinterpret_cast<float2*>(dzp + (off + j * step)) = v;
     }
     LBAR();
   }
