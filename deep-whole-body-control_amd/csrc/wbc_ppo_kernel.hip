@@ -639,86 +639,100 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
   const float* outv = smem + H_OUTV;
   float* gbuf = smem + H_G;
   PSTAMP(3);
-  if (tid < 64) {
-    const int r = tid & (HROWS - 1);
-    const bool valid = (tid < HROWS) && (row0 + r < B);
-    float surr = 0.f, vls = 0.f, preg = 0.f;
-    float dsd[18];
+  // Losses and output gradients: TPR = 256 / rows threads per row (the action and latent dimensions are dealt out to
+  // them), all four waves busy; per-tile sums through a [4 waves][24] scratch in a1 (not written before stage 0's GEMM).
+  {
+    constexpr int TPR = PT_THREADS / HROWS, NJ = (18 + TPR - 1) / TPR, NK = (20 + TPR - 1) / TPR;
+    const int r = tid / TPR, q = tid % TPR, lane = tid & 63;
+    const bool valid = row0 + r < B;
+    const size_t src = (size_t)Bt.idx[min(row0 + r, B - 1)];
+    const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
+    float lp[2] = {0.f, 0.f}, dj[NJ], sdj[NJ];
 #pragma unroll
-    for (int j = 0; j < 18; ++j) dsd[j] = 0.f;
-    if (valid) {
-      const size_t src = (size_t)Bt.idx[row0 + r];
-      const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
-      float lp[2] = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 18; ++j) {
-        const float mu = outv[r * 21 + j], sd = P.std[j];
-        const float d = Bt.actions[src * 18 + j] - mu;
-        lp[j < PT_NLEG ? 0 : 1] += -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-      }
-      const float adv0 = Bt.advantages[src * 2], adv1 = Bt.advantages[src * 2 + 1];
-      const float mixed[2] = {adv0 + Bt.mixing * adv1, adv1 + Bt.mixing * adv0};               // PPO:199-201
-      float dlp[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float ratio = expf(lp[c] - Bt.old_logp[src * 2 + c]);                               // PPO:202
-        const float rc = fminf(fmaxf(ratio, 1.f - Bt.clip), 1.f + Bt.clip);
-        const float s1 = -mixed[c] * ratio, s2 = -mixed[c] * rc;                                  // PPO:203-205
-        surr += fmaxf(s1, s2);
-        const bool inside = (ratio >= 1.f - Bt.clip) && (ratio <= 1.f + Bt.clip);
-        const float dr = (inside || s1 > s2) ? -mixed[c] : 0.f;
-        dlp[c] = inv2B * dr * ratio;
-        const float v = outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];    // PPO:209-216
-        float dv;
-        if (Bt.use_clipped_value_loss) {
-          const float dlt = v - ov;
-          const float vc = ov + fminf(fmaxf(dlt, -Bt.clip), Bt.clip);
-          const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-          vls += fmaxf(l1, l2);
-          const float m = (dlt >= -Bt.clip && dlt <= Bt.clip) ? 1.f : 0.f;
-          const float g1 = 2.f * (v - R), g2 = 2.f * (vc - R) * m;
-          dv = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
-        } else {
-          vls += (R - v) * (R - v);
-          dv = 2.f * (v - R);
-        }
-        gbuf[r * 41 + 18 + c] = Bt.value_coef * inv2B * dv;
-      }
-#pragma unroll
-      for (int j = 0; j < 18; ++j) {
-        const float mu = outv[r * 21 + j], sd = P.std[j];
-        const float d = Bt.actions[src * 18 + j] - mu;
-        const float gl = dlp[j < PT_NLEG ? 0 : 1];
-        gbuf[r * 41 + j] = gl * d / (sd * sd);
-        dsd[j] = gl * (d * d / (sd * sd * sd) - 1.f / sd);
-      }
-      float dl[20], nrm = 0.f;                                                                    // ROA regulariser PPO:174-179
-#pragma unroll
-      for (int k = 0; k < 20; ++k) {
-        dl[k] = act_stash[sidx(Bs, A_LAT, 20, row0 + r, k)] - Bt.hist_latent[src * 20 + k];
-        nrm += dl[k] * dl[k];
-      }
-      nrm = sqrtf(nrm);
-      preg = nrm;
-      const float sc = (nrm > 0.f) ? Bt.roa_coef * invB / nrm : 0.f;
-#pragma unroll
-      for (int k = 0; k < 20; ++k) gbuf[r * 41 + 20 + k] = sc * dl[k];
-    } else if (tid < HROWS) {
-      for (int k = 0; k < 40; ++k) gbuf[r * 41 + k] = 0.f;
+    for (int t = 0; t < NJ; ++t) {
+      const int j = q + TPR * t, jj = j < 18 ? j : 0;
+      const float mu = outv[r * 21 + jj], sd = P.std[jj];
+      const float d = Bt.actions[src * 18 + jj] - mu;
+      const float term = -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+      dj[t] = d; sdj[t] = sd;
+      if (j < PT_NLEG) lp[0] += term; else if (j < 18) lp[1] += term;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 1; off < TPR; off <<= 1) { lp[0] += __shfl_xor(lp[0], off); lp[1] += __shfl_xor(lp[1], off); }
+    const float adv0 = Bt.advantages[src * 2], adv1 = Bt.advantages[src * 2 + 1];
+    const float mixed[2] = {adv0 + Bt.mixing * adv1, adv1 + Bt.mixing * adv0};               // PPO:199-201
+    float dlp[2], surr = 0.f, vls = 0.f, preg = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                                                               // (every thread of the row: cheap)
+      const float ratio = expf(lp[c] - Bt.old_logp[src * 2 + c]);                               // PPO:202
+      const float rc = fminf(fmaxf(ratio, 1.f - Bt.clip), 1.f + Bt.clip);
+      const float s1 = -mixed[c] * ratio, s2 = -mixed[c] * rc;                                  // PPO:203-205
+      surr += fmaxf(s1, s2);
+      const bool inside = (ratio >= 1.f - Bt.clip) && (ratio <= 1.f + Bt.clip);
+      const float dr = (inside || s1 > s2) ? -mixed[c] : 0.f;
+      dlp[c] = valid ? inv2B * dr * ratio : 0.f;
+      const float v = outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];    // PPO:209-216
+      float dv;
+      if (Bt.use_clipped_value_loss) {
+        const float dlt = v - ov;
+        const float vc = ov + fminf(fmaxf(dlt, -Bt.clip), Bt.clip);
+        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+        vls += fmaxf(l1, l2);
+        const float m = (dlt >= -Bt.clip && dlt <= Bt.clip) ? 1.f : 0.f;
+        const float g1 = 2.f * (v - R), g2 = 2.f * (vc - R) * m;
+        dv = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+      } else {
+        vls += (R - v) * (R - v);
+        dv = 2.f * (v - R);
+      }
+      if (q == c) gbuf[r * 41 + 18 + c] = valid ? Bt.value_coef * inv2B * dv : 0.f;
+    }
+    if (q != 0 || !valid) { surr = 0.f; vls = 0.f; }                                            // one thread per row carries the row's loss terms
+    float dsd[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const int j = q + TPR * t;
+      const float gl = dlp[j < PT_NLEG ? 0 : 1], d = dj[t], sd = sdj[t];
+      if (j < 18) gbuf[r * 41 + j] = gl * d / (sd * sd);
+      dsd[t] = j < 18 ? gl * (d * d / (sd * sd * sd) - 1.f / sd) : 0.f;
+    }
+    float dl[NK], nrm = 0.f;                                                                    // ROA regulariser PPO:174-179
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+      const int k = q + TPR * t, kk = k < 20 ? k : 0;
+      dl[t] = act_stash[sidx(Bs, A_LAT, 20, row0 + r, kk)] - Bt.hist_latent[src * 20 + kk];
+      if (k >= 20) dl[t] = 0.f;
+      nrm += dl[t] * dl[t];
+    }
+#pragma unroll
+    for (int off = 1; off < TPR; off <<= 1) nrm += __shfl_xor(nrm, off);
+    nrm = sqrtf(nrm);
+    if (q == 0 && valid) preg = nrm;
+    const float sc = (nrm > 0.f && valid) ? Bt.roa_coef * invB / nrm : 0.f;
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+      const int k = q + TPR * t;
+      if (k < 20) gbuf[r * 41 + 20 + k] = sc * dl[t];
+    }
+    // sums over the wave's rows (lanes with the same q), then over the four waves
+#pragma unroll
+    for (int off = TPR; off < 64; off <<= 1) {
       surr += __shfl_xor(surr, off); vls += __shfl_xor(vls, off); preg += __shfl_xor(preg, off);
 #pragma unroll
-      for (int j = 0; j < 18; ++j) dsd[j] += __shfl_xor(dsd[j], off);
+      for (int t = 0; t < NJ; ++t) dsd[t] += __shfl_xor(dsd[t], off);
     }
-    if (tid == 0) {
-      loss_partial[tile * 3 + 0] = surr; loss_partial[tile * 3 + 1] = vls; loss_partial[tile * 3 + 2] = preg;
+    float* red = smem + H_A1;
+    if (lane < TPR) {
 #pragma unroll
-      for (int j = 0; j < 18; ++j) dstd_partial[tile * 18 + j] = dsd[j];
+      for (int t = 0; t < NJ; ++t) if (q + TPR * t < 18) red[(tid >> 6) * 24 + q + TPR * t] = dsd[t];
+      if (q == 0) { red[(tid >> 6) * 24 + 18] = surr; red[(tid >> 6) * 24 + 19] = vls; red[(tid >> 6) * 24 + 20] = preg; }
+    }
+    LBAR();
+    if (tid < 21) {
+      const float v = (red[tid] + red[24 + tid]) + (red[48 + tid] + red[72 + tid]);
+      if (tid < 18) dstd_partial[tile * 18 + tid] = v; else loss_partial[tile * 3 + (tid - 18)] = v;
     }
   }
-  LBAR();
   if (tid < HROWS) {
     dz_stash[sidx(Bs, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
     dz_stash[sidx(Bs, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
