@@ -13,7 +13,7 @@
 #include "wbc_device.h"
 
 extern "C" __global__ void wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
-                                           uint64_t seed, uint64_t step);
+                                           uint64_t seed, uint64_t step, float* __restrict__ obs_out);
 extern "C" __global__ void wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step);
 extern "C" __global__ void wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
 extern "C" __global__ void wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
@@ -298,13 +298,15 @@ extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
   return 0;
 }
 
-extern "C" int wbc_sim_step(wbc_sim* s, const float* actions_dev, void* stream) {
+extern "C" int wbc_sim_step_to(wbc_sim* s, const float* actions_dev, float* obs_out_dev, void* stream) {
   if (!s || !actions_dev) return fail(-1, "wbc_sim_step: bad arguments");
   s->step_counter += 1;
-  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter);
+  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter,
+                     obs_out_dev);
   HIP_OK(hipGetLastError());
   return 0;
 }
+extern "C" int wbc_sim_step(wbc_sim* s, const float* actions_dev, void* stream) { return wbc_sim_step_to(s, actions_dev, nullptr, stream); }
 
 extern "C" int wbc_sim_reset_all(wbc_sim* s, void* stream) {
   if (!s) return fail(-1, "wbc_sim_reset_all: null sim");

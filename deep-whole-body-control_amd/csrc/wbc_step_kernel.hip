@@ -991,7 +991,7 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
 }
 
 // compute_observations (oracle) + the HBM write-out of the step's results.
-__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset) {
+__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset, float* __restrict__ obs_out) {
   const int lane = threadIdx.x;
   const wbc_task_cfg& cf = C->cfg;
   // proprio vector o76, one or two entries per lane
@@ -1018,7 +1018,7 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   WSYNC();
   // obs_buf = [o76, priv24, old history]; history <- shifted / refilled
   const float clipv = cf.clip_obs;
-  float* obs = T.obs + (size_t)env * WBC_NOBS;
+  float* obs = (obs_out ? obs_out : T.obs) + (size_t)env * WBC_NOBS;
   float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
   const bool refill = s.ep_len <= 1;
   float old[12];
@@ -1065,9 +1065,10 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   }
 }
 
-// WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment.
+// WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment. obs_out != nullptr:
+// the observation rows go there instead of the sim's own obs_buf (the rollout storage slot of the next transition).
 extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions,
-                                                                    int num_envs, uint64_t seed, uint64_t step) {
+                                                                    int num_envs, uint64_t seed, uint64_t step, float* __restrict__ obs_out) {
   __shared__ Smem s;
   const DevTensors& T = *Tp;        // read on demand through the scalar path: 32 pointers held in SGPRs spilled the kernel
   const int env = blockIdx.x;
@@ -1155,7 +1156,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
   }
   STAMP(16);
-  observe_and_store(s, T, C, env, do_reset);
+  observe_and_store(s, T, C, env, do_reset, obs_out);
   STAMP(17);
 }
 

@@ -66,6 +66,7 @@ class BaseTask(VecEnv):
         self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
         self.privileged_obs_buf = None
+        self._obs_output = None
         self.extras = {}
         self.viewer = None
         self.enable_viewer_sync = False
@@ -376,10 +377,17 @@ class WidowGo1(LeggedRobot):
             self.extras["target_arm_torques"] = self.arm_ee_control_torques
             self.extras["current_arm_dof_pos"] = self.dof_pos[:, -8:-2].clone()
             self.extras["current_arm_dof_vel"] = self.dof_vel[:, -8:-2].clone()
-        self.sim.step(a)
+        out, self._obs_output = self._obs_output, None
+        self.sim.step(a, out)
         self.common_step_counter += 1
         self._fill_extras()
-        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.arm_rew_buf, self.reset_buf, self.extras
+        return (self.obs_buf if out is None else out), self.privileged_obs_buf, self.rew_buf, self.arm_rew_buf, self.reset_buf, self.extras
+
+    def set_obs_output(self, tensor):
+        """The NEXT step() writes its observations into `tensor` (f32 [num_envs, 860], contiguous, on the sim device) and
+        returns it instead of obs_buf -- the rollout loop passes the storage slot of the next transition, which saves the
+        14 MB copy `observations[step].copy_(obs)` per step. One-shot; obs_buf keeps the last observation written to it."""
+        self._obs_output = tensor
 
     # gym-tensor-API style helpers some callers of the reference use
     def get_foot_contacts(self):                                                    # WG:1090-1098

@@ -46,6 +46,7 @@ class PPO:
         self.counter = 0
         self.arm_fk = self.arm_fk_adaptive_gains if adaptive_arm_gains else self.arm_fk_fixed_gains
         self.fused_rollout = True        # use the fused HIP inference kernel in act() where it applies
+        self._eps_all = None
         self.fused_update = True         # use the fused HIP minibatch kernels in update() where they apply
         self._fused = None
         self.dist_group = dist_group
@@ -70,8 +71,13 @@ class PPO:
             # one HIP launch for actor + critic + sample + log-prob (csrc/wbc_policy_kernel.hip)
             if self.storage is not None and self.storage.step == 0:
                 ac.mark_params_changed()      # start of a rollout: re-pack once, whoever touched the weights since
-            eps = torch.randn(obs.shape[0], 18, device=obs.device)
             st, out = self.storage, None
+            if st is not None and st.step < st.num_transitions_per_env and st.actions.is_cuda and st.actions.shape[1:] == (obs.shape[0], 18):
+                if st.step == 0 or self._eps_all is None or self._eps_all.shape != st.actions.shape or self._eps_all.device != obs.device:
+                    self._eps_all = torch.randn(st.actions.shape, device=obs.device)      # the rollout's noise in one launch
+                eps = self._eps_all[st.step]
+            else:
+                eps = torch.randn(obs.shape[0], 18, device=obs.device)
             if (st is not None and st.step < st.num_transitions_per_env and st.actions.is_cuda and st.actions.shape[1:] == (obs.shape[0], 18)):
                 i = st.step                       # write straight into this step's storage slots
                 out = (st.actions[i], st.mu[i], st.actions_log_prob[i], st.values[i])
@@ -88,8 +94,9 @@ class PPO:
         # park the acting observation in its storage slot now instead of at process_env_step time.
         st = self.storage
         if st is not None and st.step < st.num_transitions_per_env:
-            st.observations[st.step].copy_(obs)
             obs_slot = st.observations[st.step]
+            if obs.data_ptr() != obs_slot.data_ptr():         # (already there when the env wrote into the slot: next_observation_slot)
+                obs_slot.copy_(obs)
             if st.privileged_observations is not None:
                 st.privileged_observations[st.step].copy_(critic_obs)
                 critic_slot = st.privileged_observations[st.step]
@@ -99,6 +106,15 @@ class PPO:
         else:
             tr.observations, tr.critic_observations = obs, critic_obs
         return tr.actions
+
+    def next_observation_slot(self):
+        """Storage slot the observation produced by the coming env.step() will be parked in by the next act(), or None
+        (last step of the rollout: slot 0 still holds this rollout's first observation, which update() reads)."""
+        st = self.storage
+        if st is None or st.privileged_observations is not None or not st.observations.is_cuda:
+            return None
+        i = st.step + 1
+        return st.observations[i] if i < st.num_transitions_per_env else None
 
     def _process_env_step_fused(self, rewards, arm_rewards, dones, infos):
         """rewards (+ time-out bootstrap) and dones of this step into their storage slots with one launch."""

@@ -75,6 +75,7 @@ class OnPolicyRunner:
         loss_stats = dict(mean_value_loss=0., mean_surrogate_loss=0., mean_arm_torques_loss=0., value_mixing_ratio=0.,
                           torque_supervision_weight=0., mean_hist_latent_loss=0., mean_priv_reg_loss=0., priv_reg_coef=0.)
         tot_iter = self.current_learning_iteration + num_learning_iterations
+        redirect_obs = hasattr(env, "set_obs_output") and hasattr(alg, "next_observation_slot") and getattr(alg, "fused_rollout", False)
         for it in range(self.current_learning_iteration, tot_iter):
             env.update_command_curriculum()
             sync()
@@ -83,6 +84,9 @@ class OnPolicyRunner:
             with torch.inference_mode():
                 for _ in range(self.num_steps_per_env):
                     actions = alg.act(obs, critic_obs, hist_encoding)
+                    slot = alg.next_observation_slot() if redirect_obs else None
+                    if slot is not None:
+                        env.set_obs_output(slot)              # the env writes the next observation where act() would copy it
                     obs, priv, rewards, arm_rewards, dones, infos = env.step(actions)
                     critic_obs = priv if priv is not None else obs
                     obs, critic_obs, rewards, arm_rewards, dones = (x.to(self.device) for x in (obs, critic_obs, rewards, arm_rewards, dones))

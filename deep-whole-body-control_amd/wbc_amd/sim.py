@@ -104,10 +104,16 @@ class WbcSim:
         check(self.L.wbc_sim_set_step_counter(self.h, int(v)))
 
     # ---- stepping --------------------------------------------------------------------------
-    def step(self, actions: torch.Tensor) -> None:
+    def step(self, actions: torch.Tensor, obs_out: torch.Tensor = None) -> None:
+        """One env step; obs_out (f32 [N, 860], contiguous, same device): write the observations there instead of OBS_BUF."""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
         assert actions.shape == (self.num_envs, abi.NACT)
-        check(self.L.wbc_sim_step(self.h, actions.data_ptr(), self._stream()), "wbc_sim_step")
+        if obs_out is None:
+            check(self.L.wbc_sim_step(self.h, actions.data_ptr(), self._stream()), "wbc_sim_step")
+        else:
+            assert (obs_out.is_cuda and obs_out.device == actions.device and obs_out.dtype == torch.float32 and obs_out.is_contiguous()
+                    and obs_out.shape == (self.num_envs, abi.NOBS))
+            check(self.L.wbc_sim_step_to(self.h, actions.data_ptr(), obs_out.data_ptr(), self._stream()), "wbc_sim_step_to")
 
     def reset_all(self) -> None:
         check(self.L.wbc_sim_reset_all(self.h, self._stream()), "wbc_sim_reset_all")

@@ -233,6 +233,10 @@ int wbc_sim_set_curriculum(wbc_sim* sim, const wbc_curriculum* cur);
  * {_compute_torques, simulate}, post_physics_step (EE goal, commands, pushes, termination,
  * rewards, resets, observations), obs clipping. actions: device f32 [N,18], policy order. */
 int wbc_sim_step(wbc_sim* sim, const float* actions_dev, void* stream);
+/* The same step with the observation rows written to obs_out_dev (f32 [N,860], e.g. the rollout storage slot of the next
+ * transition: what `self.observations[self.step].copy_(transition.observations)`, rollout_storage.py:66, would copy)
+ * instead of WBC_T_OBS_BUF; obs_out_dev == NULL is wbc_sim_step. */
+int wbc_sim_step_to(wbc_sim* sim, const float* actions_dev, float* obs_out_dev, void* stream);
 
 /* BaseTask.reset() first half: reset_idx(all envs, start=True) (BT:127-131, WG:695-754). */
 int wbc_sim_reset_all(wbc_sim* sim, void* stream);

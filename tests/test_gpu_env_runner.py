@@ -52,6 +52,26 @@ def test_env_surface_matches_reference_contract():
     assert env.update_counter == 1 and env.lin_vel_x_ranges[1] == pytest.approx(0.9)
 
 
+def test_step_into_a_caller_buffer_is_the_same_step():
+    """wbc_sim_step_to / WidowGo1.set_obs_output: the observation rows land in the caller's buffer (the rollout storage
+    slot), bit-identical to what obs_buf gets from the plain step of an identically seeded env; one-shot."""
+    envs = [WidowGo1(_cfg(n=96), sim_device="cuda:0", seed=5) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    slots = torch.full((3, 96, 860), float("nan"), device="cuda")
+    for i in range(6):
+        a = 0.3 * torch.randn(96, 18, device="cuda", generator=g)
+        ref = envs[0].step(a)[0]
+        if i % 2 == 0:
+            envs[1].set_obs_output(slots[i // 2])
+        got = envs[1].step(a)[0]
+        assert (got.data_ptr() == slots[i // 2].data_ptr()) == (i % 2 == 0)          # redirected once, then back to obs_buf
+        assert torch.equal(got, ref)
+    assert torch.equal(envs[1].rew_buf, envs[0].rew_buf) and torch.equal(envs[1].obs_history_buf, envs[0].obs_history_buf)
+    assert torch.isfinite(slots).all()
+
+
 def test_perlin_terrain_rollout_stays_on_the_ground():
     env = WidowGo1(_cfg(n=128, plane=False), sim_device="cuda:0", seed=2)
     assert env.terrain is not None and env.height_samples.shape == (600, 2000)
