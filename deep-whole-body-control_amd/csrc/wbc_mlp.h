@@ -421,7 +421,8 @@ static __device__ __forceinline__ void load16(float (&w)[66], const Desc16& d, c
 // A tile has MB blocks of 16 rows ("M-blocks") that share one operand set: acc[m][h] += sum over nch chunks of A_m * w for
 // both column halves h. ap = in + (L & 15) * LD16 + 8 (L >> 4) (16-byte aligned), M-block m at ap + 16 m LD16. The next
 // chunk's A operands are read before this chunk's MFMAs are issued (a chunk past the end re-reads the last one).
-template <int MB>
+// HALVES = 1: only the first 16 columns exist (the heads: 12, 6 or 1 outputs), the second half's MFMAs are skipped.
+template <int MB, int HALVES = 2>
 static __device__ __forceinline__ void mfma_chain16(const float* ap, const float (&w)[66], int nch, f32x4 (&acc)[MB][2]) {
   float4 a[MB][2];
 #pragma unroll
@@ -447,7 +448,7 @@ static __device__ __forceinline__ void mfma_chain16(const float* ap, const float
           const float4 q = a[m][j >> 2];
           const float av = (j & 3) == 0 ? q.x : ((j & 3) == 1 ? q.y : ((j & 3) == 2 ? q.z : q.w));
           acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[2 * (c * 8 + j)], acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[2 * (c * 8 + j) + 1], acc[m][1], 0, 0, 0);
+          if (HALVES == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[2 * (c * 8 + j) + 1], acc[m][1], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -542,7 +543,11 @@ static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, fl
   f32x4 acc[MB][2];
 #pragma unroll
   for (int m = 0; m < MB; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  if (active) mfma_chain16<MB>(smem + d.in_off + (lane & 15) * LD16 + 8 * (lane >> 4), w, d.nch, acc);
+  if (active) {
+    const float* ap = smem + d.in_off + (lane & 15) * LD16 + 8 * (lane >> 4);
+    if (d.n > 16) mfma_chain16<MB, 2>(ap, w, d.nch, acc);
+    else mfma_chain16<MB, 1>(ap, w, d.nch, acc);
+  }
   const float b0 = w[64], b1 = w[65];
   const Epi16 e = epilogue16_offsets(d, row0);
   pend16_flush<MB>(p);                                   // the previous layer's stash stores
