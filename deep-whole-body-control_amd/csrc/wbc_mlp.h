@@ -468,75 +468,69 @@ static __device__ __forceinline__ float act16(float x) {
   return x;
 }
 
-// Addresses of a lane's outputs, computed BEFORE the operand prefetch is issued: address arithmetic after it (the compiler
-// uses 64-bit multiply-adds whose unused high half may alias a register that a prefetch load is still writing) made the
-// epilogue wait for every outstanding load. lds16 / st16: step between M-blocks.
-struct Epi16 { uint32_t lds[4], st[4], lds16, st16; };
-static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d, int row0) {
+// LDS addresses of a lane's outputs, computed BEFORE the operand prefetch is issued: address arithmetic after it (the
+// compiler uses 64-bit multiply-adds whose unused high half may alias a register that a prefetch load is still writing) made
+// the epilogue wait for every outstanding load. lds16: step between M-blocks.
+struct Epi16 { uint32_t lds[4], lds16; };
+static __device__ __forceinline__ Epi16 epilogue16_offsets(const Desc16& d) {
   const int lane = threadIdx.x & 63, wave = wave_role();
   const int c0 = wave * 32 + (lane & 15), rb = 4 * (lane >> 4);
   Epi16 e;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    e.lds[r] = (uint32_t)(d.out_off + (rb + r) * d.ldo + c0);
-    e.st[r] = (uint32_t)((row0 + rb + r) * d.sw + c0) * 4u;           // bytes: scalar base + 32-bit lane offset addressing
-  }
-  e.lds16 = (uint32_t)(16 * d.ldo); e.st16 = (uint32_t)(16 * d.sw) * 4u;
+  for (int r = 0; r < 4; ++r) e.lds[r] = (uint32_t)(d.out_off + (rb + r) * d.ldo + c0);
+  e.lds16 = (uint32_t)(16 * d.ldo);
   return e;
 }
 
-// Stash stores of a layer are issued one layer late (after the next layer's MFMA chain, right before the operand
-// prefetch): a wave's vector-memory operations then always go [stores][loads], so the s_waitcnt vmcnt in front of an MFMA
-// chain counts only loads. Stores issued after the loads are lane-predicated, the compiler has to assume they were not
-// issued, and the chain's last waits turned into waits for the acknowledgement of the previous layer's stores.
+// The tile's output of layer d, LDS -> its stash slab, row-major with float4 (512 contiguous bytes per 32 lanes) instead
+// of 4-byte stores straight from the MFMA result layout. Called one layer late -- after the next layer's MFMA chain and
+// right before its operand prefetch: the output buffer is still intact (three-buffer rotation), and a wave's vector-memory
+// operations always go [stores][loads], so the s_waitcnt vmcnt in front of an MFMA chain counts only loads (stores issued
+// after the loads would be lane-predicated: the compiler has to assume they were not issued, and the chain's last waits
+// turn into waits for store acknowledgements). Slabs are padded to whole tiles: every tile row is stored.
 template <int MB>
-struct Pend16 { float v[MB][2][4]; uint32_t st[4], st16; float* sbase; bool ok[2]; };
-template <int MB>
-static __device__ __forceinline__ void pend16_flush(Pend16<MB>& p) {
-  if (p.sbase) {
+static __device__ __forceinline__ void stash_copy16(const Desc16& d, const float* smem, float* __restrict__ stash, int row0, int slab_rows) {
+  float* sbase = stash + (size_t)d.scol * slab_rows + (size_t)row0 * d.sw;      // [tile rows][sw]
+  const int tid = threadIdx.x;
+  if (d.sw == 128 && d.ldo == LD16) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (p.ok[h]) {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(p.sbase) + (p.st[r] + m * p.st16 + 64u * h)) = p.v[m][h][r];
-        }
-      }
+    for (int j = 0; j < 2 * MB; ++j) {                    // 16 MB rows x 32 float4 over 256 threads
+      const int row = (tid >> 5) + 8 * j, c = (tid & 31) * 4;
+      *reinterpret_cast<float4*>(sbase + row * 128 + c) = *reinterpret_cast<const float4*>(smem + d.out_off + row * LD16 + c);
+    }
+  } else {                                                // narrow layers (64, 20, 12, 6 columns): element-wise
+    const int total = 16 * MB * d.n;
+    for (int e = tid; e < total; e += blockDim.x) {
+      const int row = e / d.n, c = e - row * d.n;
+      sbase[row * d.sw + c] = smem[d.out_off + row * d.ldo + c];
     }
   }
-  p.sbase = nullptr;
 }
 
-// epilogue of one layer: act(acc + bias) to LDS; the values stay in `p` for the deferred stash store. (Starting the
-// accumulators from the bias instead saves the adds but moved the 20-step update test 3e-4 away from the eager path.)
+// epilogue of one layer: act(acc + bias) to LDS. (Starting the accumulators from the bias instead saves the adds but moved
+// the 20-step update test 3e-4 away from the eager path.)
 template <int ACT, int MB>
 static __device__ __forceinline__ void epilogue16(const Desc16& d, const Epi16& e, const f32x4 (&acc)[MB][2], float b0, float b1, float* smem,
-                                                  Pend16<MB>& p) {
+                                                  bool ok0, bool ok1) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (p.ok[h]) {
+    if (h ? ok1 : ok0) {
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = act16<ACT>(acc[m][h][r] + (h ? b1 : b0));
-          smem[e.lds[r] + m * e.lds16 + 16 * h] = v;
-          p.v[m][h][r] = v;
-        }
+        for (int r = 0; r < 4; ++r) smem[e.lds[r] + m * e.lds16 + 16 * h] = act16<ACT>(acc[m][h][r] + (h ? b1 : b0));
       }
     }
   }
 }
 
-// Forward layer d on a tile of MB x 16 rows: out = act(in W^T + b) to LDS and (d.scol >= 0, stash != nullptr) to the
-// slab-major stash whose slabs have `slab_rows` rows -- the stash store is left pending in `p` (flush it after the last
-// layer). `after_mfma` runs once `w` is no longer read (one call site: the operand registers it refills keep their
-// place). Ends with a barrier.
+// Forward layer d on a tile of MB x 16 rows: out = act(in W^T + b) to LDS. copy_prev: the output of the previous layer
+// `dprev` still has to go to the stash (stash_copy16; the caller does it itself after the last layer). `after_mfma` runs
+// once `w` is no longer read (one call site: the operand registers it refills keep their place). Ends with a barrier.
+// (Descriptors by reference into the kernel-argument table: taking their address would copy the table to scratch.)
 template <int MB, typename Hook = NoHook>
 static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, float* smem, float* __restrict__ stash, int row0, int slab_rows,
-                                             Pend16<MB>& p, Hook after_mfma = Hook(), int dbg_l = 0) {
+                                             const Desc16& dprev, bool copy_prev, Hook after_mfma = Hook(), int dbg_l = 0) {
   const int lane = threadIdx.x & 63, wave = wave_role();
   const bool active = wave < d.nblk;
   LSTAMP(dbg_l, 0);
@@ -549,21 +543,17 @@ static __device__ __forceinline__ void run16(float (&w)[66], const Desc16& d, fl
     else mfma_chain16<MB, 1>(ap, w, d.nch, acc);
   }
   const float b0 = w[64], b1 = w[65];
-  const Epi16 e = epilogue16_offsets(d, row0);
-  pend16_flush<MB>(p);                                   // the previous layer's stash stores
+  const Epi16 e = epilogue16_offsets(d);
+  if (copy_prev) stash_copy16<MB>(dprev, smem, stash, row0, slab_rows);
   LSTAMP(dbg_l, 1);
   after_mfma();
   {
     const int c0 = wave * 32 + (lane & 15);
-    p.ok[0] = active && c0 < d.n; p.ok[1] = active && c0 + 16 < d.n;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) p.st[r] = e.st[r];
-    p.st16 = e.st16;
-    p.sbase = (stash != nullptr && d.scol >= 0) ? stash + (size_t)d.scol * slab_rows : nullptr;
+    const bool ok0 = active && c0 < d.n, ok1 = active && c0 + 16 < d.n;
+    if (d.act == ACT_ELU) epilogue16<ACT_ELU, MB>(d, e, acc, b0, b1, smem, ok0, ok1);
+    else if (d.act == ACT_TANH) epilogue16<ACT_TANH, MB>(d, e, acc, b0, b1, smem, ok0, ok1);
+    else epilogue16<ACT_NONE, MB>(d, e, acc, b0, b1, smem, ok0, ok1);
   }
-  if (d.act == ACT_ELU) epilogue16<ACT_ELU, MB>(d, e, acc, b0, b1, smem, p);
-  else if (d.act == ACT_TANH) epilogue16<ACT_TANH, MB>(d, e, acc, b0, b1, smem, p);
-  else epilogue16<ACT_NONE, MB>(d, e, acc, b0, b1, smem, p);
   LSTAMP(dbg_l, 2);
   LBAR();
   LSTAMP(dbg_l, 3);

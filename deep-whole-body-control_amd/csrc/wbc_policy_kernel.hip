@@ -132,16 +132,15 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
   const int lbeg = critic ? L_CBB : (latent ? L_BB : 0), lend = critic ? NLAYERS : L_CBB;
   {
     float wa[66], wb[66];
-    Pend16<1> pend; pend.sbase = nullptr;          // (no stash in the inference kernel)
     load16(wa, T.l[lbeg], wpack16, bias);
 #pragma unroll 1
     for (int l = lbeg; l < lend; l += 2) {
       const bool two = l + 1 < lend;
       if (two) load16(wb, T.l[l + 1], wpack16, bias);
-      run16<1>(wa, T.l[l], smem, nullptr, row0, 0, pend);
+      run16<1>(wa, T.l[l], smem, nullptr, row0, 0, T.l[l], false);
       if (two) {
         if (l + 2 < lend) load16(wa, T.l[l + 2], wpack16, bias);
-        run16<1>(wb, T.l[l + 1], smem, nullptr, row0, 0, pend);
+        run16<1>(wb, T.l[l + 1], smem, nullptr, row0, 0, T.l[l], false);
       }
     }
   }

@@ -616,15 +616,15 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
   PSTAMP(1);
   {
     float w[66];
-    Pend16<PPO_MB> pend; pend.sbase = nullptr;
     load16(w, FT.l[0], blob, bias);
 #pragma unroll 1
     for (int i = 0; i < NLAYERS; ++i) {
       const int nx = i + 1 < NLAYERS ? i + 1 : i;        // (the last layer re-requests its own operands: no conditional refill)
       if (i == PPO16_CBB_POS) gather_x(false);           // (the previous layer's barrier: nobody reads this buffer any more)
-      run16<PPO_MB>(w, FT.l[i], smem, act_stash, row0, Bs, pend, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
+      const int pv = i > 0 ? i - 1 : 0;
+      run16<PPO_MB>(w, FT.l[i], smem, act_stash, row0, Bs, FT.l[pv], i > 0 && FT.l[pv].scol >= 0, [&]() { load16(w, FT.l[nx], blob, bias); }, i);
     }
-    pend16_flush<PPO_MB>(pend);
+    if (FT.l[NLAYERS - 1].scol >= 0) stash_copy16<PPO_MB>(FT.l[NLAYERS - 1], smem, act_stash, row0, Bs);
   }
   PSTAMP(2);
   __threadfence_block();
