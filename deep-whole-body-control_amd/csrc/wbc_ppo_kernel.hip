@@ -909,14 +909,27 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
 // Grid = (row ranges, layers), 4 waves per workgroup = the layer's four 32-row output blocks. About three workgroups per
 // CU: co-resident waves do not overlap each other's vector-ALU work with MFMAs, but they do hide each other's memory latency
 // (one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
+// Workgroup -> (layer, row range). All PPO_NSPLIT x 16 workgroups are resident at once (three per CU), but a 128 x 128
+// layer's workgroup issues 16 MFMAs per row pair and a head's 4 or fewer: with (split, layer) in grid order the CUs that
+// happened to get three big layers set the kernel's duration (48 work units against a mean of 33). The host deals the
+// workgroups out so that the three sharing a CU (ids i, i + 256, i + 512: workgroup i goes to XCD i % 8 and round-robin to
+// that XCD's 32 CUs) carry about the same total (wgrad_work_map: 36 at most instead of 48). Measured 172.7 -> 168.6 us only: the kernel waits
+// for the stash streams, not for its MFMAs.
+#ifndef PPO_NSPLIT
+#define PPO_NSPLIT 48
+#endif
+#define WGRAD_NWG (PPO_NSPLIT * NLAYERS)
+__device__ uint16_t g_wgrad_map[WGRAD_NWG];         // layer << 8 | split
+
 extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
                                                                          int B, int Bs, int nparams) {
-  const WgradLayer L = tab.l[blockIdx.y];
+  const int work = g_wgrad_map[blockIdx.x], split = work & 255;
+  const WgradLayer L = tab.l[work >> 8];
   const int wave = threadIdx.x >> 6;
-  if (wave * 32 >= L.out || (int)blockIdx.x >= L.nsplit) return;
-  const int r_begin = blockIdx.x * L.rows, r_end = min(B, r_begin + L.rows);
-  float* dst = wpart + (size_t)blockIdx.x * nparams + L.goff;
+  if (wave * 32 >= L.out || split >= L.nsplit) return;
+  const int r_begin = split * L.rows, r_end = min(B, r_begin + L.rows);
+  float* dst = wpart + (size_t)split * nparams + L.goff;
   const int nib = (L.in + 31) / 32;
   if (nib == 4 && ((L.aw | L.aoff) & 3) == 0) wgrad_body<4, true>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);   // 16-byte aligned rows
   else if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
@@ -1030,13 +1043,50 @@ extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, f
 // then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
 static const int kDcol[NLAYERS] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM};
 static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, A_BB, A_A1, A_A2, A_X, A_CB, A_CL1, A_CL2, A_CB, A_CA1, A_CA2};
-#ifndef PPO_NSPLIT
-#define PPO_NSPLIT 48
-#endif
 #ifndef PPO_TILE16
 #define PPO_TILE16 1        // 16-row tiles (ppo_fwd_bwd16_kernel); 0: the 32-row kernel, kept for A/B runs
 #endif
 #define PPO_WPACK_FLOATS (WPACK_FLOATS > WPACK16_FLOATS ? WPACK_FLOATS : WPACK16_FLOATS)
+
+// Upload g_wgrad_map once: longest-processing-time-first over 256 CUs with 3 slots each; a workgroup's weight = its MFMAs
+// per row pair (32-row output blocks x 32-column input blocks).
+static int wgrad_work_map() {
+  static int done = 0;                 // 0 not yet, 1 uploaded, -1 failed
+  if (done) return done < 0;
+#ifdef PPO_WGRAD_GRID_ORDER
+  uint16_t id_map[WGRAD_NWG];
+  for (int i = 0; i < WGRAD_NWG; ++i) id_map[i] = (uint16_t)(((i / PPO_NSPLIT) << 8) | (i % PPO_NSPLIT));
+  done = hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_map), id_map, sizeof(id_map)) == hipSuccess ? 1 : -1;
+  return done < 0;
+#endif
+  const int NCU = 256, SLOTS = (WGRAD_NWG + NCU - 1) / NCU;
+  int weight[NLAYERS], order[NLAYERS];
+  for (int l = 0; l < NLAYERS; ++l) { weight[l] = ((layer_out(l) + 31) / 32) * ((layer_in(l) + 31) / 32); order[l] = l; }
+  for (int a = 0; a < NLAYERS; ++a)    // layers by weight, heaviest first (stable)
+    for (int b = a + 1; b < NLAYERS; ++b)
+      if (weight[order[b]] > weight[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  int load[256] = {0}, used[256] = {0};
+  uint16_t map[WGRAD_NWG];
+  for (int i = 0; i < WGRAD_NWG; ++i) map[i] = 0;
+  for (int a = 0; a < NLAYERS; ++a) {
+    const int l = order[a];
+    for (int sp = 0; sp < PPO_NSPLIT; ++sp) {
+      int best = -1;
+      for (int c = 0; c < NCU; ++c)
+        if (used[c] < SLOTS && (best < 0 || load[c] < load[best])) best = c;
+      if (best < 0 || used[best] * NCU + best >= WGRAD_NWG) {          // (a partial last slot row: take any CU whose next id exists)
+        best = -1;
+        for (int c = 0; c < NCU; ++c)
+          if (used[c] < SLOTS && used[c] * NCU + c < WGRAD_NWG && (best < 0 || load[c] < load[best])) best = c;
+        if (best < 0) { done = -1; return 1; }
+      }
+      map[used[best] * NCU + best] = (uint16_t)((l << 8) | sp);
+      used[best] += 1; load[best] += weight[l];
+    }
+  }
+  done = hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_map), map, sizeof(map)) == hipSuccess ? 1 : -1;
+  return done < 0;
+}
 
 extern "C" int wbc_ppo_grad_floats(void) {
   int n = 0;
@@ -1101,7 +1151,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
     tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab, off, nsplit, rows};
     off += layer_out(l) * layer_in(l) + layer_out(l);
   }
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(PPO_NSPLIT, NLAYERS), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, Bs, ng);
+  if (wgrad_work_map()) return -2;
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WGRAD_NWG), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, Bs, ng);
   hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, tab, wpart, ng, grad);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(3), dim3(256), 0, st, loss_partial, tiles, 3, grad + off + 18);
