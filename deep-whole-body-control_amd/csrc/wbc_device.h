@@ -65,6 +65,7 @@ struct DevTensors {
   float* origins;     // [N,3]
   float* box_dy;      // [N]
   float* body_params; // [N,20]
+  float* reset_travel; // [N,2]
 };
 
 #define WBC_PI 3.14159265358979323846f

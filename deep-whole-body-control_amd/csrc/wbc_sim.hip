@@ -35,7 +35,8 @@ static const TensorSpec kSpecs[WBC_T_COUNT] = {
     {{0, 0, 0}, 0, WBC_F32},  {{0, 0, 0}, 0, WBC_I64},  {{0, 0, 0}, 0, WBC_U8},    {{0, 0, 0}, 0, WBC_I64},
     {{21, 0, 0}, 1, WBC_F32}, {{10, 0, 0}, 1, WBC_F32}, {{21, 0, 0}, 1, WBC_F32},  {{10, 0, 0}, 1, WBC_F32},
     {{3, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{5, 0, 0}, 1, WBC_F32},   {{0, 0, 0}, 0, WBC_F32},
-    {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32}};
+    {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32},
+    {{2, 0, 0}, 1, WBC_F32}};
 
 static size_t spec_elems(const TensorSpec& s) {
   size_t n = 1;
@@ -164,7 +165,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   T.met_sums_done = (float*)s->ptr[WBC_T_METRIC_SUMS_DONE]; T.base_lin_vel = (float*)s->ptr[WBC_T_BASE_LIN_VEL];
   T.base_ang_vel = (float*)s->ptr[WBC_T_BASE_ANG_VEL]; T.mass_params = (float*)s->ptr[WBC_T_MASS_PARAMS]; T.friction = (float*)s->ptr[WBC_T_FRICTION];
   T.motor = (float*)s->ptr[WBC_T_MOTOR_STRENGTH]; T.origins = (float*)s->ptr[WBC_T_ENV_ORIGINS]; T.box_dy = (float*)s->ptr[WBC_T_BOX_DELTA_Y];
-  T.body_params = (float*)s->ptr[WBC_T_BODY_PARAMS];
+  T.body_params = (float*)s->ptr[WBC_T_BODY_PARAMS]; T.reset_travel = (float*)s->ptr[WBC_T_RESET_TRAVEL];
   // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
   {
     const int n = num_envs;

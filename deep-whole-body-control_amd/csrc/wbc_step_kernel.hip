@@ -973,6 +973,11 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
   if (lane < WBC_NREW) s.ep_sums[lane] = 0.f;
   if (lane < WBC_NMETRIC) s.met_sums[lane] = 0.f;
   if (lane == 0) {
+    {   // what _update_terrain_curriculum reads of the finished episode (LR:431-435), before root and commands are overwritten
+      const float dx = s.root[0] - T.origins[(size_t)env * 3], dy = s.root[1] - T.origins[(size_t)env * 3 + 1];
+      T.reset_travel[(size_t)env * 2] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      T.reset_travel[(size_t)env * 2 + 1] = __fsqrt_rn(__fadd_rn(__fmul_rn(s.cmd[0], s.cmd[0]), __fmul_rn(s.cmd[1], s.cmd[1])));
+    }
     for (int j = 0; j < 13; ++j) s.root[j] = C->cfg.base_init_state[j];
     for (int j = 0; j < 3; ++j) s.root[j] += T.origins[(size_t)env * 3 + j];
     for (int j = 0; j < 2; ++j) s.root[j] += rng_range(-C->cfg.origin_perturb_range, C->cfg.origin_perturb_range, seed, env, step, SLOT_RESET_XY + j);

@@ -188,6 +188,10 @@ class WidowGo1(LeggedRobot):
         origins[:, 1] = rand(-half_row + 10, half_row - 10, n)
         self.env_origins = origins.to(self.device)
         self.custom_origins = True
+        self._terrain_levels_on = bool(t.curriculum and self.terrain is not None)
+        if self._terrain_levels_on:                 # base-class placement on the terrain's (level, type) platforms, LR:717-731
+            self.terrain.level_grid(int(t.num_rows), int(t.num_cols))
+            origins = self._get_env_origins_levels(gen).cpu()
         sign = torch.randint(0, 2, (n,), generator=gen) * 2 - 1
         box_dy = sign * rand(cfg.box.box_env_origins_y_range[0], cfg.box.box_env_origins_y_range[1], n)
         if dr.randomize_friction:
@@ -278,6 +282,11 @@ class WidowGo1(LeggedRobot):
         self.common_step_counter = 0
         self.extras = {"episode": {}}
         self._active_terms = None
+        self._reset_travel = T("RESET_TRAVEL")
+        self._sim_env_origins = T("ENV_ORIGINS")                                     # what the kernel's resets read
+        if self.cfg.terrain.measure_heights:                                         # WG:637-639
+            self.height_points = self._init_height_points()
+        self.measured_heights = 0
         self._refresh_ranges()
 
     @property
@@ -380,8 +389,95 @@ class WidowGo1(LeggedRobot):
         out, self._obs_output = self._obs_output, None
         self.sim.step(a, out)
         self.common_step_counter += 1
+        if self._terrain_levels_on:                                                  # WG:708-709 (reset_idx -> _update_terrain_curriculum)
+            self._apply_terrain_curriculum()
+        if self.cfg.terrain.measure_heights:                                         # WG:932-933
+            self.measured_heights = self._get_heights()
         self._fill_extras()
         return (self.obs_buf if out is None else out), self.privileged_obs_buf, self.rew_buf, self.arm_rew_buf, self.reset_buf, self.extras
+
+    # ---- the base class's terrain bookkeeping (legged_robot.py:421-441, 717-731, 777-829) --------------
+    def _init_height_points(self):                                                   # LR:777-791
+        """Points (base frame) at which the terrain height is sampled: [num_envs, num_height_points, 3]."""
+        y = torch.tensor(self.cfg.terrain.measured_points_y, device=self.device, requires_grad=False)
+        x = torch.tensor(self.cfg.terrain.measured_points_x, device=self.device, requires_grad=False)
+        grid_x, grid_y = torch.meshgrid(x, y, indexing="ij")
+        self.num_height_points = grid_x.numel()
+        points = torch.zeros(self.num_envs, self.num_height_points, 3, device=self.device, requires_grad=False)
+        points[:, :, 0] = grid_x.flatten()
+        points[:, :, 1] = grid_y.flatten()
+        return points
+
+    def _get_heights(self, env_ids=None):                                            # LR:793-829
+        """Terrain heights under the height points of each robot (rotated by the base yaw, offset by the base position):
+        one launch of wbc_get_heights (csrc/wbc_terrain_kernel.hip), bit-exact against oracle/terrain_oracle.py.
+        `height_samples` is the [x, y] grid the contact kernel uses (the reference views its array with the two dimensions
+        swapped, quirk Q3, which only stays harmless while measure_heights is False)."""
+        t = self.cfg.terrain
+        if t.mesh_type == "plane":
+            return torch.zeros(self.num_envs, self.num_height_points, device=self.device, requires_grad=False)
+        elif t.mesh_type == "none":
+            raise NameError("Can't measure height with terrain mesh type 'none'")
+        if self.height_samples is None:
+            raise RuntimeError("no height samples attached (set_heightfield)")
+        quat, pos, pts = self.base_quat, self.root_states, self.height_points
+        if env_ids is not None and len(env_ids) > 0:                                 # (the reference: `if env_ids:`)
+            ids = torch.as_tensor(env_ids, dtype=torch.long, device=self.device)
+            quat, pos, pts = quat[ids].contiguous(), pos[ids].contiguous(), pts[ids]
+        pts = pts.contiguous()
+        n, npts = pts.shape[0], pts.shape[1]
+        hs = self.height_samples
+        assert hs.dtype == torch.int16 and hs.is_contiguous() and quat.stride(1) == 1 and pos.stride(1) == 1
+        out = torch.empty(n, npts, dtype=torch.float32, device=self.device)
+        from .native import check, lib
+        check(lib().wbc_get_heights(quat.data_ptr(), quat.stride(0), pos.data_ptr(), pos.stride(0), pts.data_ptr(), hs.data_ptr(),
+                                    hs.shape[0], hs.shape[1], float(t.border_size), float(t.horizontal_scale), float(t.vertical_scale),
+                                    out.data_ptr(), n, npts, torch.cuda.current_stream(self.device).cuda_stream), "wbc_get_heights")
+        return out
+
+    def _get_env_origins_levels(self, gen=None):                                     # LR:717-731, the terrain-level branch
+        """terrain_levels / terrain_types / terrain_origins and env_origins on the terrain's platforms."""
+        t, n, dev = self.cfg.terrain, self.num_envs, self.device
+        max_init_level = t.max_init_terrain_level
+        if not t.curriculum:
+            max_init_level = t.num_rows - 1
+        self.terrain_levels = torch.randint(0, max_init_level + 1, (n,), generator=gen).to(dev)
+        self.terrain_types = torch.div(torch.arange(n, device=dev), (n / t.num_cols), rounding_mode="floor").to(torch.long)
+        self.max_terrain_level = t.num_rows
+        self.terrain_origins = torch.from_numpy(self.terrain.env_origins).to(dev).to(torch.float)
+        self.env_origins = torch.zeros(n, 3, device=dev, requires_grad=False)
+        self.env_origins[:] = self.terrain_origins[self.terrain_levels, self.terrain_types]
+        return self.env_origins
+
+    def _update_terrain_curriculum(self, env_ids):                                   # LR:421-441
+        """The game-inspired curriculum for the envs being reset. `distance` and the command norm are the finished episode's
+        (WBC_T_RESET_TRAVEL: the fused step has already re-placed these robots and may have resampled their commands)."""
+        if not self.init_done:
+            return                                                                   # don't change on the initial reset
+        travel = self._reset_travel[env_ids]
+        distance = travel[:, 0]
+        move_up = distance > self.terrain.env_length / 2                             # walked far enough: harder terrain
+        move_down = (distance < travel[:, 1] * self.max_episode_length_s * 0.5) * ~move_up   # less than half the commanded distance
+        self.terrain_levels[env_ids] += 1 * move_up - 1 * move_down
+        self.terrain_levels[env_ids] = torch.where(self.terrain_levels[env_ids] >= self.max_terrain_level,    # solved the last level:
+                                                   torch.randint_like(self.terrain_levels[env_ids], self.max_terrain_level),   # a random one
+                                                   torch.clip(self.terrain_levels[env_ids], 0))
+        self.env_origins[env_ids] = self.terrain_origins[self.terrain_levels[env_ids], self.terrain_types[env_ids]]
+
+    def _apply_terrain_curriculum(self):
+        """reset_idx's call of _update_terrain_curriculum (WG:708-709) for the envs the fused step has just reset: new levels
+        and origins, then those robots (and their boxes, WG:769-771) move from the old platform to the new one -- the reset
+        placed them relative to the old origin."""
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        if len(env_ids) == 0 or not self.init_done:
+            return
+        old = self._sim_env_origins[env_ids].clone()
+        self._update_terrain_curriculum(env_ids)
+        new = self.env_origins[env_ids]
+        self._sim_env_origins[env_ids] = new
+        delta = new - old
+        self.root_states[env_ids, :3] += delta
+        self.box_root_state[env_ids, 1] += delta[:, 1]
 
     def set_obs_output(self, tensor):
         """The NEXT step() writes its observations into `tensor` (f32 [num_envs, 860], contiguous, on the sim device) and

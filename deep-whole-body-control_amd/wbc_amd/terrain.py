@@ -69,3 +69,23 @@ class TerrainPerlin:
         self.heightsamples = np.clip(hs, -32768, 32767).astype(np.int16)
         self.horizontal_scale, self.vertical_scale = float(cfg.horizontal_scale), float(cfg.vertical_scale)
         self.transform = (float(cfg.transform_x), float(cfg.transform_y), float(cfg.transform_z))
+
+    def level_grid(self, num_rows: int, num_cols: int):
+        """What the base class's terrain curriculum needs from a terrain object -- `env_origins` [num_rows, num_cols, 3],
+        `env_length`, `env_width` (utils/terrain.py Terrain: one platform per (level, type), origin z = highest sample of
+        the 2 m x 2 m patch around the platform centre) -- for this field: its walkable part (x below the flattened rows,
+        quirk Q3; all of y) cut into num_rows levels along x and num_cols types along y. The reference's widowGo1 cannot
+        run with terrain.curriculum=True (its _get_env_origins override never creates terrain_levels, and its Perlin terrain
+        has no env_length), so this grid is this framework's choice; the curriculum rule itself is LR:421-441."""
+        hs, vs = self.horizontal_scale, self.vertical_scale
+        nx, ny = self.flat_beyond_row, self.heightsamples.shape[1]
+        self.env_length, self.env_width = nx * hs / num_rows, ny * hs / num_cols
+        self.env_origins = np.zeros((num_rows, num_cols, 3))
+        half = int(round(1.0 / hs))
+        for i in range(num_rows):
+            for j in range(num_cols):
+                cx, cy = (i + 0.5) * self.env_length, (j + 0.5) * self.env_width
+                ix, iy = int(cx / hs), int(cy / hs)
+                patch = self.heightsamples[max(ix - half, 0):min(ix + half, nx), max(iy - half, 0):min(iy + half, ny)]
+                self.env_origins[i, j] = (cx + self.transform[0], cy + self.transform[1], float(patch.max()) * vs + self.transform[2])
+        return self.env_origins

@@ -189,6 +189,8 @@ enum wbc_tensor_id {
   WBC_T_ENV_ORIGINS,       /* f32 [N,3]                                      (WG:212) */
   WBC_T_BOX_DELTA_Y,       /* f32 [N]                                        (WG:226) */
   WBC_T_BODY_PARAMS,       /* f32 [N,20] per-env composite root + gripper (mass, com, inertia6) */
+  WBC_T_RESET_TRAVEL,      /* f32 [N,2]  at the moment of an env's reset: ||root_xy - env_origin_xy|| and ||commands[:2]||,
+                              the two quantities _update_terrain_curriculum reads before reset_idx overwrites them (LR:431-435) */
   WBC_T_COUNT
 };
 enum wbc_dtype { WBC_F32 = 0, WBC_I64 = 1, WBC_U8 = 2 };
@@ -346,6 +348,17 @@ int wbc_rollout_store(const float* rew, const float* arm_rew, const int64_t* don
 
 /* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
 void wbc_abi_sizes(int* out3);
+
+/* LeggedRobot._get_heights (legged_gym/envs/base/legged_robot.py:793-829): terrain height under num_points points around
+ * every robot -- points rotated by the base yaw (utils/math.py:38-42) and offset by the base position, `+= border_size`,
+ * `(p / horizontal_scale).long()` (toward zero), clip to [0, dim-2], min of the three corner samples, * vertical_scale.
+ * Bit-exact against oracle/terrain_oracle.py (integer / index work; the divisor is applied as PyTorch's CUDA kernel does:
+ * multiplication by the fp32 reciprocal). base_quat: device f32 rows of (x,y,z,w), quat_stride floats apart; root_pos:
+ * device f32 rows starting with (x,y), pos_stride floats apart (root_states: 13); height_points: device f32 [N,P,3];
+ * height_samples: device int16 [rows,cols]; out: device f32 [N,P]. */
+int wbc_get_heights(const float* base_quat, int quat_stride, const float* root_pos, int pos_stride, const float* height_points,
+                    const int16_t* height_samples, int rows, int cols, float border_size, float horizontal_scale,
+                    float vertical_scale, float* out, int num_envs, int num_points, void* stream);
 
 #ifdef __cplusplus
 }

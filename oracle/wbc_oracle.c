@@ -160,6 +160,7 @@ typedef struct {
   REAL mass_params[5], friction, motor_strength[WBC_NACT];
   REAL env_origin[3], box_delta_y;
   REAL body_params[20];      /* root (m, com3, I6), gripper (m, com3, I6) */
+  REAL reset_travel[2];      /* ||root_xy - origin_xy||, ||commands[:2]|| at the moment of reset (LR:431-435) */
 } ora_env;
 
 /* goal[] slots */
@@ -668,6 +669,11 @@ static void reset_env(const ora_sim* s, ora_env* e, int env, uint64_t step, int 
     e->q[j] = (REAL)cf->default_dof_pos[j] * rng_range((REAL)cf->dof_reset_lo, (REAL)cf->dof_reset_hi, s->seed, env, step, SLOT_RESET_DOF + j);
     e->qd[j] = 0;
   }
+  {                                                                                       /* _update_terrain_curriculum's inputs, LR:431-435 */
+    const REAL dx = e->root[0][0] - e->env_origin[0], dy = e->root[0][1] - e->env_origin[1];
+    e->reset_travel[0] = sqrt(dx * dx + dy * dy);
+    e->reset_travel[1] = sqrt(e->commands[0] * e->commands[0] + e->commands[1] * e->commands[1]);
+  }
   for (int k = 0; k < 13; ++k) e->root[0][k] = (REAL)cf->base_init_state[k];              /* WG:765 */
   for (int k = 0; k < 3; ++k) e->root[0][k] += e->env_origin[k];                          /* WG:766 */
   for (int k = 0; k < 2; ++k)
@@ -954,6 +960,7 @@ static int field_ptr(ora_env* e, int id, REAL** p, int* n) {
     case WBC_T_ENV_ORIGINS: *p = e->env_origin; *n = 3; return 0;
     case WBC_T_BOX_DELTA_Y: *p = &e->box_delta_y; *n = 1; return 0;
     case WBC_T_BODY_PARAMS: *p = e->body_params; *n = 20; return 0;
+    case WBC_T_RESET_TRAVEL: *p = e->reset_travel; *n = 2; return 0;
     default: return -1;
   }
 }

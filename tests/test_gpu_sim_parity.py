@@ -85,6 +85,8 @@ def test_step_matches_oracle_from_synced_state(robot, precision, atol):
         np.testing.assert_allclose(_t(g, "ARM_REW_BUF"), o.get("ARM_REW_BUF"), atol=2e-5, rtol=1e-3)
         np.testing.assert_allclose(_t(g, "EPISODE_SUMS"), o.get("EPISODE_SUMS"), atol=2e-2, rtol=2e-3)
         np.testing.assert_allclose(_t(g, "FORCE_SENSOR"), o.get("FORCE_SENSOR"), atol=0.1, rtol=5e-3)
+        m = o.get("RESET_BUF").astype(bool)        # the finished episode's travel / command norm (terrain curriculum inputs)
+        np.testing.assert_allclose(_t(g, "RESET_TRAVEL")[m], o.get("RESET_TRAVEL")[m], atol=atol, rtol=1e-4)
     assert resets > 10     # resets (and therefore the reset path and its random draws) were exercised
     g.close()
 
