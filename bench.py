@@ -118,6 +118,8 @@ def main():
                     help="create the RCCL process group even for one rank (exercises the multi-GPU code path on one GPU)")
     ap.add_argument("--terrain", choices=["plane", "trimesh"], default="plane",
                     help="plane = BASELINE.json configs[1] (the bench line); trimesh = the shipped fractal-Perlin terrain (configs[2])")
+    ap.add_argument("--terrain-curriculum", action="store_true",
+                    help="with --terrain trimesh: terrain.curriculum=True (the base class's terrain levels, LR:421-441; configs[2] names it)")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +153,8 @@ def main():
     cfg.env.num_envs = args.envs_per_gpu
     if args.terrain == "plane":
         cfg.terrain.mesh_type = "plane"               # BASELINE.json configs[1]: flat terrain (the shipped default is the Perlin trimesh)
+    elif args.terrain_curriculum:
+        cfg.terrain.curriculum = True
     train_cfg = WidowGo1RoughCfgPPO()
     torch.manual_seed(train_cfg.seed)                 # identical replicas; env RNG differs per rank
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)
@@ -230,7 +234,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": f"synthetic (random-init policy, seeded domain randomisation, {'flat' if args.terrain == 'plane' else 'fractal-Perlin trimesh'} terrain)",
             "config": {"workload": f"widowGo1 {'flat' if args.terrain == 'plane' else 'trimesh (Perlin)'} terrain, {args.envs_per_gpu} envs per GPU, PPO fp32 "
-                                   f"(BASELINE.json configs[{1 if args.terrain == 'plane' else 2}]); T={T} steps/iteration, 5 epochs x 4 minibatches, "
+                                   f"(BASELINE.json configs[{1 if args.terrain == 'plane' else 2}]{', terrain-level curriculum on' if args.terrain_curriculum else ''}); T={T} steps/iteration, 5 epochs x 4 minibatches, "
                                    f"DAgger every 20th iteration", "envs_per_gpu": args.envs_per_gpu,
                        "global_envs": args.envs_per_gpu * world, "steps_per_env": T,
                        "parallelism": f"env-shard x{world}, 1 grad all-reduce/minibatch" if world > 1 else "single GPU",

@@ -465,19 +465,25 @@ class WidowGo1(LeggedRobot):
         self.env_origins[env_ids] = self.terrain_origins[self.terrain_levels[env_ids], self.terrain_types[env_ids]]
 
     def _apply_terrain_curriculum(self):
-        """reset_idx's call of _update_terrain_curriculum (WG:708-709) for the envs the fused step has just reset: new levels
-        and origins, then those robots (and their boxes, WG:769-771) move from the old platform to the new one -- the reset
-        placed them relative to the old origin."""
-        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
-        if len(env_ids) == 0 or not self.init_done:
+        """reset_idx's call of _update_terrain_curriculum (WG:708-709) for the envs the fused step has just reset, without a
+        host synchronisation: the rule of LR:431-441 over all envs under the reset mask (same arithmetic as
+        _update_terrain_curriculum on reset_buf.nonzero()), then those robots (and their boxes, WG:769-771) move from the old
+        platform to the new one -- the in-kernel reset placed them relative to the old origin."""
+        if not self.init_done:
             return
-        old = self._sim_env_origins[env_ids].clone()
-        self._update_terrain_curriculum(env_ids)
-        new = self.env_origins[env_ids]
-        self._sim_env_origins[env_ids] = new
-        delta = new - old
-        self.root_states[env_ids, :3] += delta
-        self.box_root_state[env_ids, 1] += delta[:, 1]
+        m = self.reset_buf.bool()
+        distance, cmd_norm = self._reset_travel[:, 0], self._reset_travel[:, 1]
+        move_up = m & (distance > self.terrain.env_length / 2)
+        move_down = m & (distance < cmd_norm * self.max_episode_length_s * 0.5) & ~move_up
+        lv = self.terrain_levels + (1 * move_up - 1 * move_down)
+        lv = torch.where(m & (lv >= self.max_terrain_level), torch.randint_like(lv, self.max_terrain_level), torch.clip(lv, 0))
+        self.terrain_levels.copy_(lv)
+        new = self.terrain_origins[lv, self.terrain_types]
+        delta = new - self._sim_env_origins                            # zero for the envs that did not reset
+        self.env_origins.copy_(new)
+        self._sim_env_origins.copy_(new)
+        self.root_states[:, :3] += delta
+        self.box_root_state[:, 1] += delta[:, 1]
 
     def set_obs_output(self, tensor):
         """The NEXT step() writes its observations into `tensor` (f32 [num_envs, 860], contiguous, on the sim device) and
