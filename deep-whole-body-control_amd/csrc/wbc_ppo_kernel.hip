@@ -976,11 +976,15 @@ extern "C" __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float*
   grad[p] = acc;
 }
 
-// out[j] = sum_t part[t*width + j] for a few columns and many partials: one block per column, fixed-order tree
+// out[j] = sum_t part[t*width + j] for a few columns and many partials: one block per column, fixed-order tree. Two
+// tables in one launch: blocks [0, width) reduce `part`, blocks [width, width + width2) reduce `part2` into out + width.
 extern "C" __global__ void __launch_bounds__(256) ppo_column_reduce_kernel(const float* __restrict__ part, int nparts, int width,
+                                                                          const float* __restrict__ part2, int width2,
                                                                           float* __restrict__ out) {
   __shared__ float sh[256];
-  const int j = blockIdx.x;
+  int j = blockIdx.x;
+  const int j_out = j;
+  if (j >= width) { j -= width; part = part2; width = width2; }
   float acc = 0.f;
   for (int t = threadIdx.x; t < nparts; t += 256) acc += part[(size_t)t * width + j];
   sh[threadIdx.x] = acc;
@@ -989,7 +993,7 @@ extern "C" __global__ void __launch_bounds__(256) ppo_column_reduce_kernel(const
     if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[j] = sh[0];
+  if (threadIdx.x == 0) out[j_out] = sh[0];
 }
 
 // ---- gradient clip + Adam on the flat gradient (nn.utils.clip_grad_norm_ + optim.Adam.step, PPO:243-246) ----
@@ -1154,8 +1158,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   if (wgrad_work_map()) return -2;
   hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WGRAD_NWG), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, Bs, ng);
   hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, tab, wpart, ng, grad);
-  hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18), dim3(256), 0, st, dstd_partial, tiles, 18, grad + off);
-  hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(3), dim3(256), 0, st, loss_partial, tiles, 3, grad + off + 18);
+  hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18 + 3), dim3(256), 0, st, dstd_partial, tiles, 18, loss_partial, 3, grad + off);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
