@@ -37,6 +37,8 @@ class OnPolicyRunner:
                 torch.distributed.broadcast(p.data, src=torch.distributed.get_global_rank(dist_group, 0), group=dist_group)
         self.alg: PPO = _ALGORITHMS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, dist_group=dist_group,
                                                                       **self.alg_cfg)
+        if hasattr(self.alg, "warm_up_collectives"):
+            self.alg.warm_up_collectives()       # RCCL's first-collective set-up here, not inside the first update
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions])
