@@ -30,16 +30,20 @@ extern "C" __global__ void __launch_bounds__(H_THREADS) wbc_hist_latent_kernel(H
                                                                               int rows) {
   __shared__ float w_enc[H_NP][H_C1 + 2];        // transposed [k][j]: thread reads 30 consecutive floats (broadcast)
   __shared__ float b_enc[H_C1];
-  __shared__ float w_c1[H_C2][H_C1 * 4], b_c1[H_C2];
-  __shared__ float w_c2[H_C3][H_C2 * 2], b_c2[H_C3];
+  // row strides padded (120 -> 124, 40 -> 42 floats): lanes of a wave read the same column of different output channels'
+  // rows; with the natural strides channels co and co + 8 share their banks
+  __shared__ __attribute__((aligned(16))) float w_c1[H_C2][H_C1 * 4 + 4];
+  __shared__ float b_c1[H_C2];
+  __shared__ __attribute__((aligned(8))) float w_c2[H_C3][H_C2 * 2 + 2];
+  __shared__ float b_c2[H_C3];
   __shared__ float w_lin[H_OUT][H_C1], b_lin[H_OUT];
   __shared__ float h1[H_ROWS][H_T][H_C1 + 1];
   __shared__ float h2[H_ROWS][4][H_C2 + 1];
   __shared__ float h3[H_ROWS][H_C1 + 1];
   const int tid = threadIdx.x, row0 = blockIdx.x * H_ROWS;
   for (int e = tid; e < H_C1 * H_NP; e += H_THREADS) { const int j = e / H_NP, k = e - j * H_NP; w_enc[k][j] = P.enc_w[e]; }
-  for (int e = tid; e < H_C2 * H_C1 * 4; e += H_THREADS) (&w_c1[0][0])[e] = P.c1_w[e];      // [co][ci][k] as stored
-  for (int e = tid; e < H_C3 * H_C2 * 2; e += H_THREADS) (&w_c2[0][0])[e] = P.c2_w[e];
+  for (int e = tid; e < H_C2 * H_C1 * 4; e += H_THREADS) w_c1[e / (H_C1 * 4)][e % (H_C1 * 4)] = P.c1_w[e];      // [co][ci][k] as stored
+  for (int e = tid; e < H_C3 * H_C2 * 2; e += H_THREADS) w_c2[e / (H_C2 * 2)][e % (H_C2 * 2)] = P.c2_w[e];
   for (int e = tid; e < H_OUT * H_C1; e += H_THREADS) (&w_lin[0][0])[e] = P.lin_w[e];
   if (tid < H_C1) b_enc[tid] = P.enc_b[tid];
   if (tid < H_C2) b_c1[tid] = P.c1_b[tid];
