@@ -83,7 +83,12 @@ class PPO:
                 out = (st.actions[i], st.mu[i], st.actions_log_prob[i], st.values[i])
             latent = ac.actor.infer_hist_latent(obs) if hist_encoding else None      # student rollouts (DAgger iterations)
             tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps, out, latent)
-            tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
+            if out is not None:                   # std is constant over a rollout: fill the storage's sigma slab once, not per step
+                if st.step == 0:
+                    st.sigma.copy_(ac.std.detach().reshape(1, 1, -1).expand_as(st.sigma))
+                tr.action_sigma = st.sigma[st.step]
+            else:
+                tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
         else:
             tr.actions = ac.act(obs, hist_encoding).detach()
             tr.values = ac.evaluate(critic_obs).detach()

@@ -63,7 +63,7 @@ class RolloutStorage:
         put(self.values[i], transition.values)
         put(self.actions_log_prob[i], transition.actions_log_prob)
         put(self.mu[i], transition.action_mean)
-        self.sigma[i].copy_(transition.action_sigma)
+        put(self.sigma[i], transition.action_sigma)
         if torque_supervision:
             self.target_arm_torques[i].copy_(transition.target_arm_torques)
             self.current_arm_dof_pos[i].copy_(transition.current_arm_dof_pos)
