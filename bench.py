@@ -263,9 +263,16 @@ def main():
             rows = int(a[9])
             flops = UPDATE_FLOPS_PER_ROW * rows
             tf = flops / (upd_ms * 1e-3) / 1e12
+            upd_traffic = None
+            upath = os.path.join(ROOT, "profiles", "ppo_update_traffic.json")
+            if os.path.exists(upath) and rows == 40960:          # counters were collected at this minibatch size
+                try:
+                    upd_traffic = json.load(open(upath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    upd_traffic = None
             out["roofline_update"] = {"kernel": "wbc_ppo_minibatch_grad = wbc_pack16 + ppo_fwd_bwd16 + ppo_wgrad + reducers", "bound": "mfma",
                                       "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                                      "traffic": None, "launch_ms": upd_ms, "algorithmic_flops_per_launch": flops, "rows_per_launch": rows,
+                                      "traffic": upd_traffic, "launch_ms": upd_ms, "algorithmic_flops_per_launch": flops, "rows_per_launch": rows,
                                       "launches_timed": reps, "timed": "after the timed region (replay of the last minibatch call)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
