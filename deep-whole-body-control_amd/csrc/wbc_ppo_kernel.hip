@@ -795,8 +795,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
 // a workgroup owns a row range of one layer, wave w the output rows [32w, 32w+32). Both MFMA operands are read
 // straight from the stashes (a fragment = two runs of 32 consecutive floats: coalesced as stored), the bias
 // gradient falls out of one extra MFMA block whose B operand is the constant 1. No LDS, no atomics.
-struct WgradLayer { int out, in, dcol, dw, acol, aw, aoff, goff, nsplit, rows; };   // nsplit row ranges of `rows` rows: proportional to the layer's MFMAs per row pair, so every wave has the same work   // dZ slab (start, width), A slab (start, width, first column in it); goff: offset of this layer's weight gradient in the flat buffer
-struct WgradTable { WgradLayer l[NLAYERS]; };
+struct WgradLayer { int out, in, dcol, dw, acol, aw, aoff, goff, nsplit, rows, ldw, boff, bias; };   // ldw: row stride of dW (the layer's full input width), goff: first element of this column range, boff: the bias gradient (written iff bias)   // nsplit row ranges of `rows` rows: proportional to the layer's MFMAs per row pair, so every wave has the same work   // dZ slab (start, width), A slab (start, width, first column in it); goff: offset of this layer's weight gradient in the flat buffer
 #ifndef WG_U
 #define WG_U 4               // row pairs per batch of operand loads (two batches in flight per wave)
 #endif
@@ -861,7 +860,36 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   };
   int r = r_begin;
   const int nfull = (r_end - r_begin) / (2 * U);                   // full batches
+#ifndef WG_STAGES
+#define WG_STAGES 2        // 3 (two batches in flight behind the one being computed) measured the same: 168.8 vs 168.2 us
+#endif
   if (nfull > 0) {
+#if WG_STAGES == 3
+    // Three operand sets: while a batch's MFMAs run, the loads of the next TWO batches are in flight (2 x 1024 cycles of
+    // latency hiding per wave instead of one; 60 operand registers, still three waves per SIMD).
+    Ops A, Bq, Cq;
+    issue(A);
+    issue(Bq);                                  // (past the last batch these read the following rows, inside the workspace, unused)
+    int i = 0;
+#pragma unroll 1
+    for (; i + 3 <= nfull; i += 3) {
+      issue(Cq);
+      __builtin_amdgcn_sched_barrier(0);        // keep the loads ahead of the MFMAs (the scheduler sinks them to their uses otherwise)
+      compute(A);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(A);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(Bq);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(Bq);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(Cq);
+      __builtin_amdgcn_sched_barrier(0);
+      r += 6 * U;
+    }
+    if (i < nfull) { compute(A); r += 2 * U; ++i; }
+    if (i < nfull) { compute(Bq); r += 2 * U; }
+#else
     Ops A, Bq;
     issue(A);
     int i = 0;
@@ -878,6 +906,7 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
       r += 4 * U;
     }
     if (i < nfull) { compute(A); r += 2 * U; }
+#endif
   }
   for (; r < r_end; r += 2) {                                      // ragged tail
     const int row = r + half;
@@ -898,63 +927,72 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int oo = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (oo < L.out) dst[(size_t)oo * L.in + col] = acc[b][q];
+        if (oo < L.out) dst[L.goff + (size_t)oo * L.ldw + col] = acc[b][q];
       }
     }
   }
   bsum += __shfl_xor(bsum, 32);                                    // even-row + odd-row halves
-  if (lane < 32 && o_ok) dst[(size_t)L.out * L.in + o] = bsum;
+  if (lane < 32 && o_ok && L.bias) dst[L.boff + o] = bsum;
 }
 
 // Grid = (row ranges, layers), 4 waves per workgroup = the layer's four 32-row output blocks. About three workgroups per
 // CU: co-resident waves do not overlap each other's vector-ALU work with MFMAs, but they do hide each other's memory latency
 // (one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
-// Workgroup -> (layer, row range). All PPO_NSPLIT x 16 workgroups are resident at once (three per CU), but a 128 x 128
-// layer's workgroup issues 16 MFMAs per row pair and a head's 4 or fewer: with (split, layer) in grid order the CUs that
-// happened to get three big layers set the kernel's duration (48 work units against a mean of 33). The host deals the
-// workgroups out so that the three sharing a CU (ids i, i + 256, i + 512: workgroup i goes to XCD i % 8 and round-robin to
-// that XCD's 32 CUs) carry about the same total (wgrad_work_map: 36 at most instead of 48). Measured 172.7 -> 168.6 us only: the kernel waits
-// for the stash streams, not for its MFMAs.
+// Work decomposition. A 32-row output block x 32-column input block of a layer costs one MFMA per row pair; the layers
+// have 2, 2, 12, 4 or 16 such blocks. With one workgroup per (layer, row range) all workgroups are resident at once (three
+// per CU) and the CUs that happen to hold three 16-block workgroups set the kernel's duration (169 us at 54 % matrix-pipe
+// use; dealing the workgroups out by work needs to know which workgroups share a CU and gave 2 %). Instead the layers are
+// bundled into WG_NVL = 11 "virtual layers" of exactly 16 blocks each -- the nine 128 x 128-class layers; backbone (12) +
+// priv0 (2) + priv2 (2, its two input blocks on different waves); the four heads (4 each) -- and every wave of every
+// workgroup gets tasks worth 4 MFMAs per row pair: all workgroups are equal, whatever the placement. 168.6 -> 150.4 us.
 #ifndef PPO_NSPLIT
-#define PPO_NSPLIT 48
+#define PPO_NSPLIT 69       // x 11 virtual layers = 759 workgroups: one resident wave of three per CU
 #endif
-#define WGRAD_NWG (PPO_NSPLIT * NLAYERS)
-__device__ uint16_t g_wgrad_map[WGRAD_NWG];         // layer << 8 | split
+struct WgradTask { int sub, ob; };                      // sub-layer (a layer or a column range of one), 32-row output block
+#define WG_NVL 11
+#define WG_NSUB (NLAYERS + 1)
+struct WgradPlan { WgradLayer sub[WG_NSUB]; WgradTask task[WG_NVL][4][2]; int ntask[WG_NVL][4]; int nsplit, rows; };
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) ppo_wgrad_kernel(WgradTable tab, const float* __restrict__ act_stash,
+extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_wgrad_kernel(WgradPlan plan, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
                                                                          int B, int Bs, int nparams) {
-  const int work = g_wgrad_map[blockIdx.x], split = work & 255;
-  const WgradLayer L = tab.l[work >> 8];
-  const int wave = threadIdx.x >> 6;
-  if (wave * 32 >= L.out || split >= L.nsplit) return;
-  const int r_begin = split * L.rows, r_end = min(B, r_begin + L.rows);
-  float* dst = wpart + (size_t)split * nparams + L.goff;
-  const int nib = (L.in + 31) / 32;
-  if (nib == 4 && ((L.aw | L.aoff) & 3) == 0) wgrad_body<4, true>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);   // 16-byte aligned rows
-  else if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
-  else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
-  else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
-  else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, wave);
+  const int vl = blockIdx.x / plan.nsplit, split = blockIdx.x - vl * plan.nsplit;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // uniform: the task and its layer live in SGPRs
+  const int r_begin = min(B, split * plan.rows), r_end = min(B, r_begin + plan.rows);     // (an empty range still writes its zeros)
+  float* dst = wpart + (size_t)split * nparams;
+  const int nt = plan.ntask[vl][wave];
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const WgradTask k = plan.task[vl][wave][t];
+    const WgradLayer L = plan.sub[k.sub];
+    const int nib = (L.in + 31) / 32;
+    if (nib == 4 && ((L.aw | L.aoff) & 3) == 0) wgrad_body<4, true>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, k.ob);   // 16-byte aligned rows
+    else if (nib == 4) wgrad_body<4>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, k.ob);
+    else if (nib == 3) wgrad_body<3>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, k.ob);
+    else if (nib == 2) wgrad_body<2>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, k.ob);
+    else wgrad_body<1>(L, act_stash, dz_stash, dst, r_begin, r_end, Bs, k.ob);
+  }
 }
 
-// grad[L.goff + i] = sum_{s < L.nsplit} part[s][L.goff + i] in a fixed order, one grid row per layer
-extern "C" __global__ void __launch_bounds__(256) ppo_layer_reduce_kernel(WgradTable tab, const float* __restrict__ part, int stride,
+struct RedLayer { int goff, count; };
+struct RedTable { RedLayer l[NLAYERS]; int nsplit; };
+// grad[goff + i] = sum_{s < nsplit} part[s][goff + i] in a fixed order, one grid row per layer
+extern "C" __global__ void __launch_bounds__(256) ppo_layer_reduce_kernel(RedTable tab, const float* __restrict__ part, int stride,
                                                                          float* __restrict__ grad) {
-  const WgradLayer L = tab.l[blockIdx.y];
+  const RedLayer L = tab.l[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L.out * L.in + L.out) return;
+  if (i >= L.count) return;
   const int p = L.goff + i;
   float acc = 0.f;
   int s2 = 0;
-  for (; s2 + 8 <= L.nsplit; s2 += 8) {
+  for (; s2 + 8 <= tab.nsplit; s2 += 8) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s2 + j) * stride + p];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc += v[j];
   }
-  for (; s2 < L.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
+  for (; s2 < tab.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
   grad[p] = acc;
 }
 
@@ -1052,44 +1090,38 @@ static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, 
 #endif
 #define PPO_WPACK_FLOATS (WPACK_FLOATS > WPACK16_FLOATS ? WPACK_FLOATS : WPACK16_FLOATS)
 
-// Upload g_wgrad_map once: longest-processing-time-first over 256 CUs with 3 slots each; a workgroup's weight = its MFMAs
-// per row pair (32-row output blocks x 32-column input blocks).
-static int wgrad_work_map() {
-  static int done = 0;                 // 0 not yet, 1 uploaded, -1 failed
-  if (done) return done < 0;
-#ifdef PPO_WGRAD_GRID_ORDER
-  uint16_t id_map[WGRAD_NWG];
-  for (int i = 0; i < WGRAD_NWG; ++i) id_map[i] = (uint16_t)(((i / PPO_NSPLIT) << 8) | (i % PPO_NSPLIT));
-  done = hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_map), id_map, sizeof(id_map)) == hipSuccess ? 1 : -1;
-  return done < 0;
-#endif
-  const int NCU = 256, SLOTS = (WGRAD_NWG + NCU - 1) / NCU;
-  int weight[NLAYERS], order[NLAYERS];
-  for (int l = 0; l < NLAYERS; ++l) { weight[l] = ((layer_out(l) + 31) / 32) * ((layer_in(l) + 31) / 32); order[l] = l; }
-  for (int a = 0; a < NLAYERS; ++a)    // layers by weight, heaviest first (stable)
-    for (int b = a + 1; b < NLAYERS; ++b)
-      if (weight[order[b]] > weight[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
-  int load[256] = {0}, used[256] = {0};
-  uint16_t map[WGRAD_NWG];
-  for (int i = 0; i < WGRAD_NWG; ++i) map[i] = 0;
-  for (int a = 0; a < NLAYERS; ++a) {
-    const int l = order[a];
-    for (int sp = 0; sp < PPO_NSPLIT; ++sp) {
-      int best = -1;
-      for (int c = 0; c < NCU; ++c)
-        if (used[c] < SLOTS && (best < 0 || load[c] < load[best])) best = c;
-      if (best < 0 || used[best] * NCU + best >= WGRAD_NWG) {          // (a partial last slot row: take any CU whose next id exists)
-        best = -1;
-        for (int c = 0; c < NCU; ++c)
-          if (used[c] < SLOTS && used[c] * NCU + c < WGRAD_NWG && (best < 0 || load[c] < load[best])) best = c;
-        if (best < 0) { done = -1; return 1; }
+// The equal-work plan of ppo_wgrad_kernel for this network (checked: every wave of every virtual layer gets 4 blocks).
+static int make_wgrad_plan(WgradPlan& plan, RedTable& red, int B) {
+  int goff[NLAYERS], off = 0;
+  for (int l = 0; l < NLAYERS; ++l) { goff[l] = off; red.l[l] = RedLayer{off, layer_out(l) * layer_in(l) + layer_out(l)}; off += layer_out(l) * layer_in(l) + layer_out(l); }
+  auto sub = [&](int l, int col0, int ncol, int bias) {
+    const int aslab = (l == L_PRIV0) ? A_X : kAcol[l];                    // priv0 reads columns 76.. of the x slab
+    return WgradLayer{layer_out(l), ncol, kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab + col0, goff[l] + col0, 0, 0,
+                      layer_in(l), goff[l] + layer_out(l) * layer_in(l), bias};
+  };
+  for (int l = 0; l < NLAYERS; ++l) plan.sub[l] = sub(l, 0, layer_in(l), 1);
+  plan.sub[L_PRIV2] = sub(L_PRIV2, 0, 32, 1);                              // priv2's two input blocks are separate tasks
+  plan.sub[NLAYERS] = sub(L_PRIV2, 32, 32, 0);
+  const int big[9] = {L_LEG0, L_LEG2, L_ARM0, L_ARM2, L_CBB, L_CLEG0, L_CLEG2, L_CARM0, L_CARM2};
+  const int heads[4] = {L_LEG4, L_ARM4, L_CLEG4, L_CARM4};
+  for (int v = 0; v < WG_NVL; ++v)
+    for (int w = 0; w < 4; ++w) {
+      plan.ntask[v][w] = 0;
+      auto add = [&](int sb, int ob) { plan.task[v][w][plan.ntask[v][w]++] = WgradTask{sb, ob}; };
+      if (v < 9) add(big[v], w);
+      else if (v == 9) { add(L_BB, w); if (w < 2) add(L_PRIV0, w); else add(w == 2 ? L_PRIV2 : NLAYERS, 0); }
+      else add(heads[w], 0);
+      int units = 0;                                                       // 4 MFMAs per row pair for every wave
+      for (int t = 0; t < plan.ntask[v][w]; ++t) {
+        const WgradLayer& S = plan.sub[plan.task[v][w][t].sub];
+        if (plan.task[v][w][t].ob * 32 >= S.out) return -1;
+        units += (S.in + 31) / 32;
       }
-      map[used[best] * NCU + best] = (uint16_t)((l << 8) | sp);
-      used[best] += 1; load[best] += weight[l];
+      if (units != 4) return -1;
     }
-  }
-  done = hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_map), map, sizeof(map)) == hipSuccess ? 1 : -1;
-  return done < 0;
+  plan.nsplit = red.nsplit = PPO_NSPLIT;
+  plan.rows = ((B + PPO_NSPLIT - 1) / PPO_NSPLIT + 7) / 8 * 8;
+  return off;
 }
 
 extern "C" int wbc_ppo_grad_floats(void) {
@@ -1145,19 +1177,12 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
     hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fop_table(kStashCols), make_bwd_table(P), wpack, Bt, act_stash,
                        dz_stash, dstd_partial, loss_partial);
   }
-  WgradTable tab;
-  int off = 0;
-  for (int l = 0; l < NLAYERS; ++l) {
-    const int aslab = (l == L_PRIV0) ? A_X : kAcol[l];                    // priv0 reads columns 76.. of the x slab
-    int nsplit = PPO_NSPLIT;
-    int rows = (B + nsplit - 1) / nsplit;
-    rows = (rows + 7) / 8 * 8;
-    tab.l[l] = WgradLayer{layer_out(l), layer_in(l), kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab, off, nsplit, rows};
-    off += layer_out(l) * layer_in(l) + layer_out(l);
-  }
-  if (wgrad_work_map()) return -2;
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WGRAD_NWG), dim3(PT_THREADS), 0, st, tab, act_stash, dz_stash, wpart, B, Bs, ng);
-  hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, tab, wpart, ng, grad);
+  WgradPlan plan;
+  RedTable red;
+  const int off = make_wgrad_plan(plan, red, B);
+  if (off < 0) return -2;
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WG_NVL * PPO_NSPLIT), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
+  hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, red, wpart, ng, grad);
   hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18 + 3), dim3(256), 0, st, dstd_partial, tiles, 18, loss_partial, 3, grad + off);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
