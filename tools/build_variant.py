@@ -8,5 +8,5 @@ name, flags = sys.argv[1], sys.argv[2:]
 out = os.path.join(os.path.dirname(g.LIB), f"libwbc_amd_{name}.so")
 srcs = [os.path.join(g.CSRC, s) for s in g.SOURCES]
 subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-Wno-unused-result", "-o", out] + flags + srcs)
+                       "-Wno-unused-result", "-fno-slp-vectorize", "-o", out] + flags + srcs)
 print(out)
