@@ -7,7 +7,10 @@
 // 68 kFLOP per row: plain fp32 FMAs with all weights in LDS (23 KB) are enough -- the eager path spent its time in
 // unfold copies, five small GEMM launches per 32768-row chunk and element-wise kernels, not in arithmetic.
 // One workgroup = 24 rows: phase A one thread per (row, time step), then the two convolutions and the output layer
-// with one thread per output element; activations stay in LDS.
+// with one thread per output element; activations stay in LDS. Measured bound: LDS bandwidth (every FMA of phase A takes
+// its weight from LDS: 608 broadcast 16-byte reads per thread; conv1 another ~1100) -- ~80 k cycles per 24 rows; neither a
+// persistent loop that prefetches the next rows' inputs (448.6 vs 450.8 us for 163840 rows) nor packed FMAs moved it.
+// The next step for this kernel is MFMA for phase A and conv1 (operands in registers), not more of the same.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
