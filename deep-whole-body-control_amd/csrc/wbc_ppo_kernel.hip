@@ -463,7 +463,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(P
 #define PPO16_OCC 3
 #endif
 #define PPO16_CBB_POS 9          // position of the critic backbone in the forward order: x is gathered again in front of it
-static_assert(HROWS <= 64 && HROWS * 41 <= HROWS * LD16, "g fits in x; the loss phase has one row per lane of wave 0");
+static_assert(HROWS <= 64 && HROWS * 41 <= HROWS * LD16, "g fits in the x buffer; loss phase: at least 4 threads per row");
 static_assert(H_END * 4 * PPO16_OCC <= 160 * 1024, "LDS");
 
 // Forward order: with three activation buffers both backbone outputs stay in LDS for their second head (no stash reload)
@@ -642,9 +642,11 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
   // Losses and output gradients: TPR = 256 / rows threads per row (the action and latent dimensions are dealt out to
   // them), all four waves busy; per-tile sums through a [4 waves][24] scratch in a1 (not written before stage 0's GEMM).
   {
-    constexpr int TPR = PT_THREADS / HROWS, NJ = (18 + TPR - 1) / TPR, NK = (20 + TPR - 1) / TPR;
-    const int r = tid / TPR, q = tid % TPR, lane = tid & 63;
-    const bool valid = row0 + r < B;
+    constexpr int TPR = (PT_THREADS / HROWS >= 16) ? 16 : ((PT_THREADS / HROWS >= 8) ? 8 : 4);      // power of two: butterflies
+    constexpr int NJ = (18 + TPR - 1) / TPR, NK = (20 + TPR - 1) / TPR;
+    const int r = min(tid / TPR, HROWS - 1), q = tid % TPR, lane = tid & 63;
+    const bool live = tid < HROWS * TPR;                       // (48-row tiles: 192 of the 256 threads)
+    const bool valid = live && row0 + r < B;
     const size_t src = (size_t)Bt.idx[min(row0 + r, B - 1)];
     const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
     float lp[2] = {0.f, 0.f}, dj[NJ], sdj[NJ];
@@ -685,7 +687,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
         vls += (R - v) * (R - v);
         dv = 2.f * (v - R);
       }
-      if (q == c) gbuf[r * 41 + 18 + c] = valid ? Bt.value_coef * inv2B * dv : 0.f;
+      if (q == c && live) gbuf[r * 41 + 18 + c] = valid ? Bt.value_coef * inv2B * dv : 0.f;
     }
     if (q != 0 || !valid) { surr = 0.f; vls = 0.f; }                                            // one thread per row carries the row's loss terms
     float dsd[NJ];
@@ -693,8 +695,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
     for (int t = 0; t < NJ; ++t) {
       const int j = q + TPR * t;
       const float gl = dlp[j < PT_NLEG ? 0 : 1], d = dj[t], sd = sdj[t];
-      if (j < 18) gbuf[r * 41 + j] = gl * d / (sd * sd);
-      dsd[t] = j < 18 ? gl * (d * d / (sd * sd * sd) - 1.f / sd) : 0.f;
+      if (j < 18 && live) gbuf[r * 41 + j] = gl * d / (sd * sd);
+      dsd[t] = (j < 18 && live) ? gl * (d * d / (sd * sd * sd) - 1.f / sd) : 0.f;
     }
     float dl[NK], nrm = 0.f;                                                                    // ROA regulariser PPO:174-179
 #pragma unroll
@@ -712,7 +714,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, PPO16_OCC) ppo_fwd_bwd1
 #pragma unroll
     for (int t = 0; t < NK; ++t) {
       const int k = q + TPR * t;
-      if (k < 20) gbuf[r * 41 + 20 + k] = sc * dl[t];
+      if (k < 20 && live) gbuf[r * 41 + 20 + k] = sc * dl[t];
     }
     // sums over the wave's rows (lanes with the same q), then over the four waves
 #pragma unroll
@@ -1129,11 +1131,13 @@ extern "C" int wbc_ppo_grad_floats(void) {
   for (int l = 0; l < NLAYERS; ++l) n += layer_out(l) * layer_in(l) + layer_out(l);
   return n + 18 + 3;
 }
+// rows of a stash slab: whole tiles (every tile row is stored), then a multiple of 64
+static int ppo_slab_rows(int B) { return ((B + HROWS - 1) / HROWS * HROWS + 63) & ~63; }
 extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
   const size_t tiles = (size_t)(B + R16 - 1) / R16;
-  return (size_t)((B + 63) & ~63) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
+  return (size_t)ppo_slab_rows(B) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
 }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
@@ -1159,7 +1163,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   const int tile_rows = PPO_TILE16 ? HROWS : PT_ROWS;
   const int tiles = (B + tile_rows - 1) / tile_rows;
   const int ng = wbc_ppo_grad_floats();
-  const int Bs = PPO_TILE16 ? ((B + 63) & ~63) : B;          // rows per stash slab
+  const int Bs = PPO_TILE16 ? ppo_slab_rows(B) : B;          // rows per stash slab
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)Bs * A_LD;
   float* dstd_partial = dz_stash + (size_t)Bs * D_LD;
