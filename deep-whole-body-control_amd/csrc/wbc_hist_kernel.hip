@@ -7,7 +7,8 @@
 // 68 kFLOP per row; the eager path spent its time in unfold copies, five small GEMM launches per 32768-row chunk and
 // element-wise kernels. The first version of this kernel (plain FMAs, all weights in LDS) was LDS-bound: every FMA of the
 // two big layers took its weight from LDS (~1700 16-byte reads per thread and 24 rows).
-// One workgroup = 24 rows; activations stay in LDS (45 KB, three workgroups per CU).
+// Persistent workgroups walk over groups of 24 rows; the weights of the two big layers stay in registers, activations in
+// LDS (45 KB). 450 -> 230 us for 163840 rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
