@@ -1030,7 +1030,7 @@ extern "C" __global__ void __launch_bounds__(256) ppo_column_reduce_kernel(const
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) out[j_out] = sh[0];
@@ -1046,7 +1046,7 @@ extern "C" __global__ void __launch_bounds__(256) ppo_sqnorm_kernel(const float*
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];

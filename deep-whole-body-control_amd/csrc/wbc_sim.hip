@@ -69,11 +69,6 @@ extern "C" size_t wbc_sim_arena_bytes(int num_envs) {
   return off + 256;
 }
 
-static int upload_const(wbc_sim* s, hipStream_t st) {
-  HIP_OK(hipMemcpyAsync(s->dc, &s->hc, sizeof(DevConst), hipMemcpyHostToDevice, st));
-  return 0;
-}
-
 static int build_chains(DevConst& hc) {
   const wbc_model& m = hc.model;
   for (int c = 0; c < WBC_NCHAIN; ++c) { hc.chain_len[c] = 0; for (int d = 0; d < WBC_MAX_DEPTH; ++d) hc.chain_body[c][d] = -1; }

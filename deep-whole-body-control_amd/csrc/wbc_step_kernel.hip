@@ -786,7 +786,7 @@ __device__ void resample_ee_goal(Smem& s, const DevConst* __restrict__ C, uint64
 }
 
 __device__ const int8_t POLICY_PERM[WBC_NDOF] = {3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19};
-// terms feeding each metric slot (inverse of MET_OF below, -1 padded, ascending): a metric slot is owned by one lane
+// terms feeding each metric slot (-1 padded, ascending): a metric slot is owned by one lane
 __device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
     /* LEG_ENERGY_ABS_SUM */ {WBC_REW_LEG_ENERGY_ABS_SUM, -1},
     /* TRACKING_LIN_VEL_X_L1 */ {WBC_REW_TRACKING_LIN_VEL_X_L1, WBC_REW_TRACKING_LIN_VEL_X_EXP},
@@ -798,10 +798,6 @@ __device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
     /* TORQUE */ {WBC_REW_TORQUES, -1},
     /* ENERGY_SQUARE */ {WBC_REW_ENERGY_SQUARE, -1},
     /* FOOT_CONTACTS_Z */ {WBC_REW_FOOT_CONTACTS_Z, -1}};
-__device__ const int8_t MET_OF[WBC_NREW] = {
-    WBC_MET_ENERGY_SQUARE, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, WBC_MET_TRACKING_ANG_VEL_YAW_EXP, WBC_MET_LEG_ACTION_L2,
-    WBC_MET_FOOT_CONTACTS_Z, WBC_MET_TRACKING_EE_SPHERE, -1, WBC_MET_TRACKING_EE_CART, -1, WBC_MET_TRACKING_EE_ORN,
-    WBC_MET_LEG_ENERGY_ABS_SUM, -1, WBC_MET_LEG_ACTION_L2, -1, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, -1, -1, -1, WBC_MET_TORQUE};
 
 // compute_reward of the oracle, executed by lane 0 on LDS state
 __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq) {
