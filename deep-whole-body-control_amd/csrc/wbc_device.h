@@ -32,6 +32,11 @@ struct DevConst {
 };
 
 // Per-env device tensors (AoS per env: one wave reads an env's block with consecutive lanes).
+// Optional extra outputs of one step (wbc_sim_step_rollout): where the observation rows go instead of obs_buf, and the rollout
+// storage's reward / done slots of this transition (PPO.process_env_step, rsl_rl/algorithms/ppo.py:129-141: the time-out
+// bootstrap rewards += gamma * values * time_outs needs the values PPO.act computed for this step).
+struct StepOut { float* obs; const float* values; float* rewards; uint8_t* dones; float gamma; };
+
 struct DevTensors {
   float* root;        // [N,2,13]
   float* dof;         // [N,20,2]

@@ -13,7 +13,7 @@
 #include "wbc_device.h"
 
 extern "C" __global__ void wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
-                                           uint64_t seed, uint64_t step, float* __restrict__ obs_out);
+                                           uint64_t seed, uint64_t step, StepOut so);
 extern "C" __global__ void wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step);
 extern "C" __global__ void wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
 extern "C" __global__ void wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
@@ -294,13 +294,19 @@ extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
   return 0;
 }
 
-extern "C" int wbc_sim_step_to(wbc_sim* s, const float* actions_dev, float* obs_out_dev, void* stream) {
+extern "C" int wbc_sim_step_rollout(wbc_sim* s, const float* actions_dev, float* obs_out_dev, const float* values_dev, float gamma,
+                                    float* out_rewards_dev, uint8_t* out_dones_dev, void* stream) {
   if (!s || !actions_dev) return fail(-1, "wbc_sim_step: bad arguments");
+  if ((out_rewards_dev != nullptr) != (out_dones_dev != nullptr) || (out_rewards_dev && !values_dev))
+    return fail(-1, "wbc_sim_step_rollout: values, out_rewards and out_dones go together");
   s->step_counter += 1;
-  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter,
-                     obs_out_dev);
+  const StepOut so{obs_out_dev, values_dev, out_rewards_dev, out_dones_dev, gamma};
+  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter, so);
   HIP_OK(hipGetLastError());
   return 0;
+}
+extern "C" int wbc_sim_step_to(wbc_sim* s, const float* actions_dev, float* obs_out_dev, void* stream) {
+  return wbc_sim_step_rollout(s, actions_dev, obs_out_dev, nullptr, 0.f, nullptr, nullptr, stream);
 }
 extern "C" int wbc_sim_step(wbc_sim* s, const float* actions_dev, void* stream) { return wbc_sim_step_to(s, actions_dev, nullptr, stream); }
 

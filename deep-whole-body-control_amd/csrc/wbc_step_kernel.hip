@@ -992,7 +992,7 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
 }
 
 // compute_observations (oracle) + the HBM write-out of the step's results.
-__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset, float* __restrict__ obs_out) {
+__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset, const StepOut& so) {
   const int lane = threadIdx.x;
   const wbc_task_cfg& cf = C->cfg;
   // proprio vector o76, one or two entries per lane
@@ -1019,7 +1019,7 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   WSYNC();
   // obs_buf = [o76, priv24, old history]; history <- shifted / refilled
   const float clipv = cf.clip_obs;
-  float* obs = (obs_out ? obs_out : T.obs) + (size_t)env * WBC_NOBS;
+  float* obs = (so.obs ? so.obs : T.obs) + (size_t)env * WBC_NOBS;
   float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
   const bool refill = s.ep_len <= 1;
   float old[12];
@@ -1063,13 +1063,20 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   if (lane == 0) {
     T.rew[env] = s.rew; T.arm_rew[env] = s.arm_rew;
     T.reset_buf[env] = s.reset_flag; T.time_out[env] = (uint8_t)s.time_out; T.ep_len[env] = s.ep_len;
+    if (so.rewards) {                                 // the same arithmetic as rollout_store_kernel (csrc/wbc_gae_kernel.hip)
+      const float to = s.time_out ? 1.f : 0.f;
+      float r0 = s.rew, r1 = s.arm_rew;
+      r0 += so.gamma * (so.values[2 * (size_t)env] * to); r1 += so.gamma * (so.values[2 * (size_t)env + 1] * to);
+      so.rewards[2 * (size_t)env] = r0; so.rewards[2 * (size_t)env + 1] = r1;
+      so.dones[env] = (uint8_t)(s.reset_flag != 0);
+    }
   }
 }
 
-// WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment. obs_out != nullptr:
-// the observation rows go there instead of the sim's own obs_buf (the rollout storage slot of the next transition).
+// WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment. so: optional
+// extra outputs (observation rows into the rollout storage slot of the next transition, this transition's reward / done slots).
 extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions,
-                                                                    int num_envs, uint64_t seed, uint64_t step, float* __restrict__ obs_out) {
+                                                                    int num_envs, uint64_t seed, uint64_t step, StepOut so) {
   __shared__ Smem s;
   const DevTensors& T = *Tp;        // read on demand through the scalar path: 32 pointers held in SGPRs spilled the kernel
   const int env = blockIdx.x;
@@ -1157,7 +1164,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
   }
   STAMP(16);
-  observe_and_store(s, T, C, env, do_reset, obs_out);
+  observe_and_store(s, T, C, env, do_reset, so);
   STAMP(17);
 }
 

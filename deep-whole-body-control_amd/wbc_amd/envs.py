@@ -67,6 +67,7 @@ class BaseTask(VecEnv):
         self.num_actions = cfg.env.num_actions
         self.privileged_obs_buf = None
         self._obs_output = None
+        self._store_output = None
         self.extras = {}
         self.viewer = None
         self.enable_viewer_sync = False
@@ -387,7 +388,9 @@ class WidowGo1(LeggedRobot):
             self.extras["current_arm_dof_pos"] = self.dof_pos[:, -8:-2].clone()
             self.extras["current_arm_dof_vel"] = self.dof_vel[:, -8:-2].clone()
         out, self._obs_output = self._obs_output, None
-        self.sim.step(a, out)
+        store, self._store_output = self._store_output, None
+        self.sim.step(a, out, store)
+        self.extras["rollout_stored"] = store[2].data_ptr() if store is not None else None
         self.common_step_counter += 1
         if self._terrain_levels_on:                                                  # WG:708-709 (reset_idx -> _update_terrain_curriculum)
             self._apply_terrain_curriculum()
@@ -484,6 +487,13 @@ class WidowGo1(LeggedRobot):
         self._sim_env_origins.copy_(new)
         self.root_states[:, :3] += delta
         self.box_root_state[:, 1] += delta[:, 1]
+
+    def set_rollout_output(self, values, gamma, rewards, dones):
+        """The NEXT step() also writes this transition's rollout-storage slots (PPO.process_env_step's tensor work, ppo.py:129-141):
+        rewards [N,2] = (rew, arm_rew) + gamma * values * time_outs, dones [N,1] u8 = reset_buf != 0; `values` = the critic's
+        [N,2] output PPO.act stored for the acting observation. One-shot; extras['rollout_stored'] = rewards.data_ptr() tells
+        the learner the slots are filled."""
+        self._store_output = (values, float(gamma), rewards, dones)
 
     def set_obs_output(self, tensor):
         """The NEXT step() writes its observations into `tensor` (f32 [num_envs, 860], contiguous, on the sim device) and

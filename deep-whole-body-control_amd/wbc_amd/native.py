@@ -40,6 +40,7 @@ def lib():
         L.wbc_sim_set_curriculum.argtypes = [c_void, C.POINTER(abi.WbcCurriculum)]
         L.wbc_sim_step.argtypes = [c_void, c_void, c_void]
         L.wbc_sim_step_to.argtypes = [c_void, c_void, c_void, c_void]
+        L.wbc_sim_step_rollout.argtypes = [c_void, c_void, c_void, c_void, C.c_float, c_void, c_void, c_void]
         L.wbc_get_heights.argtypes = [c_void, c_int, c_void, c_int, c_void, c_void, c_int, c_int, C.c_float, C.c_float, C.c_float, c_void, c_int, c_int, c_void]
         L.wbc_sim_reset_all.argtypes = [c_void, c_void]
         L.wbc_sim_set_dof_forces.argtypes = [c_void, c_void, c_void]
@@ -74,7 +75,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "wbc_last_error", "wbc_sim_arena_bytes", "wbc_sim_create", "wbc_sim_destroy", "wbc_sim_get_tensor",
-    "wbc_sim_set_env_params", "wbc_sim_set_heightfield", "wbc_sim_set_curriculum", "wbc_sim_step", "wbc_sim_step_to", "wbc_get_heights", "wbc_sim_reset_all",
+    "wbc_sim_set_env_params", "wbc_sim_set_heightfield", "wbc_sim_set_curriculum", "wbc_sim_step", "wbc_sim_step_to", "wbc_sim_step_rollout", "wbc_get_heights", "wbc_sim_reset_all",
     "wbc_sim_set_dof_forces", "wbc_sim_simulate", "wbc_sim_set_root_state", "wbc_sim_set_dof_state",
     "wbc_sim_set_root_state_indexed", "wbc_sim_set_dof_state_indexed", "wbc_sim_refresh_dof_state",
     "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force", "wbc_sim_refresh_force_sensor",

@@ -121,6 +121,15 @@ class PPO:
         i = st.step + 1
         return st.observations[i] if i < st.num_transitions_per_env else None
 
+    def rollout_slots(self):
+        """(values, gamma, rewards slot, dones slot) of the transition act() has just started, for an env that can fill them
+        inside its step (WidowGo1.set_rollout_output), or None."""
+        st, tr = self.storage, self.transition
+        if (st is None or st.step >= st.num_transitions_per_env or not st.rewards.is_cuda or tr.values is None or not tr.values.is_cuda
+                or tr.values.dtype != torch.float32 or not tr.values.is_contiguous() or tr.values.shape != (st.num_envs, 2)):
+            return None
+        return tr.values, self.gamma, st.rewards[st.step], st.dones[st.step]
+
     def _process_env_step_fused(self, rewards, arm_rewards, dones, infos):
         """rewards (+ time-out bootstrap) and dones of this step into their storage slots with one launch."""
         st, tr = self.storage, self.transition
@@ -130,6 +139,9 @@ class PPO:
                 and tr.values is not None and tr.values.is_cuda and tr.values.is_contiguous() and tr.values.dtype == torch.float32
                 and tr.values.shape == (rewards.shape[0], 2)):
             return False
+        if infos.get("rollout_stored") is not None and infos["rollout_stored"] == st.rewards[st.step].data_ptr():
+            tr.rewards, tr.dones = st.rewards[st.step], st.dones[st.step]      # the env's step has already filled the slots
+            return True
         to = infos.get("time_outs")
         if to is not None:
             if not (to.is_cuda and to.is_contiguous() and to.dtype in (torch.bool, torch.uint8) and to.shape == rewards.shape):

@@ -78,6 +78,7 @@ class OnPolicyRunner:
                           torque_supervision_weight=0., mean_hist_latent_loss=0., mean_priv_reg_loss=0., priv_reg_coef=0.)
         tot_iter = self.current_learning_iteration + num_learning_iterations
         redirect_obs = hasattr(env, "set_obs_output") and hasattr(alg, "next_observation_slot") and getattr(alg, "fused_rollout", False)
+        store_in_step = hasattr(env, "set_rollout_output") and hasattr(alg, "rollout_slots") and getattr(alg, "fused_rollout", False)
         for it in range(self.current_learning_iteration, tot_iter):
             env.update_command_curriculum()
             sync()
@@ -89,6 +90,10 @@ class OnPolicyRunner:
                     slot = alg.next_observation_slot() if redirect_obs else None
                     if slot is not None:
                         env.set_obs_output(slot)              # the env writes the next observation where act() would copy it
+                    if store_in_step:
+                        slots = alg.rollout_slots()
+                        if slots is not None:
+                            env.set_rollout_output(*slots)    # ... and this transition's reward / done slots
                     obs, priv, rewards, arm_rewards, dones, infos = env.step(actions)
                     critic_obs = priv if priv is not None else obs
                     obs, critic_obs, rewards, arm_rewards, dones = (x.to(self.device) for x in (obs, critic_obs, rewards, arm_rewards, dones))

@@ -104,16 +104,28 @@ class WbcSim:
         check(self.L.wbc_sim_set_step_counter(self.h, int(v)))
 
     # ---- stepping --------------------------------------------------------------------------
-    def step(self, actions: torch.Tensor, obs_out: torch.Tensor = None) -> None:
-        """One env step; obs_out (f32 [N, 860], contiguous, same device): write the observations there instead of OBS_BUF."""
+    def step(self, actions: torch.Tensor, obs_out: torch.Tensor = None, store=None) -> None:
+        """One env step. obs_out (f32 [N, 860], contiguous, same device): write the observations there instead of OBS_BUF.
+        store = (values f32 [N,2], gamma, out_rewards f32 [N,2], out_dones u8 [N,1] or [N]): also write this transition's
+        rollout-storage reward (with the time-out bootstrap) and done slots (wbc_sim_step_rollout)."""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
         assert actions.shape == (self.num_envs, abi.NACT)
-        if obs_out is None:
-            check(self.L.wbc_sim_step(self.h, actions.data_ptr(), self._stream()), "wbc_sim_step")
-        else:
+        if obs_out is not None:
             assert (obs_out.is_cuda and obs_out.device == actions.device and obs_out.dtype == torch.float32 and obs_out.is_contiguous()
                     and obs_out.shape == (self.num_envs, abi.NOBS))
+        if obs_out is None and store is None:
+            check(self.L.wbc_sim_step(self.h, actions.data_ptr(), self._stream()), "wbc_sim_step")
+        elif store is None:
             check(self.L.wbc_sim_step_to(self.h, actions.data_ptr(), obs_out.data_ptr(), self._stream()), "wbc_sim_step_to")
+        else:
+            values, gamma, rewards, dones = store
+            n = self.num_envs
+            assert values.is_cuda and values.dtype == torch.float32 and values.is_contiguous() and values.shape == (n, 2)
+            assert rewards.is_cuda and rewards.dtype == torch.float32 and rewards.is_contiguous() and rewards.shape == (n, 2)
+            assert dones.is_cuda and dones.dtype == torch.uint8 and dones.is_contiguous() and dones.numel() == n
+            check(self.L.wbc_sim_step_rollout(self.h, actions.data_ptr(), obs_out.data_ptr() if obs_out is not None else None,
+                                              values.data_ptr(), float(gamma), rewards.data_ptr(), dones.data_ptr(), self._stream()),
+                  "wbc_sim_step_rollout")
 
     def reset_all(self) -> None:
         check(self.L.wbc_sim_reset_all(self.h, self._stream()), "wbc_sim_reset_all")

@@ -239,6 +239,13 @@ int wbc_sim_step(wbc_sim* sim, const float* actions_dev, void* stream);
  * transition: what `self.observations[self.step].copy_(transition.observations)`, rollout_storage.py:66, would copy)
  * instead of WBC_T_OBS_BUF; obs_out_dev == NULL is wbc_sim_step. */
 int wbc_sim_step_to(wbc_sim* sim, const float* actions_dev, float* obs_out_dev, void* stream);
+/* The step with PPO.process_env_step's tensor work folded in (rsl_rl/algorithms/ppo.py:129-141, rollout_storage.py:70-72; what
+ * wbc_rollout_store does as a separate launch): out_rewards[n] = (rew[n], arm_rew[n]) + gamma * values[n] * time_out[n],
+ * out_dones[n] = reset_buf[n] != 0, written to the rollout storage's slots of this transition. values_dev: f32 [N,2], the
+ * critic's output for the observation the actions were computed from. obs_out_dev as in wbc_sim_step_to; any of the two
+ * groups may be NULL. */
+int wbc_sim_step_rollout(wbc_sim* sim, const float* actions_dev, float* obs_out_dev, const float* values_dev, float gamma,
+                         float* out_rewards_dev, uint8_t* out_dones_dev, void* stream);
 
 /* BaseTask.reset() first half: reset_idx(all envs, start=True) (BT:127-131, WG:695-754). */
 int wbc_sim_reset_all(wbc_sim* sim, void* stream);

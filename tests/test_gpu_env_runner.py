@@ -72,6 +72,36 @@ def test_step_into_a_caller_buffer_is_the_same_step():
     assert torch.isfinite(slots).all()
 
 
+def test_step_fills_the_rollout_reward_and_done_slots():
+    """wbc_sim_step_rollout / WidowGo1.set_rollout_output = the plain step followed by wbc_rollout_store (PPO.process_env_step's
+    tensor work, ppo.py:129-141) on an identically seeded env: same slots, time-out bootstrap included."""
+    from wbc_amd.native import check, lib
+    cfg = _cfg(n=192)
+    cfg.env.episode_length_s = 0.08                       # 4 steps: time-outs (the bootstrap) before anything else ends an episode
+    envs = [WidowGo1(cfg, sim_device="cuda:0", seed=8) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    L, stream = lib(), torch.cuda.current_stream().cuda_stream
+    timeouts = 0
+    for i in range(40):
+        a = 0.02 * torch.randn(192, 18, device="cuda", generator=g)     # the robots keep standing: episodes end by time-out
+        values = torch.randn(192, 2, device="cuda", generator=g)
+        _, _, rew, arm_rew, dones, infos = envs[0].step(a)
+        ref_r = torch.empty(192, 2, device="cuda"); ref_d = torch.empty(192, 1, dtype=torch.uint8, device="cuda")
+        check(L.wbc_rollout_store(rew.data_ptr(), arm_rew.data_ptr(), dones.data_ptr(), infos["time_outs"].data_ptr(), values.data_ptr(), 0.99,
+                                  ref_r.data_ptr(), ref_d.data_ptr(), 192, stream), "wbc_rollout_store")
+        got_r = torch.full((192, 2), float("nan"), device="cuda"); got_d = torch.full((192, 1), 7, dtype=torch.uint8, device="cuda")
+        envs[1].set_rollout_output(values, 0.99, got_r, got_d)
+        _, _, _, _, _, infos1 = envs[1].step(a)
+        assert infos1["rollout_stored"] == got_r.data_ptr() and infos.get("rollout_stored") is None
+        assert torch.equal(got_d, ref_d)
+        np.testing.assert_allclose(got_r.cpu().numpy(), ref_r.cpu().numpy(), rtol=0, atol=1e-7)
+        timeouts += int(infos["time_outs"].sum())
+    assert timeouts > 100
+    assert envs[1].step(a)[5]["rollout_stored"] is None   # one-shot
+
+
 def test_perlin_terrain_rollout_stays_on_the_ground():
     env = WidowGo1(_cfg(n=128, plane=False), sim_device="cuda:0", seed=2)
     assert env.terrain is not None and env.height_samples.shape == (600, 2000)
