@@ -171,16 +171,16 @@ def main():
 
     nstep = {"n": 0}
 
-    def timed_step(a, obs_out=None):
+    def timed_step(*a, **kw):                        # (whatever signature WbcSim.step has)
         nstep["n"] += 1
         if timing_on["v"] and nstep["n"] % 4 == 0:       # every 4th launch: an event pair around each one cost 0.34 ms per iteration
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            raw_step(a, obs_out)
+            raw_step(*a, **kw)
             e1.record()
             events.append((e0, e1))
         else:
-            raw_step(a, obs_out)
+            raw_step(*a, **kw)
     env.sim.step = timed_step
 
     # The fused PPO minibatch step (weight pack + ppo_fwd_bwd16 + ppo_wgrad + reducers: one C-ABI call) is timed AFTER the
