@@ -167,3 +167,31 @@ def test_perlin_terrain_matches_reference_statistics():
     # determinism in the seed
     np.testing.assert_array_equal(TerrainPerlin(cfg, seed=4).heightsamples, t.heightsamples)
     assert (TerrainPerlin(cfg, seed=5).heightsamples != t.heightsamples).any()
+
+
+def test_rollout_slot_hand_over_is_cuda_only_and_storage_skips_filled_slots():
+    """The fused-rollout hand-overs (observation / reward / done slots written by the env's step) are offered only for CUDA
+    storages, and RolloutStorage.add_transitions copies exactly the fields that are not already views of their slots."""
+    import torch
+    import golden_procedure as gp
+    from wbc_amd.rsl_rl.algorithms import PPO
+    from wbc_amd.rsl_rl.modules import ActorCritic
+    torch.manual_seed(0)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
+    alg = PPO(ac, device="cpu", **gp.ALG_KW)
+    alg.init_storage(6, 3, [860], [None], [18])
+    assert alg.next_observation_slot() is None and alg.rollout_slots() is None          # CPU storage: the eager path
+    st = alg.storage
+    obs = torch.randn(6, 860)
+    with torch.inference_mode():
+        alg.act(obs, obs, False)
+        tr = alg.transition
+        assert tr.observations.data_ptr() == st.observations[0].data_ptr()              # parked at act() time (WidowGo1 reuses its buffer)
+        # pretend the env filled the reward / done slots itself (extras['rollout_stored']): nothing is overwritten
+        st.rewards[0].fill_(3.5)
+        st.dones[0].fill_(1)
+        tr_r, tr_d = st.rewards[0], st.dones[0]
+        alg.transition.rewards, alg.transition.dones = tr_r, tr_d.view(-1)
+        alg.storage.add_transitions(alg.transition, torque_supervision=False)
+    assert st.step == 1 and (st.rewards[0] == 3.5).all() and (st.dones[0] == 1).all()
+    assert torch.equal(st.observations[0], obs) and torch.isfinite(st.values[0]).all() and (st.sigma[0] > 0).all()
