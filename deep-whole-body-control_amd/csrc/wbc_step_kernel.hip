@@ -869,25 +869,26 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
 }
 
 // rew_buf / arm_rew_buf, episode sums and metric sums from the raw terms: lane t owns term t, lane m metric slot m.
-// lsc / asc = this lane's leg / arm reward scale (lanes >= 21: 0). Per slot the order of additions is the reference's
-// (leg channel then arm channel, terms ascending); the two reward totals are butterfly sums over the wavefront.
+// lsc / asc = this lane's leg / arm reward scale (lanes >= 21: 0). A term is evaluated when its function is in the list the
+// reference builds at construction (cur.*_active_mask, WG:128-157), whatever its current (scheduled) scale. Per slot the
+// order of additions is the reference's (leg channel then arm channel, terms ascending); the two reward totals are
+// butterfly sums over the wavefront.
 __device__ __forceinline__ void reward_accumulate(Smem& s, const DevConst* __restrict__ C, float lsc, float asc) {
   const int lane = threadIdx.x;
+  const uint32_t lmask = C->cur.leg_active_mask, amask = C->cur.arm_active_mask;
   float vl = 0.f, va = 0.f;
   if (lane < WBC_NREW) {
     const float tm = s.post.term[lane];
     float e = s.ep_sums[lane];
-    if (lsc != 0.f) { vl = tm * lsc; e += vl; }
-    if (asc != 0.f) { va = tm * asc; e += va; }
+    if ((lmask >> lane) & 1u) { vl = tm * lsc; e += vl; }
+    if ((amask >> lane) & 1u) { va = tm * asc; e += va; }
     s.ep_sums[lane] = e;
   }
-  // which terms are active per channel, as bit masks every lane can test
-  const uint64_t lmask = __ballot(lsc != 0.f), amask = __ballot(asc != 0.f);
   if (lane < WBC_NMETRIC) {
     float mt = s.met_sums[lane];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const uint64_t mask = ch == 0 ? lmask : amask;
+      const uint32_t mask = ch == 0 ? lmask : amask;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int t = MET_TERMS[lane][j];

@@ -71,6 +71,7 @@ class WbcCurriculum(C.Structure):
         ("lin_vel_x_range", f32 * 2), ("ang_vel_yaw_range", f32 * 2),
         ("goal_l_range", f32 * 2), ("goal_p_range", f32 * 2), ("goal_y_range", f32 * 2),
         ("leg_reward_scale", f32 * NREW), ("arm_reward_scale", f32 * NREW),
+        ("leg_active_mask", C.c_uint32), ("arm_active_mask", C.c_uint32),
     ]
 
 

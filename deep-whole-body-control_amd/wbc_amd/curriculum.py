@@ -38,10 +38,20 @@ def make_curriculum(cfg, update_counter: int) -> abi.WbcCurriculum:
         for name, val in table.items():
             if val != 0 and (name in UNIMPLEMENTED_REWARDS or name not in abi.REWARD_TERMS):
                 raise NotImplementedError(f"reward term '{name}' has a non-zero scale but is not implemented by the fused step")
-    leg["tracking_ang_vel_yaw_exp"] = float(curriculum_value(cmd.tracking_ang_vel_yaw_schedule, 0, cr.final_tracking_ang_vel_yaw_exp, update_counter))
-    key = "tracking_ee_sphere" if arm.get("tracking_ee_sphere", 0) != 0 else "tracking_ee_cart"      # WG:689-692
-    arm[key] = float(curriculum_value(g.tracking_ee_reward_schedule, 0, ge.final_tracking_ee_reward, update_counter))
+    # the reward-function lists are fixed at construction from the config's non-zero scales (WG:128-157)
+    leg_active = {name for name, val in leg.items() if val != 0}
+    arm_active = {name for name, val in arm.items() if val != 0}
+    if update_counter >= 1:     # only update_command_curriculum overwrites the two scheduled scales (WG:683,689-692); before its
+        # first call the object still carries the config's values
+        leg["tracking_ang_vel_yaw_exp"] = float(curriculum_value(cmd.tracking_ang_vel_yaw_schedule, 0, cr.final_tracking_ang_vel_yaw_exp, update_counter))
+        key = "tracking_ee_sphere" if "tracking_ee_sphere" in arm_active else "tracking_ee_cart"     # WG:689-692
+        arm[key] = float(curriculum_value(g.tracking_ee_reward_schedule, 0, ge.final_tracking_ee_reward, update_counter))
+    lm = am = 0
     for i, name in enumerate(abi.REWARD_TERMS):
-        cur.leg_reward_scale[i] = leg.get(name, 0.0)
-        cur.arm_reward_scale[i] = arm.get(name, 0.0)
+        on_l, on_a = name in leg_active, name in arm_active
+        cur.leg_reward_scale[i] = leg.get(name, 0.0) if on_l else 0.0
+        cur.arm_reward_scale[i] = arm.get(name, 0.0) if on_a else 0.0
+        lm |= int(on_l) << i
+        am |= int(on_a) << i
+    cur.leg_active_mask, cur.arm_active_mask = lm, am
     return cur

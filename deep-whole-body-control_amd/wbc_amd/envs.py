@@ -307,8 +307,9 @@ class WidowGo1(LeggedRobot):
         self.goal_ee_l_ranges = np.array(list(cur.goal_l_range))
         self.goal_ee_p_ranges = np.array(list(cur.goal_p_range))
         self.goal_ee_y_ranges = np.array(list(cur.goal_y_range))
-        self.reward_scales = {n: cur.leg_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if cur.leg_reward_scale[i] != 0}
-        self.arm_reward_scales = {n: cur.arm_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if cur.arm_reward_scale[i] != 0}
+        # keys = the config's non-zero scales, fixed at construction (WG:128-157); values = the current (scheduled) scales
+        self.reward_scales = {n: cur.leg_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if (cur.leg_active_mask >> i) & 1}
+        self.arm_reward_scales = {n: cur.arm_reward_scale[i] for i, n in enumerate(abi.REWARD_TERMS) if (cur.arm_active_mask >> i) & 1}
         if self._active_terms is None:     # episode_sums keys = the config's non-zero scales, fixed at construction (WG:128-163)
             from .curriculum import _scales
             cfg_leg, cfg_arm = _scales(self.cfg.rewards.scales), _scales(self.cfg.rewards.arm_scales)

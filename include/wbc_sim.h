@@ -148,8 +148,12 @@ typedef struct {
 typedef struct {
   float lin_vel_x_range[2], ang_vel_yaw_range[2];
   float goal_l_range[2], goal_p_range[2], goal_y_range[2];
-  float leg_reward_scale[WBC_NREW];   /* rewards.scales, 0 = inactive (WG:128-131) */
+  float leg_reward_scale[WBC_NREW];   /* rewards.scales: CURRENT value of each term's scale (WG:176-178) */
   float arm_reward_scale[WBC_NREW];   /* rewards.arm_scales */
+  /* bit t set = term t's _reward_ function is in the list built at construction from the config's non-zero scales
+   * (_prepare_reward_function, WG:128-157): it is evaluated every step -- episode sum += term * current scale, metric side
+   * effect applied -- even while a scheduled scale is 0 */
+  uint32_t leg_active_mask, arm_active_mask;
 } wbc_curriculum;
 
 /* Device tensors owned by the sim; ids for wbc_sim_get_tensor. Shapes at N envs. */

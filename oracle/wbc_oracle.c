@@ -773,7 +773,7 @@ static void compute_reward(const ora_sim* s, ora_env* e, const REAL* base_yaw_qu
   REAL r = 0, ra = 0;
   for (int t = 0; t < WBC_NREW; ++t) {
     REAL sc = (REAL)cu->leg_reward_scale[t];
-    if (sc != 0) {                                                                        /* WG:176-180 */
+    if ((cu->leg_active_mask >> t) & 1u) {                                                /* WG:176-180; list built at WG:128-142 */
       REAL v = term[t] * sc;
       r += v; e->episode_sums[t] += v;
       if (met_of[t] >= 0) e->metric_sums[met_of[t]] += met_src[t];
@@ -783,7 +783,7 @@ static void compute_reward(const ora_sim* s, ora_env* e, const REAL* base_yaw_qu
   e->rew = r / 100;                                                                       /* WG:189 */
   for (int t = 0; t < WBC_NREW; ++t) {
     REAL sc = (REAL)cu->arm_reward_scale[t];
-    if (sc != 0) {                                                                        /* WG:192-196 */
+    if ((cu->arm_active_mask >> t) & 1u) {                                                /* WG:192-196; list built at WG:144-157 */
       REAL v = term[t] * sc;
       ra += v; e->episode_sums[t] += v;
       if (met_of[t] >= 0) e->metric_sums[met_of[t]] += met_src[t];

@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/wg_reference_*.npz by running the REFERENCE's own WidowGo1 class
+(/root/reference/legged_gym/legged_gym/envs/widowGo1/widowGo1.py, imported read-only) on the fake
+Isaac Gym of tools/ref_harness/igstub.py, whose `gym.simulate` is this framework's physics spec.
+
+Every fixture is a trajectory of the reference's `step()`: the state before the first step, the
+actions of every step, and the reference's complete state after every step, all under the tensor
+names of include/wbc_sim.h. tests/test_wg_golden.py replays each step from the recorded pre-state
+through the C oracle (CPU) and through the HIP step kernel (GPU) and compares with what the reference
+computed: torques, observations + history, both reward channels, episode / metric sums, commands,
+EE-goal state machine, reset / time-out masks (bit-exact), resets and their draws.
+
+Run in the build container only: python tools/make_golden_wg.py
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "ref_harness"))
+import numpy as np
+import torch
+
+import harness
+from harness import curriculum_struct, make_reference_env, reference_cfg, wbc_state
+
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+
+INPUT_NAMES = ["ROOT_STATES", "DOF_STATE", "TORQUES", "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL",
+               "LAST_ROOT_VEL", "COMMANDS", "GOAL_STATE", "EPISODE_LENGTH", "EPISODE_SUMS", "METRIC_SUMS", "FORCE_SENSOR",
+               "NET_CONTACT_FORCE", "RIGID_BODY_STATE", "BASE_LIN_VEL", "BASE_ANG_VEL", "TIME_OUT_BUF", "RESET_BUF"]
+OUTPUT_NAMES = INPUT_NAMES + ["OBS_BUF", "REW_BUF", "ARM_REW_BUF"]
+
+
+def cur_arrays(env):
+    c = curriculum_struct(env)
+    return np.array(list(c.lin_vel_x_range) + list(c.ang_vel_yaw_range) + list(c.goal_l_range) + list(c.goal_p_range) +
+                    list(c.goal_y_range) + list(c.leg_reward_scale) + list(c.arm_reward_scale) +
+                    [c.leg_active_mask, c.arm_active_mask], dtype=np.float64)
+
+
+def episode_extras(env):
+    from wbc_amd import abi
+    ep = env.extras.get("episode", {})
+    out = np.full(abi.NREW + abi.NMETRIC, np.nan, dtype=np.float64)
+    for i, name in enumerate(abi.REWARD_TERMS):
+        if "rew_" + name in ep:
+            out[i] = float(ep["rew_" + name])
+    for i, name in enumerate(abi.METRIC_NAMES):
+        if "metric_" + name in ep:
+            out[abi.NREW + i] = float(ep["metric_" + name])
+    return out
+
+
+def record_trajectory(env, steps, rng, tag, big_action_envs=()):
+    """Step the reference `steps` times; before every step the physics backend is re-seated on the fp32 tensors the
+    reference holds (so a replay from the recorded fp32 pre-state starts from the identical physics state)."""
+    n = env.num_envs
+    b = env._backend
+    out = {"init/" + k: v for k, v in wbc_state(env).items() if k in INPUT_NAMES}
+    out["step_counter0"] = np.int64(env.common_step_counter)
+    acts, curs, eps = [], [], []
+    for k in range(steps):
+        b.push("root")
+        b.push("dof")
+        a = 0.5 * np.tanh(rng.standard_normal((n, 18))).astype(np.float32)
+        for e in big_action_envs:
+            a[e] = rng.choice([-150.0, 150.0, 3.0, -3.0], 18).astype(np.float32)      # exercises the +-100 clip (WG:1163)
+        curs.append(cur_arrays(env))
+        env.step(torch.from_numpy(a))
+        acts.append(a)
+        st = wbc_state(env)
+        for name in OUTPUT_NAMES:
+            out[f"s{k}/{name}"] = st[name]
+        eps.append(episode_extras(env))
+        out[f"s{k}/time_outs"] = env.extras["time_outs"].numpy().astype(np.uint8)
+    out["actions"] = np.stack(acts)
+    out["curriculum"] = np.stack(curs)
+    out["episode_extras"] = np.stack(eps)
+    out["steps"] = np.int64(steps)
+    for k, v in env._env_params.items():
+        out["param/" + k] = np.asarray(v)
+    out["seed"] = np.int64(harness.CTX.seed)
+    resets = sum(int(out[f"s{k}/RESET_BUF"].sum()) for k in range(steps))
+    tos = sum(int(out[f"s{k}/TIME_OUT_BUF"].sum()) for k in range(steps))
+    print(f"[{tag}] {steps} steps x {n} envs: {resets} resets ({tos} time-outs), draws logged: {len(harness.CTX.log)}")
+    return out
+
+
+def save(name, out):
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def flat_cfg():
+    cfg = reference_cfg()
+    cfg.terrain.tot_rows = 400                      # the reference's Terrain_Perlin is still built (host, init-time); physics
+    cfg.terrain.transform_y = -400 * cfg.terrain.horizontal_scale / 2     # below runs on the flat plane of BASELINE configs[1]
+    return cfg
+
+
+def stage_events(env, rng):
+    """Put envs next to every event the step can trigger: time-outs (episode_length > 500), command resampling
+    (episode_length % 150 == 0), a global push (common_step_counter % 150 == 0), EE-goal resampling."""
+    n = env.num_envs
+    L = np.array([0, 1, 148, 149, 298, 299, 448, 497, 498, 499, 500, 501, 30, 77] + list(rng.integers(2, 480, max(n - 14, 0))))[:n]
+    env.episode_length_buf[:] = torch.from_numpy(L)
+    env.common_step_counter = 146
+    env.goal_timer[:] = torch.from_numpy(rng.integers(0, 60, n).astype(np.float32))
+    soon = rng.random(n) < 0.4
+    env.goal_timer[torch.from_numpy(soon)] = (env.traj_total_timesteps[torch.from_numpy(soon)] - torch.from_numpy(rng.integers(0, 6, int(soon.sum())).astype(np.float32)))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    rng = np.random.default_rng(20260925)
+    # ---- A: shipped config, counter 0 (the reset() the runner issues before its first curriculum update) then counter 1
+    env = make_reference_env(24, seed=7, cfg=flat_cfg(), heightfield=None)
+    env._backend.ora.set_heightfield(None, 0, 0, 0, 0, 0)
+    with torch.inference_mode():
+        env.reset()                                                           # BT:127-131: reset_idx(all, start=True) + zero-action step
+        out0 = record_trajectory(env, 3, rng, "A0 counter=0")
+        env.update_command_curriculum()                                       # OPR:126
+        stage_events(env, rng)
+        outA = record_trajectory(env, 28, rng, "A1 counter=1", big_action_envs=(3, 11))
+    save("wg_reference_counter0.npz", out0)
+    save("wg_reference_default.npz", outA)
+    # ---- B: every one of the 21 reward terms of WG:1352-1469 active
+    cfg = flat_cfg()
+    s, a = cfg.rewards.scales, cfg.rewards.arm_scales
+    leg = dict(energy_square=-6e-5, survive=0.2, tracking_lin_vel_x_l1=0.5, tracking_ang_vel_yaw_exp=0.15, hip_action_l2=-0.01,
+               foot_contacts_z=-1e-4, leg_energy_abs_sum=-3e-3, leg_energy_sum_abs=-2e-3, leg_action_l2=-0.02, leg_energy=-1e-3,
+               tracking_lin_vel=0.3, tracking_lin_vel_x_exp=0.25, tracking_ang_vel_yaw_l1=0.1, tracking_lin_vel_y_l2=-0.4,
+               tracking_lin_vel_z_l2=-0.2, torques=-1e-4)
+    arm = dict(tracking_ee_sphere=0.55, arm_energy_abs_sum=-0.004, tracking_ee_cart=0.35, tracking_ee_orn=0.2, tracking_ee_orn_ry=0.15)
+    for k, v in leg.items():
+        setattr(s, k, v)                # instance attributes: class_to_dict (helpers.py:41-56) walks dir(obj)
+    for k, v in arm.items():
+        setattr(a, k, v)
+    cfg.goal_ee.ranges.final_delta_orn = [[-0.3, 0.3], [-0.2, 0.4], [-0.5, 0.5]]   # non-degenerate orientation goals
+    env = make_reference_env(16, seed=11, cfg=cfg)
+    env._backend.ora.set_heightfield(None, 0, 0, 0, 0, 0)
+    with torch.inference_mode():
+        env.reset()
+        env.update_command_curriculum()
+        stage_events(env, rng)
+        outB = record_trajectory(env, 10, rng, "B all rewards")
+    outB["leg_scales"] = np.array([leg.get(nm, 0.0) for nm in __import__("wbc_amd").abi.REWARD_TERMS])
+    outB["arm_scales"] = np.array([arm.get(nm, 0.0) for nm in __import__("wbc_amd").abi.REWARD_TERMS])
+    outB["delta_orn"] = np.array(cfg.goal_ee.ranges.final_delta_orn)
+    save("wg_reference_allrewards.npz", outB)
+
+
+if __name__ == "__main__":
+    main()
