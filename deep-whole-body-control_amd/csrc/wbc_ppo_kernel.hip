@@ -1057,19 +1057,20 @@ struct AdamTable {
   int off[34];                    // flat offset of parameter j; off[33] = total
 };
 
-// g <- g * min(1, max_norm / (||g|| + 1e-6)); m, v, p as torch.optim.Adam (no weight decay, no amsgrad):
+// g <- s g (s = grad_scale, 1 / world_size after a SUM all-reduce), then g <- g * min(1, max_norm / (||g|| + 1e-6));
+// m, v, p as torch.optim.Adam (no weight decay, no amsgrad):
 // m += (g-m)(1-b1); v = v b2 + (1-b2) g g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                                  const float* __restrict__ part, float max_norm, float beta1, float beta2,
-                                                                 float eps, float step_size, float bc2_sqrt) {
+                                                                 float eps, float step_size, float bc2_sqrt, float grad_scale) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= T.off[33]) return;
-  float coef = 1.f;
+  float coef = grad_scale;
   if (max_norm > 0.f) {
     float tot = 0.f;
 #pragma unroll 8
     for (int b = 0; b < ADAM_NBLK; ++b) tot += part[b];
-    coef = fminf(max_norm / (sqrtf(tot) + 1e-6f), 1.f);
+    coef = grad_scale * fminf(max_norm / (sqrtf(tot) * grad_scale + 1e-6f), 1.f);      // the norm of the SCALED gradient
   }
   int lo = 0, hi = 33;            // parameter j with off[j] <= i < off[j+1]
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.off[mid] <= i) lo = mid; else hi = mid; }
@@ -1196,8 +1197,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
 // step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) (computed by the caller in double, as torch does).
 // max_norm <= 0: no clipping. workspace: >= 64 floats.
 extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
-                                 float beta2, float eps, float step_size, float bc2_sqrt, float* workspace, void* stream) {
-  if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace) return -1;
+                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, float* workspace, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace || !(grad_scale > 0.f)) return -1;
   AdamTable T;
   int off = 0, j = 0;
   for (int l = 0; l < NLAYERS; ++l) {
@@ -1210,6 +1211,6 @@ extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* 
   hipStream_t st = (hipStream_t)stream;
   if (max_norm > 0.f) hipLaunchKernelGGL(ppo_sqnorm_kernel, dim3(ADAM_NBLK), dim3(256), 0, st, grad, off, workspace);
   hipLaunchKernelGGL(ppo_adam_kernel, dim3((off + 255) / 256), dim3(256), 0, st, T, grad, exp_avg, exp_avg_sq, workspace, max_norm, beta1, beta2, eps,
-                     step_size, bc2_sqrt);
+                     step_size, bc2_sqrt, grad_scale);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

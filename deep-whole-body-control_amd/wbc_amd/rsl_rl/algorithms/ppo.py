@@ -278,12 +278,13 @@ class PPO:
                       "wbc_ppo_minibatch_grad")
                 if self.entropy_coef != 0.0:       # -coef * entropy.mean(): d/d sigma_j of (1/2) sum_j log sigma_j
                     ac.std.grad.sub_(self.entropy_coef * 0.5 / ac.std.detach())
-                if self.dist_group is not None:
+                if self.dist_group is not None:    # ONE flat bucket, SUM over ranks; the 1/world_size mean is folded into the clip + Adam kernel
                     torch.distributed.all_reduce(F["grad"][:F["nparam"]], group=self.dist_group)
-                    F["grad"][:F["nparam"]].div_(self.world_size)
                 sums += F["grad"][F["nparam"]:]
                 steps = self._bind_adam_state(params, F)
                 if steps is None:                  # optimiser options the fused kernel does not cover
+                    if self.world_size > 1:
+                        F["grad"][:F["nparam"]].div_(self.world_size)
                     nn.utils.clip_grad_norm_(params, self.max_grad_norm)
                     self.optimizer.step()
                 else:                              # clip_grad_norm_ + Adam.step in two launches on the flat buffers
@@ -292,7 +293,7 @@ class PPO:
                     b1, b2 = g0["betas"]
                     check(L.wbc_ppo_clip_adam(table, F["grad"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(),
                                               float(self.max_grad_norm), b1, b2, g0["eps"], g0["lr"] / (1.0 - b1 ** t),
-                                              (1.0 - b2 ** t) ** 0.5, F["adam_ws"].data_ptr(), stream), "wbc_ppo_clip_adam")
+                                              (1.0 - b2 ** t) ** 0.5, 1.0 / self.world_size, F["adam_ws"].data_ptr(), stream), "wbc_ppo_clip_adam")
                     torch._foreach_add_(steps, 1.0)
         num_updates = self.num_learning_epochs * self.num_mini_batches
         surr, vls, preg = (sums / num_updates).tolist()
@@ -301,11 +302,11 @@ class PPO:
         self.enforce_min_std()
         return (vls / (2 * mb), surr / (2 * mb), 0.0, value_mixing_ratio, 0, preg / mb, priv_reg_coef)
 
-    def _bind_adam_state(self, params, F):
-        """Make self.optimizer's Adam moments of the fused parameters views of the flat buffers F['m'], F['v'] (so
-        that state_dict()/load_state_dict() and the eager step keep working on the same memory). Returns the list of
-        the parameters' step counters, or None if the optimiser is not a plain Adam the fused kernel reproduces."""
-        opt = self.optimizer
+    def _bind_adam_state(self, params, F, opt=None):
+        """Make the optimiser's (default: self.optimizer) Adam moments of the fused parameters views of the flat buffers
+        F['m'], F['v'] (so that state_dict()/load_state_dict() and the eager step keep working on the same memory). Returns
+        the list of the parameters' step counters, or None if the optimiser is not a plain Adam the fused kernel reproduces."""
+        opt = self.optimizer if opt is None else opt
         if type(opt) is not optim.Adam or len(opt.param_groups) != 1:
             return None
         g0 = opt.param_groups[0]
@@ -323,8 +324,8 @@ class PPO:
             elif st["exp_avg"].data_ptr() != mv.data_ptr() or st["exp_avg_sq"].data_ptr() != vv.data_ptr():
                 mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"])      # eager steps / load_state_dict happened in between
                 st["exp_avg"], st["exp_avg_sq"] = mv, vv
-            if st["step"].is_cuda:
-                return None
+            if st["step"].is_cuda:                 # a checkpoint loaded with map_location=cuda leaves the counters on the device
+                st["step"] = st["step"].detach().cpu()     # (non-capturable Adam): keep them on the host, where the fused path reads them
             steps.append(st["step"])
             off += n
         if any(float(x) != float(steps[0]) for x in steps):
@@ -414,7 +415,77 @@ class PPO:
         return (mean_value_loss, mean_surrogate_loss, mean_arm_torques_loss, value_mixing_ratio, torque_supervision_weight,
                 mean_priv_reg_loss, priv_reg_coef)
 
+    def _fused_dagger_supported(self):
+        st, ac = self.storage, self.actor_critic
+        return (self.fused_update and st.observations.is_cuda and st.privileged_observations is None and not ac.is_recurrent
+                and ac.actor._fused_hist_supported(st.observations[0]) and ac.fused_act_supported(st.observations[0]))
+
+    def _update_dagger_fused(self):
+        """update_dagger() with each minibatch's history-encoder forward, loss, backward and weight gradients in ONE HIP
+        launch (csrc/wbc_hist_train_kernel.hip) + a fixed-order reduction + clip/Adam on flat buffers; the privileged
+        latents of all stored rows (constant: only the history encoder moves) come from one wbc_priv_latent launch."""
+        import ctypes as C
+        from ...native import check, lib
+        L, st, ac, dev = lib(), self.storage, self.actor_critic, self.storage.observations.device
+        batch = st.num_transitions_per_env * st.num_envs
+        mb = batch // self.num_mini_batches
+        he, pe = ac.actor.history_encoder, ac.actor.priv_encoder
+        hp = [he.encoder[0].weight, he.encoder[0].bias, he.conv_layers[0].weight, he.conv_layers[0].bias,
+              he.conv_layers[2].weight, he.conv_layers[2].bias, he.linear_output[0].weight, he.linear_output[0].bias]
+        pp = [pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias]
+        for p in hp + pp:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        F = self.__dict__.get("_fused_hist")
+        if F is None or F["batch"] != batch:
+            ng = L.wbc_hist_train_grad_floats()
+            F = dict(batch=batch, ng=ng, grad=torch.zeros(ng, device=dev), ws=torch.empty(L.wbc_hist_train_workspace_floats(), device=dev),
+                     m=torch.zeros(ng - 1, device=dev), v=torch.zeros(ng - 1, device=dev), priv=torch.empty(batch, 20, device=dev))
+            self._fused_hist = F
+        nparam = F["ng"] - 1
+        for p, g in zip(hp, torch.split(F["grad"][:nparam], [p.numel() for p in hp])):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g.view_as(p)               # parameter gradients are views of the flat buffer
+        table = (C.c_void_p * 8)(*[p.data_ptr() for p in hp])
+        ptable = (C.c_void_p * 4)(*[p.data_ptr() for p in pp])
+        obs = st.observations.view(batch, -1)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        check(L.wbc_priv_latent(ptable, obs.data_ptr(), F["priv"].data_ptr(), batch, stream), "wbc_priv_latent")
+        indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=dev)      # one per update (RS:163)
+        total = torch.zeros((), device=dev)
+        opt = self.hist_encoder_optimizer
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                idx = indices[i * mb:(i + 1) * mb]
+                check(L.wbc_hist_train_grad(table, obs.data_ptr(), F["priv"].data_ptr(), idx.data_ptr(), mb, F["ws"].data_ptr(),
+                                            F["grad"].data_ptr(), stream), "wbc_hist_train_grad")
+                total += F["grad"][nparam]
+                reduced = 0
+                if self.dist_group is not None:    # one flat 23 kB bucket, SUM; the mean is folded into the clip + Adam kernel
+                    torch.distributed.all_reduce(F["grad"][:nparam], group=self.dist_group)
+                    reduced = 1
+                steps = self._bind_adam_state(hp, F, opt)
+                if steps is None:
+                    if self.world_size > 1:
+                        F["grad"][:nparam].div_(self.world_size)
+                    nn.utils.clip_grad_norm_(hp, self.max_grad_norm)
+                    opt.step()
+                else:
+                    g0 = opt.param_groups[0]
+                    t = float(steps[0]) + 1.0
+                    b1, b2 = g0["betas"]
+                    check(L.wbc_hist_clip_adam(table, F["grad"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(), float(self.max_grad_norm),
+                                               b1, b2, g0["eps"], g0["lr"] / (1.0 - b1 ** t), (1.0 - b2 ** t) ** 0.5, 1.0 / self.world_size,
+                                               reduced, F["ws"].data_ptr(), stream), "wbc_hist_clip_adam")
+                    torch._foreach_add_(steps, 1.0)
+        num_updates = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        self.update_counter()
+        ac.mark_params_changed()
+        return (total / (num_updates * mb)).item()
+
     def update_dagger(self):
+        if self._fused_dagger_supported():
+            return self._update_dagger_fused()
         ac = self.actor_critic
         total = torch.zeros((), device=self.device)
         hist_params = list(ac.actor.history_encoder.parameters())
@@ -424,12 +495,7 @@ class PPO:
             batches = ((obs_b, None) for (obs_b, *_rest) in self._generator())
         for obs_b, priv_latent in batches:
             with torch.inference_mode():
-                if self.fused_rollout and obs_b.is_cuda:
-                    # the reference's act() here only samples and discards (quirk L1): keep the generator advancing by one
-                    # [mb, 18] normal draw, skip the 17 launches of the unused forward
-                    torch.empty(obs_b.shape[0], ac.std.shape[0], device=obs_b.device).normal_()
-                else:
-                    ac.act(obs_b, hist_encoding=True, masks=None, hidden_states=None)
+                ac.act(obs_b, hist_encoding=True, masks=None, hidden_states=None)       # samples and discards (quirk L1)
                 if priv_latent is None:
                     priv_latent = ac.actor.infer_priv_latent(obs_b)
             hist_latent = ac.actor.infer_hist_latent(obs_b)

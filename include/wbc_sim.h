@@ -330,10 +330,31 @@ int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const fl
 /* nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (ppo.py:243-246) for the 33 parameters of
  * `params`, reading their gradients from grad[0 : wbc_ppo_grad_floats()-3] (scaled in place by the clip factor);
  * exp_avg / exp_avg_sq are flat Adam moments in the same layout. step_size = lr/(1-beta1^t), bc2_sqrt =
- * sqrt(1-beta2^t). max_norm <= 0 disables the clip. workspace: >= 64 floats. Deterministic. */
+ * sqrt(1-beta2^t). max_norm <= 0 disables the clip. grad_scale (> 0) multiplies the gradient before the clip: 1 on one GPU,
+ * 1 / world_size after the SUM all-reduce of the sharded learner (the mean over ranks without a separate launch).
+ * workspace: >= 64 floats. Deterministic. */
 int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm,
-                      float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float* workspace,
-                      void* stream);
+                      float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
+                      float* workspace, void* stream);
+/* One minibatch of PPO.update_dagger (rsl_rl/algorithms/ppo.py:265-291): the history encoder's forward
+ * (rsl_rl/modules/actor_critic.py:39-84), loss = mean over rows of ||target - latent||_2, backward and weight gradients
+ * for the `rows` rows obs[idx[r]] (obs f32 [batch, 860], target f32 [batch, 20] = the privileged latents, idx i64 [rows]).
+ * params: the 8 tensors of wbc_hist_latent. grad (out): wbc_hist_train_grad_floats() floats = the flat gradient in
+ * history_encoder.parameters() order (5760) followed by the minibatch's SUM of row norms (divide by rows for the loss).
+ * workspace: wbc_hist_train_workspace_floats() floats. Deterministic (fixed-order reduction). */
+int wbc_hist_train_grad(const void* const* params, const float* obs, const float* target, const long long* idx, int rows,
+                        float* workspace, float* grad, void* stream);
+int wbc_hist_train_grad_floats(void);
+size_t wbc_hist_train_workspace_floats(void);
+/* clip_grad_norm_ + Adam.step (ppo.py:283-284) of the history encoder on the flat buffers, as wbc_ppo_clip_adam.
+ * grad_was_reduced != 0: grad was changed since wbc_hist_train_grad (all-reduce over ranks); the norm is re-derived.
+ * workspace: the one passed to wbc_hist_train_grad. */
+int wbc_hist_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
+                       float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, int grad_was_reduced,
+                       const float* workspace, void* stream);
+/* Actor.infer_priv_latent (actor_critic.py:219-221) for every row: params = priv_encoder.{0,2}.{weight,bias} ([64,24], [64],
+ * [20,64], [20]); obs f32 [rows, 860]; out f32 [rows, 20]. */
+int wbc_priv_latent(const void* const* params, const float* obs, float* out, int rows, void* stream);
 int wbc_ppo_grad_floats(void);
 int wbc_ppo_num_splits(void);
 size_t wbc_ppo_workspace_floats(int B);

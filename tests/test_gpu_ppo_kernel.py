@@ -93,3 +93,55 @@ def test_fused_update_full_iteration_tracks_eager():
     np.testing.assert_allclose(out_f, out_e, rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(gp.param_digest(ac_f)[:, :2], gp.param_digest(ac_e)[:, :2], rtol=2e-4, atol=2e-4)
     assert alg_f.counter == alg_e.counter == 3501
+
+
+@pytest.mark.parametrize("batch,rows", [(64, 64), (700, 333), (31, 31), (5, 1), (40960, 40960), (163840, 40960)])
+def test_fused_history_encoder_gradients_match_autograd(batch, rows):
+    """wbc_hist_train_grad (one launch: history-encoder forward, loss = mean ||priv - hist||_2, backward, weight gradients;
+    csrc/wbc_hist_train_kernel.hip) and wbc_priv_latent against PyTorch autograd over the module path that
+    tests/test_ppo_parity.py pins to the reference (PPO:265-291, AC:39-84), on a gathered subset of the stored rows."""
+    import ctypes as C
+    from wbc_amd.native import check, lib
+    torch.manual_seed(3)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).to("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(batch + rows)
+    obs = torch.randn(batch, 860, generator=g, device="cuda")
+    idx = torch.randperm(batch, generator=g, device="cuda")[:rows].contiguous()
+    he, pe = ac.actor.history_encoder, ac.actor.priv_encoder
+    hp = [he.encoder[0].weight, he.encoder[0].bias, he.conv_layers[0].weight, he.conv_layers[0].bias,
+          he.conv_layers[2].weight, he.conv_layers[2].bias, he.linear_output[0].weight, he.linear_output[0].bias]
+    assert [id(p) for p in hp] == [id(p) for p in he.parameters()]           # flat gradient layout = parameters() order
+    pp = [pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias]
+    L = lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    priv = torch.empty(batch, 20, device="cuda")
+    check(L.wbc_priv_latent((C.c_void_p * 4)(*[p.data_ptr() for p in pp]), obs.data_ptr(), priv.data_ptr(), batch, stream))
+    with torch.no_grad():
+        priv_ref = ac.actor.infer_priv_latent(obs)
+    np.testing.assert_allclose(priv.cpu().numpy(), priv_ref.cpu().numpy(), atol=2e-6, rtol=2e-5)
+    ng = L.wbc_hist_train_grad_floats()
+    grad = torch.zeros(ng, device="cuda")
+    ws = torch.empty(L.wbc_hist_train_workspace_floats(), device="cuda")
+    check(L.wbc_hist_train_grad((C.c_void_p * 8)(*[p.data_ptr() for p in hp]), obs.data_ptr(), priv_ref.data_ptr(), idx.data_ptr(), rows,
+                                ws.data_ptr(), grad.data_ptr(), stream))
+    obs_b = obs[idx]
+    hist = he(obs_b[:, -760:].view(-1, 10, 76))
+    loss = (priv_ref[idx].detach() - hist).norm(p=2, dim=1).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(grad[ng - 1].item() / rows - loss.item()) <= 2e-5 * max(1.0, abs(loss.item()))
+    flat = torch.cat([p.grad.reshape(-1) for p in hp])
+    off = 0
+    for p in hp:
+        n = p.numel()
+        a, b = grad[off:off + n], flat[off:off + n]
+        scale = b.abs().max().item() + 1e-12
+        err = (a - b).abs().max().item()
+        assert err <= 1e-4 * scale + 1e-9, (tuple(p.shape), err, scale)
+        off += n
+    # deterministic: a second launch gives the same bits
+    grad2 = torch.zeros(ng, device="cuda")
+    check(L.wbc_hist_train_grad((C.c_void_p * 8)(*[p.data_ptr() for p in hp]), obs.data_ptr(), priv_ref.data_ptr(), idx.data_ptr(), rows,
+                                ws.data_ptr(), grad2.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(grad, grad2)

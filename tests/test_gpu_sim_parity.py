@@ -231,3 +231,102 @@ def test_action_clip_timeout_and_episode_boundaries(robot):
         np.testing.assert_allclose(_t(g, name), o.get(name), atol=5e-4, rtol=5e-4, err_msg=name)
     np.testing.assert_allclose(_t(g, "EPISODE_SUMS_DONE"), o.get("EPISODE_SUMS_DONE"), atol=2e-2, rtol=2e-3)
     g.close()
+
+
+# ---- BASELINE.json configurations ----------------------------------------------------------------------------------
+def _synced_steps(robot, g, o, n, steps, rng, tag, check_travel=False):
+    import torch
+    resets = 0
+    for step in range(steps):
+        helpers.sync_oracle_from_gpu(o, g)
+        a = (0.6 * rng.normal(size=(n, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda())
+        o.step(a)
+        for name in ("RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH"):                  # integer / boolean outputs: bit-exact
+            np.testing.assert_array_equal(_t(g, name), o.get(name), err_msg=f"{tag} {name}, step {step}")
+        m = o.get("RESET_BUF").astype(bool)
+        resets += int(m.sum())
+        for name, atol, rtol in (("DOF_STATE", 4e-4, 5e-4), ("ROOT_STATES", 4e-4, 5e-4), ("TORQUES", 4e-4, 5e-4), ("COMMANDS", 1e-6, 1e-6),
+                                 ("GOAL_STATE", 2e-5, 2e-5), ("OBS_BUF", 2e-3, 5e-4), ("OBS_HISTORY", 2e-3, 5e-4),
+                                 ("REW_BUF", 2e-4, 2e-3), ("ARM_REW_BUF", 2e-5, 1e-3), ("EPISODE_SUMS", 2e-2, 2e-3)):
+            np.testing.assert_allclose(_t(g, name), o.get(name), atol=atol, rtol=rtol, err_msg=f"{tag} {name}, step {step}")
+        if check_travel and m.any():
+            np.testing.assert_allclose(_t(g, "RESET_TRAVEL")[m], o.get("RESET_TRAVEL")[m], atol=4e-4, rtol=1e-4)
+    return resets
+
+
+def test_step_at_baseline_config1_4096_flat(robot):
+    """BASELINE.json configs[1] (the bench workload): 4096 envs on the plane, the fused step against the fp32 oracle from a
+    synced state, after a settling rollout so that the batch holds standing, falling and freshly reset robots."""
+    import torch
+    n = 4096
+    params = helpers.random_env_params(n, seed=41)
+    g = helpers.make_gpu(robot, n, params)
+    o = helpers.make_oracle(robot, n, params, "f32")
+    g.reset_all()
+    rng = np.random.default_rng(42)
+    g.tensor("EPISODE_LENGTH").copy_(torch.from_numpy(rng.integers(0, 500, n)).long())   # OPR:107-108 init_at_random_ep_len
+    g.step_counter = 140
+    for _ in range(12):
+        g.step(torch.from_numpy((0.6 * rng.normal(size=(n, 18))).astype(np.float32)).cuda())
+    o.step_counter = g.step_counter
+    resets = _synced_steps(robot, g, o, n, 4, rng, "4096 flat")
+    assert resets > 20
+    g.close()
+
+
+def test_step_at_baseline_config2_8192_heightfield(robot):
+    """BASELINE.json configs[2]: 8192 envs on a height grid (sphere-vs-triangulated-grid contact, integer cell indexing) with
+    the terrain curriculum's inputs (the finished episode's travel and command norm, LR:431-435) compared on every reset."""
+    import torch
+    n = 8192
+    params = helpers.random_env_params(n, seed=43)
+    rng = np.random.default_rng(44)
+    hf = _make_heightfield(rows=400, cols=400, seed=5)
+    hs, vs = 0.1, 0.005
+    tx, ty, tz = -0.5 * hf.shape[0] * hs, -0.5 * hf.shape[1] * hs, 0.0
+    params["env_origins"] = np.stack([rng.uniform(-15, 15, n), rng.uniform(-15, 15, n), np.zeros(n)], 1).astype(np.float32)
+    g = helpers.make_gpu(robot, n, params)
+    o = helpers.make_oracle(robot, n, params, "f32")
+    g.set_heightfield(hf, hs, vs, tx, ty, tz)
+    o.set_heightfield(hf, hs, vs, tx, ty, tz)
+    g.reset_all()
+    g.tensor("EPISODE_LENGTH").copy_(torch.from_numpy(rng.integers(0, 500, n)).long())
+    for _ in range(10):
+        g.step(torch.from_numpy((0.6 * rng.normal(size=(n, 18))).astype(np.float32)).cuda())
+    o.step_counter = g.step_counter
+    resets = _synced_steps(robot, g, o, n, 3, rng, "8192 heightfield", check_travel=True)
+    assert resets > 20
+    g.close()
+
+
+def test_free_running_100_policy_steps(robot):
+    """state after 1, 4 and 400 substeps without any syncing (fp32 HIP vs fp64 oracle). Contact
+    switching makes the trajectories diverge exponentially from fp32 rounding, so the statement is about quantiles."""
+    import torch
+    n = 128
+    params = helpers.random_env_params(n, seed=19)
+    tc = copy.copy(robot["tcfg"])
+    tc.term_z_threshold = 0.05        # keep the episodes alive: this test is about the dynamics
+    tc.term_rp_threshold = 10.0
+    tc.max_episode_length = 100000
+    g = helpers.make_gpu(robot, n, params, tcfg=tc)
+    o = helpers.make_oracle(robot, n, params, "f64", tcfg=tc)
+    g.reset_all(); o.reset_all()
+    rng = np.random.default_rng(29)
+    report = {}
+    for step in range(1, 101):
+        a = (0.25 * rng.normal(size=(n, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda()); o.step(a)
+        if step in (1, 4, 25, 100):
+            err = np.abs(_t(g, "DOF_STATE")[:, :, 0] - o.get("DOF_STATE")[:, :, 0]).max(1)
+            zerr = np.abs(_t(g, "ROOT_STATES")[:, 0, 2] - o.get("ROOT_STATES")[:, 0, 2])
+            report[step] = (np.median(err), np.quantile(err, 0.9), np.median(zerr))
+    print("free run: policy step -> (median, p90 max joint error [rad], median base height error [m])",
+          {k: tuple(f"{x:.2e}" for x in v) for k, v in report.items()})
+    assert np.isfinite(_t(g, "OBS_BUF")).all()
+    assert report[1][0] < 5e-5 and report[1][1] < 5e-4          # 4 substeps
+    assert report[4][0] < 2e-4 and report[4][1] < 5e-3          # 16 substeps
+    assert report[100][0] < 0.25 and report[100][2] < 0.02      # 400 substeps: same gait regime, decorrelated joint phases allowed
+    np.testing.assert_array_equal(_t(g, "EPISODE_LENGTH"), o.get("EPISODE_LENGTH"))
+    g.close()

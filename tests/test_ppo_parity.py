@@ -114,3 +114,63 @@ def test_update_and_dagger_match_reference_gpu():
     np.testing.assert_allclose(out_g, out_c, rtol=2e-3, atol=1e-5)
     dc, dg = gp.param_digest(ac_c), gp.param_digest(ac_g)
     np.testing.assert_allclose(dg[:, :2], dc[:, :2], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_gae_kernel_at_bench_shape_matches_torch_recurrence():
+    """The HIP GAE kernels (csrc/wbc_gae_kernel.hip: multi-block fp64 partial statistics at this size) at the bench shape
+    4096 x 40 against the torch recurrence of RS:136-150 on the CPU, which test_gae_known_answer_cpu pins to the reference."""
+    N, T, dev = 4096, 40, "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    rew = 0.05 * torch.randn(T, N, 2, generator=g)
+    val = torch.randn(T, N, 2, generator=g)
+    dones = (torch.rand(T, N, 1, generator=g) < 0.03).to(torch.uint8)
+    last = torch.randn(N, 2, generator=g)
+    sc = RolloutStorage(N, T, [3], [None], [1], device="cpu")
+    sg = RolloutStorage(N, T, [3], [None], [1], device=dev)
+    for s in (sc, sg):
+        s.rewards.copy_(rew); s.values.copy_(val); s.dones.copy_(dones)
+    sc.compute_returns(last, 0.99, 0.95)
+    sg.compute_returns(last.to(dev), 0.99, 0.95)
+    err_r = (sg.returns.cpu() - sc.returns).abs().max().item()
+    err_a = (sg.advantages.cpu() - sc.advantages).abs().max().item()
+    assert err_r < 1e-3                                                   # the north-star bound
+    assert err_r < 5e-6 and err_a < 5e-5, (err_r, err_a)                  # what the kernels actually deliver
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,T", [(gp.N, gp.T), (1024, 40)])
+def test_update_dagger_gpu_matches_cpu(N, T):
+    """update_dagger (PPO:265-291) on the MI355X -- the fused history-encoder forward+backward + Adam on the device --
+    against the CPU path (pinned to the reference by test_update_and_dagger_match_reference_cpu) from identical storage,
+    identical permutation: loss and every history-encoder parameter after the 20 Adam steps."""
+    import unittest.mock as mock
+    dev = "cuda:0"
+
+    def run(device):
+        torch.manual_seed(1)
+        ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
+        alg = PPO(ac, device=device, **gp.ALG_KW)
+        alg.counter = 3500
+        alg.init_storage(N, T, [860], [None], [18])
+        return ac, alg
+    ac_c, alg_c = run("cpu")
+    ac_g, alg_g = run(dev)
+    g = torch.Generator().manual_seed(77)
+    obs = torch.randn(T, N, 860, generator=g)
+    alg_c.storage.observations.copy_(obs)
+    alg_g.storage.observations.copy_(obs)
+    alg_c.storage.step = alg_g.storage.step = T
+    perm = torch.randperm(N * T, generator=g)
+    with mock.patch("torch.randperm", lambda n, **kw: perm.to(kw.get("device", "cpu"))):
+        loss_c = alg_c.update_dagger()
+        loss_g = alg_g.update_dagger()
+    assert abs(loss_g - loss_c) <= 2e-4 * max(1.0, abs(loss_c)), (loss_g, loss_c)
+    pc = dict(ac_c.actor.history_encoder.named_parameters())
+    for name, q in ac_g.actor.history_encoder.named_parameters():
+        np.testing.assert_allclose(q.detach().cpu().numpy(), pc[name].detach().numpy(), atol=2e-4, rtol=2e-4, err_msg=name)
+    # nothing but the history encoder moved (L6), the schedule counter advanced (L7)
+    for (n1, p1), (n2, p2) in zip(ac_c.named_parameters(), ac_g.named_parameters()):
+        if "history_encoder" not in n1:
+            np.testing.assert_array_equal(p1.detach().numpy(), p2.detach().cpu().numpy(), err_msg=n1)
+    assert alg_g.counter == alg_c.counter == 3501
