@@ -253,3 +253,19 @@ def class_to_dict(obj) -> dict:
         else:
             result[key] = val
     return result
+
+
+def use_grid_terrain(cfg, num_rows=10, num_cols=20):
+    """Swap a widowGo1 config's terrain for the base class's sub-terrain grid, LeggedRobotCfg.terrain
+    (legged_robot_config.py:43-66: trimesh, 0.1 m / 5 mm scales, 25 m border, num_rows difficulty levels x num_cols
+    types of 8 m x 8 m tiles with proportions [.1, .1, .35, .25, .2], terrain-level curriculum on) -- BASELINE.json
+    configs[2] / SURVEY.md section 8d config 3. The task-specific reset ranges of the widowGo1 terrain block are kept;
+    measure_heights is off (the widowGo1 observation has no height scan, WG:966-1001)."""
+    old = cfg.terrain
+    new = LeggedRobotCfg().terrain
+    new.num_rows, new.num_cols = num_rows, num_cols
+    new.measure_heights = False
+    for k in ("origin_perturb_range", "init_vel_perturb_range"):
+        setattr(new, k, getattr(old, k))
+    cfg.terrain = new
+    return cfg

@@ -168,6 +168,14 @@ class WidowGo1(LeggedRobot):
             self.terrain = TerrainPerlin(t, seed=self._seed)
             self.set_heightfield(self.terrain.heightsamples, self.terrain.horizontal_scale, self.terrain.vertical_scale,
                                  *self.terrain.transform)
+        elif t.mesh_type in ("trimesh", "heightfield") and hasattr(t, "terrain_proportions"):
+            # the base class's sub-terrain grid (LR:79-95 create_sim -> Terrain(cfg.terrain, num_envs), utils/terrain.py:101-227);
+            # np.random is the reference's stream for it (seeded as helpers.set_seed does)
+            from .terrain import Terrain
+            np.random.seed(self._seed)
+            self.terrain = Terrain(t, self.num_envs)
+            self.set_heightfield(self.terrain.heightsamples, self.terrain.horizontal_scale, self.terrain.vertical_scale,
+                                 *self.terrain.transform)
 
     def set_heightfield(self, heights_i16: np.ndarray, horizontal_scale, vertical_scale, tx, ty, tz):
         self.sim.set_heightfield(heights_i16, horizontal_scale, vertical_scale, tx, ty, tz)
@@ -182,16 +190,19 @@ class WidowGo1(LeggedRobot):
         nprng = np.random.default_rng(self._seed)
         rand = lambda lo, hi, *shape: (hi - lo) * torch.rand(*shape, generator=gen) + lo   # noqa: E731
         t, dr = cfg.terrain, cfg.domain_rand
-        half_col = t.tot_cols * t.horizontal_scale / 2
-        half_row = t.tot_rows * t.horizontal_scale / 2
+        grid = self.terrain is not None and hasattr(self.terrain, "proportions")          # the base class's Terrain
         origins = torch.zeros(n, 3)
-        origins[:, 0] = rand(-2.5 * half_col / 5, -2 * half_col / 5, n)
-        origins[:, 1] = rand(-half_row + 10, half_row - 10, n)
+        if not grid:                                # WG:207-224: a strip in front of the (Perlin) field
+            half_col = t.tot_cols * t.horizontal_scale / 2
+            half_row = t.tot_rows * t.horizontal_scale / 2
+            origins[:, 0] = rand(-2.5 * half_col / 5, -2 * half_col / 5, n)
+            origins[:, 1] = rand(-half_row + 10, half_row - 10, n)
         self.env_origins = origins.to(self.device)
         self.custom_origins = True
-        self._terrain_levels_on = bool(t.curriculum and self.terrain is not None)
+        self._terrain_levels_on = bool(self.terrain is not None and (grid or t.curriculum))
         if self._terrain_levels_on:                 # base-class placement on the terrain's (level, type) platforms, LR:717-731
-            self.terrain.level_grid(int(t.num_rows), int(t.num_cols))
+            if not grid:
+                self.terrain.level_grid(int(t.num_rows), int(t.num_cols))
             origins = self._get_env_origins_levels(gen).cpu()
         sign = torch.randint(0, 2, (n,), generator=gen) * 2 - 1
         box_dy = sign * rand(cfg.box.box_env_origins_y_range[0], cfg.box.box_env_origins_y_range[1], n)
@@ -393,7 +404,7 @@ class WidowGo1(LeggedRobot):
         self.sim.step(a, out, store)
         self.extras["rollout_stored"] = store[2].data_ptr() if store is not None else None
         self.common_step_counter += 1
-        if self._terrain_levels_on:                                                  # WG:708-709 (reset_idx -> _update_terrain_curriculum)
+        if self._terrain_levels_on and self.cfg.terrain.curriculum:                  # WG:708-709 (reset_idx -> _update_terrain_curriculum)
             self._apply_terrain_curriculum()
         if self.cfg.terrain.measure_heights:                                         # WG:932-933
             self.measured_heights = self._get_heights()

@@ -9,7 +9,10 @@ mapped to [0, 1] and scaled by zScale; samples stored as round-toward-zero(h / v
 Quirk Q3 (SURVEY.md): the reference adds 100 km to rows >= tot_cols//2 - 100 and casts to int16; on
 x86-64 numpy that out-of-range cast yields 0, i.e. the far part of the map is FLAT at z = 0. That is
 what `flat_beyond_row` reproduces, explicitly instead of through an overflow.
-The random stream is numpy's Generator seeded by the caller, not the reference's global np.random.
+The random stream is numpy's Generator seeded by the caller, not the reference's global np.random; fed the same
+uniforms (tools/make_golden_terrain.py patches the reference's np.random.rand with the same Generator) the two grids
+agree to the last int16 bit except where a 1e-11 difference in evaluation order crosses a truncation boundary
+(tests/test_terrain_golden.py).
 """
 from __future__ import annotations
 
@@ -64,7 +67,7 @@ class TerrainPerlin:
         rng = np.random.default_rng(seed)
         self.heightsamples_float = fractal_noise(int(x_size), int(y_size), self.tot_cols, self.tot_rows, rng, z_scale=cfg.zScale)
         self.flat_beyond_row = self.tot_cols // 2 - 100
-        hs = np.trunc(self.heightsamples_float / cfg.vertical_scale)
+        hs = np.trunc(self.heightsamples_float * (1 / cfg.vertical_scale))       # terrain.py:51: h * (1 / vertical_scale), cast = truncation
         hs[self.flat_beyond_row:, :] = 0            # quirk Q3, see module docstring
         self.heightsamples = np.clip(hs, -32768, 32767).astype(np.int16)
         self.horizontal_scale, self.vertical_scale = float(cfg.horizontal_scale), float(cfg.vertical_scale)
@@ -89,3 +92,100 @@ class TerrainPerlin:
                 patch = self.heightsamples[max(ix - half, 0):min(ix + half, nx), max(iy - half, 0):min(iy + half, ny)]
                 self.env_origins[i, j] = (cx + self.transform[0], cy + self.transform[1], float(patch.max()) * vs + self.transform[2])
         return self.env_origins
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The base class's terrain: a grid of num_rows (difficulty levels) x num_cols (terrain types) square tiles
+# (legged_gym/utils/terrain.py:101-250, used with LeggedRobotCfg.terrain, legged_robot_config.py:43-66).
+def _gap(tile, gap_size, platform_size=1.0):                                       # terrain.py:229-241
+    gap, plat = int(gap_size / tile.horizontal_scale), int(platform_size / tile.horizontal_scale)
+    cx, cy = tile.length // 2, tile.width // 2
+    x1, y1 = (tile.length - plat) // 2, (tile.width - plat) // 2
+    x2, y2 = x1 + gap, y1 + gap
+    tile.height_field_raw[cx - x2:cx + x2, cy - y2:cy + y2] = -1000
+    tile.height_field_raw[cx - x1:cx + x1, cy - y1:cy + y1] = 0
+
+
+def _pit(tile, depth, platform_size=1.0):                                          # terrain.py:243-250
+    d, half = int(depth / tile.vertical_scale), int(platform_size / tile.horizontal_scale / 2)
+    x1, x2 = tile.length // 2 - half, tile.length // 2 + half
+    y1, y2 = tile.width // 2 - half, tile.width // 2 + half
+    tile.height_field_raw[x1:x2, y1:y2] = -d
+
+
+class Terrain:
+    """Attributes as the reference object: env_length / env_width, proportions (cumulative), border (cells), tot_rows /
+    tot_cols, height_field_raw = heightsamples (int16 [tot_rows, tot_cols]), env_origins [num_rows, num_cols, 3]
+    (tile centre, z = highest sample of the 2 m x 2 m patch around it), and for mesh_type 'trimesh' vertices / triangles.
+    Tile (i, j) has difficulty i / num_rows and type j / num_cols + 0.001 under cfg.curriculum; otherwise a random type and
+    one of three difficulties per tile (np.random, same call order as the reference)."""
+
+    def __init__(self, cfg, num_robots) -> None:
+        self.cfg, self.num_robots, self.type = cfg, num_robots, cfg.mesh_type
+        if self.type in ("none", "plane"):
+            return
+        from . import terrain_utils
+        self._tu = terrain_utils
+        self.env_length, self.env_width = cfg.terrain_length, cfg.terrain_width
+        self.proportions = [np.sum(cfg.terrain_proportions[:i + 1]) for i in range(len(cfg.terrain_proportions))]
+        cfg.num_sub_terrains = cfg.num_rows * cfg.num_cols
+        self.env_origins = np.zeros((cfg.num_rows, cfg.num_cols, 3))
+        hs = cfg.horizontal_scale
+        self.width_per_env_pixels, self.length_per_env_pixels = int(self.env_width / hs), int(self.env_length / hs)
+        self.border = int(cfg.border_size / hs)
+        self.tot_cols = int(cfg.num_cols * self.width_per_env_pixels) + 2 * self.border
+        self.tot_rows = int(cfg.num_rows * self.length_per_env_pixels) + 2 * self.border
+        self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
+        tiles = [(i, j) for j in range(cfg.num_cols) for i in range(cfg.num_rows)] if cfg.curriculum else \
+                [tuple(np.unravel_index(k, (cfg.num_rows, cfg.num_cols))) for k in range(cfg.num_sub_terrains)]
+        if not cfg.curriculum and getattr(cfg, "selected", False):
+            raise NotImplementedError("terrain.selected (a single generator by name) is broken in the reference too (terrain.py:160-173 "
+                                      "reads attributes the class never sets)")
+        for i, j in tiles:
+            if cfg.curriculum:
+                difficulty, choice = i / cfg.num_rows, j / cfg.num_cols + 0.001
+            else:
+                choice = np.random.uniform(0, 1)
+                difficulty = np.random.choice([0.5, 0.75, 0.9])
+            self._place(self.make_terrain(choice, difficulty), i, j)
+        self.heightsamples = self.height_field_raw
+        self.horizontal_scale, self.vertical_scale = float(hs), float(cfg.vertical_scale)
+        self.transform = (-float(cfg.border_size), -float(cfg.border_size), 0.0)           # LR:_create_trimesh / _create_heightfield
+        if self.type == "trimesh":
+            self.vertices, self.triangles = terrain_utils.convert_heightfield_to_trimesh(self.height_field_raw, hs, cfg.vertical_scale,
+                                                                                         cfg.slope_treshold)
+
+    def make_terrain(self, choice, difficulty):
+        tu, cfg = self._tu, self.cfg
+        tile = tu.SubTerrain("terrain", width=self.width_per_env_pixels, length=self.width_per_env_pixels,
+                             vertical_scale=cfg.vertical_scale, horizontal_scale=cfg.horizontal_scale)
+        slope, step_h = difficulty * 0.4, 0.05 + 0.18 * difficulty
+        P = list(self.proportions) + [np.inf] * 8                   # types beyond the configured proportions are never chosen
+        if choice < P[0]:                                           # smooth slope (lower half of the band: inverted)
+            tu.pyramid_sloped_terrain(tile, slope=-slope if choice < P[0] / 2 else slope, platform_size=3.)
+        elif choice < P[1]:                                         # rough slope
+            tu.pyramid_sloped_terrain(tile, slope=slope, platform_size=3.)
+            tu.random_uniform_terrain(tile, min_height=-0.05, max_height=0.05, step=0.005, downsampled_scale=0.2)
+        elif choice < P[3]:                                         # stairs: below P[2] descending, else ascending
+            tu.pyramid_stairs_terrain(tile, step_width=0.31, step_height=-step_h if choice < P[2] else step_h, platform_size=3.)
+        elif choice < P[4]:                                         # discrete obstacles
+            tu.discrete_obstacles_terrain(tile, 0.05 + difficulty * 0.2, 1., 2., 20, platform_size=3.)
+        elif choice < P[5]:
+            tu.stepping_stones_terrain(tile, stone_size=1.5 * (1.05 - difficulty), stone_distance=0.05 if difficulty == 0 else 0.1,
+                                       max_height=0., platform_size=4.)
+        elif choice < P[6]:
+            _gap(tile, gap_size=1. * difficulty, platform_size=3.)
+        else:
+            _pit(tile, depth=1. * difficulty, platform_size=4.)
+        return tile
+
+    def _place(self, tile, i, j):
+        x0, y0 = self.border + i * self.length_per_env_pixels, self.border + j * self.width_per_env_pixels
+        self.height_field_raw[x0:x0 + self.length_per_env_pixels, y0:y0 + self.width_per_env_pixels] = tile.height_field_raw
+        hs = tile.horizontal_scale
+        x1, x2 = int((self.env_length / 2. - 1) / hs), int((self.env_length / 2. + 1) / hs)
+        y1, y2 = int((self.env_width / 2. - 1) / hs), int((self.env_width / 2. + 1) / hs)
+        self.env_origins[i, j] = [(i + 0.5) * self.env_length, (j + 0.5) * self.env_width,
+                                  np.max(tile.height_field_raw[x1:x2, y1:y2]) * tile.vertical_scale]
+
+    add_terrain_to_map = _place

@@ -128,3 +128,38 @@ def test_terrain_level_curriculum_on_the_fused_step():
             np.testing.assert_allclose(root[:, 2], cfg.init_state.pos[2] + o[m, 2], atol=1e-5)
     assert changed > 200 and ups + downs > 0
     assert torch.isfinite(env.obs_buf).all()
+
+
+def test_subterrain_grid_env_with_curriculum():
+    """BASELINE.json configs[2] as surveyed: the base class's Terrain grid (levels x types of
+    8 m tiles, LRC:43-66) under the widowGo1 task with terrain.curriculum=True: placement on the platforms (LR:717-731),
+    heightfield contact on the stairs / slopes, levels moving by LR:421-441 on resets, robots re-placed on the new platform."""
+    import torch
+    from wbc_amd.config import WidowGo1RoughCfg, use_grid_terrain
+    from wbc_amd.envs import WidowGo1
+    n = 360
+    cfg = use_grid_terrain(WidowGo1RoughCfg(), num_rows=4, num_cols=6)
+    cfg.env.num_envs = n
+    cfg.terrain.max_init_terrain_level = 2
+    cfg.env.episode_length_s = 0.5
+    env = WidowGo1(cfg, sim_device="cuda:0", seed=8)
+    t = env.terrain
+    assert t.heightsamples.shape == (4 * 80 + 500, 6 * 80 + 500) and env.terrain_origins.shape == (4, 6, 3)
+    assert env.terrain.env_length == 8.0 and env.max_terrain_level == 4
+    tab = env.terrain_origins.cpu().numpy()
+    np.testing.assert_allclose(tab[..., 0], (np.arange(4)[:, None] + 0.5) * 8.0 * np.ones((1, 6)))
+    env.reset()
+    z0 = env.root_states[:, 2].cpu().numpy() - env.env_origins[:, 2].cpu().numpy()
+    assert np.all(z0 > 0.25) and np.all(z0 < 0.5)                        # standing on their platforms, whatever the tile's height
+    torch.manual_seed(0)
+    moved = 0
+    for step in range(60):
+        lv0 = env.terrain_levels.clone()
+        env.step(0.4 * torch.randn(n, 18, device="cuda"))
+        m = env.reset_buf.bool()
+        assert torch.equal(env.terrain_levels[~m], lv0[~m])
+        moved += int((env.terrain_levels != lv0).sum())
+        o = env.env_origins.cpu().numpy()
+        np.testing.assert_array_equal(o, tab[env.terrain_levels.cpu().numpy(), env.terrain_types.cpu().numpy()])
+    assert moved > 0 and torch.isfinite(env.obs_buf).all()
+    assert (env.root_states[:, 2] > -1.5).all()                           # nobody fell through the terrain
