@@ -164,32 +164,67 @@ class OnPolicyRunner:
         lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}", f"{'Total time:':>{pad}} {self.tot_time:.2f}s"]
         print("\n".join(lines))
 
-    def save(self, path, infos=None):
-        """Reference checkpoint format (OPR:276-282) plus, under 'wbc_extra', what it forgets:
-        history-encoder optimiser, schedule counter, env curriculum counter."""
+    def save(self, path, infos=None, save_env_state=False):
+        """Reference checkpoint format (OPR:276-282: the four keys a reference-side loader reads) plus, under 'wbc_extra', what
+        the reference forgets: the history-encoder optimiser, the schedule counter, the env's
+        curriculum counter and common step counter (the sim's draw counter), terrain levels, torch's CPU and device generator
+        states, and -- with save_env_state -- every device tensor of the sim (64 MB at 4096 envs), so that a resumed run
+        continues the same trajectories."""
+        env = self.env
+        extra = {"hist_encoder_optimizer_state_dict": self.alg.hist_encoder_optimizer.state_dict(),
+                 "ppo_counter": self.alg.counter,
+                 "env_update_counter": getattr(env, "update_counter", 0),
+                 "env_common_step_counter": getattr(env, "common_step_counter", 0),
+                 "torch_rng_state": torch.get_rng_state()}
+        sim = getattr(env, "sim", None)
+        if sim is not None and hasattr(sim, "step_counter"):
+            extra["sim_step_counter"] = int(sim.step_counter)
+        if torch.device(self.device).type == "cuda":
+            extra["cuda_rng_state"] = torch.cuda.get_rng_state(self.device)
+        if getattr(env, "terrain_levels", None) is not None and torch.is_tensor(getattr(env, "terrain_levels", None)):
+            extra["terrain_levels"] = env.terrain_levels.detach().cpu()
+        if save_env_state and sim is not None and hasattr(sim, "arena"):
+            extra["sim_arena"] = sim.arena.detach().cpu()
         torch.save({
             "model_state_dict": self.alg.actor_critic.state_dict(),
             "optimizer_state_dict": self.alg.optimizer.state_dict(),
             "iter": self.current_learning_iteration,
             "infos": infos,
-            "wbc_extra": {"hist_encoder_optimizer_state_dict": self.alg.hist_encoder_optimizer.state_dict(),
-                          "ppo_counter": self.alg.counter,
-                          "env_update_counter": getattr(self.env, "update_counter", 0)},
+            "wbc_extra": extra,
         }, path)
 
-    def load(self, path, load_optimizer=True):
+    def load(self, path, load_optimizer=True, restore_rng=True):
+        """OPR:284-290; a checkpoint written by the reference (no 'wbc_extra') loads the same way."""
         d = torch.load(path, map_location=self.device)
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
+        if hasattr(self.alg.actor_critic, "mark_params_changed"):
+            self.alg.actor_critic.mark_params_changed()          # the fused kernels re-pack the weights
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
         self.current_learning_iteration = d["iter"]
         extra = d.get("wbc_extra")
         if extra is not None:
+            env = self.env
             if load_optimizer:
                 self.alg.hist_encoder_optimizer.load_state_dict(extra["hist_encoder_optimizer_state_dict"])
             self.alg.counter = extra["ppo_counter"]
-            if hasattr(self.env, "update_counter"):
-                self.env.update_counter = extra["env_update_counter"]
+            if hasattr(env, "update_counter"):
+                env.update_counter = extra["env_update_counter"]
+                if hasattr(env, "_refresh_ranges") and hasattr(env, "sim"):
+                    env.sim.set_curriculum(env._refresh_ranges())
+            if "env_common_step_counter" in extra and hasattr(env, "common_step_counter"):
+                env.common_step_counter = extra["env_common_step_counter"]
+            sim = getattr(env, "sim", None)
+            if "sim_arena" in extra and sim is not None and hasattr(sim, "arena") and sim.arena.shape == extra["sim_arena"].shape:
+                sim.arena.copy_(extra["sim_arena"])
+            if "sim_step_counter" in extra and sim is not None:
+                sim.step_counter = int(extra["sim_step_counter"])
+            if "terrain_levels" in extra and torch.is_tensor(getattr(env, "terrain_levels", None)):
+                env.terrain_levels.copy_(extra["terrain_levels"].to(env.terrain_levels.device))
+            if restore_rng:
+                torch.set_rng_state(extra["torch_rng_state"].cpu())
+                if "cuda_rng_state" in extra and torch.device(self.device).type == "cuda":
+                    torch.cuda.set_rng_state(extra["cuda_rng_state"].cpu(), self.device)
         return d["infos"]
 
     def get_inference_policy(self, device=None, stochastic=False):
