@@ -376,48 +376,47 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
   }
 }
 
-// grad[i] = sum over workgroups (fixed order) of partial[wg][i]; part[block] = this block's sum of squares over i < N_GRAD
+// grad[i] = sum over workgroups of partial[wg][i] in a fixed order: a block owns 16 columns, its 16 slices of lanes each sum every
+// 16th workgroup, the 16 slice sums are added in slice order. sq[i] = grad[i]^2 (i < N_GRAD) for the norm.
+#define RED_COLS 16
+#define RED_SLICES 16
 extern "C" __global__ void __launch_bounds__(256) hist_reduce_kernel(const float* __restrict__ partial, int nwg, float* __restrict__ grad,
-                                                                    float* __restrict__ part) {
+                                                                    float* __restrict__ sq) {
+  __shared__ float sh[RED_SLICES][RED_COLS + 1];
+  const int c = threadIdx.x % RED_COLS, sl = threadIdx.x / RED_COLS;
+  const int i = blockIdx.x * RED_COLS + c;
+  float a = 0.f;
+  if (i < N_PART) for (int w = sl; w < nwg; w += RED_SLICES) a += partial[(size_t)w * N_PART + i];
+  sh[sl][c] = a;
+  __syncthreads();
+  if (sl == 0 && i < N_PART) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < RED_SLICES; ++k) t += sh[k][c];
+    grad[i] = t;
+    if (i < N_GRAD) sq[i] = t * t;
+  }
+}
+
+struct HistAdamTable { float* p[8]; int off[9]; };
+
+// clip_grad_norm_ + Adam.step on the 8 tensors (as ppo_adam_kernel). Every block derives the squared norm itself, in a fixed
+// order, from sq[] (written by hist_reduce_kernel) or -- after an all-reduce changed g -- from g.
+extern "C" __global__ void __launch_bounds__(256) hist_adam_kernel(HistAdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                                  const float* __restrict__ sq, int recompute_norm, float max_norm, float beta1,
+                                                                  float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
   __shared__ float sh[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float a = 0.f;
-  if (i < N_PART) {
-    for (int w = 0; w < nwg; ++w) a += partial[(size_t)w * N_PART + i];
-    grad[i] = a;
-  }
-  sh[threadIdx.x] = (i < N_GRAD) ? a * a : 0.f;
+  if (recompute_norm) { for (int e = threadIdx.x; e < N_GRAD; e += 256) a += g[e] * g[e]; }
+  else { for (int e = threadIdx.x; e < N_GRAD; e += 256) a += sq[e]; }
+  sh[threadIdx.x] = a;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
-}
-
-struct HistAdamTable { float* p[8]; int off[9]; };
-#define HIST_NBLK ((N_PART + 255) / 256)
-
-// clip_grad_norm_ + Adam.step on the 8 tensors (as ppo_adam_kernel; `part` holds the squares of the UNSCALED gradient)
-extern "C" __global__ void __launch_bounds__(256) hist_adam_kernel(HistAdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                                  const float* __restrict__ part, int recompute_norm, float max_norm, float beta1,
-                                                                  float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
-  __shared__ float sh[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float tot = 0.f;
-  if (recompute_norm) {                 // the gradient was changed after hist_reduce_kernel (all-reduce over ranks): every block re-derives the norm
-    float a = 0.f;
-    for (int e = threadIdx.x; e < N_GRAD; e += 256) a += g[e] * g[e];
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-      __syncthreads();
-    }
-    tot = sh[0];
-  } else {
-    for (int b = 0; b < HIST_NBLK; ++b) tot += part[b];
-  }
+  const float tot = sh[0];
   if (i >= N_GRAD) return;
   float coef = grad_scale;
   if (max_norm > 0.f) coef = grad_scale * fminf(max_norm / (sqrtf(tot) * grad_scale + 1e-6f), 1.f);
@@ -470,7 +469,7 @@ extern "C" __global__ void __launch_bounds__(256) priv_latent_kernel(const float
 // ---- C-ABI (include/wbc_sim.h) ------------------------------------------------------------------------------
 #define HIST_TRAIN_MAX_WG 512
 extern "C" int wbc_hist_train_grad_floats(void) { return N_PART; }
-extern "C" size_t wbc_hist_train_workspace_floats(void) { return (size_t)HIST_TRAIN_MAX_WG * N_PART + 64; }
+extern "C" size_t wbc_hist_train_workspace_floats(void) { return (size_t)HIST_TRAIN_MAX_WG * N_PART + N_PART; }
 
 extern "C" int wbc_hist_train_grad(const void* const* params, const float* obs, const float* target, const long long* idx, int rows,
                                    float* workspace, float* grad, void* stream) {
@@ -482,7 +481,7 @@ extern "C" int wbc_hist_train_grad(const void* const* params, const float* obs, 
   const int nwg = ngroups < HIST_TRAIN_MAX_WG ? ngroups : HIST_TRAIN_MAX_WG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(hist_train_kernel, dim3(nwg), dim3(G_THREADS), 0, st, P, obs, target, idx, rows, workspace);
-  hipLaunchKernelGGL(hist_reduce_kernel, dim3(HIST_NBLK), dim3(256), 0, st, workspace, nwg, grad, workspace + (size_t)HIST_TRAIN_MAX_WG * N_PART);
+  hipLaunchKernelGGL(hist_reduce_kernel, dim3((N_PART + RED_COLS - 1) / RED_COLS), dim3(256), 0, st, workspace, nwg, grad, workspace + (size_t)HIST_TRAIN_MAX_WG * N_PART);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

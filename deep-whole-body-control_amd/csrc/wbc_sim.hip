@@ -290,6 +290,7 @@ extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
   HIP_OK(hipSetDevice(s->device));
   s->hc.cur = *cur;
   // plain (synchronising) copy: the previous step's kernel must not see a half-written table
+  HIP_OK(hipDeviceSynchronize());      // a step kernel still in flight on a non-blocking stream reads DevConst.cur
   HIP_OK(hipMemcpy((char*)s->dc + offsetof(DevConst, cur), &s->hc.cur, sizeof(wbc_curriculum), hipMemcpyHostToDevice));
   return 0;
 }
@@ -375,10 +376,11 @@ extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
 
 // extras["episode"] of reset_idx (WG:743-754): mean over the envs that reset in the last step of their finished
 // episode's reward sums [WBC_NREW] and metric sums [WBC_NMETRIC], times `scale` (1 / max_episode_length_s).
-// One block per column, fixed-order tree: deterministic. No reset -> zeros (the reference divides by max(count,1) too
-// in this framework's host layer).
+// One block per column, fixed-order tree: deterministic. No reset in this step -> the previously published value (prev), as the
+// reference's extras["episode"] is only rebuilt inside reset_idx when env_ids is non-empty (WG:705-706, 742-750).
 static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* __restrict__ ep_done, const float* __restrict__ met_done,
-                                                                  const int64_t* __restrict__ reset_buf, int n, float scale, float* __restrict__ out) {
+                                                                  const int64_t* __restrict__ reset_buf, int n, float scale,
+                                                                  const float* __restrict__ prev, float* __restrict__ out) {
   __shared__ float sh[256];
   __shared__ float shc[256];
   const int col = blockIdx.x;
@@ -396,13 +398,13 @@ static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* 
     if (threadIdx.x < off) { sh[threadIdx.x] += sh[threadIdx.x + off]; shc[threadIdx.x] += shc[threadIdx.x + off]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[col] = sh[0] / fmaxf(shc[0], 1.f) * scale;
+  if (threadIdx.x == 0) out[col] = shc[0] > 0.f ? sh[0] / shc[0] * scale : (prev ? prev[col] : 0.f);
 }
 
-extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, float* out, void* stream) {
+extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, const float* prev, float* out, void* stream) {
   if (!s || !out) return fail(-1, "wbc_sim_episode_stats: null argument");
   hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC), dim3(256), 0, (hipStream_t)stream, s->T.ep_sums_done, s->T.met_sums_done,
-                     s->T.reset_buf, s->n, scale, out);
+                     s->T.reset_buf, s->n, scale, prev, out);
   return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
 }
 

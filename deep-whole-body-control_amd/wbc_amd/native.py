@@ -61,7 +61,7 @@ def lib():
         L.wbc_abi_sizes.argtypes = [C.POINTER(c_int)]
         L.wbc_hist_latent.argtypes = [c_void, c_void, c_void, c_int, c_void]
         L.wbc_sim_arm_dynamics.argtypes = [c_void, c_void, c_void, c_void, c_void, c_void, c_void]
-        L.wbc_sim_episode_stats.argtypes = [c_void, C.c_float, c_void, c_void]
+        L.wbc_sim_episode_stats.argtypes = [c_void, C.c_float, c_void, c_void, c_void]
         L.wbc_rollout_store.argtypes = [c_void] * 5 + [C.c_float, c_void, c_void, c_int, c_void]
         L.wbc_policy_act.argtypes = [c_void] * 9 + [c_int, c_void]
         L.wbc_policy_pack.argtypes = [c_void, c_void, c_void]

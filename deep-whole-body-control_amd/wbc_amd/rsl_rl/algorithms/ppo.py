@@ -171,7 +171,11 @@ class PPO:
         self.actor_critic.reset(dones)
 
     def compute_returns(self, last_critic_obs):
-        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        ac = self.actor_critic
+        if self.fused_rollout and not torch.is_grad_enabled() and ac.fused_act_supported(last_critic_obs):
+            last_values = ac.fused_act(last_critic_obs)[3]          # the critic half of the inference kernel (one launch)
+        else:
+            last_values = ac.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
     # ---- gradient exchange -----------------------------------------------------------------

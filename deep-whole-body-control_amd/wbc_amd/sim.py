@@ -22,6 +22,10 @@ class WbcSim:
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("WbcSim needs a ROCm device: the rollout step only exists as HIP kernels")
+        if device.index is not None and device.index != torch.cuda.current_device():
+            raise RuntimeError(f"WbcSim on {device} while torch's current device is cuda:{torch.cuda.current_device()}: call "
+                               "torch.cuda.set_device(device) first (one process per GPU; the C-ABI launches on the caller's "
+                               "current stream and does not switch devices behind torch's back)")
         self.L = lib()
         self.device = device
         self.num_envs = num_envs
@@ -146,7 +150,10 @@ class WbcSim:
         """Means over the envs that reset in the last step of their finished episode's reward sums [NREW] and metric
         sums [NMETRIC], times `scale`, as one fresh device tensor (WG:743-754 without a host sync)."""
         out = torch.empty(abi.NREW + abi.NMETRIC, dtype=torch.float32, device=self.device)
-        check(self.L.wbc_sim_episode_stats(self.h, float(scale), out.data_ptr(), self._stream()), "wbc_sim_episode_stats")
+        prev = self.__dict__.get("_last_episode_stats")         # a step without resets re-publishes the previous values (WG:705-706)
+        check(self.L.wbc_sim_episode_stats(self.h, float(scale), prev.data_ptr() if prev is not None else None, out.data_ptr(),
+                                           self._stream()), "wbc_sim_episode_stats")
+        self._last_episode_stats = out
         return out
 
     def set_dof_forces(self, torques: torch.Tensor) -> None:

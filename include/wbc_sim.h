@@ -369,8 +369,10 @@ int wbc_sim_arm_dynamics(wbc_sim* sim, const int* link_rb9, const float* link_ma
 
 /* extras["episode"] of reset_idx (widowGo1.py:743-754): out[0:WBC_NREW] = mean over the envs that reset in the last
  * step of their finished episode's reward sums, out[WBC_NREW:+WBC_NMETRIC] the same for the metric sums, both
- * times `scale` (1 / max_episode_length_s). `out`: device, WBC_NREW + WBC_NMETRIC floats. */
-int wbc_sim_episode_stats(wbc_sim* sim, float scale, float* out, void* stream);
+ * times `scale` (1 / max_episode_length_s). `out`: device, WBC_NREW + WBC_NMETRIC floats. On a step in which no env reset
+ * the reference does not touch extras["episode"] (reset_idx returns early, widowGo1.py:705-706), i.e. the previous values
+ * stay published: out = prev then (prev: the previous call's output, or NULL = zeros). */
+int wbc_sim_episode_stats(wbc_sim* sim, float scale, const float* prev, float* out, void* stream);
 
 /* PPO.process_env_step's tensor work (rsl_rl/algorithms/ppo.py:129-141 + rollout_storage.py:70-72) in one launch:
  * out_rewards[n] = (rew[n], arm_rew[n]) + gamma * values[n] * time_outs[n], out_dones[n] = dones[n] != 0.

@@ -143,6 +143,7 @@ def test_subterrain_grid_env_with_curriculum():
     cfg.terrain.max_init_terrain_level = 2
     cfg.env.episode_length_s = 0.5
     env = WidowGo1(cfg, sim_device="cuda:0", seed=8)
+    env.update_command_curriculum()                                      # counter 1: the final command ranges (v_x up to 0.9 m/s)
     t = env.terrain
     assert t.heightsamples.shape == (4 * 80 + 500, 6 * 80 + 500) and env.terrain_origins.shape == (4, 6, 3)
     assert env.terrain.env_length == 8.0 and env.max_terrain_level == 4

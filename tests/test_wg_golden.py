@@ -187,4 +187,13 @@ def test_hip_step_matches_reference_step(robot, fixture):
         w = compare(f"{fixture} step {k}", lambda nm: sim.tensor(nm).cpu().numpy(), ref, CHECK_GPU)
         for kk, v in w.items():
             worst[kk] = max(worst.get(kk, 0.0), v)
+        # extras['episode'] (WG:742-750): means over the envs that reset in this step; untouched on a step without resets
+        stats = sim.episode_stats(1.0 / 10.0).cpu().numpy()
+        if ref["RESET_BUF"].any():
+            want = g["episode_extras"][k]
+            ok = ~np.isnan(want)
+            np.testing.assert_allclose(stats[ok], want[ok], rtol=3e-3, atol=2e-4, err_msg=f"{fixture} episode stats, step {k}")
+        elif k > 0:
+            np.testing.assert_array_equal(stats, last_stats)
+        last_stats = stats
     print("max abs deviation from the reference per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
