@@ -64,106 +64,11 @@ __host__ __device__ constexpr int layer_bias_off(int l) { return l == 0 ? 0 : la
 
 enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2 };
 
-// LDS layout shared by the kernels: offsets in floats from the workgroup's LDS base
-#define S_X 0                                   // x[32][101]: obs[:, :100]
-#define S_A0 (PT_ROWS * 101)                    // a0, a1, a2 [32][LDA]
-#define S_A1 (S_A0 + PT_ROWS * LDA)
-#define S_A2 (S_A1 + PT_ROWS * LDA)
-#define S_OUTV (S_A2 + PT_ROWS * LDA)           // outv[32][21]: mean 18, values 2
-#define S_END (S_OUTV + PT_ROWS * 21)
-static_assert(PT_ROWS * LDA >= 4 * 1024 + 32, "K-split partials + bias fit in one activation buffer");
 
-struct FwdDesc {            // one forward layer: out = act(in * W^T + b)
-  int woff, boff, kb, nblk, n;       // packed-weight offset, bias offset (from the bias region), K/2, 32-col blocks, outputs
-  int in_off, ldi, out_off, ldo;     // LDS float offsets (out_off includes the column offset) and row strides
-  int act, scol;                     // activation; column in the activation stash (-1: not stashed)
-  int ksplit;                        // head layers (one 32-column block, K = 128): the 4 waves split K instead of idling
-  int scratch_off;                   // ksplit: LDS offset of an activation buffer that is dead during this layer (partials)
-  int sw;                            // stash slab width: the stash is slab-major, element (row, scol + c) lives at scol * rows + row * sw + c
-};
-struct FwdTable { FwdDesc l[NLAYERS]; };
 
-// The 16 layers of the teacher-path ActorCritic. priv2 writes the latent next to the proprio block that the caller
-// has already copied into a1[:, :76], so the backbone reads z = [prop, latent] from a1 with no step in between.
-static inline FwdTable make_fwd_table(const int* stash_cols /* NLAYERS entries or nullptr */) {
-  FwdTable t;
-  const int in_off[NLAYERS] = {S_X + PT_NPROP, S_A0, S_A1, S_A2, S_A0, S_A1, S_A2, S_A0, S_A1, S_X, S_A2, S_A0, S_A1, S_A2, S_A0, S_A1};
-  const int ldi[NLAYERS] = {101, LDA, LDA, LDA, LDA, LDA, LDA, LDA, LDA, 101, LDA, LDA, LDA, LDA, LDA, LDA};
-  const int out_off[NLAYERS] = {S_A0, S_A1 + PT_NPROP, S_A2, S_A0, S_A1, S_OUTV, S_A0, S_A1, S_OUTV + PT_NLEG, S_A2, S_A0, S_A1, S_OUTV + 18,
-                                S_A0, S_A1, S_OUTV + 19};
-  const int ldo[NLAYERS] = {LDA, LDA, LDA, LDA, LDA, 21, LDA, LDA, 21, LDA, LDA, LDA, 21, LDA, LDA, 21};
-  const int act[NLAYERS] = {ACT_ELU, ACT_ELU, ACT_ELU, ACT_ELU, ACT_ELU, ACT_TANH, ACT_ELU, ACT_ELU, ACT_TANH, ACT_ELU, ACT_ELU, ACT_ELU, ACT_NONE,
-                            ACT_ELU, ACT_ELU, ACT_NONE};
-  for (int l = 0; l < NLAYERS; ++l)
-    t.l[l] = FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off[l], ldi[l], out_off[l], ldo[l],
-                     act[l], stash_cols ? stash_cols[l] : -1, (layer_nblk(l) == 1 && layer_in(l) == 128 && in_off[l] == S_A1) ? 1 : 0, S_A0, 0};
-  return t;
-}
 
-static __device__ __forceinline__ float apply_act(float x, int act) {
-  if (act == ACT_ELU) return x > 0.f ? x : __expf(x) - 1.f;   // abs error <= 1 ulp(1.0); the derivative uses the stored value
-  if (act == ACT_TANH) return tanhf(x);
-  return x;
-}
 
-// Pack all 16 weight matrices into the fragment orders described above (blockIdx.z = 0: forward, 1: transposed) and
-// append the biases. grid = (blocks, NLAYERS, 2). `wpack` must be 16-byte aligned. The per-layer offsets come in a
-// host-built table (evaluating the constexpr recursions per thread at run time cost 40 us per launch).
-struct PackTable { int n[NLAYERS], k[NLAYERS], off[NLAYERS], offT[NLAYERS], boff[NLAYERS]; };
-static inline PackTable make_pack_table() {
-  PackTable t;
-  for (int l = 0; l < NLAYERS; ++l) { t.n[l] = layer_out(l); t.k[l] = layer_in(l); t.off[l] = layer_pack_off(l); t.offT[l] = layer_packT_off(l); t.boff[l] = layer_bias_off(l); }
-  return t;
-}
-static __global__ void wbc_pack_weights_kernel(PolicyParams P, PackTable T, float* __restrict__ wpack) {
-  const int l = blockIdx.y;
-  const bool tr = blockIdx.z != 0;
-  const float* const* wp = reinterpret_cast<const float* const*>(&P);
-  const float* W = wp[2 * l];
-  const float* bsrc = wp[2 * l + 1];
-  const int N = T.n[l], K = T.k[l];
-  const int off = tr ? T.offT[l] : T.off[l];
-  const int nblk = tr ? (K + 31) / 32 : (N + 31) / 32;
-  const int kg = tr ? ((N + 1) / 2 + 3) / 4 : (K / 2 + 3) / 4;
-  const int total = kg * nblk * 256;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int j = e & 3, lane = (e >> 2) & 63, frag = e >> 8;
-    const int cb = frag % nblk, kb = 4 * (frag / nblk) + j;
-    const int c = cb * 32 + (lane & 31), k = 2 * kb + (lane >> 5);
-    float v;
-    if (!tr) v = (c < N && k < K) ? W[(size_t)c * K + k] : 0.f;      // B[k][c] = W[c][k]
-    else v = (k < N && c < K) ? W[(size_t)k * K + c] : 0.f;          // B[k][c] = W[k][c]
-    wpack[off + e] = v;
-  }
-  if (blockIdx.x == 0 && !tr)
-    for (int e = threadIdx.x; e < N; e += blockDim.x) wpack[WPACK_WEIGHT_FLOATS + T.boff[l] + e] = bsrc[e];
-}
 
-// x[32, 100] (LDS, row stride 101) <- src rows' first 100 floats. 800 float4 loads, <= 4 per thread, all in flight
-// at once. `row_ptr(r)` returns the global pointer of tile row r (16-byte aligned: 860-float rows are) or nullptr.
-template <typename F>
-static __device__ __forceinline__ void load_x_tile(float* x, F row_ptr) {
-  const int tid = threadIdx.x;
-  float4 v[4];
-  int rr[4], cc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e4 = tid + j * PT_THREADS;
-    rr[j] = e4 / 25; cc[j] = (e4 - rr[j] * 25) * 4;
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e4 < PT_ROWS * 25) {
-      const float* p = row_ptr(rr[j]);
-      if (p) v[j] = *reinterpret_cast<const float4*>(p + cc[j]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (tid + j * PT_THREADS < PT_ROWS * 25) {
-      float* d = x + rr[j] * 101 + cc[j];
-      d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
-    }
-  }
-}
 
 // ---- one MFMA operand set: 64 registers per lane ---------------------------------------------------------
 // The B fragments of a wave's 32-column block, k-pairs 0..kb-1, as 16 float4 loads of 4 k-pairs each. `base` points
@@ -181,23 +86,6 @@ static __device__ __forceinline__ void load_operands(float (&w)[NW], const float
   }
 }
 
-// acc += sum_{k < kb} A[.., 2k + half] * w[k], A from LDS (ap = this lane's row/half). Each chunk of 16 k-pairs
-// reads its 16 A operands first and then issues its MFMAs; chunks and the MFMAs of a ragged last chunk are guarded
-// by uniform predicates (one copy of the chain serves every layer shape).
-template <int NW>
-static __device__ __forceinline__ void mfma_chain(const float* ap, const float (&w)[NW], int kb, f32x16& acc) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c * 16 < kb) {
-      float a[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) a[j] = ap[2 * (c * 16 + j)];       // reads past the row's k range stay inside LDS
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (c * 16 + j < kb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[c * 16 + j], acc, 0, 0, 0);
-    }
-  }
-}
 
 // development aid (-DWBC_PPO_TIMING): workgroup 0 / thread 0 stamps inside the forward layers, slots 32 + 4*layer + i
 #ifdef WBC_PPO_TIMING
@@ -207,119 +95,11 @@ static __device__ long long* g_mlp_dbg = nullptr;
 #define LSTAMP(l, i) do { } while (0)
 #endif
 
-// Request the fragments of forward layer d for this wave, and this lane's bias (w[64]).
-static __device__ __forceinline__ void fwd_load(float (&w)[65], const FwdDesc& d, const float* __restrict__ wpack) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cb = wave < d.nblk ? wave : 0;       // idle waves fetch block 0 (unused)
-  if (d.ksplit) load_operands(w, reinterpret_cast<const float4*>(wpack + d.woff), lane, 64, d.kb >> 2, wave * (d.kb >> 4));   // this wave's quarter of K
-  else load_operands(w, reinterpret_cast<const float4*>(wpack + d.woff), cb * 64 + lane, d.nblk * 64, d.kb);
-  const int col = wave * 32 + (lane & 31);
-  w[64] = wpack[WPACK_WEIGHT_FLOATS + d.boff + (col < d.n ? col : 0)];
-}
 
 // Run forward layer d with its fragments in `w`. smem = LDS base (floats). Outputs go to LDS and, if d.scol >= 0, to
 // the slab-major stash (see FwdDesc::sw; `num_rows` = total rows of the stash) for valid rows. Ends with a barrier.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `after_mfma` runs once this wave's MFMA chain has been issued and `w` is no longer read (single-buffered callers
-// request the next layer's operands there).
-template <typename Hook = NoHook>
-static __device__ __forceinline__ void fwd_run(float (&w)[65], const FwdDesc& d, float* smem,
-                                               float* __restrict__ stash, int lds, int row0, int num_rows, int dbg_l = 0,
-                                               Hook after_mfma = Hook()) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float bias_reg = w[64];
-  LSTAMP(dbg_l, 0);
-  if (d.ksplit) {
-    // each wave: its quarter of K into a partial 32x32 block in a0 (dead at every head layer), then all threads
-    // reduce the 4 partials, add the bias, activate and write the n (<= 32) real columns
-    const int kq = d.kb >> 2;
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5) + 2 * wave * kq, w, kq, acc);
-    after_mfma();
-    float* part = smem + d.scratch_off + wave * 1024 + (lane & 31) + 4 * (lane >> 5) * 32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2)) * 32] = acc[r];
-    if (wave == 0 && lane < 32) smem[d.scratch_off + 4096 + lane] = bias_reg;
-    LSTAMP(dbg_l, 1);
-    __syncthreads();
-    const float* p = smem + d.scratch_off;
-    for (int e = threadIdx.x; e < PT_ROWS * d.n; e += PT_THREADS) {
-      const int row = e / d.n, col = e - row * d.n;
-      const int q = row * 32 + col;
-      const float x = ((p[q] + p[1024 + q]) + (p[2048 + q] + p[3072 + q])) + p[4096 + col];
-      const float v = d.act == ACT_TANH ? tanhf(x) : (d.act == ACT_ELU ? (x > 0.f ? x : __expf(x) - 1.f) : x);
-      smem[d.out_off + row * d.ldo + col] = v;
-      if (stash != nullptr && d.scol >= 0 && row0 + row < num_rows) stash[(size_t)d.scol * num_rows + (size_t)(row0 + row) * d.sw + col] = v;
-    }
-    LSTAMP(dbg_l, 2);
-    __syncthreads();
-    LSTAMP(dbg_l, 3);
-    return;
-  }
-  if (wave < d.nblk) {
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    mfma_chain(smem + d.in_off + (lane & 31) * d.ldi + (lane >> 5), w, d.kb, acc);
-#ifdef WBC_PPO_TIMING
-    asm volatile("s_nop 0" :: "v"(acc[0]));      // stamp 1 after the last MFMA has produced its result
-#endif
-    LSTAMP(dbg_l, 1);
-    after_mfma();
-    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int col = wave * 32 + (lane & 31);
-    if (col < d.n) {
-      const float bias = bias_reg;
-      float v[16];
-      if (d.act == ACT_ELU) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float x = acc[r] + bias; v[r] = x > 0.f ? x : __expf(x) - 1.f; }   // abs error <= 1 ulp(1.0)
-      } else if (d.act == ACT_TANH) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = tanhf(acc[r] + bias);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
-      }
-      const int rbase = 4 * (lane >> 5);                 // this lane's rows: rbase + (r & 3) + 8 * (r >> 2)
-      float* out = smem + d.out_off + col + rbase * d.ldo;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * d.ldo] = v[r];
-      if (stash != nullptr && d.scol >= 0) {
-        float* sp = stash + (size_t)d.scol * num_rows + (size_t)(row0 + rbase) * d.sw + col;
-        if (row0 + PT_ROWS <= num_rows) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * d.sw] = v[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (row0 + rbase + (r & 3) + 8 * (r >> 2) < num_rows) sp[((r & 3) + 8 * (r >> 2)) * d.sw] = v[r];
-        }
-      }
-    }
-  } else {
-    after_mfma();
-  }
-  LSTAMP(dbg_l, 2);
-  __syncthreads();
-  LSTAMP(dbg_l, 3);
-}
 
-// The forward chain over layers [lbeg, lend): two register sets alternate so that layer l+1's operands are in flight
-// while layer l's MFMA chain runs. The loop body (two layers) is the only copy of the layer code in the kernel.
-static __device__ __forceinline__ void fwd_chain(const FwdTable& T, float* smem, const float* __restrict__ wpack, float* __restrict__ stash,
-                                                 int lds, int row0, int num_rows, int lbeg = 0, int lend = NLAYERS) {
-  float wa[65], wb[65];
-  fwd_load(wa, T.l[lbeg], wpack);
-#pragma unroll 1
-  for (int l = lbeg; l < lend; l += 2) {
-    const bool two = l + 1 < lend;
-    if (two) fwd_load(wb, T.l[l + 1], wpack);
-    fwd_run(wa, T.l[l], smem, stash, lds, row0, num_rows, l);
-    if (two) {
-      if (l + 2 < lend) fwd_load(wa, T.l[l + 2], wpack);
-      fwd_run(wb, T.l[l + 1], smem, stash, lds, row0, num_rows, l + 1);
-    }
-  }
-}
 
 // ==== 16-row tiles: v_mfma_f32_16x16x4_f32 ===================================================================================
 // A: lane L supplies A[row = L & 15][k-slot g = L >> 4]; B: B[g][col = L & 15]; C/D: 4 registers, D[row = 4 g + r][col = L & 15].

@@ -4,82 +4,19 @@
 // Actor.forward AC:204-217 with the privileged latent, Critic.forward AC:281-286, Normal.sample,
 // get_actions_log_prob AC:341-345) by ONE launch: a workgroup takes 32 envs, keeps every activation of
 // those 32 rows in LDS, reads each layer's weights as pre-packed MFMA fragments straight from L2 (wbc_mlp.h),
-// and runs the GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32, one 32x32 output block per wave, 4 waves =
-// 128 output features).
+// and runs the GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32; 16-row tiles: 4096 envs = 512 workgroups).
 // The epilogue samples the action from pre-drawn standard normals and writes mean, action, the two
 // log-probabilities (12 leg / 6 arm dims) and the two values.
 // Grid = (row tiles, 2): blockIdx.y = 0 runs the actor (9 layers), 1 the critic (7 layers), so that 4096 envs give
 // 256 workgroups (one per CU) and the dependent layer chain per workgroup is half as long.
 #include "wbc_mlp.h"
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS) wbc_policy_act_kernel(PolicyParams P, FwdTable T, const float* __restrict__ wpack,
-                                                                              const float* __restrict__ obs, const float* __restrict__ latent,
-                                                                              const float* __restrict__ eps,
-                                                                              float* __restrict__ actions, float* __restrict__ mean_out,
-                                                                              float* __restrict__ logp_out, float* __restrict__ value_out,
-                                                                              int num_rows, long long* __restrict__ dbg) {
-  __shared__ float smem[S_END];
-  const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * PT_ROWS;
-  int dbg_i = 0;
-#define DBG_STAMP() do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) dbg[dbg_i] = clock64(); ++dbg_i; } while (0)
-  DBG_STAMP();
-  // load obs[:, :100] of 32 rows (rows past the end are zero); the proprio block also goes to a1[:, :76], next to
-  // where priv2 will put the latent (the backbone input z = [prop, latent])
-  load_x_tile(smem + S_X, [&](int r) { return (row0 + r < num_rows) ? obs + (size_t)(row0 + r) * PT_NOBS : (const float*)nullptr; });
-  __syncthreads();
-  const bool critic = blockIdx.y != 0;
-  if (!critic) {
-    for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
-      const int r = e / PT_NPROP, c = e - r * PT_NPROP;
-      smem[S_A1 + r * LDA + c] = smem[S_X + r * 101 + c];
-    }
-    if (latent)       // student path (hist_encoding=True, AC:206-209): the given latent replaces the privileged encoder's
-      for (int e = tid; e < PT_ROWS * 20; e += PT_THREADS) {
-        const int r = e / 20, c = e - r * 20;
-        smem[S_A1 + r * LDA + PT_NPROP + c] = (row0 + r < num_rows) ? latent[(size_t)(row0 + r) * 20 + c] : 0.f;
-      }
-    __syncthreads();
-  }
-  DBG_STAMP();
-  // actor (AC:204-221): layers 0..8; critic (AC:281-286): layers 9..15; table-driven (wbc_mlp.h)
-  fwd_chain(T, smem, wpack, nullptr, 0, row0, num_rows, critic ? L_CBB : (latent ? L_BB : 0), critic ? NLAYERS : L_CBB);
-  DBG_STAMP();
-  const float* outv = smem + S_OUTV;
-  if (critic) {
-    if (tid < PT_ROWS && row0 + tid < num_rows) {
-      const size_t g = (size_t)(row0 + tid);
-      value_out[g * 2] = outv[tid * 21 + 18]; value_out[g * 2 + 1] = outv[tid * 21 + 19];
-    }
-    return;
-  }
-  // ---- epilogue: sample, log-probabilities (Normal.log_prob summed over leg / arm dims), outputs
-  if (tid < PT_ROWS && row0 + tid < num_rows) {
-    const int r = tid;
-    const size_t g = (size_t)(row0 + r);
-    float lp_leg = 0.f, lp_arm = 0.f;
-#pragma unroll
-    for (int j = 0; j < 18; ++j) {
-      const float mu = outv[r * 21 + j], sd = P.std[j];
-      const float e = eps ? eps[g * 18 + j] : 0.f;
-      const float a = mu + sd * e;
-      const float d = a - mu;
-      const float lp = -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-      if (j < PT_NLEG) lp_leg += lp; else lp_arm += lp;
-      actions[g * 18 + j] = a;
-      mean_out[g * 18 + j] = mu;
-    }
-    logp_out[g * 2] = lp_leg; logp_out[g * 2 + 1] = lp_arm;
-  }
-  DBG_STAMP();
-#undef DBG_STAMP
-}
-
-// ==== 16-row tiles (v_mfma_f32_16x16x4_f32): the default path ================================================
-// 4096 envs are only 128 tiles of 32 rows: one workgroup per CU, one wave per SIMD, nothing to hide the LDS / barrier /
-// operand latencies of the 9-layer chain behind. With 16-row tiles the same batch gives 512 workgroups, each layer costs a
-// wave 64 MFMAs of 32 cycles instead of 64 cycles and the epilogue handles 8 outputs per lane instead of 16 (helpers in
-// wbc_mlp.h). Measured faster at every batch size (4096 rows: 33 vs 51 us, 40960: 211 vs 281 us).
+// ==== 16-row tiles (v_mfma_f32_16x16x4_f32) =====================================================================
+// 4096 envs would be only 128 tiles of 32 rows (the first version: v_mfma_f32_32x32x2_f32, one workgroup per CU, one wave per
+// SIMD, nothing to hide the LDS / barrier / operand latencies of the 9-layer chain behind). With 16-row tiles the same batch
+// gives 512 workgroups, each layer costs a wave 64 MFMAs of 32 cycles instead of 64 cycles and the epilogue handles 8 outputs
+// per lane instead of 16 (helpers in wbc_mlp.h). Measured faster at every batch size (4096 rows: 33 vs 51 us, 40960: 211 vs
+// 281 us), so the 32-row kernel is gone.
 #define T_X 0
 #define T_A0 (R16 * LD16)
 #define T_A1 (T_A0 + R16 * LD16)
@@ -172,8 +109,6 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
 }
 
 // Development aid: when set to a device buffer of >= 32 int64, block 0 records clock64() at every stage boundary.
-static long long* g_policy_dbg = nullptr;
-extern "C" void wbc_debug_set_policy_timing(void* dev_buf) { g_policy_dbg = (long long*)dev_buf; }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
   const float** dst = reinterpret_cast<const float**>(P);
@@ -191,7 +126,6 @@ extern "C" int wbc_policy_pack_floats(void) { return WPACK16_OFF + WPACK16_FLOAT
 extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* stream) {
   PolicyParams P;
   if (!params || !wpack || (reinterpret_cast<uintptr_t>(wpack) & 15) || fill_params(params, &P)) return -1;
-  hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, (hipStream_t)stream, P, make_pack_table(), wpack);
   hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 1), dim3(256), 0, (hipStream_t)stream, P, make_pack16_table(), wpack + WPACK16_OFF);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -200,18 +134,8 @@ extern "C" int wbc_policy_act(const void* const* params, const float* wpack, con
                               float* actions, float* mean, float* logp, float* values, int num_rows, void* stream) {
   PolicyParams P;
   if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
-#ifndef ACT16_MAX_ROWS
-#define ACT16_MAX_ROWS 0x7fffffff      // measured faster at every batch size (4096: 33 vs 51 us, 40960: 211 vs 281 us); 32-row path kept for A/B runs
-#endif
-  if (num_rows <= ACT16_MAX_ROWS && !g_policy_dbg) {       // rollout-sized batch: 16-row tiles
-    static const Tab16 T16 = make_tab16();
-    hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3((num_rows + R16 - 1) / R16, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
-                       wpack + WPACK16_OFF, wpack + WPACK16_OFF + WPACK16_BIAS_OFF, obs, latent, eps, actions, mean, logp, values, num_rows);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-  }
-  const int blocks = (num_rows + PT_ROWS - 1) / PT_ROWS;
-  static const FwdTable T = make_fwd_table(nullptr);
-  hipLaunchKernelGGL(wbc_policy_act_kernel, dim3(blocks, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T, wpack, obs, latent, eps, actions, mean, logp,
-                     values, num_rows, g_policy_dbg);
+  static const Tab16 T16 = make_tab16();
+  hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3((num_rows + R16 - 1) / R16, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
+                     wpack + WPACK16_OFF, wpack + WPACK16_OFF + WPACK16_BIAS_OFF, obs, latent, eps, actions, mean, logp, values, num_rows);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

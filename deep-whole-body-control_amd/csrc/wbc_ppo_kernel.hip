@@ -119,327 +119,9 @@ static BwdTable make_bwd_table(const PolicyParams& P) {
   return t;
 }
 
-// ---- forward op list: layers in an order that needs two activation buffers (critic first, x stays alive for both
-// backbones), stash reloads of the backbone outputs for their second head, the proprio copy next to the latent
-enum { FOP_LAYER = 0, FOP_RELOAD, FOP_COPY_PROP };
-struct FOp { int type, next_layer; FwdDesc d; int rcol, rdst; };
-#define NFOPS 19
-struct FOpTable { FOp op[NFOPS]; };
-
-static FOpTable make_fop_table(const int* stash_cols) {
-  FOpTable t;
-  int i = 0;
-  auto layer = [&](int l, int in_off, int ldi, int out_off, int ldo, int scratch) {
-    const int act = (l == L_LEG4 || l == L_ARM4) ? ACT_TANH : ((l == L_CLEG4 || l == L_CARM4) ? ACT_NONE : ACT_ELU);
-    t.op[i++] = FOp{FOP_LAYER, -1, FwdDesc{layer_pack_off(l), layer_bias_off(l), layer_in(l) / 2, layer_nblk(l), layer_out(l), in_off, ldi, out_off, ldo,
-                                           act, stash_cols[l], (layer_nblk(l) == 1 && layer_in(l) == 128) ? 1 : 0, scratch,
-                                           stash_cols[l] >= 0 ? a_slab_w(stash_cols[l]) : 0}, 0, 0};
-  };
-  auto reload = [&](int col, int dst) { t.op[i] = FOp{}; t.op[i].type = FOP_RELOAD; t.op[i].next_layer = -1; t.op[i].rcol = col; t.op[i].rdst = dst; ++i; };
-  layer(L_CBB, Q_X, 101, Q_A0, LDA, 0);
-  layer(L_CLEG0, Q_A0, LDA, Q_A1, LDA, 0);
-  layer(L_CLEG2, Q_A1, LDA, Q_A0, LDA, 0);
-  layer(L_CLEG4, Q_A0, LDA, Q_OUTV + 18, 21, Q_A1);
-  reload(A_CB, Q_A0);
-  layer(L_CARM0, Q_A0, LDA, Q_A1, LDA, 0);
-  layer(L_CARM2, Q_A1, LDA, Q_A0, LDA, 0);
-  layer(L_CARM4, Q_A0, LDA, Q_OUTV + 19, 21, Q_A1);
-  t.op[i] = FOp{}; t.op[i].type = FOP_COPY_PROP; t.op[i].next_layer = -1; ++i;
-  layer(L_PRIV0, Q_X + PT_NPROP, 101, Q_A0, LDA, 0);
-  layer(L_PRIV2, Q_A0, LDA, Q_A1 + PT_NPROP, LDA, 0);
-  layer(L_BB, Q_A1, LDA, Q_A0, LDA, 0);
-  layer(L_LEG0, Q_A0, LDA, Q_A1, LDA, 0);
-  layer(L_LEG2, Q_A1, LDA, Q_A0, LDA, 0);
-  layer(L_LEG4, Q_A0, LDA, Q_OUTV, 21, Q_A1);
-  reload(A_BB, Q_A0);
-  layer(L_ARM0, Q_A0, LDA, Q_A1, LDA, 0);
-  layer(L_ARM2, Q_A1, LDA, Q_A0, LDA, 0);
-  layer(L_ARM4, Q_A0, LDA, Q_OUTV + PT_NLEG, 21, Q_A1);
-  for (int a = 0; a < NFOPS; ++a) {            // the next LAYER op after each op (operand prefetch target)
-    t.op[a].next_layer = -1;
-    for (int b2 = a + 1; b2 < NFOPS; ++b2) if (t.op[b2].type == FOP_LAYER) { t.op[a].next_layer = b2; break; }
-  }
-  return t;
-}
-
-// Request the B operand of a backward stage from the transposed pack (columns past in_dim are packed as zeros).
-static __device__ __forceinline__ void bwd_load(float (&w)[64], const BwdDesc& d, const float* __restrict__ wpack) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cb = wave < d.nblkT ? wave : 0;      // idle waves / stages without a GEMM fetch valid, unused data
-  load_operands(w, reinterpret_cast<const float4*>(wpack + d.woffT), cb * 64 + lane, d.nblkT * 64, (d.out_dim + 1) / 2);
-}
-
 template <int ACTV>
 static __device__ __forceinline__ float act_deriv(float a) {
   return (ACTV == ACT_ELU) ? (a > 0.f ? 1.f : a + 1.f) : 1.f - a * a;
-}
-
-// This stage's activation-stash values (8 float2 per thread) and, for the critic-head stages, this thread's element of
-// the head's weight row: requested BEFORE the next stage's operand prefetch so that waiting for them leaves it in flight.
-struct BwdFetch { float2 a[8]; float wv; };
-// Fixed thread -> element mapping of the activation-derivative pass, independent of the stage's width n (no run-time
-// divisions, constant column per thread): thread t owns columns c, c+1 with c = 2 (t & 63) of rows (t >> 6) + 4 j, j < 8.
-static __device__ __forceinline__ void bwd_fetch(BwdFetch& f, const BwdDesc& d, const float* __restrict__ act_stash, int row0, int num_rows) {
-  const int tid = threadIdx.x;
-  const int c = (tid & 63) * 2, rb = tid >> 6;
-  const bool c_ok = c < d.n;
-  const float* base = act_stash + sidx(num_rows, d.acol, d.aw, row0 + rb, c_ok ? c : 0);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const bool ok = c_ok && row0 + rb + 4 * j < num_rows;
-    const float2 v = *reinterpret_cast<const float2*>(ok ? base + (size_t)(4 * j) * d.aw : act_stash);   // unconditional load
-    f.a[j] = ok ? v : make_float2(1.f, 1.f);
-  }
-  const float* wv = (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) ? d.wvec : act_stash;
-  f.wv = wv[tid & 127];
-}
-
-// First half of a stage: pre-step and buf <- buf * act'(A) (+ dZ stash). Consumes f.
-static __device__ __forceinline__ void bwd_pre_act(const BwdDesc& d, const BwdFetch& f, float* smem, float* __restrict__ dz_stash,
-                                                   int row0, int num_rows) {
-  const int tid = threadIdx.x;
-  float* buf = smem + d.buf_off;
-  const float* g = smem + Q_G;
-  // pre-step
-  if (d.pre == PRE_OUTER_V0 || d.pre == PRE_OUTER_V1) {          // dA = dZ_v (x) W_last (1 x 128)
-    const int gi = (d.pre == PRE_OUTER_V0) ? 18 : 19;
-    for (int e = tid; e < PT_ROWS * 128; e += PT_THREADS) { const int r = e >> 7, c = e & 127; buf[r * LDA + c] = g[r * 41 + gi] * f.wv; }
-    __syncthreads();
-  } else if (d.pre == PRE_COPY_LEG || d.pre == PRE_COPY_ARM) {
-    const int n = d.n, go = (d.pre == PRE_COPY_LEG) ? 0 : PT_NLEG;
-    const int r = tid >> 3, c0 = tid & 7;                          // 8 threads per row
-    for (int c = c0; c < n; c += 8) buf[r * LDA + c] = g[r * 41 + go + c];
-    __syncthreads();
-  } else if (d.pre == PRE_LATENT) {                                // d latent = dA_z[:, 76:96] + ROA gradient
-    const float* src = smem + d.src_off;
-    const int r = tid >> 3, c0 = tid & 7;
-    for (int c = c0; c < 20; c += 8) buf[r * LDA + c] = src[r * LDA + PT_NPROP + c] + g[r * 41 + 20 + c];
-    __syncthreads();
-  }
-  // buf <- buf * act'(A) with A the stashed post-activation (fetched by bwd_fetch)
-  {
-    const int c = (tid & 63) * 2, rb = tid >> 6;
-    if (c < d.n) {
-      float* bp = buf + rb * LDA + c;
-      float* dzp = dz_stash + sidx(num_rows, d.dcol, d.dw, row0 + rb, c);
-      const bool elu = d.act == ACT_ELU;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool ok = row0 + rb + 4 * j < num_rows;
-        const float dx = elu ? act_deriv<ACT_ELU>(f.a[j].x) : act_deriv<ACT_TANH>(f.a[j].x);
-        const float dy = elu ? act_deriv<ACT_ELU>(f.a[j].y) : act_deriv<ACT_TANH>(f.a[j].y);
-        float2 v = make_float2(bp[4 * j * LDA] * dx, bp[4 * j * LDA + 1] * dy);
-        if (!ok) v = make_float2(0.f, 0.f);
-        bp[4 * j * LDA] = v.x; bp[4 * j * LDA + 1] = v.y;
-        if (ok) *reinterpret_cast<float2*>(dzp + (size_t)(4 * j) * d.dw) = v;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// [32 x 128] tile of the activation stash back into an LDS activation buffer (rows past the end: zeros)
-static __device__ __forceinline__ void reload_tile(float* dst, const float* __restrict__ stash, int col, int row0, int num_rows) {
-  const int tid = threadIdx.x;
-  float4 v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
-    v[j] = (row0 + r < num_rows) ? *reinterpret_cast<const float4*>(stash + sidx(num_rows, col, 128, row0 + r, c)) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + j * PT_THREADS, r = e >> 5, c = (e & 31) * 4;
-    float* d = dst + r * LDA + c;
-    d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
-  }
-}
-
-extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_fwd_bwd_kernel(PolicyParams P, FOpTable FT, BwdTable BT, const float* __restrict__ wpack,
-                                                                           PpoBatch Bt, float* __restrict__ act_stash,
-                                                                           float* __restrict__ dz_stash, float* __restrict__ dstd_partial,
-                                                                           float* __restrict__ loss_partial) {
-  __shared__ float smem[Q_END];
-  const int tid = threadIdx.x;
-  const int tile = blockIdx.x, row0 = tile * PT_ROWS, B = Bt.B;
-  PSTAMP(0);
-  // gather obs[idx, :100] (float4 loads, all in flight); stash it (input of priv0 / critic backbone) and copy the proprio
-  // block to a1[:, :76], next to where priv2 will put the latent
-  load_x_tile(smem + Q_X, [&](int r) { return (row0 + r < B) ? Bt.obs + (size_t)Bt.idx[row0 + r] * PT_NOBS : (const float*)nullptr; });
-  __syncthreads();
-  for (int e = tid; e < PT_ROWS * 25; e += PT_THREADS) {
-    const int r = e / 25, c = (e - r * 25) * 4;
-    if (row0 + r < B) {
-      const float* xp = smem + Q_X + r * 101 + c;
-      *reinterpret_cast<float4*>(act_stash + sidx(B, A_X, 100, row0 + r, c)) = make_float4(xp[0], xp[1], xp[2], xp[3]);
-    }
-  }
-  PSTAMP(1);
-  // ---------------- forward: op list (layers, stash reloads, the proprio copy), post-activations stashed. One operand
-  // set: the next layer's fragments are requested as soon as this layer's MFMA chain has consumed the current ones.
-  {
-    float w[65];
-    fwd_load(w, FT.op[0].d, wpack);
-#pragma unroll 1
-    for (int i = 0; i < NFOPS; ++i) {
-      const FOp& o = FT.op[i];
-      if (o.type == FOP_RELOAD) {
-        __threadfence_block();
-        __syncthreads();
-        reload_tile(smem + o.rdst, act_stash, o.rcol, row0, B);
-        __syncthreads();
-      } else if (o.type == FOP_COPY_PROP) {
-        for (int e = tid; e < PT_ROWS * PT_NPROP; e += PT_THREADS) {
-          const int r = e / PT_NPROP, c = e - r * PT_NPROP;
-          smem[Q_A1 + r * LDA + c] = smem[Q_X + r * 101 + c];
-        }
-        __syncthreads();
-      } else {
-        const int nx = o.next_layer;
-        fwd_run(w, o.d, smem, act_stash, A_LD, row0, B, i, [&]() { if (nx >= 0) fwd_load(w, FT.op[nx].d, wpack); });
-      }
-    }
-  }
-  PSTAMP(2);
-  __threadfence_block();
-  __syncthreads();
-  // z = [prop, latent], the backbone's input, for its weight gradient: prop from x, latent from the stash just written
-  for (int e = tid; e < PT_ROWS * 24; e += PT_THREADS) {
-    const int r = e / 24, c = (e - r * 24) * 4;
-    if (row0 + r < B) {
-      float4 v;
-      if (c < PT_NPROP) { const float* xp = smem + Q_X + r * 101 + c; v = make_float4(xp[0], xp[1], xp[2], xp[3]); }
-      else v = *reinterpret_cast<const float4*>(act_stash + sidx(B, A_LAT, 20, row0 + r, c - PT_NPROP));
-      *reinterpret_cast<float4*>(act_stash + sidx(B, A_Z, 100, row0 + r, c)) = v;
-    }
-  }
-  __syncthreads();                      // g re-uses x: every read of x is done
-  const float* outv = smem + Q_OUTV;
-  float* gbuf = smem + Q_G;
-  PSTAMP(3);
-  // ---------------- losses and output gradients: one row per lane of wave 0
-  if (tid < 64) {
-    const int r = tid & 31;
-    const bool valid = (tid < PT_ROWS) && (row0 + r < B);
-    float surr = 0.f, vls = 0.f, preg = 0.f;
-    float dsd[18];
-#pragma unroll
-    for (int j = 0; j < 18; ++j) dsd[j] = 0.f;
-    if (valid) {
-      const size_t src = (size_t)Bt.idx[row0 + r];
-      const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
-      float lp[2] = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 18; ++j) {
-        const float mu = outv[r * 21 + j], sd = P.std[j];
-        const float d = Bt.actions[src * 18 + j] - mu;
-        lp[j < PT_NLEG ? 0 : 1] += -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-      }
-      const float adv0 = Bt.advantages[src * 2], adv1 = Bt.advantages[src * 2 + 1];
-      const float mixed[2] = {adv0 + Bt.mixing * adv1, adv1 + Bt.mixing * adv0};               // PPO:199-201
-      float dlp[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float ratio = expf(lp[c] - Bt.old_logp[src * 2 + c]);                               // PPO:202
-        const float rc = fminf(fmaxf(ratio, 1.f - Bt.clip), 1.f + Bt.clip);
-        const float s1 = -mixed[c] * ratio, s2 = -mixed[c] * rc;                                  // PPO:203-205
-        surr += fmaxf(s1, s2);
-        const bool inside = (ratio >= 1.f - Bt.clip) && (ratio <= 1.f + Bt.clip);
-        const float dr = (inside || s1 > s2) ? -mixed[c] : 0.f;                                   // d max(s1,s2) / d ratio
-        dlp[c] = inv2B * dr * ratio;
-        // value loss PPO:209-216
-        const float v = outv[r * 21 + 18 + c], ov = Bt.old_values[src * 2 + c], R = Bt.returns[src * 2 + c];
-        float dv;
-        if (Bt.use_clipped_value_loss) {
-          const float dlt = v - ov;
-          const float vc = ov + fminf(fmaxf(dlt, -Bt.clip), Bt.clip);
-          const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-          vls += fmaxf(l1, l2);
-          const float m = (dlt >= -Bt.clip && dlt <= Bt.clip) ? 1.f : 0.f;
-          const float g1 = 2.f * (v - R), g2 = 2.f * (vc - R) * m;
-          dv = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
-        } else {
-          vls += (R - v) * (R - v);
-          dv = 2.f * (v - R);
-        }
-        gbuf[r * 41 + 18 + c] = Bt.value_coef * inv2B * dv;
-      }
-#pragma unroll
-      for (int j = 0; j < 18; ++j) {
-        const float mu = outv[r * 21 + j], sd = P.std[j];
-        const float d = Bt.actions[src * 18 + j] - mu;
-        const float gl = dlp[j < PT_NLEG ? 0 : 1];
-        gbuf[r * 41 + j] = gl * d / (sd * sd);                                                    // d logp / d mu
-        dsd[j] = gl * (d * d / (sd * sd * sd) - 1.f / sd);                                       // d logp / d sigma
-      }
-      // ROA regulariser PPO:174-179: mean_B || priv_latent - hist_latent ||_2
-      float dl[20], nrm = 0.f;
-#pragma unroll
-      for (int k = 0; k < 20; ++k) {
-        dl[k] = act_stash[sidx(B, A_LAT, 20, row0 + r, k)] - Bt.hist_latent[src * 20 + k];
-        nrm += dl[k] * dl[k];
-      }
-      nrm = sqrtf(nrm);
-      preg = nrm;
-      const float sc = (nrm > 0.f) ? Bt.roa_coef * invB / nrm : 0.f;
-#pragma unroll
-      for (int k = 0; k < 20; ++k) gbuf[r * 41 + 20 + k] = sc * dl[k];
-    } else if (tid < PT_ROWS) {
-      for (int k = 0; k < 40; ++k) gbuf[r * 41 + k] = 0.f;
-    }
-    // reduce the tile's loss sums and sigma gradients over the 32 rows (lanes 32..63 carry zeros)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      surr += __shfl_xor(surr, off); vls += __shfl_xor(vls, off); preg += __shfl_xor(preg, off);
-#pragma unroll
-      for (int j = 0; j < 18; ++j) dsd[j] += __shfl_xor(dsd[j], off);
-    }
-    if (tid == 0) {
-      loss_partial[tile * 3 + 0] = surr; loss_partial[tile * 3 + 1] = vls; loss_partial[tile * 3 + 2] = preg;
-#pragma unroll
-      for (int j = 0; j < 18; ++j) dstd_partial[tile * 18 + j] = dsd[j];
-    }
-  }
-  __syncthreads();
-  // ---------------- backward: 14 table-driven stages, the next stage's weight rows in flight during the current one
-  if (tid < PT_ROWS && row0 + tid < B) {
-    dz_stash[sidx(B, D_VLEG, 4, row0 + tid, 0)] = gbuf[tid * 41 + 18];
-    dz_stash[sidx(B, D_VARM, 4, row0 + tid, 0)] = gbuf[tid * 41 + 19];
-  }
-  {
-    // per stage: pre-step + act' pass (stash values fetched during the previous stage's GEMM), this stage's GEMM, then --
-    // its operands consumed -- the next stage's operands and stash values are requested before the product is written out
-    float w[64];
-    BwdFetch f;
-    f32x16 saved = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    PSTAMP(4);
-    bwd_load(w, BT.s[0], wpack);
-    bwd_fetch(f, BT.s[0], act_stash, row0, B);
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll 1
-    for (int st = 0; st < NBWD; ++st) {
-      const BwdDesc& d = BT.s[st];
-      bwd_pre_act(d, f, smem, dz_stash, row0, B);
-      const bool mma = d.has_mma && wave < d.nblkT;
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (d.add_saved) acc = saved;
-      if (mma) mfma_chain(smem + d.buf_off + (lane & 31) * LDA + (lane >> 5), w, (d.out_dim + 1) / 2, acc);
-      if (st + 1 < NBWD) { bwd_load(w, BT.s[st + 1], wpack); bwd_fetch(f, BT.s[st + 1], act_stash, row0, B); }
-      if (mma) {
-        if (d.save_out) saved = acc;
-        else {
-          const int col = wave * 32 + (lane & 31);
-          if (col < d.in_dim) {
-            float* out = smem + d.out_off + col + 4 * (lane >> 5) * LDA;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * LDA] = acc[r];
-          }
-        }
-      }
-      if (d.has_mma) __syncthreads();
-      PSTAMP(5 + st);
-    }
-  }
 }
 
 // ==== 16-row tiles =======================================================================================================
@@ -1088,10 +770,7 @@ extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, f
 // then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
 static const int kDcol[NLAYERS] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM};
 static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, A_BB, A_A1, A_A2, A_X, A_CB, A_CL1, A_CL2, A_CB, A_CA1, A_CA2};
-#ifndef PPO_TILE16
-#define PPO_TILE16 1        // 16-row tiles (ppo_fwd_bwd16_kernel); 0: the 32-row kernel, kept for A/B runs
-#endif
-#define PPO_WPACK_FLOATS (WPACK_FLOATS > WPACK16_FLOATS ? WPACK_FLOATS : WPACK16_FLOATS)
+#define PPO_WPACK_FLOATS WPACK16_FLOATS
 
 // The equal-work plan of ppo_wgrad_kernel for this network (checked: every wave of every virtual layer gets 4 blocks).
 static int make_wgrad_plan(WgradPlan& plan, RedTable& red, int B) {
@@ -1161,27 +840,21 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
       B <= 0 || fill_params(params, &P))
     return -1;
   hipStream_t st = (hipStream_t)stream;
-  const int tile_rows = PPO_TILE16 ? HROWS : PT_ROWS;
+  const int tile_rows = HROWS;
   const int tiles = (B + tile_rows - 1) / tile_rows;
   const int ng = wbc_ppo_grad_floats();
-  const int Bs = PPO_TILE16 ? ppo_slab_rows(B) : B;          // rows per stash slab
+  const int Bs = ppo_slab_rows(B);          // rows per stash slab
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)Bs * A_LD;
   float* dstd_partial = dz_stash + (size_t)Bs * D_LD;
   float* loss_partial = dstd_partial + (size_t)tiles * 18;
   float* wpart = loss_partial + (size_t)tiles * 3;
   float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
-  if (PPO_TILE16) hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 2), dim3(256), 0, st, P, make_pack16_table(), wpack);
-  else hipLaunchKernelGGL(wbc_pack_weights_kernel, dim3(16, NLAYERS, 2), dim3(256), 0, st, P, make_pack_table(), wpack);
+  hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 2), dim3(256), 0, st, P, make_pack16_table(), wpack);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, Bs, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
-  if (PPO_TILE16) {
-    hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fwd_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
-                       act_stash, dz_stash, dstd_partial, loss_partial);
-  } else {
-    hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fop_table(kStashCols), make_bwd_table(P), wpack, Bt, act_stash,
-                       dz_stash, dstd_partial, loss_partial);
-  }
+  hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fwd_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
+                     act_stash, dz_stash, dstd_partial, loss_partial);
   WgradPlan plan;
   RedTable red;
   const int off = make_wgrad_plan(plan, red, B);
