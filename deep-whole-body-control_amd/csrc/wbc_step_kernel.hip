@@ -993,7 +993,8 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
 }
 
 // compute_observations (oracle) + the HBM write-out of the step's results.
-__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset, const StepOut& so) {
+__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset, const StepOut& so,
+                                  const float (&hist_in)[12]) {
   const int lane = threadIdx.x;
   const wbc_task_cfg& cf = C->cfg;
   // proprio vector o76, one or two entries per lane
@@ -1023,13 +1024,11 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   float* obs = (so.obs ? so.obs : T.obs) + (size_t)env * WBC_NOBS;
   float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
   const bool refill = s.ep_len <= 1;
+  // the old history was requested right after the substeps (hist_in: its HBM latency ran under the rigid-body pass and the task
+  // logic); every lane's reads were issued long before the first write of the in-place shift below
   float old[12];
 #pragma unroll
-  for (int r = 0; r < 12; ++r) {
-    const int idx = lane + r * LANES;
-    old[r] = (idx < WBC_HIST * WBC_NPROP && !was_reset) ? hist[idx] : 0.f;
-  }
-  WSYNC();   // all history reads done before the in-place shift
+  for (int r = 0; r < 12; ++r) old[r] = was_reset ? 0.f : hist_in[r];
 #pragma unroll
   for (int r = 0; r < 12; ++r) {
     const int idx = lane + r * LANES;
@@ -1116,6 +1115,17 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
   STAMP(13);
+  // the observation's history block (obs_history_buf before this step's update, WG:992): 12 coalesced loads per lane, consumed by
+  // observe_and_store at the very end
+  float hist_in[12];
+  {
+    const float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      const int idx = lane + r * LANES;
+      hist_in[r] = (idx < WBC_HIST * WBC_NPROP) ? hist[idx] : 0.f;
+    }
+  }
   // post_physics_step (WG:865-915)
   float rsc_leg = 0.f, rsc_arm = 0.f;             // this lane's reward scales (consumed after the lane-0 task logic)
   if (lane < WBC_NREW) { rsc_leg = C->cur.leg_reward_scale[lane]; rsc_arm = C->cur.arm_reward_scale[lane]; }
@@ -1165,7 +1175,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
   }
   STAMP(16);
-  observe_and_store(s, T, C, env, do_reset, so);
+  observe_and_store(s, T, C, env, do_reset, so, hist_in);
   STAMP(17);
 }
 
