@@ -1,0 +1,20 @@
+# SQ counters and HBM traffic of hist_train_kernel (separate rocprofv3 --pmc passes; MI355X_MICROARCH.md, HBM section)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+export WBC_ITERS=6
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY" "SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_hist_train/$tag -- python $R/tools/time_hist_train.py > /dev/null 2>&1
+done
+python - <<'PY'
+import csv, glob, os, collections
+R=os.environ['GRAFT_REPO_ROOT']
+for kn in ("hist_train_kernel", "priv_latent_kernel"):
+    print(kn)
+    for f in sorted(glob.glob(R+'/gpurun_out/pmc_hist_train/*/*/*counter_collection.csv')):
+        acc=collections.defaultdict(lambda: [0,0])
+        for r in csv.DictReader(open(f)):
+            if r['Kernel_Name'].startswith(kn):
+                a=acc[r['Counter_Name']]; a[0]+=float(r['Counter_Value']); a[1]+=1
+        for k,(v,n) in acc.items(): print("  ",k, v/n)
+PY
