@@ -1,7 +1,11 @@
 """PPO with two-channel (leg / arm) advantages, Advantage Mixing, Regularized Online Adaptation
 (privileged-latent regulariser + DAgger step for the history encoder) and a minimum policy std
 (reference rsl_rl/algorithms/ppo.py:39-324; the quirks that decide seed-identical parity are
-SURVEY.md section 8a L1-L10 and are kept).
+SURVEY.md section 8a L1-L10). They are all kept by the eager paths (CPU, and the GPU fallback), which
+tests/test_ppo_parity.py pins to the reference seed for seed. The fused GPU paths keep L2-L10 and drop
+the random-stream bookkeeping (L1: update() / update_dagger() sample-and-discard one [mb, 18] normal per
+minibatch; the rollout noise is drawn per rollout, not per step): a device generator's stream is not the
+reference's CPU stream in the first place, and nothing computed depends on the discarded draws.
 
 Multi-GPU (not in the reference): with `dist_group` set, every rank owns a shard of the envs and a
 replica of the networks; gradients are flattened into ONE bucket and all-reduced (RCCL over xGMI on
