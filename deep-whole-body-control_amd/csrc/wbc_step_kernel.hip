@@ -36,6 +36,24 @@ __device__ __forceinline__ float pair_swap(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
 }
 
+// Sum over an aligned group of 8 lanes, every lane gets the total: three DPP adds at VALU speed, no LDS round trip.
+// ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7)), the same bits in all 8 lanes (each step adds the same two operands).
+__device__ __forceinline__ float sum8(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, false));   // row_half_mirror
+  return x;
+}
+
+// Packed bodies (DevConst::chain_pack_body) of chain `sch` of the 8-lane sweep layout: five scalar loads and a select chain
+// (LDS has no room for another table: 16 robots per CU need <= 10240 B each).
+__device__ __forceinline__ uint32_t sweep_chain_bodies(const DevConst* __restrict__ C, int sch) {
+  uint32_t b = C->chain_pack_body[WBC_NCHAIN];
+#pragma unroll
+  for (int c = 0; c < WBC_NCHAIN; ++c) b = (sch == c) ? C->chain_pack_body[c] : b;
+  return b;
+}
+
 struct PostBuf {                  // post-physics staging; shares LDS with IA (dead once the substeps are done)
   float out_rb[WBC_NRB_ENV][13];
   float quatB[WBC_NB][4], omB[WBC_NB][3], voB[WBC_NB][3];
@@ -394,20 +412,23 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     s.pA[0][r] = acc;
   }
   WSYNC();
-  // K0 = IA0^-1 by six Gauss-Jordan sweeps, one matrix entry per lane (all reads of a sweep precede its writes:
-  // one wavefront, LDS in program order)
+  // K0 = IA0^-1 by six Gauss-Jordan sweeps, one matrix entry per lane. The matrix stays in registers: the pivot is a
+  // v_readlane, the pivot row / column entries come through the LDS crossbar (ds_bpermute: no memory, no hand-over); one
+  // store at the end. (Twelve LDS round trips before: 2.5 k of a substep's 48 k cycles.)
   if (lane < 36) {
     const int r = lane / 6, cc = lane % 6;
-#pragma unroll 1
+    float own = s.IA[0][lane];
+#pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
-      const float piv = s.IA[0][kk * 6 + kk], rowv = s.IA[0][kk * 6 + cc], colv = s.IA[0][r * 6 + kk], own = s.IA[0][lane];
+      const float piv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(own), kk * 7));
+      const float rowv = __int_as_float(__builtin_amdgcn_ds_bpermute((kk * 6 + cc) * 4, __float_as_int(own)));
+      const float colv = __int_as_float(__builtin_amdgcn_ds_bpermute((r * 6 + kk) * 4, __float_as_int(own)));
       const float id = rcpf(piv);
       const float on_row = (cc == kk) ? id : rowv * id;
       const float off_row = (cc == kk) ? -colv * id : own - colv * rowv * id;
-      WSYNC();
-      s.IA[0][lane] = (r == kk) ? on_row : off_row;
-      WSYNC();
+      own = (r == kk) ? on_row : off_row;
     }
+    s.IA[0][lane] = own;
   }
   WSYNC();
   if (lane < 6) s.a[0][lane] = -dot6(&s.IA[0][lane * 6], s.pA[0]);
@@ -553,21 +574,22 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         s.uD[lane] = 0.f;                          // levels the inward sweep skips
       }
       WSYNC();
-      {   // inward: lane (chain, k<6) carries component k of the accumulated wrench in a register
+      {   // inward. Sweep layout: 8 lanes per chain (sch = lane >> 3, component sk = lane & 7 < 6): lane (sch, sk) carries
+          // component sk of the accumulated wrench in a register, the 6-term products S.p are DPP sums (no LDS hand-over)
+        const int sch = lane >> 3, sk = lane & 7;
+        const uint32_t sbody = sweep_chain_bodies(C, sch);
         float carry = 0.f;
 #pragma unroll 1
         for (int d = dmax - 1; d >= 0; --d) {
-          const int i = ch_body(cr, d);
-          const bool act = i != CH_NONE && k < 6;
-          float pk = 0.f;
-          if (act) { pk = PD(s)[i][k] + carry; TT(s)[i][k] = s.S[i][k] * pk; }
-          WSYNC();
+          const int i = (sbody >> (5 * d)) & 31;
+          const bool act = i != CH_NONE && sk < 6;
+          float pk = 0.f, t = 0.f;
+          if (act) { pk = PD(s)[i][sk] + carry; t = s.S[i][sk] * pk; }
+          const float uD = -sum8(t);
           if (act) {
-            const float* t = TT(s)[i];
-            const float uD = -(((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5]);
-            if (k == 0) s.uD[i] = uD;
-            carry = pk + s.U[i][k] * (uD * s.iD[i]);
-            if (d == 0) s.pa1[chain][k] = carry;
+            if (sk == 0) s.uD[i] = uD;
+            carry = pk + s.U[i][sk] * (uD * s.iD[i]);
+            if (d == 0) s.pa1[sch][sk] = carry;
           }
         }
         WSYNC();
@@ -585,20 +607,20 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       }
       WSYNC();
       const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
-      {   // outward: component k of the parent's acceleration change travels in a register
-        float adk = (k < 6) ? AD(s)[0][k] : 0.f;
+      {   // outward: component sk of the parent's acceleration change travels in a register
+        const int sch = lane >> 3, sk = lane & 7;
+        const uint32_t sbody = sweep_chain_bodies(C, sch);
+        float adk = (sk < 6) ? AD(s)[0][sk] : 0.f;
 #pragma unroll 1
         for (int d = 0; d < dout; ++d) {
-          const int i = ch_body(cr, d);
-          const bool act = i != CH_NONE && k < 6;
-          if (act) TT(s)[i][k] = s.U[i][k] * adk;
-          WSYNC();
+          const int i = (sbody >> (5 * d)) & 31;
+          const bool act = i != CH_NONE && sk < 6;
+          const float ut = sum8(act ? s.U[i][sk] * adk : 0.f);
           if (act) {
-            const float* t = TT(s)[i];
-            const float qdd = (s.uD[i] - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * s.iD[i];
-            adk += s.S[i][k] * qdd;
-            AD(s)[i][k] = adk;
-            if (k == 0) s.qddD[i] = qdd;
+            const float qdd = (s.uD[i] - ut) * s.iD[i];
+            adk += s.S[i][sk] * qdd;
+            AD(s)[i][sk] = adk;
+            if (sk == 0) s.qddD[i] = qdd;
           }
         }
         WSYNC();
@@ -1246,6 +1268,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
+static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");
 
 extern "C" void wbc_debug_set_step_timing(void* dev_buf) {
   long long* p = (long long*)dev_buf;

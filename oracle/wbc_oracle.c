@@ -13,6 +13,11 @@
  *     WG:917-935, _resample_commands WG:831-843, _push_robots WG:804-814, check_termination
  *     WG:937-963, compute_reward WG:170-205 + _reward_* WG:1352-1469, reset_idx WG:695-754,
  *     _reset_dofs WG:816-828, _reset_root_states WG:757-788, compute_observations WG:966-1001.
+ *     PINNED to the reference: tests/golden/wg_reference_*.npz are trajectories of the reference's
+ *     own WidowGo1.step (tools/make_golden_wg.py runs that class on the fake Isaac Gym of
+ *     tools/ref_harness/, whose gym.simulate is physics_substep below); tests/test_wg_golden.py
+ *     replays every recorded step through this file (fp64: 2e-5, masks bit-exact) and through the
+ *     HIP kernel.
  *   - PHYSICS (what WG:1183-1187 hands to Isaac Gym / PhysX, closed source and absent) is this
  *     framework's own specification: Featherstone articulated-body algorithm for the floating
  *     base + 18 revolute joints, velocity-level contact impulses from per-body inverse
@@ -22,10 +27,12 @@
  *     conservation laws.
  *   - the six helpers the reference imports from an author-patched isaacgym.torch_utils
  *     (euler_from_quat, sphere2cart, cart2sphere, torch_wrap_to_pi_minuspi, ...) follow
- *     SURVEY.md Appendix D; parity unpinned for those as well.
+ *     SURVEY.md Appendix D (their source is in neither tree); the harness uses the same
+ *     reconstruction, so the fixtures pin how the reference USES them, not their definitions.
  *   - random draws: the reference draws from torch's global generator (torch_rand_float);
  *     here every draw is a counter-based hash of (seed, env, step, slot) so the kernels and
- *     this file produce bit-identical integers.
+ *     this file produce bit-identical integers (the harness feeds the reference the same
+ *     uniforms through its own torch_rand_float formula).
  */
 #include <math.h>
 #include <stdint.h>
