@@ -130,6 +130,11 @@ class WidowGo1(LeggedRobot):
         if cfg.terrain.mesh_type not in ["heightfield", "trimesh"]:
             cfg.terrain.curriculum = False
         self.collect_episode_stats = True
+        # opt-in (OnPolicyRunner.learn sets it): extras['episode'] is computed on a side stream, overlapping the next policy
+        # inference; its consumer must synchronise the DEVICE before reading the values (the runner does, at the end of the rollout)
+        self.async_episode_stats = False
+        self._stats_stream = None
+        self._stats_pending = False
 
     # ---- construction ----------------------------------------------------------------------
     def create_sim(self):                                                           # WG:230-237, 255-429
@@ -343,7 +348,17 @@ class WidowGo1(LeggedRobot):
     def _fill_extras(self, start=False):
         """extras['episode'] / extras['time_outs'] of WG:743-754, 902-906, without host syncs."""
         if self.collect_episode_stats:
-            st = self.sim.episode_stats(1.0 / self.max_episode_length_s).unbind(0)      # one launch, 31 scalar views
+            if self.async_episode_stats and self.device.type == "cuda":
+                if self._stats_stream is None:
+                    self._stats_stream = torch.cuda.Stream(self.device)
+                side = self._stats_stream
+                side.wait_stream(torch.cuda.current_stream(self.device))                # after the step kernel's writes
+                with torch.cuda.stream(side):
+                    stv = self.sim.episode_stats(1.0 / self.max_episode_length_s)
+                self._stats_pending = True                                              # the next step() waits for it (it rewrites the inputs)
+            else:
+                stv = self.sim.episode_stats(1.0 / self.max_episode_length_s)
+            st = stv.unbind(0)                                                           # one launch, 31 scalar views
             ep = {}
             for i, name in self._active_terms:
                 ep["rew_" + name] = st[i]
@@ -401,6 +416,9 @@ class WidowGo1(LeggedRobot):
             self.extras["current_arm_dof_vel"] = self.dof_vel[:, -8:-2].clone()
         out, self._obs_output = self._obs_output, None
         store, self._store_output = self._store_output, None
+        if self._stats_pending:                       # the side-stream statistics of the previous step read what this step overwrites
+            torch.cuda.current_stream(self.device).wait_stream(self._stats_stream)
+            self._stats_pending = False
         self.sim.step(a, out, store)
         self.extras["rollout_stored"] = store[2].data_ptr() if store is not None else None
         self.common_step_counter += 1

@@ -79,6 +79,8 @@ class OnPolicyRunner:
         tot_iter = self.current_learning_iteration + num_learning_iterations
         redirect_obs = hasattr(env, "set_obs_output") and hasattr(alg, "next_observation_slot") and getattr(alg, "fused_rollout", False)
         store_in_step = hasattr(env, "set_rollout_output") and hasattr(alg, "rollout_slots") and getattr(alg, "fused_rollout", False)
+        if hasattr(env, "async_episode_stats"):
+            env.async_episode_stats = True               # every read of infos['episode'] below comes after a device synchronisation
         for it in range(self.current_learning_iteration, tot_iter):
             env.update_command_curriculum()
             sync()
@@ -140,6 +142,9 @@ class OnPolicyRunner:
             self.history.append(rec)
             ep_infos.clear()
         self.current_learning_iteration += num_learning_iterations
+        if hasattr(env, "async_episode_stats"):
+            env.async_episode_stats = False
+            sync()
         if logging:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 
