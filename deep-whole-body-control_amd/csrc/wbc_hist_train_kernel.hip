@@ -57,7 +57,7 @@ struct TrainSmem {
   float dz2[G_ROWS][4][H_C2 + 1];       // conv1 pre-activation gradient (its own buffer: no register staging of 8 values per lane)
   float h3[G_ROWS][H_C1 + 1];           // [co*3 + l]; becomes dz3
   float y[G_ROWS][H_OUT];               // becomes dz4
-  float w1[H_C2][H_C1 * 4];             // conv1 weights (input gradient)
+  float w1[H_C2 * 4][32];               // conv1 weights as [co][tap k][ci] (ci contiguous, rows padded to 32: bank = ci, conflict-free)
   __attribute__((aligned(8))) float w_c2[H_C3][H_C2 * 2 + 2];
   float w_lin[H_OUT][H_C1];
   float b_enc[H_C1], b_c1[H_C2], b_c2[H_C3], b_lin[H_OUT];
@@ -72,7 +72,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
   const int lane = tid & 63, wave = tid >> 6, p = lane & 15, g = lane >> 4;
   for (int e = tid; e < H_C3 * H_C2 * 2; e += G_THREADS) s.w_c2[e / (H_C2 * 2)][e % (H_C2 * 2)] = P.c2_w[e];
   for (int e = tid; e < H_OUT * H_C1; e += G_THREADS) (&s.w_lin[0][0])[e] = P.lin_w[e];
-  for (int e = tid; e < H_C2 * H_C1 * 4; e += G_THREADS) (&s.w1[0][0])[e] = P.c1_w[e];
+  for (int e = tid; e < H_C2 * H_C1 * 4; e += G_THREADS) { const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4); s.w1[co * 4 + (rem & 3)][rem >> 2] = P.c1_w[e]; }
   if (tid < H_C1) s.b_enc[tid] = P.enc_b[tid];
   if (tid < H_C2) s.b_c1[tid] = P.c1_b[tid];
   if (tid < H_C3) s.b_c2[tid] = P.c2_b[tid];
@@ -150,8 +150,8 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       const float* w1p = &s.w1[0][0] + opaque;
 #pragma unroll
       for (int ci = 0; ci < H_C1; ++ci) {
-        wB[2 * ci] = w1p[p * (H_C1 * 4) + ci * 4 + g];
-        wB[2 * ci + 1] = (p + 16 < H_C2) ? w1p[(p + 16) * (H_C1 * 4) + ci * 4 + g] : 0.f;
+        wB[2 * ci] = w1p[(p * 4 + g) * 32 + ci];
+        wB[2 * ci + 1] = (p + 16 < H_C2) ? w1p[((p + 16) * 4 + g) * 32 + ci] : 0.f;
       }
     }
 #pragma unroll 1
@@ -178,7 +178,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       const int rr = e / (3 * H_C3), rem = e - rr * (3 * H_C3), l = rem / H_C3, co = rem - l * H_C3;
       float acc = s.b_c2[co];
       const float* wr = s.w_c2[co];
-#pragma unroll 4
+#pragma unroll
       for (int ci = 0; ci < H_C2; ++ci) acc += s.h2[rr][l][ci] * wr[ci * 2] + s.h2[rr][l + 1][ci] * wr[ci * 2 + 1];
       s.h3[rr][co * 3 + l] = elu1(acc);
     }
@@ -187,7 +187,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     for (int e = tid; e < G_ROWS * H_OUT; e += G_THREADS) {
       const int rr = e / H_OUT, j = e - rr * H_OUT;
       float acc = s.b_lin[j];
-#pragma unroll 6
+#pragma unroll 15
       for (int i = 0; i < H_C1; ++i) acc += s.h3[rr][i] * s.w_lin[j][i];
       s.y[rr][j] = elu1(acc);
     }
@@ -218,7 +218,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       if (e < H_OUT * H_C1) {
         const int j = e / H_C1, i3 = e - j * H_C1;
         float a = 0.f;
-#pragma unroll 4
+#pragma unroll 12
         for (int rr = 0; rr < G_ROWS; ++rr) a += s.y[rr][j] * s.h3[rr][i3];
         accL[i] += a;
       }
@@ -236,7 +236,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       if (e < G_ROWS * H_C1) {
         const int rr = e / H_C1, i3 = e - rr * H_C1;
         float a = 0.f;
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < H_OUT; ++j) a += s.w_lin[j][i3] * s.y[rr][j];
         dz3r[i] = a * delu_from_out(s.h3[rr][i3]);
       }
@@ -255,7 +255,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       if (e < H_C3 * H_C2 * 2) {
         const int co = e / (H_C2 * 2), rem = e - co * (H_C2 * 2), ci = rem >> 1, k = rem & 1;
         float a = 0.f;
-#pragma unroll 2
+#pragma unroll 6
         for (int rr = 0; rr < G_ROWS; ++rr) {
 #pragma unroll
           for (int l = 0; l < 3; ++l) a += s.h3[rr][co * 3 + l] * s.h2[rr][l + k][ci];
@@ -275,7 +275,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       for (int k = 0; k < 2; ++k) {
         const int l = lp - k;
         if (l >= 0 && l < 3) {
-#pragma unroll 5
+#pragma unroll
           for (int co = 0; co < H_C3; ++co) a += s.w_c2[co][ci * 2 + k] * s.h3[rr][co * 3 + l];
         }
       }
@@ -286,10 +286,10 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const int e = tid + G_THREADS * i;
-      if (e < H_C2 * H_C1 * 4) {
-        const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4), ci = rem >> 2, k = rem & 3;
+      if (e < H_C2 * H_C1 * 4) {                       // thread entries in (co, tap k, ci) order: consecutive lanes = consecutive ci (LDS banks)
+        const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4), k = rem / H_C1, ci = rem - k * H_C1;
         float a = 0.f;
-#pragma unroll 2
+#pragma unroll 4
         for (int rr = 0; rr < G_ROWS; ++rr) {
 #pragma unroll
           for (int l = 0; l < 4; ++l) a += s.dz2[rr][l][co] * s.h1[rr * H_T + 2 * l + k][ci];
@@ -311,8 +311,8 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       for (int l = 0; l < 4; ++l) {
         const int k = t - 2 * l;
         if (k >= 0 && k < 4) {
-#pragma unroll 4
-          for (int co = 0; co < H_C2; ++co) a += s.w1[co][ci * 4 + k] * s.dz2[rr][l][co];
+#pragma unroll
+          for (int co = 0; co < H_C2; ++co) a += s.w1[co * 4 + k][ci] * s.dz2[rr][l][co];
         }
       }
       s.h1[q][ci] = a * delu_from_out(s.h1[q][ci]);
@@ -358,7 +358,13 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     }
   }
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { const int e = tid + G_THREADS * i; if (e < H_C2 * H_C1 * 4) out[O_C1_W + e] = accC1[i]; }
+  for (int i = 0; i < 10; ++i) {
+    const int e = tid + G_THREADS * i;
+    if (e < H_C2 * H_C1 * 4) {
+      const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4), k = rem / H_C1, ci = rem - k * H_C1;
+      out[O_C1_W + co * (H_C1 * 4) + ci * 4 + k] = accC1[i];              // back to conv_layers.0.weight's [co][ci][k]
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) { const int e = tid + G_THREADS * i; if (e < H_C3 * H_C2 * 2) out[O_C2_W + e] = accC2[i]; }
 #pragma unroll
