@@ -10,7 +10,8 @@
 //      stashes; per-tile column sums of the latter are the bias-gradient partials.
 //   2. ppo_wgrad_kernel: dW_l = dZ_l^T A_{l-1} for all 16 layers, split 64..80 ways over the rows
 //      (the reduction length is the minibatch, 40960), 32x32x2 MFMA with both operands staged through LDS.
-//   3. ppo_reduce_kernel: fixed-order sums of the split partials into the flat gradient buffer.
+//   3. ppo_grad_reduce_kernel: fixed-order sums of the split partials into the flat gradient buffer, the std-gradient and
+//      loss columns, and the partial sums of squares the gradient clip needs.
 //
 // Everything is deterministic (no atomics). The history-encoder latent that the regulariser targets is an
 // input (its weights do not change during update(), PPO:175-176).
@@ -660,62 +661,62 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_wgrad_kernel(Wgr
 
 struct RedLayer { int goff, count; };
 struct RedTable { RedLayer l[NLAYERS]; int nsplit; };
-// grad[goff + i] = sum_{s < nsplit} part[s][goff + i] in a fixed order, one grid row per layer
-extern "C" __global__ void __launch_bounds__(256) ppo_layer_reduce_kernel(RedTable tab, const float* __restrict__ part, int stride,
-                                                                         float* __restrict__ grad) {
-  const RedLayer L = tab.l[blockIdx.y];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L.count) return;
-  const int p = L.goff + i;
-  float acc = 0.f;
-  int s2 = 0;
-  for (; s2 + 8 <= tab.nsplit; s2 += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s2 + j) * stride + p];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc += v[j];
-  }
-  for (; s2 < tab.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
-  grad[p] = acc;
-}
-
-// grad[p] = sum_s part[s][p] in a fixed order; `stride` floats between consecutive partials
-extern "C" __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict__ part, int nparts, int stride, int n,
-                                                                   float* __restrict__ grad) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  float acc = 0.f;
-  int s = 0;
-  for (; s + 8 <= nparts; s += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s + j) * stride + p];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc += v[j];
-  }
-  for (; s < nparts; ++s) acc += part[(size_t)s * stride + p];
-  grad[p] = acc;
-}
-
-// out[j] = sum_t part[t*width + j] for a few columns and many partials: one block per column, fixed-order tree. Two
-// tables in one launch: blocks [0, width) reduce `part`, blocks [width, width + width2) reduce `part2` into out + width.
-extern "C" __global__ void __launch_bounds__(256) ppo_column_reduce_kernel(const float* __restrict__ part, int nparts, int width,
-                                                                          const float* __restrict__ part2, int width2,
-                                                                          float* __restrict__ out) {
+#define RED_BX ((128 * 128 + 128 + 255) / 256)            // blocks per grid row (the largest layer: 65)
+#define PPO_SQ_PARTS ((NLAYERS + 1) * RED_BX)             // one partial sum of squares per block of ppo_grad_reduce_kernel
+// ONE reduction launch per minibatch. Grid rows 0 .. NLAYERS-1: grad[goff + i] = sum_{s < nsplit} part[s][goff + i] in a fixed
+// order (the split-K weight-gradient partials). Grid row NLAYERS: block j < 18 + 3 sums the per-tile partials of column j of
+// the std gradient (18) / the loss sums (3) -- fixed-order tree -- into out_cols[j]; the loss sums are also ADDED to
+// loss_accum[0..2] (if given: the update's running totals). Every block leaves the sum of squares of the gradient entries it
+// produced in sq[blockIdx.y * RED_BX + blockIdx.x] (0 if none): clip_grad_norm_'s norm without another pass over the gradient.
+extern "C" __global__ void __launch_bounds__(256) ppo_grad_reduce_kernel(RedTable tab, const float* __restrict__ part, int stride, float* __restrict__ grad,
+                                                                        const float* __restrict__ col_part, int nparts, const float* __restrict__ loss_part,
+                                                                        float* __restrict__ out_cols, float* __restrict__ loss_accum,
+                                                                        float* __restrict__ sq) {
   __shared__ float sh[256];
-  int j = blockIdx.x;
-  const int j_out = j;
-  if (j >= width) { j -= width; part = part2; width = width2; }
   float acc = 0.f;
-  for (int t = threadIdx.x; t < nparts; t += 256) acc += part[(size_t)t * width + j];
+  bool counts = false;                                     // does this thread's value belong to the clipped gradient?
+  if (blockIdx.y < NLAYERS) {
+    const RedLayer L = tab.l[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L.count) {
+      const int p = L.goff + i;
+      int s2 = 0;
+      for (; s2 + 8 <= tab.nsplit; s2 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s2 + j) * stride + p];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+      }
+      for (; s2 < tab.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
+      grad[p] = acc;
+      counts = true;
+    }
+    sh[threadIdx.x] = counts ? acc * acc : 0.f;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sq[blockIdx.y * RED_BX + blockIdx.x] = sh[0];
+    return;
+  }
+  const int j = blockIdx.x;
+  if (j >= 18 + 3) { if (threadIdx.x == 0) sq[blockIdx.y * RED_BX + blockIdx.x] = 0.f; return; }
+  const float* src = j < 18 ? col_part + j : loss_part + (j - 18);
+  const int width = j < 18 ? 18 : 3;
+  for (int t = threadIdx.x; t < nparts; t += 256) acc += src[(size_t)t * width];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[j_out] = sh[0];
+  if (threadIdx.x == 0) {
+    out_cols[j] = sh[0];
+    if (j >= 18 && loss_accum) loss_accum[j - 18] += sh[0];
+    sq[blockIdx.y * RED_BX + blockIdx.x] = j < 18 ? sh[0] * sh[0] : 0.f;
+  }
 }
 
 // ---- gradient clip + Adam on the flat gradient (nn.utils.clip_grad_norm_ + optim.Adam.step, PPO:243-246) ----
@@ -743,17 +744,23 @@ struct AdamTable {
 // m, v, p as torch.optim.Adam (no weight decay, no amsgrad):
 // m += (g-m)(1-b1); v = v b2 + (1-b2) g g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                                 const float* __restrict__ part, float max_norm, float beta1, float beta2,
-                                                                 float eps, float step_size, float bc2_sqrt, float grad_scale) {
+                                                                 const float* __restrict__ part, int nparts, float max_norm, float beta1,
+                                                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
+  __shared__ float sh[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= T.off[33]) return;
   float coef = grad_scale;
-  if (max_norm > 0.f) {
-    float tot = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < ADAM_NBLK; ++b) tot += part[b];
-    coef = grad_scale * fminf(max_norm / (sqrtf(tot) * grad_scale + 1e-6f), 1.f);      // the norm of the SCALED gradient
+  if (max_norm > 0.f) {                                    // block-uniform
+    float a = 0.f;                                         // every block: the same strided partial sums, the same tree -> the same bits
+    for (int b = threadIdx.x; b < nparts; b += 256) a += part[b];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    coef = grad_scale * fminf(max_norm / (sqrtf(sh[0]) * grad_scale + 1e-6f), 1.f);      // the norm of the SCALED gradient
   }
+  if (i >= T.off[33]) return;
   int lo = 0, hi = 33;            // parameter j with off[j] <= i < off[j+1]
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (T.off[mid] <= i) lo = mid; else hi = mid; }
   const float gi = g[i] * coef;
@@ -817,8 +824,13 @@ extern "C" int wbc_ppo_num_splits(void) { return PPO_NSPLIT; }
 // floats of workspace for a minibatch of B rows
 extern "C" size_t wbc_ppo_workspace_floats(int B) {
   const size_t tiles = (size_t)(B + R16 - 1) / R16;
-  return (size_t)ppo_slab_rows(B) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4;
+  return (size_t)ppo_slab_rows(B) * (A_LD + D_LD) + tiles * (18 + 3) + (size_t)PPO_NSPLIT * (size_t)wbc_ppo_grad_floats() + (size_t)PPO_WPACK_FLOATS + 4 +
+         PPO_SQ_PARTS;
 }
+// where wbc_ppo_minibatch_grad leaves the partial sums of squares of the gradient it produced (floats from the start of a workspace
+// for B rows), for wbc_ppo_clip_adam's sq_partials argument
+static size_t ppo_sq_offset(int B) { return wbc_ppo_workspace_floats(B) - PPO_SQ_PARTS; }
+extern "C" size_t wbc_ppo_sq_partials_offset(int B) { return ppo_sq_offset(B); }
 
 static int fill_params(const void* const* params, PolicyParams* P) {
   const float** dst = reinterpret_cast<const float**>(P);
@@ -834,7 +846,7 @@ static int fill_params(const void* const* params, PolicyParams* P) {
 extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions, const float* old_values,
                                       const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
                                       const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
-                                      int use_clipped_value_loss, float* workspace, float* grad, void* stream) {
+                                      int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream) {
   PolicyParams P;
   if (!params || !obs || !actions || !old_values || !advantages || !returns || !old_logp || !hist_latent || !idx || !workspace || !grad ||
       B <= 0 || fill_params(params, &P))
@@ -860,8 +872,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   const int off = make_wgrad_plan(plan, red, B);
   if (off < 0) return -2;
   hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WG_NVL * PPO_NSPLIT), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
-  hipLaunchKernelGGL(ppo_layer_reduce_kernel, dim3((128 * 128 + 128 + 255) / 256, NLAYERS), dim3(256), 0, st, red, wpart, ng, grad);
-  hipLaunchKernelGGL(ppo_column_reduce_kernel, dim3(18 + 3), dim3(256), 0, st, dstd_partial, tiles, 18, loss_partial, 3, grad + off);
+  hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, wpart, ng, grad, dstd_partial, tiles, loss_partial,
+                     grad + off, loss_accum, workspace + ppo_sq_offset(B));
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -870,7 +882,8 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
 // step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) (computed by the caller in double, as torch does).
 // max_norm <= 0: no clipping. workspace: >= 64 floats.
 extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
-                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, float* workspace, void* stream) {
+                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, const float* sq_partials, float* workspace,
+                                 void* stream) {
   if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace || !(grad_scale > 0.f)) return -1;
   AdamTable T;
   int off = 0, j = 0;
@@ -882,8 +895,10 @@ extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* 
   if (!params[32]) return -1;
   T.p[32] = (float*)params[32]; T.off[32] = off; off += 18; T.off[33] = off;
   hipStream_t st = (hipStream_t)stream;
-  if (max_norm > 0.f) hipLaunchKernelGGL(ppo_sqnorm_kernel, dim3(ADAM_NBLK), dim3(256), 0, st, grad, off, workspace);
-  hipLaunchKernelGGL(ppo_adam_kernel, dim3((off + 255) / 256), dim3(256), 0, st, T, grad, exp_avg, exp_avg_sq, workspace, max_norm, beta1, beta2, eps,
-                     step_size, bc2_sqrt, grad_scale);
+  // the norm: from the partials wbc_ppo_minibatch_grad left (the gradient is still the one it produced), or a pass over grad
+  const bool have = sq_partials != nullptr;
+  if (max_norm > 0.f && !have) hipLaunchKernelGGL(ppo_sqnorm_kernel, dim3(ADAM_NBLK), dim3(256), 0, st, grad, off, workspace);
+  hipLaunchKernelGGL(ppo_adam_kernel, dim3((off + 255) / 256), dim3(256), 0, st, T, grad, exp_avg, exp_avg_sq, have ? sq_partials : workspace,
+                     have ? PPO_SQ_PARTS : ADAM_NBLK, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

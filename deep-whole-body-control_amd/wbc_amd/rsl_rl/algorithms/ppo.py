@@ -252,7 +252,7 @@ class PPO:
             assert off == ng - 3
             self._fused = dict(mb=mb, grad=grad, nparam=off, ws=torch.empty(L.wbc_ppo_workspace_floats(mb), device=dev),
                                hist=torch.empty(batch, 20, device=dev), m=torch.zeros(off, device=dev), v=torch.zeros(off, device=dev),
-                               adam_ws=torch.empty(64, device=dev))
+                               adam_ws=torch.empty(64, device=dev), sq_off=int(L.wbc_ppo_sq_partials_offset(mb)))
         F = self._fused
         for p, g in zip(params, torch.split(F["grad"][:F["nparam"]], [p.numel() for p in params])):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
@@ -282,13 +282,15 @@ class PPO:
                 check(L.wbc_ppo_minibatch_grad(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(),
                                                returns.data_ptr(), logp.data_ptr(), F["hist"].data_ptr(), idx.data_ptr(), mb,
                                                float(self.clip_param), float(vcoef), float(value_mixing_ratio), float(priv_reg_coef),
-                                               int(self.use_clipped_value_loss), F["ws"].data_ptr(), F["grad"].data_ptr(), stream),
-                      "wbc_ppo_minibatch_grad")
+                                               int(self.use_clipped_value_loss), F["ws"].data_ptr(), F["grad"].data_ptr(), sums.data_ptr(), stream),
+                      "wbc_ppo_minibatch_grad")            # (the three loss sums are accumulated into `sums` by the reduction kernel)
+                grad_is_fresh = True                   # still exactly what the kernels wrote: their partial sums of squares give the norm
                 if self.entropy_coef != 0.0:       # -coef * entropy.mean(): d/d sigma_j of (1/2) sum_j log sigma_j
                     ac.std.grad.sub_(self.entropy_coef * 0.5 / ac.std.detach())
+                    grad_is_fresh = False
                 if self.dist_group is not None:    # ONE flat bucket, SUM over ranks; the 1/world_size mean is folded into the clip + Adam kernel
                     torch.distributed.all_reduce(F["grad"][:F["nparam"]], group=self.dist_group)
-                sums += F["grad"][F["nparam"]:]
+                    grad_is_fresh = False
                 steps = self._bind_adam_state(params, F)
                 if steps is None:                  # optimiser options the fused kernel does not cover
                     if self.world_size > 1:
@@ -301,7 +303,9 @@ class PPO:
                     b1, b2 = g0["betas"]
                     check(L.wbc_ppo_clip_adam(table, F["grad"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(),
                                               float(self.max_grad_norm), b1, b2, g0["eps"], g0["lr"] / (1.0 - b1 ** t),
-                                              (1.0 - b2 ** t) ** 0.5, 1.0 / self.world_size, F["adam_ws"].data_ptr(), stream), "wbc_ppo_clip_adam")
+                                              (1.0 - b2 ** t) ** 0.5, 1.0 / self.world_size,
+                                              F["ws"].data_ptr() + 4 * F["sq_off"] if grad_is_fresh else None,
+                                              F["adam_ws"].data_ptr(), stream), "wbc_ppo_clip_adam")
                     torch._foreach_add_(steps, 1.0)
         num_updates = self.num_learning_epochs * self.num_mini_batches
         surr, vls, preg = (sums / num_updates).tolist()

@@ -321,21 +321,27 @@ int wbc_hist_latent(const void* const* params, const float* obs, float* out, int
  * surrogate + value_coef*value_loss + roa_coef*priv_reg in the order: for each of the 16 layers of
  * `params` (same table as wbc_policy_act) weight then bias; std[18]; then the three loss SUMS (surrogate and
  * value over B*2 entries, priv_reg over B). `hist_latent` f32 [T*N,20]: history-encoder latent of every
- * stored row (constant during update()). `workspace`: wbc_ppo_workspace_floats(B) floats. Deterministic. */
+ * stored row (constant during update()). `workspace`: wbc_ppo_workspace_floats(B) floats. `loss_accum` (device, 3 floats,
+ * or NULL): the three loss sums are also ADDED to it (an update's running totals without a launch of its own).
+ * Also leaves, at workspace + wbc_ppo_sq_partials_offset(B), partial sums of squares of the gradient it wrote
+ * (wbc_ppo_clip_adam's `sq_partials`). Deterministic. */
 int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions,
                            const float* old_values, const float* advantages, const float* returns,
                            const float* old_logp, const float* hist_latent, const int64_t* idx, int B,
                            float clip, float value_coef, float mixing, float roa_coef,
-                           int use_clipped_value_loss, float* workspace, float* grad, void* stream);
+                           int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream);
+size_t wbc_ppo_sq_partials_offset(int B);
 /* nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (ppo.py:243-246) for the 33 parameters of
  * `params`, reading their gradients from grad[0 : wbc_ppo_grad_floats()-3] (scaled in place by the clip factor);
  * exp_avg / exp_avg_sq are flat Adam moments in the same layout. step_size = lr/(1-beta1^t), bc2_sqrt =
  * sqrt(1-beta2^t). max_norm <= 0 disables the clip. grad_scale (> 0) multiplies the gradient before the clip: 1 on one GPU,
  * 1 / world_size after the SUM all-reduce of the sharded learner (the mean over ranks without a separate launch).
+ * sq_partials: the partial sums of squares wbc_ppo_minibatch_grad left for THIS gradient (pass them only while grad is
+ * exactly what that call wrote -- not after an all-reduce), or NULL: the norm is then computed by a pass over grad.
  * workspace: >= 64 floats. Deterministic. */
 int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm,
                       float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
-                      float* workspace, void* stream);
+                      const float* sq_partials, float* workspace, void* stream);
 /* One minibatch of PPO.update_dagger (rsl_rl/algorithms/ppo.py:265-291): the history encoder's forward
  * (rsl_rl/modules/actor_critic.py:39-84), loss = mean over rows of ||target - latent||_2, backward and weight gradients
  * for the `rows` rows obs[idx[r]] (obs f32 [batch, 860], target f32 [batch, 20] = the privileged latents, idx i64 [rows]).

@@ -23,7 +23,7 @@ ws = torch.empty(L.wbc_ppo_workspace_floats(B), device=dev); grad = torch.zeros(
 stream = torch.cuda.current_stream().cuda_stream
 def run():
     check(L.wbc_ppo_minibatch_grad(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp.data_ptr(),
-                                   hist.data_ptr(), idx.data_ptr(), B, 0.2, 1.0, 0.5, 0.1, 1, ws.data_ptr(), grad.data_ptr(), stream), "grad")
+                                   hist.data_ptr(), idx.data_ptr(), B, 0.2, 1.0, 0.5, 0.1, 1, ws.data_ptr(), grad.data_ptr(), None, stream), "grad")
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
