@@ -67,6 +67,8 @@ extern "C" void wbc_debug_set_ppo_timing(void* dev_buf) {
 #endif
 }
 
+#include "wbc_ppo_chain.h"
+
 // LDS plan of the update kernel: x[32][101] (re-used as g[32][41] -- output grads dmu 18, dv 2, dlat 20 -- once the forward
 // is done), TWO activation buffers and outv: 48.6 KB, three workgroups per CU. The third buffer the chain would like (the
 // backbone output feeds two heads) is replaced by a reload from the activation stash (forward) and by keeping the first
@@ -777,7 +779,7 @@ extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, f
 // then 3 loss sums (surrogate, value, priv_reg; divide by 2B, 2B, B for the means).
 static const int kDcol[NLAYERS] = {D_H1, D_LAT, D_BB, D_L1, D_L2, D_LEG, D_A1, D_A2, D_ARM, D_CB, D_CL1, D_CL2, D_VLEG, D_CA1, D_CA2, D_VARM};
 static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, A_BB, A_A1, A_A2, A_X, A_CB, A_CL1, A_CL2, A_CB, A_CA1, A_CA2};
-#define PPO_WPACK_FLOATS WPACK16_FLOATS
+#define PPO_WPACK_FLOATS (WPACK16_FLOATS > CHAIN_PACK_FLOATS ? WPACK16_FLOATS : CHAIN_PACK_FLOATS)
 
 // The equal-work plan of ppo_wgrad_kernel for this network (checked: every wave of every virtual layer gets 4 blocks).
 static int make_wgrad_plan(WgradPlan& plan, RedTable& red, int B) {
@@ -859,20 +861,32 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)Bs * A_LD;
   float* dstd_partial = dz_stash + (size_t)Bs * D_LD;
-  float* loss_partial = dstd_partial + (size_t)tiles * 18;
-  float* wpart = loss_partial + (size_t)tiles * 3;
+  const size_t tiles16w = (size_t)(B + R16 - 1) / R16;                // the workspace holds one partial per 16-row tile
+  float* loss_partial = dstd_partial + tiles16w * 18;
+  float* wpart = loss_partial + tiles16w * 3;
   float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
-  hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 2), dim3(256), 0, st, P, make_pack16_table(), wpack);
+  static const bool use_old = getenv("WBC_PPO_OLD16") != nullptr;          // development A/B switch
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, Bs, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
-  static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
-  hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fwd_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
-                     act_stash, dz_stash, dstd_partial, loss_partial);
+  int nparts = tiles;
+  if (use_old) {
+    hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 2), dim3(256), 0, st, P, make_pack16_table(), wpack);
+    static const int kStashCols[NLAYERS] = {A_H1, A_LAT, A_BB, A_L1, A_L2, A_LEG, A_A1, A_A2, A_ARM, A_CB, A_CL1, A_CL2, -1, A_CA1, A_CA2, -1};
+    hipLaunchKernelGGL(ppo_fwd_bwd16_kernel, dim3(tiles), dim3(PT_THREADS), 0, st, P, make_fwd_table16(kStashCols), make_bwd_table16(P), wpack, Bt,
+                       act_stash, dz_stash, dstd_partial, loss_partial);
+  } else {
+    const ChainStreams& S = chain_streams();
+    const int tiles16 = (B + 15) / 16;
+    nparts = tiles16;
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(96, 2), dim3(256), 0, st, P, S, wpack);
+    hipLaunchKernelGGL(ppo_chain_kernel, dim3((2 * tiles16 + 3) / 4), dim3(PT_THREADS), 0, st, wpack, S.base[1], S.nelem[0] * 1024, S.nelem[1] * 1024, Bt, P.std, act_stash, dz_stash,
+                       dstd_partial, loss_partial, tiles16);
+  }
   WgradPlan plan;
   RedTable red;
   const int off = make_wgrad_plan(plan, red, B);
   if (off < 0) return -2;
   hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WG_NVL * PPO_NSPLIT), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
-  hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, wpart, ng, grad, dstd_partial, tiles, loss_partial,
+  hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, wpart, ng, grad, dstd_partial, nparts, loss_partial,
                      grad + off, loss_accum, workspace + ppo_sq_offset(B));
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
