@@ -273,7 +273,7 @@ def main():
             raw_step(*a, **kw)
     env.sim.step = timed_step
 
-    # The fused PPO minibatch step (weight pack + ppo_fwd_bwd16 + ppo_wgrad + reducers: one C-ABI call) is timed INSIDE the
+    # The fused PPO minibatch step (weight pack + ppo_chain + ppo_wgrad + reducers: one C-ABI call) is timed INSIDE the
     # timed region on every 10th call (2 of an update's 20 minibatches: an event pair around every call cost 4.5 ms per
     # iteration, around 1 in 10 it is below the run-to-run noise).
     from wbc_amd.native import lib as _lib
@@ -382,7 +382,7 @@ def main():
             rows = int(last_grad_args["a"][9])
             flops = UPDATE_FLOPS_PER_ROW * rows
             tf = flops / (upd_ms * 1e-3) / 1e12
-            out["roofline_update"] = {"kernel": "wbc_ppo_minibatch_grad = wbc_pack16 + ppo_fwd_bwd16 + ppo_wgrad + reducers", "bound": "mfma",
+            out["roofline_update"] = {"kernel": "wbc_ppo_minibatch_grad = chain_pack + ppo_chain + ppo_wgrad + reducers", "bound": "mfma",
                                       "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                       "traffic": counter_file("ppo_update_traffic.json") if rows == 40960 else None,
                                       "launch_ms": upd_ms, "algorithmic_flops_per_launch": flops, "rows_per_launch": rows,

@@ -21,10 +21,18 @@
 // (one out-block ahead), the address is a scalar pointer bumped by 1 KB per element. 717 (actor) + 666 (critic) KB, L2 resident.
 #pragma once
 
-#define CH_D 9                    // ring depth (stream elements in flight)
-#ifndef CH_OCC
-#define CH_OCC 3                  // waves per SIMD the register budget is set for
+#ifndef CH_D
+#define CH_D 9                    // ring depth (stream elements in flight); must divide 153 (a head chain's forward elements)
 #endif
+// zero elements that bring the stream position back to a multiple of the ring depth in front of / behind the looped bodies
+#define CH_PAD_PRIV ((CH_D - 26 % CH_D) % CH_D)
+#define CH_PAD_BB ((CH_D - 64 % CH_D) % CH_D)
+#define CH_PAD_BWD ((CH_D - 136 % CH_D) % CH_D)
+static_assert(153 % CH_D == 0, "ring depth");
+#ifndef CH_OCC
+#define CH_OCC 2                  // waves per SIMD the register budget is set for
+#endif
+
 
 // ---- stream layout ----------------------------------------------------------------------------------------------------
 enum { SEG_FWD = 0, SEG_BWD = 1, SEG_PAD = 2 };
@@ -42,19 +50,19 @@ static ChainStreams make_chain_streams() {
       pos += kind == SEG_FWD ? nblk * (ngrp + 1) : (kind == SEG_BWD ? nblk * ngrp : nblk);
     };
     if (p == 0) {
-      seg(L_PRIV0, SEG_FWD, 4, 3); seg(L_PRIV2, SEG_FWD, 2, 4); seg(-1, SEG_PAD, 1, 0);            // 16 + 10 + 1 = 27
-      seg(L_BB, SEG_FWD, 8, 7); seg(-1, SEG_PAD, 8, 0);                                              // 64 + 8
+      seg(L_PRIV0, SEG_FWD, 4, 3); seg(L_PRIV2, SEG_FWD, 2, 4); seg(-1, SEG_PAD, CH_PAD_PRIV, 0);            // 16 + 10 + 1 = 27
+      seg(L_BB, SEG_FWD, 8, 7); seg(-1, SEG_PAD, CH_PAD_BB, 0);                                              // 64 + 8
       seg(L_LEG0, SEG_FWD, 8, 8); seg(L_LEG2, SEG_FWD, 8, 8); seg(L_LEG4, SEG_FWD, 1, 8);           // 153
       seg(L_ARM0, SEG_FWD, 8, 8); seg(L_ARM2, SEG_FWD, 8, 8); seg(L_ARM4, SEG_FWD, 1, 8);
-      seg(L_LEG4, SEG_BWD, 8, 1); seg(L_LEG2, SEG_BWD, 8, 8); seg(L_LEG0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, 8, 0);    // 144
-      seg(L_ARM4, SEG_BWD, 8, 1); seg(L_ARM2, SEG_BWD, 8, 8); seg(L_ARM0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, 8, 0);
+      seg(L_LEG4, SEG_BWD, 8, 1); seg(L_LEG2, SEG_BWD, 8, 8); seg(L_LEG0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, CH_PAD_BWD, 0);    // 144
+      seg(L_ARM4, SEG_BWD, 8, 1); seg(L_ARM2, SEG_BWD, 8, 8); seg(L_ARM0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, CH_PAD_BWD, 0);
       seg(L_BB, SEG_BWD, 2, 8); seg(L_PRIV2, SEG_BWD, 4, 2);                                         // 16 + 8
     } else {
-      seg(L_CBB, SEG_FWD, 8, 7); seg(-1, SEG_PAD, 8, 0);
+      seg(L_CBB, SEG_FWD, 8, 7); seg(-1, SEG_PAD, CH_PAD_BB, 0);
       seg(L_CLEG0, SEG_FWD, 8, 8); seg(L_CLEG2, SEG_FWD, 8, 8); seg(L_CLEG4, SEG_FWD, 1, 8);
       seg(L_CARM0, SEG_FWD, 8, 8); seg(L_CARM2, SEG_FWD, 8, 8); seg(L_CARM4, SEG_FWD, 1, 8);
-      seg(L_CLEG4, SEG_BWD, 8, 1); seg(L_CLEG2, SEG_BWD, 8, 8); seg(L_CLEG0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, 8, 0);
-      seg(L_CARM4, SEG_BWD, 8, 1); seg(L_CARM2, SEG_BWD, 8, 8); seg(L_CARM0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, 8, 0);
+      seg(L_CLEG4, SEG_BWD, 8, 1); seg(L_CLEG2, SEG_BWD, 8, 8); seg(L_CLEG0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, CH_PAD_BWD, 0);
+      seg(L_CARM4, SEG_BWD, 8, 1); seg(L_CARM2, SEG_BWD, 8, 8); seg(L_CARM0, SEG_BWD, 8, 8); seg(-1, SEG_PAD, CH_PAD_BWD, 0);
     }
     seg(-1, SEG_PAD, CH_D, 0);                    // the ring reads CH_D elements past the last one consumed
     t.nseg[p] = n; t.nelem[p] = pos;
@@ -73,41 +81,51 @@ static __device__ __forceinline__ int chain_fwd_kcol(int layer, int kq, int g, i
   return t < layer_in(layer) ? t : -1;
 }
 
-// grid = (blocks, 2 parts). One thread per float of the streams.
+// grid = (blocks, 2 parts), one thread per (element, lane): a float4 of the stream.
 static __global__ void __launch_bounds__(256) chain_pack_kernel(PolicyParams P, ChainStreams S, float* __restrict__ pack) {
   const int p = blockIdx.y;
-  const int total = S.nelem[p] * 256;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int i = e & 3, lane = (e >> 2) & 63, el = e >> 8;
-    const int g = lane >> 4, m = lane & 15;
-    int si = 0;
-    while (si + 1 < S.nseg[p] && S.s[p][si + 1].start <= el) ++si;
-    const ChainSeg sg = S.s[p][si];
-    float v = 0.f;
-    if (sg.kind != SEG_PAD) {
-      const float* W = reinterpret_cast<const float* const*>(&P)[2 * sg.layer];
-      const float* bsrc = reinterpret_cast<const float* const*>(&P)[2 * sg.layer + 1];
-      const int N = layer_out(sg.layer), K = layer_in(sg.layer);
-      const int rel = el - sg.start;
-      if (sg.kind == SEG_FWD) {
-        const int blk = rel / (sg.ngrp + 1), kq = rel - blk * (sg.ngrp + 1);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = t & 63, el = t >> 6;
+  if (el >= S.nelem[p]) return;
+  const int g = lane >> 4, m = lane & 15;
+  int si = 0;
+  while (si + 1 < S.nseg[p] && S.s[p][si + 1].start <= el) ++si;
+  const ChainSeg sg = S.s[p][si];
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (sg.kind != SEG_PAD) {
+    const float* W = reinterpret_cast<const float* const*>(&P)[2 * sg.layer];
+    const float* bsrc = reinterpret_cast<const float* const*>(&P)[2 * sg.layer + 1];
+    const int N = layer_out(sg.layer), K = layer_in(sg.layer);
+    const int rel = el - sg.start;
+    // blocks come in pairs (2 p, 2 p + 1) whose elements alternate: two independent accumulators per wave (a dependent
+    // v_mfma_f32_16x16x4_f32 issues every 40 cycles, an independent one every 32); single-block layers (heads) keep k order
+    if (sg.kind == SEG_FWD) {
+      int blk, kq;
+      if (sg.nblk == 1) { blk = 0; kq = rel; }
+      else { const int pe = 2 * (sg.ngrp + 1), pr = rel / pe, r2 = rel - pr * pe; blk = 2 * pr + (r2 & 1); kq = r2 >> 1; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         if (kq == sg.ngrp) {                                   // bias quadruple of lane group g: features 16 blk + 4 g + i
           const int o = 16 * blk + 4 * g + i;
-          v = o < N ? bsrc[o] : 0.f;
+          v[i] = o < N ? bsrc[o] : 0.f;
         } else {
           const int o = 16 * blk + m, c = chain_fwd_kcol(sg.layer, kq, g, i);
-          v = (o < N && c >= 0) ? W[(size_t)o * K + c] : 0.f;
+          v[i] = (o < N && c >= 0) ? W[(size_t)o * K + c] : 0.f;
         }
-      } else {                                                 // dIn^T = W^T dZ^T: rows = the layer's inputs, k over its outputs
-        const int blk = rel / sg.ngrp, kq = rel - blk * sg.ngrp;
+      }
+    } else {                                                   // dIn^T = W^T dZ^T: rows = the layer's inputs, k over its outputs
+      const int pe = 2 * sg.ngrp, pr = rel / pe, r2 = rel - pr * pe;
+      const int blk = 2 * pr + (r2 & 1), kq = r2 >> 1;
+      int c = 16 * blk + m;
+      if (sg.layer == L_BB) c = c < 20 ? PT_NPROP + c : K;    // only the latent columns of the backbone's input need a gradient
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         const int o = 16 * kq + 4 * g + i;
-        int c = 16 * blk + m;
-        if (sg.layer == L_BB) c = c < 20 ? PT_NPROP + c : K;  // only the latent columns of the backbone's input need a gradient
-        v = (o < N && c < K) ? W[(size_t)o * K + c] : 0.f;
+        v[i] = (o < N && c < K) ? W[(size_t)o * K + c] : 0.f;
       }
     }
-    pack[S.base[p] + e] = v;
   }
+  reinterpret_cast<float4*>(pack + S.base[p])[t] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ---- the ring ---------------------------------------------------------------------------------------------------------
@@ -130,7 +148,11 @@ struct ChainRing {
   // the element at ring slot `slot` (a compile-time constant after unrolling); its slot is refilled from the stream head
   __device__ __forceinline__ f32x4 take(int slot) {
     const f32x4 v = r[slot];
+#ifdef CH_EXP_L1          // experiment: the whole stream aliased onto 8 KB (L1 resident; results wrong)
+    r[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, so & CH_EXP_L1, 0));
+#else
     r[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, so, 0));
+#endif
     so += 1024;
     CH_PIN();
     return v;
@@ -142,15 +164,44 @@ static __device__ __forceinline__ f32x4 ch_ld4(__amdgpu_buffer_rsrc_t rs, int vo
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 static __device__ __forceinline__ void ch_st4(__amdgpu_buffer_rsrc_t rs, int voff, int soff, f32x4 v) {
+#ifdef CH_EXP_HOTSTORE    // experiment: every stash store lands in one 4 KB window per slab (results wrong)
+  voff &= 0xfff;
+#endif
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff, 0);
 }
-static __device__ __forceinline__ f32x4 ch_mfma4(const f32x4 w, const f32x4 b, f32x4 acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], b[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], b[3], acc, 0, 0, 0);
-  return acc;
+// 8 MFMAs on two independent accumulators, strictly alternating (one asm statement: the compiler neither reorders them nor
+// renames an accumulator in mid-chain, which costs hazard nops). A dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles,
+// alternating chains every 32. FIRST: the accumulators start from 0. The compiler does not see the matrix pipe's result
+// latency through an asm statement: results are read CH_MFMA_SETTLE() or >= 8 further MFMAs later.
+template <bool FIRST>
+static __device__ __forceinline__ void ch_mfma8(const f32x4 w0, const f32x4 w1, const f32x4 b0, const f32x4 b1, f32x4& a0, f32x4& a1) {
+  if (FIRST)
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, 0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %6, %14, 0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %9, %17, %1"
+                 : "=&v"(a0), "=&v"(a1)
+                 : "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]),
+                   "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
+  else
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %6, %14, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %7, %15, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %8, %16, %1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %1, %9, %17, %1"
+                 : "+v"(a0), "+v"(a1)
+                 : "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]),
+                   "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]));
 }
+// 16 wait states: an 8-pass MFMA result is readable by the vector ALU / as an MFMA A/B operand 11 states after its issue
+#define CH_MFMA_SETTLE() asm volatile("s_nop 7\n\ts_nop 7" ::: "memory")
 static __device__ __forceinline__ float ch_elu(float x) {       // as act16<ACT_ELU>
   const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.f;
   return x > 0.f ? x : e;
@@ -165,54 +216,124 @@ static __device__ __forceinline__ f32x4 ch_delu4(f32x4 d, f32x4 a) {
   for (int r = 0; r < 4; ++r) o[r] = d[r] * (a[r] > 0.f ? 1.f : a[r] + 1.f);
   return o;
 }
+#define CH_Z4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 
-// Forward layer: out[ob] = act(W in + b) for NOB out-blocks over NKG k-groups; POS0 = ring position (mod CH_D) of its first
-// element. STASH: the output goes to the activation slab at (uniform byte offset soff) + (lane offset voff) + 64 ob. The
-// epilogue of a block runs after the next block's MFMAs were issued (the matrix pipe's result latency is not waited for).
-template <int NOB, int NKG, int POS0, bool ELU, bool STASH>
+// Forward layer: out[ob] = ELU(W in + b) for NOB (even) out-blocks over NKG k-groups, two blocks at a time; POS0 = ring
+// position (mod CH_D) of its first element. STASH: the output goes to the activation slab at (uniform byte offset soff) +
+// (lane offset voff) + 64 ob. The epilogue of a pair runs after the next pair's MFMAs were issued (the matrix pipe's result
+// latency is not waited for).
+template <int NOB, int NKG, int POS0, bool STASH>
 static __device__ __forceinline__ void chain_fwd(ChainRing& R, const f32x4* bin, f32x4* out, __amdgpu_buffer_rsrc_t ars, int voff, int soff) {
-  f32x4 bprev = (f32x4){0.f, 0.f, 0.f, 0.f};
+  static_assert(NOB % 2 == 0, "pairs of out-blocks");
+  constexpr int PE = 2 * (NKG + 1);
+  f32x4 bp0 = CH_Z4, bp1 = CH_Z4;
 #pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < NOB / 2; ++p) {
+    f32x4 a0, a1;
 #pragma unroll
-    for (int kq = 0; kq < NKG; ++kq) acc = ch_mfma4(R.take((POS0 + ob * (NKG + 1) + kq) % CH_D), bin[kq], acc);
-    out[ob] = acc;
-    const f32x4 b = R.take((POS0 + ob * (NKG + 1) + NKG) % CH_D);
-    if (ob > 0) {
-      out[ob - 1] = ELU ? ch_elu4(out[ob - 1], bprev) : out[ob - 1] + bprev;
-      if (STASH) ch_st4(ars, voff + 64 * (ob - 1), soff, out[ob - 1]);
+    for (int kq = 0; kq < NKG; ++kq) {
+      const f32x4 w0 = R.take((POS0 + p * PE + 2 * kq) % CH_D), w1 = R.take((POS0 + p * PE + 2 * kq + 1) % CH_D);
+      if (kq == 0) ch_mfma8<true>(w0, w1, bin[kq], bin[kq], a0, a1);
+      else ch_mfma8<false>(w0, w1, bin[kq], bin[kq], a0, a1);
     }
-    bprev = b;
+    out[2 * p] = a0; out[2 * p + 1] = a1;
+    const f32x4 b0 = R.take((POS0 + p * PE + 2 * NKG) % CH_D), b1 = R.take((POS0 + p * PE + 2 * NKG + 1) % CH_D);
+    if (p > 0) {
+      out[2 * p - 2] = ch_elu4(out[2 * p - 2], bp0);
+      out[2 * p - 1] = ch_elu4(out[2 * p - 1], bp1);
+      if (STASH) { ch_st4(ars, voff + 64 * (2 * p - 2), soff, out[2 * p - 2]); ch_st4(ars, voff + 64 * (2 * p - 1), soff, out[2 * p - 1]); }
+    }
+    bp0 = b0; bp1 = b1;
   }
-  out[NOB - 1] = ELU ? ch_elu4(out[NOB - 1], bprev) : out[NOB - 1] + bprev;
-  if (STASH) ch_st4(ars, voff + 64 * (NOB - 1), soff, out[NOB - 1]);
+  CH_MFMA_SETTLE();
+  out[NOB - 2] = ch_elu4(out[NOB - 2], bp0);
+  out[NOB - 1] = ch_elu4(out[NOB - 1], bp1);
+  if (STASH) { ch_st4(ars, voff + 64 * (NOB - 2), soff, out[NOB - 2]); ch_st4(ars, voff + 64 * (NOB - 1), soff, out[NOB - 1]); }
 }
 
-// Backward stage: dout[ib] (+)= W^T dz over NKG k-groups for NIB in-blocks; then, DERIV: dout[ib] *= ELU'(a[ib]) with a read
-// from the activation slab (asoff) one block ahead of its use, and the result stored to the dZ slab (dsoff), both at the lane
-// offset voff + 64 ib. ACCUM: the accumulators start from dout (no derivative pass).
-template <int NIB, int NKG, int POS0, bool DERIV, bool ACCUM>
-static __device__ __forceinline__ void chain_bwd(ChainRing& R, const f32x4* dz, f32x4* dout, __amdgpu_buffer_rsrc_t ars, int asoff,
-                                                 __amdgpu_buffer_rsrc_t drs, int dsoff, int voff) {
+// Head layer (one out-block, no activation): the k-groups alternate between two accumulators. NKG even, NKG + 1 elements.
+template <int NKG, int POS0>
+static __device__ __forceinline__ f32x4 chain_head(ChainRing& R, const f32x4* bin) {
+  static_assert(NKG % 2 == 0, "pairs of k-groups");
+  f32x4 a0, a1;
+#pragma unroll
+  for (int kq = 0; kq < NKG; kq += 2) {
+    const f32x4 w0 = R.take((POS0 + kq) % CH_D), w1 = R.take((POS0 + kq + 1) % CH_D);
+    if (kq == 0) ch_mfma8<true>(w0, w1, bin[kq], bin[kq + 1], a0, a1);
+    else ch_mfma8<false>(w0, w1, bin[kq], bin[kq + 1], a0, a1);
+  }
+  const f32x4 b = R.take((POS0 + NKG) % CH_D);
+  CH_MFMA_SETTLE();
+  return (a0 + a1) + b;
+}
+
+// Backward stages: dout[ib] = W^T dz over NKG k-groups for NIB (even) in-blocks, two blocks at a time.
+// chain_bwd_deriv: dout[ib] *= ELU'(a[ib]) and the result goes to the dZ slab (dsoff), lane offset voff + 64 ib. The
+// post-activations a come from the activation slab (asoff), requested when their pair starts and used after the NEXT pair's
+// MFMAs were issued -- or, ALL, every block's at stage entry (a stage of 8 MFMAs per pair is too short for the former).
+template <int NIB, int NKG, int POS0, bool ALL = false>
+static __device__ __forceinline__ void chain_bwd_deriv(ChainRing& R, const f32x4* dz, f32x4* dout, __amdgpu_buffer_rsrc_t ars, int asoff,
+                                                       __amdgpu_buffer_rsrc_t drs, int dsoff, int voff) {
+  static_assert(NIB % 2 == 0, "pairs of in-blocks");
+  constexpr int PE = 2 * NKG;
   f32x4 ap[NIB];
-  if (DERIV) ap[0] = ch_ld4(ars, voff, asoff);
+  if (ALL) {
 #pragma unroll
-  for (int ib = 0; ib < NIB; ++ib) {
-    if (DERIV && ib + 1 < NIB) ap[ib + 1] = ch_ld4(ars, voff + 64 * (ib + 1), asoff);
-    f32x4 acc = ACCUM ? dout[ib] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NIB; ++j) ap[j] = ch_ld4(ars, voff + 64 * j, asoff);
+  }
 #pragma unroll
-    for (int kq = 0; kq < NKG; ++kq) acc = ch_mfma4(R.take((POS0 + ib * NKG + kq) % CH_D), dz[kq], acc);
-    dout[ib] = acc;
-    if (DERIV && ib > 0) {
-      dout[ib - 1] = ch_delu4(dout[ib - 1], ap[ib - 1]);
-      ch_st4(drs, voff + 64 * (ib - 1), dsoff, dout[ib - 1]);
+  for (int p = 0; p < NIB / 2; ++p) {
+    if (!ALL) { ap[2 * p] = ch_ld4(ars, voff + 64 * (2 * p), asoff); ap[2 * p + 1] = ch_ld4(ars, voff + 64 * (2 * p + 1), asoff); }
+    f32x4 a0, a1;
+#pragma unroll
+    for (int kq = 0; kq < NKG; ++kq) {
+      const f32x4 w0 = R.take((POS0 + p * PE + 2 * kq) % CH_D), w1 = R.take((POS0 + p * PE + 2 * kq + 1) % CH_D);
+      if (kq == 0) ch_mfma8<true>(w0, w1, dz[kq], dz[kq], a0, a1);
+      else ch_mfma8<false>(w0, w1, dz[kq], dz[kq], a0, a1);
+    }
+    dout[2 * p] = a0; dout[2 * p + 1] = a1;
+    if (p > 0) {
+      if (NKG == 1) CH_MFMA_SETTLE();                  // (a pair of this stage is 8 MFMAs: the previous pair's last result may still be in flight)
+#pragma unroll
+      for (int j = 2 * p - 2; j < 2 * p; ++j) { dout[j] = ch_delu4(dout[j], ap[j]); ch_st4(drs, voff + 64 * j, dsoff, dout[j]); }
     }
   }
-  if (DERIV) {
-    dout[NIB - 1] = ch_delu4(dout[NIB - 1], ap[NIB - 1]);
-    ch_st4(drs, voff + 64 * (NIB - 1), dsoff, dout[NIB - 1]);
+  CH_MFMA_SETTLE();
+#pragma unroll
+  for (int j = NIB - 2; j < NIB; ++j) { dout[j] = ch_delu4(dout[j], ap[j]); ch_st4(drs, voff + 64 * j, dsoff, dout[j]); }
+}
+
+// chain_bwd_accreg: dacc += W^T dz, the accumulators held by the caller (the backbone-output gradient, summed over the two heads)
+template <int NIB, int NKG, int POS0>
+static __device__ __forceinline__ void chain_bwd_accreg(ChainRing& R, const f32x4* dz, f32x4* dacc) {
+  constexpr int PE = 2 * NKG;
+#pragma unroll
+  for (int p = 0; p < NIB / 2; ++p) {
+#pragma unroll
+    for (int kq = 0; kq < NKG; ++kq) {
+      const f32x4 w0 = R.take((POS0 + p * PE + 2 * kq) % CH_D), w1 = R.take((POS0 + p * PE + 2 * kq + 1) % CH_D);
+      ch_mfma8<false>(w0, w1, dz[kq], dz[kq], dacc[2 * p], dacc[2 * p + 1]);
+    }
   }
+  CH_MFMA_SETTLE();
+}
+
+// chain_bwd_plain: no epilogue (the caller finishes the blocks)
+template <int NIB, int NKG, int POS0>
+static __device__ __forceinline__ void chain_bwd_plain(ChainRing& R, const f32x4* dz, f32x4* dout) {
+  constexpr int PE = 2 * NKG;
+#pragma unroll
+  for (int p = 0; p < NIB / 2; ++p) {
+    f32x4 a0, a1;
+#pragma unroll
+    for (int kq = 0; kq < NKG; ++kq) {
+      const f32x4 w0 = R.take((POS0 + p * PE + 2 * kq) % CH_D), w1 = R.take((POS0 + p * PE + 2 * kq + 1) % CH_D);
+      if (kq == 0) ch_mfma8<true>(w0, w1, dz[kq], dz[kq], a0, a1);
+      else ch_mfma8<false>(w0, w1, dz[kq], dz[kq], a0, a1);
+    }
+    dout[2 * p] = a0; dout[2 * p + 1] = a1;
+  }
+  CH_MFMA_SETTLE();
 }
 
 static __device__ __forceinline__ float ch_sum_g(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }       // over the 4 lane groups of a row
@@ -223,6 +344,11 @@ static __device__ __forceinline__ float ch_sum_n(float v) {                     
 
 // ntiles 16-row tiles; stream_bytes[p], off_critic: the two streams inside `pack`. Stashes: Bs rows per slab, slab of start
 // column c0 at byte offset 4 c0 Bs (both stashes stay below 4 GB: 32-bit buffer offsets).
+#ifdef WBC_PPO_TIMING      // development aid: clock stamps of the first actor / critic unit (slots 0.. / 64..)
+#define CSTAMP(i) do { if (g_ppo_dbg && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 64)) g_ppo_dbg[(threadIdx.x == 64 ? 64 : 0) + (i)] = clock64(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
 extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kernel(const float* __restrict__ pack, int off_critic, int bytes_actor,
                                                                                  int bytes_critic, PpoBatch Bt, const float* __restrict__ stdp,
                                                                                  float* __restrict__ act_stash, float* __restrict__ dz_stash,
@@ -238,6 +364,13 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
   const int row0 = tile * 16, row = row0 + n;
   const bool valid = row < B;
   const size_t src = (size_t)Bt.idx[min(row, B - 1)];
+  CSTAMP(0);
+#ifdef WBC_PPO_TIMING      // per-unit trace: [128 + 4 unit + {0, 1, 2, 3}] = wall clock (100 MHz) at start / end, shader clock at start / end
+  if (g_ppo_dbg && lane == 0) { g_ppo_dbg[128 + 4 * unit] = wall_clock64(); g_ppo_dbg[128 + 4 * unit + 2] = clock64(); }
+#define CH_UNIT_END() do { if (g_ppo_dbg && lane == 0) { g_ppo_dbg[128 + 4 * unit + 1] = wall_clock64(); g_ppo_dbg[128 + 4 * unit + 3] = clock64(); } } while (0)
+#else
+#define CH_UNIT_END() do { } while (0)
+#endif
   ChainRing R;
   R.init(pack + (critic ? off_critic : 0), critic ? bytes_critic : bytes_actor, lane);
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(act_stash, 0, Bs * (A_LD * 4), CH_RSRC_FLAGS);
@@ -255,6 +388,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
     zin[q] = v;
   }
   f32x4 hbb[8];
+  CSTAMP(1);
   if (!critic) {
     // the x slab and the proprio part of the z = [prop, latent] slab (inputs of the priv0 / cbb / bb weight gradients)
 #pragma unroll
@@ -264,36 +398,57 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
       if (c < PT_NPROP) ch_st4(ars, v100 + 64 * q, A_Z * slab, zin[q]);
     }
     f32x4 h1[4], lat[2];
-    chain_fwd<4, 3, 0, true, true>(R, zin + 4, h1, ars, v64, A_H1 * slab);
-    chain_fwd<2, 4, 16, true, false>(R, h1, lat, ars, 0, 0);
-    (void)R.take(26 % CH_D);
+    chain_fwd<4, 3, 0, true>(R, zin + 4, h1, ars, v64, A_H1 * slab);
+    chain_fwd<2, 4, 16 % CH_D, false>(R, h1, lat, ars, 0, 0);
+#pragma unroll
+    for (int s = 0; s < CH_PAD_PRIV; ++s) (void)R.take((26 + s) % CH_D);
     // latent: the 20-wide slab and the z slab's columns 76..95
     ch_st4(ars, v20, A_LAT * slab, lat[0]);
     ch_st4(ars, v100 + 4 * PT_NPROP, A_Z * slab, lat[0]);
     if (g == 0) { ch_st4(ars, v20 + 64, A_LAT * slab, lat[1]); ch_st4(ars, v100 + 4 * PT_NPROP + 64, A_Z * slab, lat[1]); }
     zin[5] = lat[0]; zin[6] = lat[1];
   }
+  CSTAMP(2);
   // backbone (actor: [prop, latent] -> 128; critic: x -> 128): the same code, the stream holds the part's weights
-  chain_fwd<8, 7, 0, true, true>(R, zin, hbb, ars, v128, (critic ? A_CB : A_BB) * slab);
+  const int bb_a = (critic ? A_CB : A_BB) * slab, bb_d = (critic ? D_CB : D_BB) * slab;
+  chain_fwd<8, 7, 0, true>(R, zin, hbb, ars, v128, bb_a);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) (void)R.take((64 + s) % CH_D);
+  for (int s = 0; s < CH_PAD_BB; ++s) (void)R.take((64 + s) % CH_D);
+  CSTAMP(3);
+  // per-row inputs of the loss terms, requested a whole head chain ahead of their use
+  float ld_a[2][4], ld_p[2], ld_q[2];                 // actor: actions of this lane's features, old log-probs, advantages; critic: old values, returns
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = 4 * g + r;
+      const bool ok = c ? jj < PT_NARM : jj < PT_NLEG;
+      ld_a[c][r] = critic ? 0.f : Bt.actions[src * 18 + (ok ? (c ? PT_NLEG + jj : jj) : 0)];
+    }
+    ld_p[c] = critic ? Bt.old_values[src * 2 + c] : Bt.old_logp[src * 2 + c];
+    ld_q[c] = critic ? Bt.returns[src * 2 + c] : Bt.advantages[src * 2 + c];
+  }
   // the two heads of the part: 128 -> 128 -> 128 -> (12 | 6 | 1 | 1)
-  f32x4 out0 = (f32x4){0.f, 0.f, 0.f, 0.f}, out1 = out0;
+  f32x4 out0 = CH_Z4, out1 = CH_Z4;
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     const int c_l0 = critic ? (h ? A_CA1 : A_CL1) : (h ? A_A1 : A_L1), c_l2 = critic ? (h ? A_CA2 : A_CL2) : (h ? A_A2 : A_L2);
-    f32x4 a1[8], a2[8], o[1];
-    chain_fwd<8, 8, 0, true, true>(R, hbb, a1, ars, v128, c_l0 * slab);
-    chain_fwd<8, 8, 0, true, true>(R, a1, a2, ars, v128, c_l2 * slab);
-    chain_fwd<1, 8, 0, false, false>(R, a2, o, ars, 0, 0);
+    f32x4 a1[8], a2[8];
+    chain_fwd<8, 8, 0, true>(R, hbb, a1, ars, v128, c_l0 * slab);
+    CSTAMP(4 + 3 * h);
+    chain_fwd<8, 8, 72 % CH_D, true>(R, a1, a2, ars, v128, c_l2 * slab);
+    CSTAMP(5 + 3 * h);
+    f32x4 o = chain_head<8, 144 % CH_D>(R, a2);
+    CSTAMP(6 + 3 * h);
     if (!critic) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[0][r] = tanhf(o[0][r]);
+      for (int r = 0; r < 4; ++r) o[r] = tanhf(o[r]);
       const int w = h ? 8 : PT_NLEG;
-      if (4 * g < w) ch_st4(ars, (row * w + 4 * g) * 4, (h ? A_ARM : A_LEG) * slab, o[0]);
+      if (4 * g < w) ch_st4(ars, (row * w + 4 * g) * 4, (h ? A_ARM : A_LEG) * slab, o);
     }
-    if (h == 0) out0 = o[0]; else out1 = o[0];
+    if (h == 0) out0 = o; else out1 = o;
   }
+  CSTAMP(10);
   // ---- losses and output gradients (PPO:199-216) -------------------------------------------------------------------------
   const float inv2B = 1.f / (2.f * (float)B), invB = 1.f / (float)B;
   f32x4 dz0 = (f32x4){0.f, 0.f, 0.f, 0.f}, dz1 = dz0;
@@ -309,17 +464,17 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
         const int j = ok[c][r] ? (c ? PT_NLEG + jj : jj) : 0;
         const float mu = c ? out1[r] : out0[r];
         sd[c][r] = stdp[j];
-        d[c][r] = Bt.actions[src * 18 + j] - mu;
+        d[c][r] = ld_a[c][r] - mu;
         const float term = -(d[c][r] * d[c][r]) / (2.f * sd[c][r] * sd[c][r]) - logf(sd[c][r]) - 0.91893853320467274178f;
         if (ok[c][r]) lp[c] += term;
       }
     lp[0] = ch_sum_g(lp[0]); lp[1] = ch_sum_g(lp[1]);
-    const float adv0 = Bt.advantages[src * 2], adv1 = Bt.advantages[src * 2 + 1];
+    const float adv0 = ld_q[0], adv1 = ld_q[1];
     const float mixed[2] = {adv0 + Bt.mixing * adv1, adv1 + Bt.mixing * adv0};               // PPO:199-201
     float dlp[2], surr = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const float ratio = expf(lp[c] - Bt.old_logp[src * 2 + c]);                               // PPO:202
+      const float ratio = expf(lp[c] - ld_p[c]);                               // PPO:202
       const float rc = fminf(fmaxf(ratio, 1.f - Bt.clip), 1.f + Bt.clip);
       const float s1 = -mixed[c] * ratio, s2 = -mixed[c] * rc;                                  // PPO:203-205
       surr += fmaxf(s1, s2);
@@ -353,7 +508,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
     float vls = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {                                                                 // PPO:209-216
-      const float v = c ? out1[0] : out0[0], ov = Bt.old_values[src * 2 + c], Rt = Bt.returns[src * 2 + c];
+      const float v = c ? out1[0] : out0[0], ov = ld_p[c], Rt = ld_q[c];
       float dv;
       if (Bt.use_clipped_value_loss) {
         const float dlt = v - ov;
@@ -375,9 +530,10 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
     if (lane == 0) loss_partial[(size_t)tile * 3 + 1] = vls;
   }
   // ---- backward ----------------------------------------------------------------------------------------------------------
+  CSTAMP(11);
   f32x4 dbb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dbb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < 8; ++j) dbb[j] = CH_Z4;
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     const int c_l0 = critic ? (h ? A_CA1 : A_CL1) : (h ? A_A1 : A_L1), c_l2 = critic ? (h ? A_CA2 : A_CL2) : (h ? A_A2 : A_L2);
@@ -388,21 +544,19 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
     dzo[0] = h ? dz1 : dz0;
     if (4 * g < w_hd) ch_st4(drs, (row * w_hd + 4 * g) * 4, e_hd * slab, dzo[0]);
     f32x4 d2[8], d1[8];
-    chain_bwd<8, 1, 0, true, false>(R, dzo, d2, ars, c_l2 * slab, drs, e_l2 * slab, v128);
-    chain_bwd<8, 8, 8, true, false>(R, d2, d1, ars, c_l0 * slab, drs, e_l0 * slab, v128);
-    chain_bwd<8, 8, 72 % CH_D, false, true>(R, d1, dbb, ars, 0, drs, 0, 0);
+    chain_bwd_deriv<8, 1, 0, true>(R, dzo, d2, ars, c_l2 * slab, drs, e_l2 * slab, v128);
+    CSTAMP(12 + 3 * h);
+    chain_bwd_deriv<8, 8, 8 % CH_D>(R, d2, d1, ars, c_l0 * slab, drs, e_l0 * slab, v128);
+    CSTAMP(13 + 3 * h);
+    chain_bwd_accreg<8, 8, 72 % CH_D>(R, d1, dbb);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) (void)R.take((136 + s) % CH_D);
+    for (int s = 0; s < CH_PAD_BWD; ++s) (void)R.take((136 + s) % CH_D);
+    CSTAMP(14 + 3 * h);
   }
-  {                                                      // through the backbone's ELU
-    const int asoff = (critic ? A_CB : A_BB) * slab, dsoff = (critic ? D_CB : D_BB) * slab;
-    f32x4 a[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = ch_ld4(ars, v128 + 64 * j, asoff);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { dbb[j] = ch_delu4(dbb[j], a[j]); ch_st4(drs, v128 + 64 * j, dsoff, dbb[j]); }
-  }
-  if (critic) return;
+  for (int j = 0; j < 8; ++j) { dbb[j] = ch_delu4(dbb[j], hbb[j]); ch_st4(drs, v128 + 64 * j, bb_d, dbb[j]); }      // through the backbone's ELU
+  CSTAMP(18);
+  if (critic) { CH_UNIT_END(); return; }
   // actor: latent gradient = backbone's input gradient (columns 76..95) + the ROA regulariser's (PPO:174-179), then priv2, priv0
   {
     f32x4 lat[2];
@@ -424,7 +578,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
     preg = ch_sum_n(preg);
     if (lane == 0) loss_partial[(size_t)tile * 3 + 2] = preg;
     f32x4 dlat[2];
-    chain_bwd<2, 8, 0, false, false>(R, dbb, dlat, ars, 0, drs, 0, 0);
+    chain_bwd_plain<2, 8, 0>(R, dbb, dlat);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { dlat[0][r] += sc * dl0[r]; dlat[1][r] += sc * dl1[r]; }
     dlat[0] = ch_delu4(dlat[0], lat[0]);
@@ -433,6 +587,8 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kerne
     ch_st4(drs, v20, D_LAT * slab, dlat[0]);
     if (g == 0) ch_st4(drs, v20 + 64, D_LAT * slab, dlat[1]);
     f32x4 dh1[4];
-    chain_bwd<4, 2, 16 % CH_D, true, false>(R, dlat, dh1, ars, A_H1 * slab, drs, D_H1 * slab, v64);
+    chain_bwd_deriv<4, 2, 16 % CH_D>(R, dlat, dh1, ars, A_H1 * slab, drs, D_H1 * slab, v64);
   }
+  CSTAMP(19);
+  CH_UNIT_END();
 }

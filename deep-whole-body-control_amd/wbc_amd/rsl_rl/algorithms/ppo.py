@@ -252,7 +252,7 @@ class PPO:
             assert off == ng - 3
             self._fused = dict(mb=mb, grad=grad, nparam=off, ws=torch.empty(L.wbc_ppo_workspace_floats(mb), device=dev),
                                hist=torch.empty(batch, 20, device=dev), m=torch.zeros(off, device=dev), v=torch.zeros(off, device=dev),
-                               adam_ws=torch.empty(64, device=dev), sq_off=int(L.wbc_ppo_sq_partials_offset(mb)))
+                               adam_ws=torch.empty(int(L.wbc_ppo_clip_adam_workspace_floats()), device=dev), sq_off=int(L.wbc_ppo_sq_partials_offset(mb)))
         F = self._fused
         for p, g in zip(params, torch.split(F["grad"][:F["nparam"]], [p.numel() for p in params])):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():

@@ -337,8 +337,10 @@ size_t wbc_ppo_sq_partials_offset(int B);
  * sqrt(1-beta2^t). max_norm <= 0 disables the clip. grad_scale (> 0) multiplies the gradient before the clip: 1 on one GPU,
  * 1 / world_size after the SUM all-reduce of the sharded learner (the mean over ranks without a separate launch).
  * sq_partials: the partial sums of squares wbc_ppo_minibatch_grad left for THIS gradient (pass them only while grad is
- * exactly what that call wrote -- not after an all-reduce), or NULL: the norm is then computed by a pass over grad.
- * workspace: >= 64 floats. Deterministic. */
+ * exactly what that call wrote -- not after an all-reduce), or NULL: the same partials are then recomputed from grad (same
+ * blocks, same order: the two ways give the same bits for the same gradient).
+ * workspace: >= wbc_ppo_clip_adam_workspace_floats() floats. Deterministic. */
+int wbc_ppo_clip_adam_workspace_floats(void);
 int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm,
                       float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
                       const float* sq_partials, float* workspace, void* stream);

@@ -7,7 +7,7 @@ done
 python - <<'PY'
 import csv, glob, os, collections
 R=os.environ['GRAFT_REPO_ROOT']
-for kn in ("ppo_fwd_bwd","ppo_wgrad_kernel"):
+for kn in ("ppo_chain","ppo_fwd_bwd","ppo_wgrad_kernel"):
     print(kn)
     for f in sorted(glob.glob(R+'/gpurun_out/pmc_ppo/*/*/*counter_collection.csv')):
         acc=collections.defaultdict(lambda: [0,0])

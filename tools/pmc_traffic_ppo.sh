@@ -8,7 +8,7 @@ done
 python - <<'PY'
 import csv, glob, os, statistics
 R=os.environ['GRAFT_REPO_ROOT']
-for kn in ("ppo_fwd_bwd16_kernel", "ppo_wgrad_kernel", "ppo_layer_reduce_kernel", "wbc_pack16_kernel"):
+for kn in ("ppo_chain_kernel", "ppo_wgrad_kernel", "ppo_grad_reduce_kernel", "chain_pack_kernel"):
     for c in ("FETCH_SIZE","WRITE_SIZE"):
         f=sorted(glob.glob(f"{R}/gpurun_out/pmc_traffic_ppo/{c}/*/*counter_collection.csv"))[-1]
         v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith(kn) and r['Counter_Name']==c]

@@ -2,7 +2,7 @@
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-_lib = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_ppotiming.so")   # tools/build_variant.py ppotiming -DWBC_PPO_TIMING
+_lib = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", os.environ.get("WBC_TIMING_LIB", "libwbc_amd_ppotiming.so"))   # tools/build_variant.py ppotiming -DWBC_PPO_TIMING
 if os.path.exists(_lib) and os.environ.get("WBC_STAMPS"):
     os.environ["WBC_AMD_LIB"] = _lib
 import torch
@@ -34,15 +34,30 @@ e1.record(); torch.cuda.synchronize()
 print(f"minibatch B={B}: {e0.elapsed_time(e1)/NIT*1000:.1f} us per call (pack + fwd_bwd + wgrad + reducers)")
 if os.environ.get("WBC_STAMPS"):
     L.wbc_debug_set_ppo_timing.argtypes = [C.c_void_p]
-    buf = torch.zeros(128, dtype=torch.int64, device=dev)
+    buf = torch.zeros(128 + 4 * 2 * ((B + 15) // 16) + 64, dtype=torch.int64, device=dev)
     L.wbc_debug_set_ppo_timing(buf.data_ptr())
     run(); torch.cuda.synchronize()
     t = buf.cpu().numpy()
-    names = ["load x", "forward 16 layers", "z stash", "losses"] + [f"bwd stage {i}" for i in range(14)]
-    d = [int(t[i + 1] - t[i]) for i in range(18)]
-    print("workgroup 0 cycles:", dict(zip(names, d)), "total", int(t[18] - t[0]))
-    for l in range(16):
-        q = t[32 + 4 * l: 36 + 4 * l]
-        nxt = t[32 + 4 * (l + 1)] if l < 15 else q[3]
-        print(f"  fwd layer {l:2d}: mfma chain {int(q[1]-q[0]):6d}  epilogue {int(q[2]-q[1]):6d}  barrier {int(q[3]-q[2]):6d}  to next layer start {int(nxt-q[3]):6d}")
+    names = ["ring init + gather", "priv0/priv2 (actor)", "backbone", "h0 L0", "h0 L2", "h0 head", "h1 L0", "h1 L2", "h1 head", "(pad)", "loss", "h0 headT", "h0 L2T", "h0 L0T",
+             "h1 headT", "h1 L2T", "h1 L0T", "backbone ELU'", "latent/priv2T (actor)"]
+    for base, who in ((0, "actor unit 0"), (64, "critic unit 1")):
+        q = t[base:base + 20]
+        d = {names[i]: int(q[i + 1] - q[i]) for i in range(19) if q[i + 1] > 0 and q[i] > 0}
+        print(who, "cycles:", d, "total", int(max(q) - q[0]))
+    import numpy as np
+    nu = 2 * ((B + 15) // 16)
+    u = t[128:128 + 4 * nu].reshape(nu, 4).astype(np.float64)
+    if u[:, 1].max() > 0:
+        t0 = u[:, 0].min()
+        st, en = (u[:, 0] - t0) / 100.0, (u[:, 1] - t0) / 100.0                      # us (100 MHz wall clock)
+        dur = en - st
+        ghz = (u[:, 3] - u[:, 2]) / (dur * 1000.0)
+        print(f"units {nu}: kernel span {en.max():.1f} us; unit duration actor {dur[0::2].mean():.1f} us critic {dur[1::2].mean():.1f} us; shader clock {np.median(ghz):.2f} GHz")
+        order = np.argsort(st)
+        for q in (0.0, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0):
+            i = order[min(nu - 1, int(q * (nu - 1)))]
+            print(f"   start quantile {q:.2f}: unit {i} starts {st[i]:.1f} us, runs {dur[i]:.1f} us")
+        edges = np.linspace(0, en.max(), 11)
+        active = [(int(((st < b) & (en > a)).sum())) for a, b in zip(edges[:-1], edges[1:])]
+        print("   units alive per tenth of the span:", active)
     L.wbc_debug_set_ppo_timing(None)
