@@ -29,6 +29,9 @@
 #define CH_PAD_BB ((CH_D - 64 % CH_D) % CH_D)
 #define CH_PAD_BWD ((CH_D - 136 % CH_D) % CH_D)
 static_assert(153 % CH_D == 0, "ring depth");
+#ifndef CH_WG
+#define CH_WG 256                 // threads per workgroup: CH_WG / 64 independent units (nothing is shared between its waves)
+#endif
 #ifndef CH_OCC
 #define CH_OCC 2                  // waves per SIMD the register budget is set for
 #endif
@@ -349,13 +352,13 @@ static __device__ __forceinline__ float ch_sum_n(float v) {                     
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
-extern "C" __global__ void __launch_bounds__(PT_THREADS, CH_OCC) ppo_chain_kernel(const float* __restrict__ pack, int off_critic, int bytes_actor,
+extern "C" __global__ void __launch_bounds__(CH_WG, CH_OCC) ppo_chain_kernel(const float* __restrict__ pack, int off_critic, int bytes_actor,
                                                                                  int bytes_critic, PpoBatch Bt, const float* __restrict__ stdp,
                                                                                  float* __restrict__ act_stash, float* __restrict__ dz_stash,
                                                                                  float* __restrict__ dstd_partial, float* __restrict__ loss_partial,
                                                                                  int ntiles) {
   const int lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * (PT_THREADS / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int unit = blockIdx.x * (CH_WG / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = unit >> 1;
   const bool critic = (unit & 1) != 0;                 // wave-uniform
   if (tile >= ntiles) return;

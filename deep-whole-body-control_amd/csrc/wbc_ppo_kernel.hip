@@ -463,7 +463,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   const ChainStreams& S = chain_streams();
   const int tiles16 = (B + 15) / 16;
   hipLaunchKernelGGL(chain_pack_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, st, P, S, wpack);
-  hipLaunchKernelGGL(ppo_chain_kernel, dim3(2 * ((tiles16 + 3) / 4)), dim3(PT_THREADS), 0, st, wpack, S.base[1], S.nelem[0] * 1024, S.nelem[1] * 1024, Bt,
+  hipLaunchKernelGGL(ppo_chain_kernel, dim3((2 * tiles16 + CH_WG / 64 - 1) / (CH_WG / 64)), dim3(CH_WG), 0, st, wpack, S.base[1], S.nelem[0] * 1024, S.nelem[1] * 1024, Bt,
                      P.std, act_stash, dz_stash, dstd_partial, loss_partial, tiles16);
   WgradPlan plan;
   RedTable red;
