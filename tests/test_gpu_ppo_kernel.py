@@ -145,3 +145,29 @@ def test_fused_history_encoder_gradients_match_autograd(batch, rows):
                                 ws.data_ptr(), grad2.data_ptr(), stream))
     torch.cuda.synchronize()
     assert torch.equal(grad, grad2)
+
+
+@pytest.mark.parametrize("B", [40960, 1000])
+def test_fused_minibatch_is_bitwise_reproducible(B):
+    """wbc_ppo_minibatch_grad has no atomics and a fixed reduction order: two calls on the same inputs (into workspaces filled with
+    NaN: nothing uninitialised is read) give the same gradient bit for bit, at the bench's minibatch size and at a ragged one."""
+    from wbc_amd.native import check, lib
+    L = lib()
+    torch.manual_seed(0)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
+    TN, dev = 2 * B, "cuda"
+    obs = torch.randn(TN, 860, device=dev); actions = torch.randn(TN, 18, device=dev); values = torch.randn(TN, 2, device=dev)
+    adv = torch.randn(TN, 2, device=dev); ret = torch.randn(TN, 2, device=dev); logp = -torch.rand(TN, 2, device=dev) * 20
+    hist = torch.randn(TN, 20, device=dev); idx = torch.randperm(TN, device=dev)[:B].contiguous()
+    table = ac.fused_param_table()
+    stream = torch.cuda.current_stream().cuda_stream
+    grads = []
+    for _ in range(2):
+        ws = torch.full((L.wbc_ppo_workspace_floats(B),), float("nan"), device=dev)
+        grad = torch.zeros(L.wbc_ppo_grad_floats(), device=dev)
+        check(L.wbc_ppo_minibatch_grad(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp.data_ptr(),
+                                       hist.data_ptr(), idx.data_ptr(), B, 0.2, 1.0, 0.5, 0.1, 1, ws.data_ptr(), grad.data_ptr(), None, stream), "grad")
+        torch.cuda.synchronize()
+        grads.append(grad.clone())
+    assert torch.isfinite(grads[0]).all()
+    assert torch.equal(grads[0], grads[1])
