@@ -452,6 +452,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   hipStream_t st = (hipStream_t)stream;
   const int ng = wbc_ppo_grad_floats();
   const int Bs = ppo_slab_rows(B);          // rows per stash slab
+  if ((long long)Bs * A_LD * 4 >= (1ll << 31)) return -3;          // the update kernel addresses a stash with 32-bit buffer offsets (B < 338 000 rows)
   float* act_stash = workspace;
   float* dz_stash = act_stash + (size_t)Bs * A_LD;
   float* dstd_partial = dz_stash + (size_t)Bs * D_LD;

@@ -324,7 +324,7 @@ int wbc_hist_latent(const void* const* params, const float* obs, float* out, int
  * stored row (constant during update()). `workspace`: wbc_ppo_workspace_floats(B) floats. `loss_accum` (device, 3 floats,
  * or NULL): the three loss sums are also ADDED to it (an update's running totals without a launch of its own).
  * Also leaves, at workspace + wbc_ppo_sq_partials_offset(B), partial sums of squares of the gradient it wrote
- * (wbc_ppo_clip_adam's `sq_partials`). Deterministic. */
+ * (wbc_ppo_clip_adam's `sq_partials`). Deterministic. B < 338 000 rows (32-bit offsets into the workspace); -3 beyond. */
 int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions,
                            const float* old_values, const float* advantages, const float* returns,
                            const float* old_logp, const float* hist_latent, const int64_t* idx, int B,
