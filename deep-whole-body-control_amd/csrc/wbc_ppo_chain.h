@@ -151,11 +151,7 @@ struct ChainRing {
   // the element at ring slot `slot` (a compile-time constant after unrolling); its slot is refilled from the stream head
   __device__ __forceinline__ f32x4 take(int slot) {
     const f32x4 v = r[slot];
-#ifdef CH_EXP_L1          // experiment: the whole stream aliased onto 8 KB (L1 resident; results wrong)
-    r[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, so & CH_EXP_L1, 0));
-#else
     r[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, so, 0));
-#endif
     so += 1024;
     CH_PIN();
     return v;
@@ -167,9 +163,6 @@ static __device__ __forceinline__ f32x4 ch_ld4(__amdgpu_buffer_rsrc_t rs, int vo
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 static __device__ __forceinline__ void ch_st4(__amdgpu_buffer_rsrc_t rs, int voff, int soff, f32x4 v) {
-#ifdef CH_EXP_HOTSTORE    // experiment: every stash store lands in one 4 KB window per slab (results wrong)
-  voff &= 0xfff;
-#endif
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff, 0);
 }
 // 8 MFMAs on two independent accumulators, strictly alternating (one asm statement: the compiler neither reorders them nor
