@@ -7,6 +7,7 @@
 // one thread per env walks the 6-joint arm chain (forward kinematics in the base frame F, composite spatial inertias
 // from the tip inwards, M_ij = S_i^T Ic_j S_j) -- an optional, once-per-step pre-pass (torque_supervision=False as shipped).
 #include "wbc_device.h"
+#include "wbc_stream_guard.h"
 
 #define ARM_N 6
 #define ARM_NLINK 9          // rigid bodies whose weight the reference compensates: the last 9 of the actor
@@ -166,6 +167,7 @@ extern "C" int wbc_sim_internal_arm_inputs(wbc_sim* s, const DevConst** hc, cons
 // link_mass9: masses of the actor's last 9 rigid bodies (host pointer). Outputs (device): mm f32 [N,6,6], jac f32 [N,6,6]
 // (rows linear xyz then angular xyz, world frame), gtorque f32 [N,6].
 extern "C" int wbc_sim_arm_dynamics(wbc_sim* s, const int* link_rb9, const float* link_mass9, float* mm, float* jac, float* gtorque, void* stream) {
+  StreamDeviceGuard sdg(stream);
   const DevConst* hc; const float *root, *dofs, *bp, *mp; int n;
   if (!s || !link_rb9 || !link_mass9 || !mm || !jac || !gtorque) return -1;
   if (wbc_sim_internal_arm_inputs(s, &hc, &root, &dofs, &bp, &mp, &n) != 0) return -1;

@@ -5,6 +5,7 @@
 // The joint normalisation over both channels (RS:150, unbiased std) is a third, elementwise launch so
 // that a multi-GPU learner can all-reduce the three statistics in between.
 #include <hip/hip_runtime.h>
+#include "wbc_stream_guard.h"
 #include <stdint.h>
 
 #include <string>
@@ -68,6 +69,7 @@ extern "C" int wbc_gae_workspace_doubles(int N) { return 3 + 2 * ((2 * N + GAE_B
 
 extern "C" int wbc_gae_compute(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, float* returns,
                                float* advantages, double* stats_dev, int T, int N, float gamma, float lam, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!rewards || !values || !dones || !last_values || !returns || !advantages || !stats_dev || T <= 0 || N <= 0) return -1;
   const int nblocks = (2 * N + GAE_BLOCK - 1) / GAE_BLOCK;
   hipLaunchKernelGGL(gae_scan_kernel, dim3(nblocks), dim3(GAE_BLOCK), 0, (hipStream_t)stream, rewards, values, dones, last_values, returns,
@@ -77,6 +79,7 @@ extern "C" int wbc_gae_compute(const float* rewards, const float* values, const 
 }
 
 extern "C" int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t total, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!advantages || !stats_dev || total <= 0) return -1;
   int64_t blocks = (total + GAE_BLOCK - 1) / GAE_BLOCK;
   if (blocks > 2048) blocks = 2048;
@@ -102,6 +105,7 @@ extern "C" __global__ void __launch_bounds__(256) rollout_store_kernel(const flo
 
 extern "C" int wbc_rollout_store(const float* rew, const float* arm_rew, const int64_t* dones, const uint8_t* time_outs, const float* values,
                                  float gamma, float* out_rewards, uint8_t* out_dones, int n, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!rew || !arm_rew || !dones || !values || !out_rewards || !out_dones || n <= 0) return -1;
   hipLaunchKernelGGL(rollout_store_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, arm_rew, dones, time_outs, values, gamma,
                      out_rewards, out_dones, n);

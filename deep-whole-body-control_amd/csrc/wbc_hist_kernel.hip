@@ -10,6 +10,7 @@
 // Persistent workgroups walk over groups of 24 rows; the weights of the two big layers stay in registers, activations in
 // LDS (45 KB). 450 -> 230 us for 163840 rows.
 #include <hip/hip_runtime.h>
+#include "wbc_stream_guard.h"
 #include <stdint.h>
 
 #define H_T 10
@@ -163,6 +164,7 @@ extern "C" __global__ void __launch_bounds__(H_THREADS, 2) wbc_hist_latent_small
 // C-ABI. params: 8 device pointers (encoder.0.weight [30,76], .bias, conv_layers.0.weight [20,30,4], .bias,
 // conv_layers.2.weight [10,20,2], .bias, linear_output.0.weight [20,30], .bias); obs f32 [rows, 860]; out f32 [rows, 20].
 extern "C" int wbc_hist_latent(const void* const* params, const float* obs, float* out, int rows, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!params || !obs || !out || rows <= 0) return -1;
   HistParams P;
   const float** dst = reinterpret_cast<const float**>(&P);

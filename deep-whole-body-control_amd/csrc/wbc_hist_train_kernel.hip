@@ -16,6 +16,7 @@
 // is an MFMA GEMM over the 240 (row, time step) pairs of a group with B operands re-read from obs (L2). At the end each
 // workgroup writes ONE partial gradient vector; hist_reduce_kernel sums them in workgroup order (deterministic).
 #include <hip/hip_runtime.h>
+#include "wbc_stream_guard.h"
 #include <stdint.h>
 
 #define H_T 10
@@ -479,6 +480,7 @@ extern "C" size_t wbc_hist_train_workspace_floats(void) { return (size_t)HIST_TR
 
 extern "C" int wbc_hist_train_grad(const void* const* params, const float* obs, const float* target, const long long* idx, int rows,
                                    float* workspace, float* grad, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!params || !obs || !target || !idx || !workspace || !grad || rows <= 0) return -1;
   HistParams P;
   const float** dst = reinterpret_cast<const float**>(&P);
@@ -494,6 +496,7 @@ extern "C" int wbc_hist_train_grad(const void* const* params, const float* obs, 
 extern "C" int wbc_hist_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
                                   float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, int grad_was_reduced,
                                   const float* workspace, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace || !(grad_scale > 0.f)) return -1;
   static const int sizes[8] = {H_C1 * H_NP, H_C1, H_C2 * H_C1 * 4, H_C2, H_C3 * H_C2 * 2, H_C3, H_OUT * H_C1, H_OUT};
   HistAdamTable T;
@@ -506,6 +509,7 @@ extern "C" int wbc_hist_clip_adam(const void* const* params, float* grad, float*
 }
 
 extern "C" int wbc_priv_latent(const void* const* params, const float* obs, float* out, int rows, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!params || !obs || !out || rows <= 0) return -1;
   for (int i = 0; i < 4; ++i) if (!params[i]) return -1;
   hipLaunchKernelGGL(priv_latent_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)params[0], (const float*)params[1],

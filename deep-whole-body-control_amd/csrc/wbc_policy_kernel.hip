@@ -10,6 +10,7 @@
 // Grid = (row tiles, 2): blockIdx.y = 0 runs the actor (9 layers), 1 the critic (7 layers), so that 4096 envs give
 // 256 workgroups (one per CU) and the dependent layer chain per workgroup is half as long.
 #include "wbc_mlp.h"
+#include "wbc_stream_guard.h"
 
 // ==== 16-row tiles (v_mfma_f32_16x16x4_f32) =====================================================================
 // 4096 envs would be only 128 tiles of 32 rows (the first version: v_mfma_f32_32x32x2_f32, one workgroup per CU, one wave per
@@ -124,6 +125,7 @@ extern "C" int wbc_policy_pack_floats(void) { return WPACK16_OFF + WPACK16_FLOAT
 
 // Re-pack the weights into MFMA fragment order (call after the parameters changed).
 extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* stream) {
+  StreamDeviceGuard sdg(stream);
   PolicyParams P;
   if (!params || !wpack || (reinterpret_cast<uintptr_t>(wpack) & 15) || fill_params(params, &P)) return -1;
   hipLaunchKernelGGL(wbc_pack16_kernel, dim3(8, NLAYERS, 1), dim3(256), 0, (hipStream_t)stream, P, make_pack16_table(), wpack + WPACK16_OFF);
@@ -132,6 +134,7 @@ extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* st
 
 extern "C" int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* latent, const float* eps,
                               float* actions, float* mean, float* logp, float* values, int num_rows, void* stream) {
+  StreamDeviceGuard sdg(stream);
   PolicyParams P;
   if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
   static const Tab16 T16 = make_tab16();

@@ -14,6 +14,7 @@
 // Everything is deterministic (no atomics). The history-encoder latent that the regulariser targets is an
 // input (its weights do not change during update(), PPO:175-176).
 #include "wbc_mlp.h"
+#include "wbc_stream_guard.h"
 
 // ---- stash layouts (floats per row) -------------------------------------------------------------
 // every block starts at a multiple of 4 floats and the row strides are multiples of 4: float4 accesses stay aligned
@@ -445,6 +446,7 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
                                       const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
                                       const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
                                       int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream) {
+  StreamDeviceGuard sdg(stream);
   PolicyParams P;
   if (!params || !obs || !actions || !old_values || !advantages || !returns || !old_logp || !hist_latent || !idx || !workspace || !grad ||
       B <= 0 || fill_params(params, &P))
@@ -484,6 +486,7 @@ extern "C" int wbc_ppo_clip_adam_workspace_floats(void) { return PPO_SQ_PARTS; }
 extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
                                  float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, const float* sq_partials, float* workspace,
                                  void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace || !(grad_scale > 0.f)) return -1;
   AdamTable T;
   int off = 0, j = 0;

@@ -26,6 +26,15 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// Every entry point runs with the sim's device current and leaves the caller's current device as it found it (a caller that
+// keeps the env on cuda:1 without torch.cuda.set_device(1) would otherwise launch into a stream of another device, and the
+// setters would switch its device underneath it).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct TensorSpec { int dims[3]; int ndim; int dtype; };
 static const TensorSpec kSpecs[WBC_T_COUNT] = {
     {{2, 13, 0}, 2, WBC_F32}, {{20, 2, 0}, 2, WBC_F32}, {{28, 3, 0}, 2, WBC_F32}, {{28, 13, 0}, 2, WBC_F32},
@@ -126,7 +135,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
                               size_t arena_bytes, wbc_sim** out) {
   if (!model || !cfg || !out || num_envs <= 0) return fail(-1, "wbc_sim_create: bad arguments");
   if (model->ncp != WBC_NCP) return fail(-1, "wbc_sim_create: model.ncp must equal WBC_NCP");
-  HIP_OK(hipSetDevice(hip_device));
+  DeviceGuard dg(hip_device);
   wbc_sim* s = new wbc_sim();
   s->n = num_envs; s->device = hip_device; s->seed = seed;
   memset(&s->hc, 0, sizeof(DevConst));
@@ -193,7 +202,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
 
 extern "C" int wbc_sim_destroy(wbc_sim* s) {
   if (!s) return 0;
-  (void)hipSetDevice(s->device);
+  DeviceGuard dg(s->device);
   if (s->own_arena && s->arena) (void)hipFree(s->arena);
   if (s->dc) (void)hipFree(s->dc);
   if (s->dT) (void)hipFree(s->dT);
@@ -231,7 +240,7 @@ extern "C" int wbc_sim_set_env_params(wbc_sim* s, const float* friction, const f
                                       const float* gripper_dmass, const float* motor_strength, const float* env_origins,
                                       const float* box_delta_y, const float* traj_timesteps, const float* traj_total_timesteps) {
   if (!s) return fail(-1, "wbc_sim_set_env_params: null sim");
-  HIP_OK(hipSetDevice(s->device));
+  DeviceGuard dg(s->device);
   const int n = s->n;
   const wbc_model& m = s->hc.model;
   if (friction) HIP_OK(hipMemcpy(s->T.friction, friction, (size_t)n * 4, hipMemcpyHostToDevice));
@@ -270,7 +279,7 @@ extern "C" int wbc_sim_set_env_params(wbc_sim* s, const float* friction, const f
 
 extern "C" int wbc_sim_set_heightfield(wbc_sim* s, const int16_t* heights, int rows, int cols, float hs, float vs, float tx, float ty, float tz) {
   if (!s) return fail(-1, "wbc_sim_set_heightfield: null sim");
-  HIP_OK(hipSetDevice(s->device));
+  DeviceGuard dg(s->device);
   HIP_OK(hipDeviceSynchronize());
   if (s->hf_dev) { (void)hipFree(s->hf_dev); s->hf_dev = nullptr; }
   s->hc.hf = nullptr;
@@ -287,7 +296,7 @@ extern "C" int wbc_sim_set_heightfield(wbc_sim* s, const int16_t* heights, int r
 
 extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
   if (!s || !cur) return fail(-1, "wbc_sim_set_curriculum: bad arguments");
-  HIP_OK(hipSetDevice(s->device));
+  DeviceGuard dg(s->device);
   s->hc.cur = *cur;
   // plain (synchronising) copy: the previous step's kernel must not see a half-written table
   HIP_OK(hipDeviceSynchronize());      // a step kernel still in flight on a non-blocking stream reads DevConst.cur
@@ -298,6 +307,7 @@ extern "C" int wbc_sim_set_curriculum(wbc_sim* s, const wbc_curriculum* cur) {
 extern "C" int wbc_sim_step_rollout(wbc_sim* s, const float* actions_dev, float* obs_out_dev, const float* values_dev, float gamma,
                                     float* out_rewards_dev, uint8_t* out_dones_dev, void* stream) {
   if (!s || !actions_dev) return fail(-1, "wbc_sim_step: bad arguments");
+  DeviceGuard dg(s->device);
   if ((out_rewards_dev != nullptr) != (out_dones_dev != nullptr) || (out_rewards_dev && !values_dev))
     return fail(-1, "wbc_sim_step_rollout: values, out_rewards and out_dones go together");
   s->step_counter += 1;
@@ -313,6 +323,7 @@ extern "C" int wbc_sim_step(wbc_sim* s, const float* actions_dev, void* stream) 
 
 extern "C" int wbc_sim_reset_all(wbc_sim* s, void* stream) {
   if (!s) return fail(-1, "wbc_sim_reset_all: null sim");
+  DeviceGuard dg(s->device);
   hipLaunchKernelGGL(wbc_reset_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n, s->seed, (uint64_t)s->step_counter);
   HIP_OK(hipGetLastError());
   return 0;
@@ -320,6 +331,7 @@ extern "C" int wbc_sim_reset_all(wbc_sim* s, void* stream) {
 
 extern "C" int wbc_sim_set_dof_forces(wbc_sim* s, const float* torques_dev, void* stream) {
   if (!s || !torques_dev) return fail(-1, "wbc_sim_set_dof_forces: bad arguments");
+  DeviceGuard dg(s->device);
   if (torques_dev != s->T.torques)
     HIP_OK(hipMemcpyAsync(s->T.torques, torques_dev, (size_t)s->n * WBC_NDOF * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
@@ -327,6 +339,7 @@ extern "C" int wbc_sim_set_dof_forces(wbc_sim* s, const float* torques_dev, void
 
 extern "C" int wbc_sim_simulate(wbc_sim* s, void* stream) {
   if (!s) return fail(-1, "wbc_sim_simulate: null sim");
+  DeviceGuard dg(s->device);
   hipLaunchKernelGGL(wbc_simulate_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n);
   HIP_OK(hipGetLastError());
   return 0;
@@ -334,11 +347,13 @@ extern "C" int wbc_sim_simulate(wbc_sim* s, void* stream) {
 
 extern "C" int wbc_sim_set_root_state(wbc_sim* s, const float* root_dev, void* stream) {
   if (!s || !root_dev) return fail(-1, "wbc_sim_set_root_state: bad arguments");
+  DeviceGuard dg(s->device);
   if (root_dev != s->T.root) HIP_OK(hipMemcpyAsync(s->T.root, root_dev, (size_t)s->n * 26 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 extern "C" int wbc_sim_set_dof_state(wbc_sim* s, const float* dof_dev, void* stream) {
   if (!s || !dof_dev) return fail(-1, "wbc_sim_set_dof_state: bad arguments");
+  DeviceGuard dg(s->device);
   if (dof_dev != s->T.dof) HIP_OK(hipMemcpyAsync(s->T.dof, dof_dev, (size_t)s->n * 40 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
@@ -352,12 +367,14 @@ __global__ void copy_rows_indexed(float* dst, const float* src, const int32_t* i
 }
 extern "C" int wbc_sim_set_root_state_indexed(wbc_sim* s, const float* root_dev, const int32_t* env_ids_dev, int n, void* stream) {
   if (!s || !root_dev || !env_ids_dev) return fail(-1, "wbc_sim_set_root_state_indexed: bad arguments");
+  DeviceGuard dg(s->device);
   if (n > 0 && root_dev != s->T.root) hipLaunchKernelGGL(copy_rows_indexed, dim3(n), dim3(64), 0, (hipStream_t)stream, s->T.root, root_dev, env_ids_dev, n, 26, s->n);
   HIP_OK(hipGetLastError());
   return 0;
 }
 extern "C" int wbc_sim_set_dof_state_indexed(wbc_sim* s, const float* dof_dev, const int32_t* env_ids_dev, int n, void* stream) {
   if (!s || !dof_dev || !env_ids_dev) return fail(-1, "wbc_sim_set_dof_state_indexed: bad arguments");
+  DeviceGuard dg(s->device);
   if (n > 0 && dof_dev != s->T.dof) hipLaunchKernelGGL(copy_rows_indexed, dim3(n), dim3(64), 0, (hipStream_t)stream, s->T.dof, dof_dev, env_ids_dev, n, 40, s->n);
   HIP_OK(hipGetLastError());
   return 0;
@@ -369,6 +386,7 @@ extern "C" int wbc_sim_refresh_net_contact_force(wbc_sim*) { return 0; }
 extern "C" int wbc_sim_refresh_force_sensor(wbc_sim*) { return 0; }
 extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
   if (!s) return fail(-1, "wbc_sim_refresh_rigid_body_state: null sim");
+  DeviceGuard dg(s->device);
   hipLaunchKernelGGL(wbc_fk_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->T, s->dc, s->n);
   HIP_OK(hipGetLastError());
   return 0;
@@ -413,6 +431,7 @@ static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* 
 
 extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, const float* prev, float* out, void* stream) {
   if (!s || !out) return fail(-1, "wbc_sim_episode_stats: null argument");
+  DeviceGuard dg(s->device);
   hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC), dim3(256), 0, (hipStream_t)stream, s->T.ep_sums_done, s->T.met_sums_done,
                      s->T.reset_buf, s->n, scale, prev, out);
   return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");

@@ -13,6 +13,7 @@
 // decides the index of points that sit on a cell boundary; the kernel and the oracle do the same. No fused multiply-adds:
 // every product and sum below is rounded separately, as the reference's chain of element-wise kernels does.
 #include <hip/hip_runtime.h>
+#include "wbc_stream_guard.h"
 #include <stdint.h>
 
 extern "C" __global__ void __launch_bounds__(256) wbc_get_heights_kernel(const float* __restrict__ base_quat, int quat_stride,
@@ -49,6 +50,7 @@ extern "C" __global__ void __launch_bounds__(256) wbc_get_heights_kernel(const f
 extern "C" int wbc_get_heights(const float* base_quat, int quat_stride, const float* root_pos, int pos_stride, const float* height_points,
                                const int16_t* height_samples, int rows, int cols, float border_size, float horizontal_scale,
                                float vertical_scale, float* out, int num_envs, int num_points, void* stream) {
+  StreamDeviceGuard sdg(stream);
   if (!base_quat || !root_pos || !height_points || !height_samples || !out || rows < 2 || cols < 2 || num_envs <= 0 || num_points <= 0 ||
       quat_stride < 4 || pos_stride < 2 || !(horizontal_scale > 0.f))
     return -1;
