@@ -57,26 +57,12 @@ def _usable_cores(cap=16):
 
 
 CPU_BASELINE_THREADS = _usable_cores()
-REFERENCE_RSL_RL = "/root/reference/rsl_rl"          # exists in the build container only, never on the GPU box
 
 
 def _cpu_learner_classes():
-    """(kind, PPO, ActorCritic): the REFERENCE's own rsl_rl when its tree is present (imported read-only), else this
-    package's eager torch path (the same op sequence: tests/test_ppo_parity.py pins it to the reference's outputs)."""
-    if os.path.isdir(os.path.join(REFERENCE_RSL_RL, "rsl_rl")):
-        import contextlib
-        import io
-        sys.dont_write_bytecode = True
-        sys.path.insert(0, REFERENCE_RSL_RL)
-        try:
-            with contextlib.redirect_stdout(io.StringIO()):
-                from rsl_rl.algorithms import PPO
-                from rsl_rl.modules import ActorCritic
-            return "reference", PPO, ActorCritic
-        except Exception:
-            pass
-        finally:
-            sys.path.remove(REFERENCE_RSL_RL)
+    """(kind, PPO, ActorCritic) of the CPU baseline: always this package's eager torch path -- the same op sequence as the
+    reference's rsl_rl, pinned to it seed for seed by tests/test_ppo_parity.py -- so that the reported baseline does not depend
+    on which box runs the bench and no code outside this repository executes inside it."""
     from wbc_amd.rsl_rl.algorithms import PPO
     from wbc_amd.rsl_rl.modules import ActorCritic
     return "port", PPO, ActorCritic
@@ -138,7 +124,9 @@ def cpu_baseline(runner, sim_sample_envs=512):
         t_dag = time.perf_counter() - t0
     ret_s, upd_s = statistics.median(t_ret), statistics.median(t_upd)
     out = {"value": N * T / (ret_s + upd_s), "unit": "env-steps/s", "cores": nthreads, "kind": kind,
-           "sample": f"rsl_rl PPO-update path on the host ({'the reference tree' if kind == 'reference' else 'this package, eager torch CPU; the reference tree is absent on this box'}): "
+           "scope": "learner only: compute_returns + PPO.update on the host; a ceiling for a CPU run, not an end-to-end rate "
+                    "(the reference has no CPU simulator; sim_port below is this framework's scalar C oracle)",
+           "sample": f"rsl_rl PPO-update path on the host (this package's eager torch CPU path, pinned to the reference by tests/test_ppo_parity.py): "
                      f"compute_returns {ret_s * 1e3:.1f} ms + update() {upd_s:.2f} s (median of {len(t_upd)}; 5 epochs x 4 minibatches over the "
                      f"{N}x{T} rollout the GPU learner consumed), update_dagger() {t_dag:.2f} s (once); learner only, no CPU sim exists",
            "compute_returns_s": ret_s, "update_s": upd_s, "update_dagger_s": t_dag,
@@ -191,6 +179,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL process group even for one rank (exercises the multi-GPU code path on one GPU)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend: nccl = RCCL over xGMI (production); gloo = host-staged collectives (single-device rigs)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="all ranks on cuda:0 (needs --backend gloo): runs the sharded learner with world_size > 1 on a 1-GPU box; "
+                         "the ranks share the device, so the value is not a scaling figure")
+    ap.add_argument("--log", action="store_true",
+                    help="run the loop as train.py does (log_dir set: per-step episode bookkeeping, per-iteration log text, checkpoints)")
     ap.add_argument("--terrain", choices=["plane", "trimesh", "grid"], default="plane",
                     help="plane = BASELINE.json configs[1] (the bench line); trimesh = the shipped fractal-Perlin terrain; "
                          "grid = the base class's sub-terrain grid with the terrain-level curriculum (configs[2])")
@@ -213,6 +208,9 @@ def main():
     if args.global_envs:
         assert args.global_envs % world == 0, "--global-envs must divide evenly over the ranks"
         args.envs_per_gpu = args.global_envs // world
+    if args.same_device:
+        assert args.backend == "gloo", "--same-device needs --backend gloo (RCCL cannot put two ranks on one device)"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     group = None
@@ -221,7 +219,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         group = dist.group.WORLD
 
     import __graft_entry__ as ge
@@ -249,7 +250,11 @@ def main():
     torch.manual_seed(train_cfg.seed)                 # identical replicas; env RNG differs per rank
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)
     train = class_to_dict(train_cfg)
-    runner = OnPolicyRunner(env, train, log_dir=None, device=device, dist_group=group)
+    log_dir = None
+    if args.log:                                       # the logged loop (train.py): text goes to /dev/null, checkpoints to a scratch directory
+        import tempfile
+        log_dir = tempfile.mkdtemp(prefix=f"wbc_bench_log_r{rank}_")
+    runner = OnPolicyRunner(env, train, log_dir=log_dir, device=device, dist_group=group)
     env.collect_episode_stats = True                  # extras['episode'] is filled on every step as the reference does (WG:743-750)
     torch.manual_seed(train_cfg.seed + 1000 * rank)   # replicas are identical (broadcast at construction); exploration noise is per rank
     T = runner.num_steps_per_env
@@ -305,21 +310,24 @@ def main():
     def note(msg):
         if rank == 0 and os.environ.get("WBC_BENCH_VERBOSE"):
             print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+    import contextlib
     t_start = time.perf_counter()
-    runner.learn(2, init_at_random_ep_len=True)
-    barrier()
-    note("primed")
-    runner.learn(max(args.warmup, 0)) if args.warmup > 0 else None
-    barrier()
-    timing_on["v"] = rank == 0
-    t0 = time.perf_counter()
-    runner.learn(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    sink = open(os.devnull, "w") if args.log else None
+    with (contextlib.redirect_stdout(sink) if sink is not None else contextlib.nullcontext()):
+        runner.learn(2, init_at_random_ep_len=True)
+        barrier()
+        note("primed")
+        runner.learn(max(args.warmup, 0)) if args.warmup > 0 else None
+        barrier()
+        timing_on["v"] = rank == 0
+        t0 = time.perf_counter()
+        runner.learn(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
     timing_on["v"] = False
     note(f"timed region done: {elapsed:.3f}s")
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     total_env_steps = args.envs_per_gpu * world * T * args.steps
@@ -330,16 +338,24 @@ def main():
     if use_dist:
         nparam = sum(p.numel() for p in runner.alg.actor_critic.parameters())
         buf = torch.zeros(nparam, device=device)
+        from wbc_amd import collectives
         for _ in range(5):
-            dist.all_reduce(buf, group=group)
+            collectives.all_reduce(buf, group)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            dist.all_reduce(buf, group=group)
-        e1.record()
-        torch.cuda.synchronize()
-        allreduce_us = e0.elapsed_time(e1) * 1e3 / 50
+        if args.backend == "nccl":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                collectives.all_reduce(buf, group)
+            e1.record()
+            torch.cuda.synchronize()
+            allreduce_us = e0.elapsed_time(e1) * 1e3 / 50
+        else:                                             # host-staged: wall clock (device -> host, gloo, host -> device)
+            tw = time.perf_counter()
+            for _ in range(50):
+                collectives.all_reduce(buf, group)
+            torch.cuda.synchronize()
+            allreduce_us = (time.perf_counter() - tw) * 1e6 / 50
 
     if rank == 0:
         hist = runner.history[-args.steps:]
@@ -367,9 +383,12 @@ def main():
                                    f"(BASELINE.json configs[{cfg_idx}]); T={T} steps/iteration, 5 epochs x 4 minibatches, "
                                    f"DAgger every 20th iteration", "envs_per_gpu": args.envs_per_gpu,
                        "global_envs": args.envs_per_gpu * world, "steps_per_env": T,
-                       "parallelism": (f"env-shard x{world}, 1 RCCL grad all-reduce/minibatch + 1 three-scalar all-reduce/iteration"
+                       "parallelism": (f"env-shard x{world}, 1 {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} grad all-reduce/minibatch"
+                                       f" + 1 three-scalar all-reduce/iteration" + (", ALL RANKS ON ONE DEVICE (functional run, not a scaling figure)" if args.same_device else "")
                                        if use_dist else "single GPU"),
-                       "rccl_ranks": dist.get_world_size(group) if use_dist else 0,
+                       "rccl_ranks": dist.get_world_size(group) if use_dist and args.backend == "nccl" else 0,
+                       "backend": args.backend if use_dist else None, "same_device": bool(args.same_device),
+                       "logged": bool(args.log),
                        "grad_allreduce_us": allreduce_us,
                        "collection_ms": 1e3 * sum(h["collection_time"] for h in hist) / len(hist),
                        "learn_ms": 1e3 * sum(h["learn_time"] for h in hist) / len(hist)},

@@ -407,16 +407,23 @@ extern "C" __global__ void __launch_bounds__(256) hist_reduce_kernel(const float
 
 struct HistAdamTable { float* p[8]; int off[9]; };
 
+// sq[i] = g[i]^2 for a gradient that went through an all-reduce (the squares hist_reduce_kernel left are of the LOCAL gradient).
+// Its own launch: hist_adam_kernel rewrites g in place, so no block of that launch may read g for the norm (a late block would
+// sum entries its peers have already scaled: a different clip coefficient per block, replicas drifting apart).
+extern "C" __global__ void __launch_bounds__(256) hist_sq_kernel(const float* __restrict__ g, float* __restrict__ sq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N_GRAD) { const float t = g[i]; sq[i] = t * t; }
+}
+
 // clip_grad_norm_ + Adam.step on the 8 tensors (as ppo_adam_kernel). Every block derives the squared norm itself, in a fixed
-// order, from sq[] (written by hist_reduce_kernel) or -- after an all-reduce changed g -- from g.
+// order, from sq[] (written by an EARLIER launch: hist_reduce_kernel, or hist_sq_kernel after an all-reduce changed g).
 extern "C" __global__ void __launch_bounds__(256) hist_adam_kernel(HistAdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                                  const float* __restrict__ sq, int recompute_norm, float max_norm, float beta1,
+                                                                  const float* __restrict__ sq, float max_norm, float beta1,
                                                                   float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
   __shared__ float sh[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float a = 0.f;
-  if (recompute_norm) { for (int e = threadIdx.x; e < N_GRAD; e += 256) a += g[e] * g[e]; }
-  else { for (int e = threadIdx.x; e < N_GRAD; e += 256) a += sq[e]; }
+  for (int e = threadIdx.x; e < N_GRAD; e += 256) a += sq[e];
   sh[threadIdx.x] = a;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
@@ -495,7 +502,7 @@ extern "C" int wbc_hist_train_grad(const void* const* params, const float* obs, 
 
 extern "C" int wbc_hist_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
                                   float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, int grad_was_reduced,
-                                  const float* workspace, void* stream) {
+                                  float* workspace, void* stream) {
   StreamDeviceGuard sdg(stream);
   if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace || !(grad_scale > 0.f)) return -1;
   static const int sizes[8] = {H_C1 * H_NP, H_C1, H_C2 * H_C1 * 4, H_C2, H_C3 * H_C2 * 2, H_C3, H_OUT * H_C1, H_OUT};
@@ -503,8 +510,10 @@ extern "C" int wbc_hist_clip_adam(const void* const* params, float* grad, float*
   int off = 0;
   for (int i = 0; i < 8; ++i) { if (!params[i]) return -1; T.p[i] = (float*)params[i]; T.off[i] = off; off += sizes[i]; }
   T.off[8] = off;
+  float* sq = workspace + (size_t)HIST_TRAIN_MAX_WG * N_PART;
+  if (grad_was_reduced) hipLaunchKernelGGL(hist_sq_kernel, dim3((N_GRAD + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad, sq);
   hipLaunchKernelGGL(hist_adam_kernel, dim3((N_GRAD + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, grad, exp_avg, exp_avg_sq,
-                     workspace + (size_t)HIST_TRAIN_MAX_WG * N_PART, grad_was_reduced, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+                     sq, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -67,7 +67,9 @@ _GRID_Y = [round(-0.5 + 0.1 * i, 1) for i in range(11)]
 
 LeggedRobotCfg = make_cfg("LeggedRobotCfg", BaseConfig, {
     "env": dict(num_envs=4096, num_observations=235, num_privileged_obs=None, num_actions=12,
-                env_spacing=3.0, send_timeouts=True, episode_length_s=20),
+                env_spacing=3.0, send_timeouts=True, episode_length_s=20,
+                # not in the reference: True reproduces its stale extras['time_outs'] (quirk Q9, envs.stale_time_outs)
+                reference_stale_time_outs=False),
     "terrain": dict(mesh_type="trimesh", horizontal_scale=0.1, vertical_scale=0.005, border_size=25,
                     curriculum=True, static_friction=1.0, dynamic_friction=1.0, restitution=0.0,
                     measure_heights=True, measured_points_x=_GRID_X, measured_points_y=_GRID_Y,

@@ -51,6 +51,14 @@ def _yaw_quat(quat):
     return torch.stack([zero, zero, torch.sin(yaw / 2), torch.cos(yaw / 2)], dim=-1)
 
 
+def stale_time_outs(prev, time_out_buf, reset_buf):
+    """extras['time_outs'] as the reference publishes it (quirk Q9). `check_termination` builds a NEW time_out_buf tensor every
+    step (WG:943-944) but `extras["time_outs"]` is only re-bound inside reset_idx after its early return for an empty env_ids
+    (WG:705-706, 753-754): on a step in which no env resets, the learner is handed the mask of the LAST step that had a reset and
+    bootstraps those envs' rewards once more (PPO:133-134). Device-side select, no host synchronisation."""
+    return torch.where((reset_buf != 0).any(), time_out_buf, prev)
+
+
 class BaseTask(VecEnv):
     """Buffer/attribute contract of legged_gym/envs/base/base_task.py:41-131 (viewer omitted: headless)."""
 
@@ -135,6 +143,11 @@ class WidowGo1(LeggedRobot):
         self.async_episode_stats = False
         self._stats_stream = None
         self._stats_pending = False
+        # cfg.env.reference_stale_time_outs: publish extras['time_outs'] the way the reference does (quirk Q9). The fused step's
+        # in-kernel reward bootstrap uses the CURRENT mask, so with the option on the reward / done slots are filled by
+        # wbc_rollout_store from the published (possibly stale) mask instead.
+        self._stale_time_outs_on = bool(getattr(cfg.env, "reference_stale_time_outs", False))
+        self._stale_mask = None
 
     # ---- construction ----------------------------------------------------------------------
     def create_sim(self):                                                           # WG:230-237, 255-429
@@ -177,8 +190,12 @@ class WidowGo1(LeggedRobot):
             # the base class's sub-terrain grid (LR:79-95 create_sim -> Terrain(cfg.terrain, num_envs), utils/terrain.py:101-227);
             # np.random is the reference's stream for it (seeded as helpers.set_seed does)
             from .terrain import Terrain
-            np.random.seed(self._seed)
-            self.terrain = Terrain(t, self.num_envs)
+            saved = np.random.get_state()             # building an env must not reseed the process-global numpy stream
+            try:
+                np.random.seed(self._seed)
+                self.terrain = Terrain(t, self.num_envs)
+            finally:
+                np.random.set_state(saved)
             self.set_heightfield(self.terrain.heightsamples, self.terrain.horizontal_scale, self.terrain.vertical_scale,
                                  *self.terrain.transform)
 
@@ -371,7 +388,26 @@ class WidowGo1(LeggedRobot):
             ep["coeff_tracking_ang_vel_yaw_exp"] = self.reward_scales.get("tracking_ang_vel_yaw_exp", 0.0)
             self.extras["episode"] = ep
         if self.cfg.env.send_timeouts:
-            self.extras["time_outs"] = self.time_out_buf
+            if self._stale_time_outs_on:                 # opt-in quirk Q9; at construction the reference binds the all-False initial mask
+                prev = self._stale_mask if self._stale_mask is not None and not start else torch.zeros_like(self.time_out_buf)
+                self._stale_mask = stale_time_outs(prev, self.time_out_buf, self.reset_buf) if not start else prev
+                self.extras["time_outs"] = self._stale_mask
+            else:
+                self.extras["time_outs"] = self.time_out_buf
+
+    def run_on_stats_stream(self, launch):
+        """Run `launch()` (kernel launches reading this step's reward / reset buffers) where extras['episode'] is computed: on the
+        statistics side stream in async mode (ordered after this step's kernel, and the next step() waits for it), else inline."""
+        if self.async_episode_stats and self.device.type == "cuda":
+            if self._stats_stream is None:
+                self._stats_stream = torch.cuda.Stream(self.device)
+            side = self._stats_stream
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                launch()
+            self._stats_pending = True
+        else:
+            launch()
 
     # ---- torque supervision (WG:1178-1181, 1201-1242): default off (WGC:173) ------------------------------------
     def _refresh_arm_dynamics(self):
@@ -416,6 +452,8 @@ class WidowGo1(LeggedRobot):
             self.extras["current_arm_dof_vel"] = self.dof_vel[:, -8:-2].clone()
         out, self._obs_output = self._obs_output, None
         store, self._store_output = self._store_output, None
+        if self._stale_time_outs_on:
+            store = None                              # the learner's process_env_step bootstraps from extras['time_outs']
         if self._stats_pending:                       # the side-stream statistics of the previous step read what this step overwrites
             torch.cuda.current_stream(self.device).wait_stream(self._stats_stream)
             self._stats_pending = False
@@ -517,6 +555,21 @@ class WidowGo1(LeggedRobot):
         self._sim_env_origins.copy_(new)
         self.root_states[:, :3] += delta
         self.box_root_state[:, 1] += delta[:, 1]
+
+    def restore_terrain_levels(self, levels, arena_restored=False):
+        """Checkpoint resume (OnPolicyRunner.load): adopt saved terrain levels. env_origins and the sim's ENV_ORIGINS are
+        re-derived from terrain_origins[level, type]; unless the whole sim arena came back with them (then every robot already
+        stands where it stood), all robots are re-placed by a full reset on their restored platforms -- the next
+        _apply_terrain_curriculum must see a zero origin delta for every env that did not just reset."""
+        if not self._terrain_levels_on:
+            return
+        self.terrain_levels.copy_(levels.to(self.terrain_levels.device, self.terrain_levels.dtype))
+        new = self.terrain_origins[self.terrain_levels, self.terrain_types]
+        self.env_origins.copy_(new)
+        if not arena_restored:
+            self._sim_env_origins.copy_(new)
+            self.sim.reset_all()                      # in-kernel reset: places robot + box relative to ENV_ORIGINS
+            self._fill_extras(start=True)
 
     def set_rollout_output(self, values, gamma, rewards, dones):
         """The NEXT step() also writes this transition's rollout-storage slots (PPO.process_env_step's tensor work, ppo.py:129-141):

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
+from ... import collectives
 from ..modules import ActorCritic
 from ..storage import RolloutStorage
 
@@ -177,6 +178,7 @@ class PPO:
     def compute_returns(self, last_critic_obs):
         ac = self.actor_critic
         if self.fused_rollout and not torch.is_grad_enabled() and ac.fused_act_supported(last_critic_obs):
+            ac.mark_params_changed()       # a version compare; re-packs only if somebody stepped the weights since the rollout's first act()
             last_values = ac.fused_act(last_critic_obs)[3]          # the critic half of the inference kernel (one launch)
         else:
             last_values = ac.evaluate(last_critic_obs).detach()
@@ -194,7 +196,7 @@ class PPO:
                  sum(p.numel() for p in self.actor_critic.actor.history_encoder.parameters()), 3, 1}
         for n in sorted(sizes):
             t = torch.zeros(n, device=dev)
-            torch.distributed.all_reduce(t, group=self.dist_group)
+            collectives.all_reduce(t, self.dist_group)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
@@ -212,7 +214,7 @@ class PPO:
         for p in params:
             flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
-        torch.distributed.all_reduce(flat, group=self.dist_group)
+        collectives.all_reduce(flat, self.dist_group)
         flat.div_(self.world_size)
         off = 0
         for p in params:
@@ -276,6 +278,7 @@ class PPO:
         sums = torch.zeros(3, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         vcoef = self.value_loss_coef
+        steps = self._bind_adam_state(params, F)   # once per update: nothing re-binds the optimiser's state inside it
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = indices[i * mb:(i + 1) * mb]
@@ -289,9 +292,8 @@ class PPO:
                     ac.std.grad.sub_(self.entropy_coef * 0.5 / ac.std.detach())
                     grad_is_fresh = False
                 if self.dist_group is not None:    # ONE flat bucket, SUM over ranks; the 1/world_size mean is folded into the clip + Adam kernel
-                    torch.distributed.all_reduce(F["grad"][:F["nparam"]], group=self.dist_group)
+                    collectives.all_reduce(F["grad"][:F["nparam"]], self.dist_group)
                     grad_is_fresh = False
-                steps = self._bind_adam_state(params, F)
                 if steps is None:                  # optimiser options the fused kernel does not cover
                     if self.world_size > 1:
                         F["grad"][:F["nparam"]].div_(self.world_size)
@@ -375,7 +377,7 @@ class PPO:
                                    axis=-1)
                     kl_mean = torch.mean(kl)
                     if self.dist_group is not None:
-                        torch.distributed.all_reduce(kl_mean, group=self.dist_group)
+                        collectives.all_reduce(kl_mean, self.dist_group)
                         kl_mean /= self.world_size
                     if kl_mean > self.desired_kl * 2.0:
                         self.learning_rate = max(1e-5, self.learning_rate / 1.5)
@@ -465,6 +467,7 @@ class PPO:
         indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=dev)      # one per update (RS:163)
         total = torch.zeros((), device=dev)
         opt = self.hist_encoder_optimizer
+        steps = self._bind_adam_state(hp, F, opt)
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = indices[i * mb:(i + 1) * mb]
@@ -473,9 +476,8 @@ class PPO:
                 total += F["grad"][nparam]
                 reduced = 0
                 if self.dist_group is not None:    # one flat 23 kB bucket, SUM; the mean is folded into the clip + Adam kernel
-                    torch.distributed.all_reduce(F["grad"][:nparam], group=self.dist_group)
+                    collectives.all_reduce(F["grad"][:nparam], self.dist_group)
                     reduced = 1
-                steps = self._bind_adam_state(hp, F, opt)
                 if steps is None:
                     if self.world_size > 1:
                         F["grad"][:nparam].div_(self.world_size)

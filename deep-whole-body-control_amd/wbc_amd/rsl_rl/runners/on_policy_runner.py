@@ -15,12 +15,57 @@ from collections import deque
 
 import torch
 
+from ... import collectives
 from ..algorithms import PPO
 from ..env import VecEnv
 from ..modules import ActorCritic
 
 _POLICIES = {"ActorCritic": ActorCritic}
 _ALGORITHMS = {"PPO": PPO}
+
+
+class _EpisodeTracker:
+    """learn()'s episode bookkeeping (OPR:140-154) as device state: running (reward, arm reward, length) per env and the
+    deque(maxlen=100) trio + the done-fraction deque as device rings, advanced by one launch per env step
+    (wbc_runner_track_episodes) and read back once per iteration."""
+    CAP = 100                                            # the reference's deque maxlen (OPR:103-106)
+
+    @classmethod
+    def create(cls, env, rewards, arm_rewards, dones):
+        ok = all(t.is_cuda and t.is_contiguous() for t in (rewards, arm_rewards, dones)) and rewards.dtype == torch.float32 \
+            and arm_rewards.dtype == torch.float32 and dones.dtype == torch.int64 and rewards.dim() == 1
+        return cls(env, rewards.shape[0], rewards.device) if ok else None
+
+    def __init__(self, env, n, device):
+        from ...native import check, lib
+        self._check, self._L = check, lib()
+        self.n, self.device = n, device
+        self.state = torch.zeros(self._L.wbc_runner_track_state_floats(n, self.CAP), device=device)
+        self._side = getattr(env, "run_on_stats_stream", None)      # overlaps the next policy inference when the env offers it
+
+    def step(self, rewards, arm_rewards, dones):
+        def launch():
+            self._check(self._L.wbc_runner_track_episodes(rewards.data_ptr(), arm_rewards.data_ptr(), dones.data_ptr(), self.n, self.CAP,
+                                                          self.state.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
+                        "wbc_runner_track_episodes")
+        if self._side is not None:
+            self._side(launch)
+        else:
+            launch()
+
+    def summary(self):
+        """{mean_reward, mean_arm_reward, mean_episode_length, dones} over the rings (empty before the first finished episode,
+        as the reference's `if len(rewbuffer) > 0`). The caller has synchronised the device."""
+        tail = self.state[3 * self.n:].cpu()
+        cap = self.CAP
+        ring, done_ring = tail[:3 * cap].view(cap, 3).double(), tail[3 * cap:4 * cap].double()
+        hdr = tail[4 * cap:4 * cap + 4].view(torch.int32)
+        fill, dfill = int(hdr[1]), int(hdr[3])
+        if fill == 0:
+            return {}
+        m = ring[:fill].mean(0) if fill < cap else ring.mean(0)
+        d = done_ring[:dfill].mean() if dfill < cap else done_ring.mean()
+        return dict(mean_reward=float(m[0]), mean_arm_reward=float(m[1]), mean_episode_length=float(m[2]), dones=float(d))
 
 
 class OnPolicyRunner:
@@ -34,7 +79,7 @@ class OnPolicyRunner:
         self.dist_group = dist_group
         if dist_group is not None:      # identical initial replicas on every rank
             for p in actor_critic.parameters():
-                torch.distributed.broadcast(p.data, src=torch.distributed.get_global_rank(dist_group, 0), group=dist_group)
+                collectives.broadcast(p.data, 0, dist_group)
         self.alg: PPO = _ALGORITHMS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, dist_group=dist_group,
                                                                       **self.alg_cfg)
         if hasattr(self.alg, "warm_up_collectives"):
@@ -81,70 +126,80 @@ class OnPolicyRunner:
         store_in_step = hasattr(env, "set_rollout_output") and hasattr(alg, "rollout_slots") and getattr(alg, "fused_rollout", False)
         if hasattr(env, "async_episode_stats"):
             env.async_episode_stats = True               # every read of infos['episode'] below comes after a device synchronisation
-        for it in range(self.current_learning_iteration, tot_iter):
-            env.update_command_curriculum()
-            sync()
-            start = time.time()
-            hist_encoding = it % self.dagger_update_freq == 0
-            with torch.inference_mode():
-                for _ in range(self.num_steps_per_env):
-                    actions = alg.act(obs, critic_obs, hist_encoding)
-                    slot = alg.next_observation_slot() if redirect_obs else None
-                    if slot is not None:
-                        env.set_obs_output(slot)              # the env writes the next observation where act() would copy it
-                    if store_in_step:
-                        slots = alg.rollout_slots()
-                        if slots is not None:
-                            env.set_rollout_output(*slots)    # ... and this transition's reward / done slots
-                    obs, priv, rewards, arm_rewards, dones, infos = env.step(actions)
-                    critic_obs = priv if priv is not None else obs
-                    obs, critic_obs, rewards, arm_rewards, dones = (x.to(self.device) for x in (obs, critic_obs, rewards, arm_rewards, dones))
-                    alg.process_env_step(rewards, arm_rewards, dones, infos)
-                    if logging:
-                        if "episode" in infos:
-                            ep_infos.append(infos["episode"])
-                        cur_rew += rewards
-                        cur_arm += arm_rewards
-                        cur_len += 1
-                        new_ids = (dones > 0).nonzero(as_tuple=False)
-                        rewbuffer.extend(cur_rew[new_ids][:, 0].cpu().numpy().tolist())
-                        armrewbuffer.extend(cur_arm[new_ids][:, 0].cpu().numpy().tolist())
-                        lenbuffer.extend(cur_len[new_ids][:, 0].cpu().numpy().tolist())
-                        donebuffer.append(len(new_ids) / n)
-                        cur_rew[new_ids] = 0
-                        cur_arm[new_ids] = 0
-                        cur_len[new_ids] = 0
+        tracker = None                                   # device-side deques (wbc_runner_track_episodes), set up on the first logged step
+        try:
+            for it in range(self.current_learning_iteration, tot_iter):
+                env.update_command_curriculum()
+                sync()
+                start = time.time()
+                hist_encoding = it % self.dagger_update_freq == 0
+                with torch.inference_mode():
+                    for _ in range(self.num_steps_per_env):
+                        actions = alg.act(obs, critic_obs, hist_encoding)
+                        slot = alg.next_observation_slot() if redirect_obs else None
+                        if slot is not None:
+                            env.set_obs_output(slot)              # the env writes the next observation where act() would copy it
+                        if store_in_step:
+                            slots = alg.rollout_slots()
+                            if slots is not None:
+                                env.set_rollout_output(*slots)    # ... and this transition's reward / done slots
+                        obs, priv, rewards, arm_rewards, dones, infos = env.step(actions)
+                        critic_obs = priv if priv is not None else obs
+                        obs, critic_obs, rewards, arm_rewards, dones = (x.to(self.device) for x in (obs, critic_obs, rewards, arm_rewards, dones))
+                        alg.process_env_step(rewards, arm_rewards, dones, infos)
+                        if logging:
+                            if "episode" in infos:
+                                ep_infos.append(infos["episode"])
+                            if tracker is None:
+                                tracker = _EpisodeTracker.create(env, rewards, arm_rewards, dones) or False
+                            if tracker:                           # OPR:140-154 in one launch, no host copies
+                                tracker.step(rewards, arm_rewards, dones)
+                                continue
+                            cur_rew += rewards                    # the reference's host path (CPU envs / foreign env classes)
+                            cur_arm += arm_rewards
+                            cur_len += 1
+                            new_ids = (dones > 0).nonzero(as_tuple=False)
+                            rewbuffer.extend(cur_rew[new_ids][:, 0].cpu().numpy().tolist())
+                            armrewbuffer.extend(cur_arm[new_ids][:, 0].cpu().numpy().tolist())
+                            lenbuffer.extend(cur_len[new_ids][:, 0].cpu().numpy().tolist())
+                            donebuffer.append(len(new_ids) / n)
+                            cur_rew[new_ids] = 0
+                            cur_arm[new_ids] = 0
+                            cur_len[new_ids] = 0
+                    sync()
+                    stop = time.time()
+                    collection_time = stop - start
+                    start = stop
+                    alg.compute_returns(critic_obs)
+                if hist_encoding:
+                    loss_stats["mean_hist_latent_loss"] = alg.update_dagger()
+                else:
+                    (loss_stats["mean_value_loss"], loss_stats["mean_surrogate_loss"], loss_stats["mean_arm_torques_loss"],
+                     loss_stats["value_mixing_ratio"], loss_stats["torque_supervision_weight"], loss_stats["mean_priv_reg_loss"],
+                     loss_stats["priv_reg_coef"]) = alg.update()
                 sync()
                 stop = time.time()
-                collection_time = stop - start
-                start = stop
-                alg.compute_returns(critic_obs)
-            if hist_encoding:
-                loss_stats["mean_hist_latent_loss"] = alg.update_dagger()
-            else:
-                (loss_stats["mean_value_loss"], loss_stats["mean_surrogate_loss"], loss_stats["mean_arm_torques_loss"],
-                 loss_stats["value_mixing_ratio"], loss_stats["torque_supervision_weight"], loss_stats["mean_priv_reg_loss"],
-                 loss_stats["priv_reg_coef"]) = alg.update()
-            sync()
-            stop = time.time()
-            learn_time = stop - start
-            fps = int(self.num_steps_per_env * n / (collection_time + learn_time))       # OPR:206
-            rec = dict(it=it, collection_time=collection_time, learn_time=learn_time, fps=fps, **loss_stats)
-            self.tot_timesteps += self.num_steps_per_env * n
-            self.tot_time += collection_time + learn_time
-            if logging:
-                if len(rewbuffer) > 0:
-                    rec.update(mean_reward=statistics.mean(rewbuffer), mean_arm_reward=statistics.mean(armrewbuffer),
-                               mean_episode_length=statistics.mean(lenbuffer), dones=statistics.mean(donebuffer))
-                self.log(rec, ep_infos, tot_iter)
-                if it % self.save_interval == 0:
-                    self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
-            self.history.append(rec)
-            ep_infos.clear()
+                learn_time = stop - start
+                fps = int(self.num_steps_per_env * n / (collection_time + learn_time))       # OPR:206
+                rec = dict(it=it, collection_time=collection_time, learn_time=learn_time, fps=fps, **loss_stats)
+                self.tot_timesteps += self.num_steps_per_env * n
+                self.tot_time += collection_time + learn_time
+                if logging:
+                    if tracker:
+                        rec.update(tracker.summary())         # one small device-to-host copy per iteration
+                    elif len(rewbuffer) > 0:
+                        rec.update(mean_reward=statistics.mean(rewbuffer), mean_arm_reward=statistics.mean(armrewbuffer),
+                                   mean_episode_length=statistics.mean(lenbuffer), dones=statistics.mean(donebuffer))
+                    self.log(rec, ep_infos, tot_iter)
+                    if it % self.save_interval == 0:
+                        self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+                self.history.append(rec)
+                ep_infos.clear()
+        finally:                                         # also on an exception / KeyboardInterrupt: later callers of env.step()
+            if hasattr(env, "async_episode_stats"):      # must not read side-stream results unsynchronised
+                env.async_episode_stats = False
+                sync()
         self.current_learning_iteration += num_learning_iterations
-        if hasattr(env, "async_episode_stats"):
-            env.async_episode_stats = False
-            sync()
         if logging:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 
@@ -220,12 +275,17 @@ class OnPolicyRunner:
             if "env_common_step_counter" in extra and hasattr(env, "common_step_counter"):
                 env.common_step_counter = extra["env_common_step_counter"]
             sim = getattr(env, "sim", None)
+            arena_restored = False
             if "sim_arena" in extra and sim is not None and hasattr(sim, "arena") and sim.arena.shape == extra["sim_arena"].shape:
                 sim.arena.copy_(extra["sim_arena"])
+                arena_restored = True
+            if "terrain_levels" in extra and torch.is_tensor(getattr(env, "terrain_levels", None)):
+                if hasattr(env, "restore_terrain_levels"):      # origins follow the levels; robots re-placed unless the arena came back
+                    env.restore_terrain_levels(extra["terrain_levels"], arena_restored)
+                else:
+                    env.terrain_levels.copy_(extra["terrain_levels"].to(env.terrain_levels.device))
             if "sim_step_counter" in extra and sim is not None:
                 sim.step_counter = int(extra["sim_step_counter"])
-            if "terrain_levels" in extra and torch.is_tensor(getattr(env, "terrain_levels", None)):
-                env.terrain_levels.copy_(extra["terrain_levels"].to(env.terrain_levels.device))
             if restore_rng:
                 torch.set_rng_state(extra["torch_rng_state"].cpu())
                 if "cuda_rng_state" in extra and torch.device(self.device).type == "cuda":

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import torch
 
+from ... import collectives
+
 
 class RolloutStorage:
     class Transition:
@@ -92,7 +94,7 @@ class RolloutStorage:
                                 self.returns.data_ptr(), self.advantages.data_ptr(), self._gae_ws.data_ptr(), T, N,
                                 float(gamma), float(lam), stream), "wbc_gae_compute")
         if self.dist_group is not None:
-            torch.distributed.all_reduce(self._gae_ws[:3], group=self.dist_group)
+            collectives.all_reduce(self._gae_ws[:3], self.dist_group)
         check(L.wbc_gae_normalize(self.advantages.data_ptr(), self._gae_ws.data_ptr(), T * N * 2, stream), "wbc_gae_normalize")
 
     def _compute_returns_torch(self, last_values, gamma, lam):

@@ -355,11 +355,12 @@ int wbc_hist_train_grad(const void* const* params, const float* obs, const float
 int wbc_hist_train_grad_floats(void);
 size_t wbc_hist_train_workspace_floats(void);
 /* clip_grad_norm_ + Adam.step (ppo.py:283-284) of the history encoder on the flat buffers, as wbc_ppo_clip_adam.
- * grad_was_reduced != 0: grad was changed since wbc_hist_train_grad (all-reduce over ranks); the norm is re-derived.
- * workspace: the one passed to wbc_hist_train_grad. */
+ * grad_was_reduced != 0: grad was changed since wbc_hist_train_grad (all-reduce over ranks); the squares of the reduced
+ * gradient are re-derived by a launch of their own BEFORE the one that rescales grad in place (every block of the Adam
+ * launch sees the same norm). workspace: the one passed to wbc_hist_train_grad (its squared-gradient tail is rewritten). */
 int wbc_hist_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
                        float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, int grad_was_reduced,
-                       const float* workspace, void* stream);
+                       float* workspace, void* stream);
 /* Actor.infer_priv_latent (actor_critic.py:219-221) for every row: params = priv_encoder.{0,2}.{weight,bias} ([64,24], [64],
  * [20,64], [20]); obs f32 [rows, 860]; out f32 [rows, 20]. */
 int wbc_priv_latent(const void* const* params, const float* obs, float* out, int rows, void* stream);
@@ -387,6 +388,18 @@ int wbc_sim_episode_stats(wbc_sim* sim, float scale, const float* prev, float* o
  * time_outs may be NULL (no bootstrap). All pointers device; out_* are the rollout-storage slots of this step. */
 int wbc_rollout_store(const float* rew, const float* arm_rew, const int64_t* dones, const uint8_t* time_outs,
                       const float* values, float gamma, float* out_rewards, uint8_t* out_dones, int n, void* stream);
+
+/* OnPolicyRunner.learn's per-step episode bookkeeping (rsl_rl/runners/on_policy_runner.py:140-154: cur_reward_sum +=
+ * rewards, cur_episode_length += 1, new_ids = (dones > 0).nonzero(), rewbuffer / armrewbuffer / lenbuffer.extend(...),
+ * donebuffer.append(len(new_ids) / N), the sums of new_ids zeroed) in one launch and without the reference's three host
+ * copies per env step. `state` (device f32, wbc_runner_track_state_floats(n, cap), zero-initialised by the caller):
+ *   cur[n][3] running (reward, arm reward, length) | ring[cap][3] the last `cap` finished episodes in the order the
+ *   reference's deques receive them (step by step, ascending env index) | done_ring[cap] the last `cap` per-step done
+ *   fractions | 4 int32: ring head, ring fill (<= cap), done_ring head, done_ring fill.
+ * cap = the deques' maxlen (100). The host reads ring / done_ring once per iteration. */
+int wbc_runner_track_episodes(const float* rew, const float* arm_rew, const int64_t* dones, int n, int cap, float* state,
+                              void* stream);
+size_t wbc_runner_track_state_floats(int n, int cap);
 
 /* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
 void wbc_abi_sizes(int* out3);

@@ -167,3 +167,126 @@ def test_runner_with_rccl_process_group_single_rank():
         np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_device_episode_tracker_equals_the_reference_host_bookkeeping():
+    """wbc_runner_track_episodes (one launch per env step, rings read once per iteration) against OPR:140-154 executed
+    literally on the host: running sums, deque(maxlen=100) of finished episodes in (step, env) order, done fractions --
+    with more than 100 episodes finishing in single steps and fewer than 100 in total at the start."""
+    import statistics
+    from collections import deque
+    from wbc_amd.rsl_rl.runners.on_policy_runner import _EpisodeTracker
+    n = 2500                                             # not a multiple of the kernel's 1024-env chunk
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rew0 = torch.zeros(n, device="cuda")
+    trk = _EpisodeTracker.create(None, rew0, rew0.clone(), torch.zeros(n, dtype=torch.int64, device="cuda"))
+    assert trk is not None and trk.summary() == {}
+    rewbuffer, armbuffer, lenbuffer, donebuffer = (deque(maxlen=100) for _ in range(4))
+    cur = torch.zeros(3, n, dtype=torch.float64)
+    for step in range(130):
+        rew = torch.randn(n, device="cuda", generator=g)
+        arm = torch.randn(n, device="cuda", generator=g)
+        p = 0.0 if step < 3 else (0.001 if step < 20 else (0.2 if step % 7 == 0 else 0.01))
+        dones = (torch.rand(n, device="cuda", generator=g) < p).long()
+        trk.step(rew, arm, dones)
+        cur[0] += rew.cpu().float().double(); cur[1] += arm.cpu().float().double(); cur[2] += 1
+        ids = dones.cpu().nonzero()[:, 0]
+        rewbuffer.extend(cur[0][ids].tolist()); armbuffer.extend(cur[1][ids].tolist()); lenbuffer.extend(cur[2][ids].tolist())
+        donebuffer.append(len(ids) / n)
+        cur[:, ids] = 0
+        if step in (2, 10, 19, 21, 129):
+            torch.cuda.synchronize()
+            got = trk.summary()
+            if len(rewbuffer) == 0:
+                assert got == {}
+                continue
+            assert got["mean_reward"] == pytest.approx(statistics.mean(rewbuffer), abs=2e-4)
+            assert got["mean_arm_reward"] == pytest.approx(statistics.mean(armbuffer), abs=2e-4)
+            assert got["mean_episode_length"] == pytest.approx(statistics.mean(lenbuffer), abs=1e-6)
+            assert got["dones"] == pytest.approx(statistics.mean(donebuffer), abs=1e-7)
+
+
+def test_logged_runner_reports_episode_statistics_from_the_device_rings(tmp_path, capsys):
+    cfg = _cfg(n=256)
+    cfg.env.episode_length_s = 0.2                       # 10-step episodes: plenty of finished episodes in 2 x 8 steps
+    env = WidowGo1(cfg, sim_device="cuda:0", seed=3)
+    train = class_to_dict(WidowGo1RoughCfgPPO())
+    train["runner"]["num_steps_per_env"] = 8
+    runner = OnPolicyRunner(env, train, log_dir=str(tmp_path), device="cuda:0")
+    runner.learn(2, init_at_random_ep_len=True)
+    rec = runner.history[-1]
+    assert 0 < rec["mean_episode_length"] <= 10 and 0 < rec["dones"] <= 1 and np.isfinite(rec["mean_reward"])
+    assert "Mean episode length:" in capsys.readouterr().out
+    assert env.async_episode_stats is False
+
+
+def test_resume_with_terrain_levels_keeps_every_robot_on_its_platform(tmp_path):
+    """OnPolicyRunner.load on the sub-terrain grid with the terrain curriculum (no sim arena in the checkpoint): the restored
+    levels come with their origins, all robots are re-placed on them, and the next steps teleport nobody."""
+    from wbc_amd.config import use_grid_terrain
+
+    def make(seed):
+        cfg = _cfg(n=200)
+        use_grid_terrain(cfg)
+        env = WidowGo1(cfg, sim_device="cuda:0", seed=seed)
+        train = class_to_dict(WidowGo1RoughCfgPPO())
+        train["runner"]["num_steps_per_env"] = 4
+        return env, OnPolicyRunner(env, train, log_dir=None, device="cuda:0")
+    env, runner = make(3)
+    env.terrain_levels.copy_(torch.randint(0, env.max_terrain_level, (200,), device="cuda"))       # a curriculum that has moved
+    path = os.path.join(str(tmp_path), "ck.pt")
+    runner.save(path)
+    env2, runner2 = make(3)
+    assert not torch.equal(env2.terrain_levels, env.terrain_levels)
+    runner2.load(path)
+    torch.cuda.synchronize()
+    assert torch.equal(env2.terrain_levels, env.terrain_levels)
+    want = env2.terrain_origins[env2.terrain_levels, env2.terrain_types]
+    assert torch.equal(env2.env_origins, want) and torch.equal(env2._sim_env_origins, want)
+    d0 = (env2.root_states[:, :2] - want[:, :2]).norm(dim=1)
+    assert (d0 < 1.5).all()                               # re-placed around the restored platform centres (WG:759-767 offsets)
+    for _ in range(3):
+        env2.step(torch.zeros(200, 18, device="cuda"))
+    torch.cuda.synchronize()
+    assert ((env2.root_states[:, :2] - env2.env_origins[:, :2]).norm(dim=1) < 2.0).all()
+    assert (env2.root_states[:, 2] - env2.env_origins[:, 2] > 0.1).all()                        # nobody inside the terrain
+
+
+def test_stale_time_outs_option_goes_through_the_learner():
+    """cfg.env.reference_stale_time_outs (quirk Q9): the published mask only changes on steps with a reset, the in-step reward
+    store is bypassed (the bootstrap must use the published mask) and the rollout's reward slots carry exactly that bootstrap."""
+    cfg = _cfg(n=32)
+    cfg.env.reference_stale_time_outs = True
+    cfg.env.episode_length_s = 0.1                       # 5-step episodes, all envs in phase: resets only every 5th step
+    env = WidowGo1(cfg, sim_device="cuda:0", seed=9)
+    train = class_to_dict(WidowGo1RoughCfgPPO())
+    train["runner"]["num_steps_per_env"] = 12
+    runner = OnPolicyRunner(env, train, log_dir=None, device="cuda:0")
+    masks, resets, rews = [], [], []
+    raw = env.step
+
+    def spy(a):
+        out = raw(0.0 * a)                               # zero actions: the robots stand, episodes end by time-out only
+        masks.append(out[5]["time_outs"].clone()); resets.append(out[4].clone()); rews.append(out[2].clone())
+        assert out[5]["rollout_stored"] is None
+        return out
+    env.step = spy
+    st = runner.alg.storage
+    kept = {}
+
+    def keep_rollout():
+        kept["rewards"], kept["values"] = st.rewards.clone(), st.values.clone()
+        st.clear()
+    runner.alg.update = lambda: (keep_rollout(), (0.,) * 7)[1]
+    runner.alg.update_dagger = lambda: (keep_rollout(), 0.)[1]
+    runner.learn(1)
+    torch.cuda.synchronize()
+    stale = [t for t in range(12) if not resets[t].any() and masks[t].any()]
+    assert len(stale) >= 4                                # steps without a reset that still publish the last reset step's time-outs
+    for t in range(1, 12):
+        if not resets[t].any():
+            assert torch.equal(masks[t], masks[t - 1])
+    gamma = runner.alg.gamma
+    for t in range(12):                                   # PPO:133-134 with the PUBLISHED mask, stale or not
+        want = rews[t] + gamma * kept["values"][t, :, 0] * masks[t].float()
+        np.testing.assert_allclose(kept["rewards"][t, :, 0].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)

@@ -24,12 +24,17 @@ CHECK_F64 = [("TORQUES", 2e-5, 1e-5), ("ROOT_STATES", 2e-5, 1e-5), ("DOF_STATE",
              ("OBS_HISTORY", 5e-5, 2e-5), ("ACTION_HISTORY", 0, 0), ("ACTIONS", 0, 0), ("LAST_ACTIONS", 0, 0),
              ("LAST_DOF_VEL", 5e-5, 1e-5), ("LAST_ROOT_VEL", 2e-5, 1e-5), ("COMMANDS", 1e-6, 1e-6), ("GOAL_STATE", 2e-6, 2e-6),
              ("REW_BUF", 2e-6, 2e-5), ("ARM_REW_BUF", 2e-6, 2e-5), ("EPISODE_SUMS", 2e-4, 3e-5), ("METRIC_SUMS", 2e-3, 3e-5),
-             ("BASE_LIN_VEL", 2e-5, 1e-5), ("BASE_ANG_VEL", 2e-5, 1e-5)]
+             ("BASE_LIN_VEL", 2e-5, 1e-5), ("BASE_ANG_VEL", 2e-5, 1e-5),
+             # physics outputs the reference only reads (the fake gym's tensors): recorded with the post-state all the same
+             ("FORCE_SENSOR", 5e-4, 1e-5), ("NET_CONTACT_FORCE", 5e-4, 1e-5), ("RIGID_BODY_STATE", 3e-5, 1e-5)]
 # the fp32 step kernel carries its own physics rounding through four substeps: the tolerances of test_gpu_sim_parity.py
 CHECK_GPU = [("TORQUES", 3e-3, 1e-3), ("ROOT_STATES", 3e-4, 5e-4), ("DOF_STATE", 1.5e-3, 1e-3), ("OBS_BUF", 1.5e-3, 1e-3),
              ("OBS_HISTORY", 1.5e-3, 1e-3), ("ACTION_HISTORY", 0, 0), ("ACTIONS", 0, 0), ("LAST_ACTIONS", 0, 0),
              ("COMMANDS", 1e-6, 1e-6), ("GOAL_STATE", 2e-5, 2e-5), ("REW_BUF", 3e-5, 2e-3), ("ARM_REW_BUF", 3e-5, 2e-3),
-             ("BASE_LIN_VEL", 5e-4, 1e-3), ("BASE_ANG_VEL", 2e-3, 1e-3)]
+             ("BASE_LIN_VEL", 5e-4, 1e-3), ("BASE_ANG_VEL", 2e-3, 1e-3),
+             # every other tensor the fixture records with the post-state (the fp64 list above has them too)
+             ("LAST_DOF_VEL", 1.5e-3, 1e-3), ("LAST_ROOT_VEL", 5e-4, 1e-3), ("EPISODE_SUMS", 2e-4, 2e-3), ("METRIC_SUMS", 5e-3, 2e-3),
+             ("FORCE_SENSOR", 0.05, 3e-3), ("NET_CONTACT_FORCE", 0.05, 3e-3), ("RIGID_BODY_STATE", 1e-3, 1e-3)]
 
 FIXTURES = ["wg_reference_counter0.npz", "wg_reference_default.npz", "wg_reference_allrewards.npz"]
 
@@ -197,3 +202,23 @@ def test_hip_step_matches_reference_step(robot, fixture):
             np.testing.assert_array_equal(stats, last_stats)
         last_stats = stats
     print("max abs deviation from the reference per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_stale_time_outs_option_reproduces_reference_extras():
+    """Quirk Q9 (cfg.env.reference_stale_time_outs): the reference re-binds extras['time_outs'] only inside reset_idx, so a step
+    without resets publishes the mask of the last step that had one. envs.stale_time_outs over the recorded reset / time-out
+    masks must give the recorded extras -- including wg_reference_allrewards step 4, where no env resets, the current mask is
+    empty and the reference still hands the learner one time-out."""
+    import torch
+    from wbc_amd.envs import stale_time_outs
+    stale_steps = 0
+    for fixture in FIXTURES:
+        g = load(fixture)
+        prev = torch.zeros(g["actions"].shape[1], dtype=torch.bool)
+        for k in range(int(g["steps"])):
+            cur = torch.from_numpy(g[f"s{k}/TIME_OUT_BUF"].astype(bool))
+            reset = torch.from_numpy(g[f"s{k}/RESET_BUF"].astype(np.int64))
+            prev = stale_time_outs(prev, cur, reset)
+            np.testing.assert_array_equal(prev.numpy().astype(np.uint8), g[f"s{k}/time_outs"], err_msg=f"{fixture} step {k}")
+            stale_steps += int(not reset.any() and not torch.equal(prev, cur))
+    assert stale_steps >= 1
