@@ -10,9 +10,8 @@ Quirk Q3 (SURVEY.md): the reference adds 100 km to rows >= tot_cols//2 - 100 and
 x86-64 numpy that out-of-range cast yields 0, i.e. the far part of the map is FLAT at z = 0. That is
 what `flat_beyond_row` reproduces, explicitly instead of through an overflow.
 The random stream is numpy's Generator seeded by the caller, not the reference's global np.random; fed the same
-uniforms (tools/make_golden_terrain.py patches the reference's np.random.rand with the same Generator) the two grids
-agree to the last int16 bit except where a 1e-11 difference in evaluation order crosses a truncation boundary
-(tests/test_terrain_golden.py).
+uniforms (tools/make_golden_terrain.py patches the reference's np.random.rand with the same Generator) the two int16
+grids are identical: the float64 field is evaluated in the reference's operation order (tests/test_terrain_golden.py).
 """
 from __future__ import annotations
 
@@ -20,36 +19,40 @@ import numpy as np
 
 
 def _fade(t):
-    return t * t * t * (t * (6.0 * t - 15.0) + 10.0)
+    # the reference's polynomial AS WRITTEN (terrain.py:66: numpy powers, this operation order): the Horner form differs from it
+    # by an ulp here and there, which moves a sample across an int16 truncation boundary on 1 cell in 1000
+    return 6 * t**5 - 15 * t**4 + 10 * t**3
 
 
 def perlin_2d(shape, periods, rng) -> np.ndarray:
-    """Gradient noise on a (shape[0], shape[1]) grid with periods[0] x periods[1] lattice cells, in [0, 1]."""
+    """Gradient noise on a (shape[0], shape[1]) grid with periods[0] x periods[1] lattice cells, in [0, 1]: terrain.py:64-89
+    operation by operation (same fractional coordinates i * delta % 1, lattice cell = i // (samples per cell) as its
+    `repeat`, same ramp / interpolation order), so that the same uniforms give the same float64 field bit for bit. Broadcast
+    1-D coordinate vectors stand in for the reference's [nx, ny, 2] mgrid."""
     nx, ny = shape
     px, py = periods
     assert nx % px == 0 and ny % py == 0, "grid must be divisible by the lattice (terrain.py:45 has the same assert)"
-    ang = 2.0 * np.pi * rng.random((px + 1, py + 1))
+    ang = 2 * np.pi * rng.random((px + 1, py + 1))
     gx, gy = np.cos(ang), np.sin(ang)
-    u = (np.arange(nx) * (px / nx))
-    v = (np.arange(ny) * (py / ny))
-    ix, iy = u.astype(np.int64), v.astype(np.int64)
-    fx, fy = (u - ix)[:, None], (v - iy)[None, :]
-    ix, iy = ix[:, None], iy[None, :]
+    fx = ((np.arange(nx) * (px / nx)) % 1)[:, None]          # np.mgrid[0:res:delta] = index * delta (+ 0)
+    fy = ((np.arange(ny) * (py / ny)) % 1)[None, :]
+    ix = (np.arange(nx) // (nx // px))[:, None]               # gradients[...].repeat(d, axis)
+    iy = (np.arange(ny) // (ny // py))[None, :]
 
-    def corner(dx, dy):
-        return gx[ix + dx, iy + dy] * (fx - dx) + gy[ix + dx, iy + dy] * (fy - dy)
-    sx, sy = _fade(fx), _fade(fy)
-    n0 = corner(0, 0) * (1 - sx) + corner(1, 0) * sx
-    n1 = corner(0, 1) * (1 - sx) + corner(1, 1) * sx
-    return np.sqrt(2.0) * (n0 * (1 - sy) + n1 * sy) * 0.5 + 0.5
+    def corner(dx, dy):                                      # np.sum(dstack((grid0 - dx, grid1 - dy)) * g, 2)
+        return (fx - dx if dx else fx) * gx[ix + dx, iy + dy] + (fy - dy if dy else fy) * gy[ix + dx, iy + dy]
+    tx, ty = _fade(fx), _fade(fy)
+    n0 = corner(0, 0) * (1 - tx) + tx * corner(1, 0)
+    n1 = corner(0, 1) * (1 - tx) + tx * corner(1, 1)
+    return np.sqrt(2) * ((1 - ty) * n0 + ty * n1) * 0.5 + 0.5
 
 
 def fractal_noise(x_size, y_size, x_samples, y_samples, rng, frequency=10, octaves=2, lacunarity=2.0, gain=0.25, z_scale=0.23):
     px, py = frequency * x_size, frequency * y_size
-    amp = 1.0
+    amp = 1
     out = np.zeros((x_samples, y_samples))
     for _ in range(octaves):
-        out += amp * z_scale * perlin_2d((x_samples, y_samples), (px, py), rng)
+        out += amp * perlin_2d((x_samples, y_samples), (px, py), rng) * z_scale      # terrain.py:96: (amplitude * noise) * zScale
         amp *= gain
         px, py = int(lacunarity * px), int(lacunarity * py)
     return out

@@ -19,16 +19,15 @@ G = dict(np.load(os.path.join(ROOT, "tests", "golden", "terrain_reference.npz"))
 
 
 def test_perlin_matches_reference():
-    """utils/terrain.py:40-99 fed the same uniforms: identical int16 samples, except where a 1e-11 difference in evaluation
-    order crosses a truncation boundary (one LSB = 1e-5 m)."""
+    """utils/terrain.py:40-99 fed the same uniforms: the identical int16 grid, every sample (the float64 field is evaluated in
+    the reference's operation order)."""
     hs, vs, cols, rows, zs, seed = G["perlin_cfg"]
     cfg = types.SimpleNamespace(horizontal_scale=float(hs), vertical_scale=float(vs), tot_cols=int(cols), tot_rows=int(rows), zScale=float(zs),
                                 transform_x=0.0, transform_y=0.0, transform_z=0.0)
     ours = TerrainPerlin(cfg, seed=int(seed)).heightsamples
     ref = G["perlin_heightsamples"]
     assert ours.shape == ref.shape and ours.dtype == ref.dtype == np.int16
-    d = np.abs(ours.astype(np.int64) - ref.astype(np.int64))
-    assert d.max() <= 1 and (d != 0).mean() < 1e-3, (d.max(), (d != 0).mean())
+    np.testing.assert_array_equal(ours, ref)
     assert np.abs(ref[int(cols) // 2 - 100:]).max() == 0 and ref.max() > 10000       # quirk Q3's flat part, real relief elsewhere
 
 
