@@ -1010,6 +1010,9 @@ ORA_API int ora_set(ora_sim* s, int id, const double* in) {
 /* WidowGo1.step over all envs; actions double [N,18] policy order */
 ORA_API void ora_step(ora_sim* s, const double* actions) {
   s->step_counter += 1;                                                                   /* WG:876 */
+  /* envs are independent (each writes only its own ora_env; draws are counter hashes of (seed, env, step, slot)): the host's
+   * cores share the batch. Results do not depend on the thread count. */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < s->n; ++i) {
     REAL a[WBC_NACT];
     for (int j = 0; j < WBC_NACT; ++j) a[j] = (REAL)actions[(size_t)i * WBC_NACT + j];

@@ -312,6 +312,85 @@ def test_step_at_baseline_config2_8192_heightfield(robot):
     g.close()
 
 
+def test_step_at_baseline_config2_8192_on_the_terrain_grid_with_curriculum(robot):
+    """BASELINE.json configs[2] AS THE BENCH RUNS IT (`bench.py --terrain grid`): 8192 envs on the base class's sub-terrain grid
+    (10 levels x 20 types of 8 m tiles: slopes, 5-23 cm stairs, discrete obstacles; utils/terrain.py:101-227) with
+    terrain.curriculum=True, stepped through WidowGo1.step -- the fused kernel + _apply_terrain_curriculum -- against the fp32
+    oracle + the rule of LR:421-441 in numpy, from a synced state. The robots are scattered over their tiles first so that feet
+    meet stair edges, not only the flat platforms. Masks, episode lengths and terrain levels bit-exact; state to tolerance."""
+    import torch
+    from wbc_amd.config import WidowGo1RoughCfg, use_grid_terrain
+    from wbc_amd.envs import WidowGo1
+    from wbc_amd import abi
+    from oracle import OracleSim, default_curriculum
+    n = 8192
+    cfg = use_grid_terrain(WidowGo1RoughCfg())
+    cfg.env.num_envs = n
+    env = WidowGo1(cfg, sim_device="cuda:0", seed=21)
+    assert cfg.terrain.curriculum and env.terrain.heightsamples.shape == (1300, 2100)
+    env.reset()
+    rng = np.random.default_rng(45)
+    # scatter: up to 3.5 m from the platform centre, on the terrain surface under the new position (+ the spawn clearance)
+    hs_grid, t = env.terrain.heightsamples, cfg.terrain
+    off = rng.uniform(-3.5, 3.5, (n, 2))
+    root = env.root_states.cpu().numpy().copy()
+    xy = root[:, :2] + off
+    ij = np.clip(((xy + t.border_size) / t.horizontal_scale).astype(np.int64), 0, np.array(hs_grid.shape) - 2)
+    patch = np.stack([hs_grid[ij[:, 0] + a, ij[:, 1] + b] for a in (0, 1) for b in (0, 1)], 1).max(1) * t.vertical_scale
+    root[:, :2], root[:, 2] = xy, patch + 0.40
+    env.root_states.copy_(torch.from_numpy(root).cuda())
+    env.episode_length_buf = torch.from_numpy(rng.integers(0, 500, n)).cuda()
+    for _ in range(10):                                   # settle: standing on edges, falling, freshly reset, levels moving
+        env.step(torch.from_numpy((0.6 * rng.normal(size=(n, 18))).astype(np.float32)).cuda())
+    torch.cuda.synchronize()
+    o = OracleSim(env.wmodel, env.tcfg, n, seed=21, precision="f32")
+    o.set_curriculum(default_curriculum(cfg, env.update_counter))
+    o.set_heightfield(hs_grid, env.terrain.horizontal_scale, env.terrain.vertical_scale, *env.terrain.transform)
+    names = [nm for nm in abi.TENSOR_IDS if nm != "OBS_BUF"]
+    origins = env.terrain_origins.cpu().numpy()
+    types, max_level, L = env.terrain_types.cpu().numpy(), env.max_terrain_level, env.max_episode_length_s
+    resets = moved = on_rough = 0
+    for step in range(4):
+        helpers.sync_oracle_from_gpu(o, env.sim, names)
+        levels0 = env.terrain_levels.cpu().numpy().copy()
+        a = (0.6 * rng.normal(size=(n, 18))).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        o.step(a)
+        torch.cuda.synchronize()
+        tag = f"8192 terrain grid, step {step}"
+        for name in ("RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH"):
+            np.testing.assert_array_equal(_t(env.sim, name), o.get(name), err_msg=f"{tag} {name}")
+        m = o.get("RESET_BUF").astype(bool)
+        travel = o.get("RESET_TRAVEL")
+        up = m & (travel[:, 0] > env.terrain.env_length / 2)                                       # LR:431-435
+        down = m & (travel[:, 0] < travel[:, 1] * L * 0.5) & ~up
+        lv = levels0 + up.astype(np.int64) - down.astype(np.int64)
+        wrapped = m & (lv >= max_level)                                                           # LR:438: a random level
+        want = np.where(wrapped, -1, np.clip(lv, 0, None))
+        got = env.terrain_levels.cpu().numpy()
+        np.testing.assert_array_equal(got[~wrapped], want[~wrapped], err_msg=f"{tag} terrain levels")
+        assert ((got[wrapped] >= 0) & (got[wrapped] < max_level)).all()
+        new_origin = origins[got, types]
+        np.testing.assert_array_equal(_t(env.sim, "ENV_ORIGINS"), new_origin.astype(np.float32))
+        # the oracle's robots were reset relative to the OLD origin; move them as _apply_terrain_curriculum moved the kernel's
+        oroot = o.get("ROOT_STATES")
+        delta = new_origin - o.get("ENV_ORIGINS")
+        oroot[:, 0, :3] += delta
+        oroot[:, 1, 1] += delta[:, 1]
+        for name, atol, rtol in (("DOF_STATE", 4e-4, 5e-4), ("TORQUES", 4e-4, 5e-4), ("COMMANDS", 1e-6, 1e-6), ("GOAL_STATE", 2e-5, 2e-5),
+                                 ("OBS_BUF", 2e-3, 5e-4), ("OBS_HISTORY", 2e-3, 5e-4), ("REW_BUF", 2e-4, 2e-3), ("ARM_REW_BUF", 2e-5, 1e-3),
+                                 ("EPISODE_SUMS", 2e-2, 2e-3)):
+            _assert_close_bulk(_t(env.sim, name), o.get(name), atol, rtol, f"{tag} {name}", frac=1e-4)
+        _assert_close_bulk(_t(env.sim, "ROOT_STATES"), oroot, 4e-4, 5e-4, f"{tag} ROOT_STATES", frac=1e-4)
+        if m.any():
+            np.testing.assert_allclose(_t(env.sim, "RESET_TRAVEL")[m], travel[m], atol=4e-4, rtol=1e-4)
+        resets += int(m.sum()); moved += int((got != levels0).sum())
+        fz = np.abs(o.get("NET_CONTACT_FORCE")[:, :, :2]).sum((1, 2))                              # horizontal contact force: an edge or a slope
+        on_rough += int((fz > 1.0).sum())
+    assert resets > 40 and moved > 5 and on_rough > 200
+    env.sim.close()
+
+
 def test_free_running_100_policy_steps(robot):
     """state after 1, 4 and 400 substeps without any syncing (fp32 HIP vs fp64 oracle). Contact
     switching makes the trajectories diverge exponentially from fp32 rounding, so the statement is about quantiles."""
@@ -341,4 +420,62 @@ def test_free_running_100_policy_steps(robot):
     assert report[4][0] < 2e-4 and report[4][1] < 5e-3          # 16 substeps
     assert report[100][0] < 0.25 and report[100][2] < 0.02      # 400 substeps: same gait regime, decorrelated joint phases allowed
     np.testing.assert_array_equal(_t(g, "EPISODE_LENGTH"), o.get("EPISODE_LENGTH"))
+    g.close()
+
+
+def test_free_run_statistics_match_the_fp64_oracle(robot):
+    """What the trajectory-level free-run test above cannot pin (contact switching decorrelates joint phases within seconds):
+    the STATISTICS of a long free run. 2048 envs x 500 policy steps = 10 s of simulated time each, the same seeds and the same
+    action stream through the fp32 HIP kernel and the fp64 oracle, nothing synced in between, episodes ending by falls
+    (z threshold lowered to 0.22 m so that robots survive landing and fall from the 0.6-sigma action noise instead) and by
+    150-step time-outs. Compared: finished episodes, fall rate, time-out count, mean episode length and the mean reward of
+    both channels, each within 4 standard errors of the oracle's own estimate plus 2 % -- the stated confidence interval."""
+    import torch
+    n, steps = 2048, 500
+    params = helpers.random_env_params(n, seed=23)
+    tc = copy.copy(robot["tcfg"])
+    tc.term_z_threshold = 0.22
+    tc.max_episode_length = 150
+    g = helpers.make_gpu(robot, n, params, tcfg=tc)
+    o = helpers.make_oracle(robot, n, params, "f64", tcfg=tc)
+    g.reset_all(); o.reset_all()
+    rng = np.random.default_rng(31)
+    acts = (0.6 * rng.normal(size=(steps, n, 18))).astype(np.float32)
+    dev_acts = torch.from_numpy(acts).cuda()
+    # device side: accumulate without host round trips
+    dsum = dict(rew=torch.zeros(n, device="cuda"), arm=torch.zeros(n, device="cuda"), resets=torch.zeros(n, device="cuda"),
+                touts=torch.zeros(n, device="cuda"), lens=torch.zeros(n, device="cuda"), len2=torch.zeros(n, device="cuda"))
+    for k in range(steps):
+        ep = g.tensor("EPISODE_LENGTH").clone()
+        g.step(dev_acts[k])
+        r, t = g.tensor("RESET_BUF") != 0, g.tensor("TIME_OUT_BUF") != 0
+        ln = (ep + 1).float() * r
+        dsum["rew"] += g.tensor("REW_BUF"); dsum["arm"] += g.tensor("ARM_REW_BUF")
+        dsum["resets"] += r; dsum["touts"] += t; dsum["lens"] += ln; dsum["len2"] += ln * ln
+    torch.cuda.synchronize()
+    hsum = {k: np.zeros(n) for k in dsum}
+    for k in range(steps):
+        ep = o.get("EPISODE_LENGTH").copy()
+        o.step(acts[k])
+        r, t = o.get("RESET_BUF") != 0, o.get("TIME_OUT_BUF") != 0
+        ln = (ep + 1) * r
+        hsum["rew"] += o.get("REW_BUF"); hsum["arm"] += o.get("ARM_REW_BUF")
+        hsum["resets"] += r; hsum["touts"] += t; hsum["lens"] += ln; hsum["len2"] += ln * ln
+
+    def stats(s):
+        s = {k: (v.double().cpu().numpy() if hasattr(v, "cpu") else v) for k, v in s.items()}
+        n_ep = s["resets"].sum()
+        mean_len = s["lens"].sum() / n_ep
+        se_len = np.sqrt(max(s["len2"].sum() / n_ep - mean_len ** 2, 0.0) / n_ep)
+        per_env = lambda x: (x.mean() / steps, x.std() / steps / np.sqrt(n))      # noqa: E731  (mean per step, its standard error)
+        falls = s["resets"] - s["touts"]
+        return dict(episodes=(n_ep, np.sqrt(n_ep)), fall_rate=per_env(falls), timeouts=(s["touts"].sum(), np.sqrt(max(s["touts"].sum(), 1.0))),
+                    mean_len=(mean_len, se_len), rew=per_env(s["rew"]), arm_rew=per_env(s["arm"]))
+    hip, ora = stats(dsum), stats(hsum)
+    print("free-run statistics (value, standard error): HIP", {k: tuple(f"{x:.5g}" for x in v) for k, v in hip.items()},
+          "fp64 oracle", {k: tuple(f"{x:.5g}" for x in v) for k, v in ora.items()})
+    assert ora["episodes"][0] > 5000 and ora["timeouts"][0] > 100 and ora["fall_rate"][0] > 1e-3       # a mix of both endings
+    for key in ora:
+        (a, _), (b, se) = hip[key], ora[key]
+        assert abs(a - b) <= 4.0 * se + 0.02 * abs(b), (key, a, b, se)
     g.close()
