@@ -195,6 +195,11 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _self_launch(args)
+    # stdout carries ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner on
+    # communicator creation) are sent to stderr by re-pointing fd 1; the JSON line goes out through a private duplicate
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -409,7 +414,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(runner)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

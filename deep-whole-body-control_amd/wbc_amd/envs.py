@@ -59,6 +59,14 @@ def stale_time_outs(prev, time_out_buf, reset_buf):
     return torch.where((reset_buf != 0).any(), time_out_buf, prev)
 
 
+class EpisodeInfo(dict):
+    """extras['episode'] (WG:743-750): a dict of 0-dim device tensors and floats, as the reference's. `vector` is the one device
+    tensor the tensor entries are views of and `vector_index` maps their keys to its rows, so a logger can average a rollout's
+    worth of these with one stack + one host copy instead of one .item() per key (OnPolicyRunner.log)."""
+    vector = None
+    vector_index = None
+
+
 class BaseTask(VecEnv):
     """Buffer/attribute contract of legged_gym/envs/base/base_task.py:41-131 (viewer omitted: headless)."""
 
@@ -143,6 +151,7 @@ class WidowGo1(LeggedRobot):
         self.async_episode_stats = False
         self._stats_stream = None
         self._stats_pending = False
+        self.stats_hooks = []            # callables launched right after the episode statistics, on the same (side) stream
         # cfg.env.reference_stale_time_outs: publish extras['time_outs'] the way the reference does (quirk Q9). The fused step's
         # in-kernel reward bootstrap uses the CURRENT mask, so with the option on the reward / done slots are filled by
         # wbc_rollout_store from the published (possibly stale) mask instead.
@@ -347,6 +356,8 @@ class WidowGo1(LeggedRobot):
             from .curriculum import _scales
             cfg_leg, cfg_arm = _scales(self.cfg.rewards.scales), _scales(self.cfg.rewards.arm_scales)
             self._active_terms = [(i, n) for i, n in enumerate(abi.REWARD_TERMS) if cfg_leg.get(n, 0) != 0 or cfg_arm.get(n, 0) != 0]
+            self._episode_vector_index = {"rew_" + n: i for i, n in self._active_terms}
+            self._episode_vector_index.update({"metric_" + n: abi.NREW + i for i, n in enumerate(abi.METRIC_NAMES)})
         return cur
 
     def update_command_curriculum(self):                                            # WG:678-692
@@ -372,11 +383,16 @@ class WidowGo1(LeggedRobot):
                 side.wait_stream(torch.cuda.current_stream(self.device))                # after the step kernel's writes
                 with torch.cuda.stream(side):
                     stv = self.sim.episode_stats(1.0 / self.max_episode_length_s)
+                    for hook in self.stats_hooks:                                       # e.g. the runner's episode deques (one launch)
+                        hook()
                 self._stats_pending = True                                              # the next step() waits for it (it rewrites the inputs)
             else:
                 stv = self.sim.episode_stats(1.0 / self.max_episode_length_s)
+                for hook in self.stats_hooks:
+                    hook()
             st = stv.unbind(0)                                                           # one launch, 31 scalar views
-            ep = {}
+            ep = EpisodeInfo()
+            ep.vector, ep.vector_index = stv, self._episode_vector_index                 # the same numbers as ONE device tensor
             for i, name in self._active_terms:
                 ep["rew_" + name] = st[i]
             for i, name in enumerate(abi.METRIC_NAMES):
@@ -387,6 +403,9 @@ class WidowGo1(LeggedRobot):
             ep["coeff_ang_vel_yaw_lower_bound"] = self.ang_vel_yaw_ranges[0]
             ep["coeff_tracking_ang_vel_yaw_exp"] = self.reward_scales.get("tracking_ang_vel_yaw_exp", 0.0)
             self.extras["episode"] = ep
+        elif self.stats_hooks:
+            for hook in self.stats_hooks:
+                hook()
         if self.cfg.env.send_timeouts:
             if self._stale_time_outs_on:                 # opt-in quirk Q9; at construction the reference binds the all-False initial mask
                 prev = self._stale_mask if self._stale_mask is not None and not start else torch.zeros_like(self.time_out_buf)
@@ -394,20 +413,6 @@ class WidowGo1(LeggedRobot):
                 self.extras["time_outs"] = self._stale_mask
             else:
                 self.extras["time_outs"] = self.time_out_buf
-
-    def run_on_stats_stream(self, launch):
-        """Run `launch()` (kernel launches reading this step's reward / reset buffers) where extras['episode'] is computed: on the
-        statistics side stream in async mode (ordered after this step's kernel, and the next step() waits for it), else inline."""
-        if self.async_episode_stats and self.device.type == "cuda":
-            if self._stats_stream is None:
-                self._stats_stream = torch.cuda.Stream(self.device)
-            side = self._stats_stream
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                launch()
-            self._stats_pending = True
-        else:
-            launch()
 
     # ---- torque supervision (WG:1178-1181, 1201-1242): default off (WGC:173) ------------------------------------
     def _refresh_arm_dynamics(self):

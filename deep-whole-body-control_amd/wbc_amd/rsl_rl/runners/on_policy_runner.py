@@ -41,17 +41,32 @@ class _EpisodeTracker:
         self._check, self._L = check, lib()
         self.n, self.device = n, device
         self.state = torch.zeros(self._L.wbc_runner_track_state_floats(n, self.CAP), device=device)
-        self._side = getattr(env, "run_on_stats_stream", None)      # overlaps the next policy inference when the env offers it
+        # An env that computes extras['episode'] on a side stream (WidowGo1.stats_hooks) launches the bookkeeping there too, right
+        # behind its statistics kernel: it overlaps the next policy inference and costs the loop no stream hop of its own.
+        self._hooked_env, self._hook = None, None
+        hooks = getattr(env, "stats_hooks", None)
+        if hooks is not None and all(hasattr(env, a) for a in ("rew_buf", "arm_rew_buf", "reset_buf")):
+            self._hook = lambda: self._launch(env.rew_buf, env.arm_rew_buf, env.reset_buf)
+            hooks.append(self._hook)
+            self._hooked_env = env
+
+    def _launch(self, rewards, arm_rewards, dones):
+        self._check(self._L.wbc_runner_track_episodes(rewards.data_ptr(), arm_rewards.data_ptr(), dones.data_ptr(), self.n, self.CAP,
+                                                      self.state.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
+                    "wbc_runner_track_episodes")
 
     def step(self, rewards, arm_rewards, dones):
-        def launch():
-            self._check(self._L.wbc_runner_track_episodes(rewards.data_ptr(), arm_rewards.data_ptr(), dones.data_ptr(), self.n, self.CAP,
-                                                          self.state.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream),
-                        "wbc_runner_track_episodes")
-        if self._side is not None:
-            self._side(launch)
-        else:
-            launch()
+        """Account for the env step that has just produced these tensors. With a hooked env the launch was issued inside its
+        step() already -- but only from the step AFTER the hook was installed, so the very first call launches here."""
+        if self._hooked_env is None or not self._armed:
+            self._launch(rewards, arm_rewards, dones)
+            self._armed = True
+    _armed = False
+
+    def close(self):
+        if self._hooked_env is not None and self._hook in self._hooked_env.stats_hooks:
+            self._hooked_env.stats_hooks.remove(self._hook)
+        self._hooked_env = None
 
     def summary(self):
         """{mean_reward, mean_arm_reward, mean_episode_length, dones} over the rings (empty before the first finished episode,
@@ -196,6 +211,8 @@ class OnPolicyRunner:
                 self.history.append(rec)
                 ep_infos.clear()
         finally:                                         # also on an exception / KeyboardInterrupt: later callers of env.step()
+            if tracker:
+                tracker.close()
             if hasattr(env, "async_episode_stats"):      # must not read side-stream results unsynchronised
                 env.async_episode_stats = False
                 sync()
@@ -218,9 +235,20 @@ class OnPolicyRunner:
         lines.append(f"{'Leg mean action noise std:':>{pad}} {std[:, :12].mean().item():.2f}")
         lines.append(f"{'Arm mean action noise std:':>{pad}} {std[:, 12:].mean().item():.2f}")
         if ep_infos:
-            for key in ep_infos[0]:
-                vals = [torch.as_tensor(info[key], dtype=torch.float32, device=self.device).reshape(-1) for info in ep_infos]
-                lines.append(f"{'Mean episode ' + key + ':':>{pad}} {torch.cat(vals).mean().item():.4f}")
+            first = ep_infos[0]
+            index = getattr(first, "vector_index", None)
+            means = None
+            if index is not None and all(getattr(i, "vector", None) is not None for i in ep_infos):
+                means = torch.stack([i.vector for i in ep_infos]).mean(0).cpu()      # every tensor entry of every step: one host copy
+            for key in first:
+                if means is not None and key in index:
+                    val = means[index[key]].item()
+                elif means is not None and not torch.is_tensor(first[key]):
+                    val = sum(float(info[key]) for info in ep_infos) / len(ep_infos)
+                else:                                    # the reference's way (OPR:214-226): one cat + mean + item per key
+                    vals = [torch.as_tensor(info[key], dtype=torch.float32, device=self.device).reshape(-1) for info in ep_infos]
+                    val = torch.cat(vals).mean().item()
+                lines.append(f"{'Mean episode ' + key + ':':>{pad}} {val:.4f}")
         lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}", f"{'Total time:':>{pad}} {self.tot_time:.2f}s"]
         print("\n".join(lines))
 
