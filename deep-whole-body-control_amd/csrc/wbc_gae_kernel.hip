@@ -119,63 +119,12 @@ extern "C" int wbc_rollout_store(const float* rew, const float* arm_rew, const i
 //   state (floats): cur[3 N] | ring[3 cap] | done_ring[cap] | header (4 ints: ring head, ring fill, step head, step fill)
 // One block walks the envs in ascending order (the order `extend(...tolist())` appends in), so the ring holds exactly the
 // last `cap` finished episodes the reference's deques would hold, whatever the number that finished in one step.
+#include "wbc_track.h"
 #define TRK_THREADS 1024
 extern "C" __global__ void __launch_bounds__(TRK_THREADS) track_episodes_kernel(const float* __restrict__ rew, const float* __restrict__ arm_rew,
                                                                                const int64_t* __restrict__ dones, int n, int cap,
                                                                                float* __restrict__ state) {
-  __shared__ int wave_cnt[TRK_THREADS / 64];
-  __shared__ int total_sh;
-  float* cur = state;
-  float* ring = state + 3 * (size_t)n;
-  float* done_ring = ring + 3 * (size_t)cap;
-  int* hdr = reinterpret_cast<int*>(done_ring + cap);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // pass 1: how many episodes finish in this step
-  int c = 0;
-  for (int i = tid; i < n; i += TRK_THREADS) c += dones[i] != 0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-  if (lane == 0) wave_cnt[wave] = c;
-  __syncthreads();
-  if (tid == 0) { int t = 0; for (int w = 0; w < TRK_THREADS / 64; ++w) t += wave_cnt[w]; total_sh = t; }
-  __syncthreads();
-  const int total = total_sh, head = hdr[0];
-  // pass 2: accumulate, and append the finished episodes in env order (only the last `cap` of this step can survive)
-  int before = 0;
-  for (int base = 0; base < n; base += TRK_THREADS) {
-    const int i = base + tid;
-    const bool in = i < n;
-    float r = 0.f, a = 0.f, l = 0.f;
-    bool d = false;
-    if (in) {
-      r = cur[3 * (size_t)i] + rew[i]; a = cur[3 * (size_t)i + 1] + arm_rew[i]; l = cur[3 * (size_t)i + 2] + 1.f;
-      d = dones[i] != 0;
-    }
-    const unsigned long long bal = __ballot(d);
-    __syncthreads();
-    if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int pre = 0, chunk = 0;
-    for (int w = 0; w < TRK_THREADS / 64; ++w) { const int k = wave_cnt[w]; if (w < wave) pre += k; chunk += k; }
-    if (d) {
-      const int rank = before + pre + __popcll(bal & ((1ull << lane) - 1ull));
-      if (rank >= total - cap) {
-        const int slot = (head + rank) % cap;
-        ring[3 * slot] = r; ring[3 * slot + 1] = a; ring[3 * slot + 2] = l;
-      }
-      r = 0.f; a = 0.f; l = 0.f;
-    }
-    if (in) { cur[3 * (size_t)i] = r; cur[3 * (size_t)i + 1] = a; cur[3 * (size_t)i + 2] = l; }
-    before += chunk;
-  }
-  if (tid == 0) {
-    hdr[0] = (head + total) % cap;
-    const int fill = hdr[1] + total;
-    hdr[1] = fill < cap ? fill : cap;
-    done_ring[hdr[2]] = (float)total / (float)n;
-    hdr[2] = (hdr[2] + 1) % cap;
-    hdr[3] = hdr[3] + 1 < cap ? hdr[3] + 1 : cap;
-  }
+  track_episodes_block<TRK_THREADS>(rew, arm_rew, dones, n, cap, state);
 }
 
 extern "C" size_t wbc_runner_track_state_floats(int n, int cap) { return 3 * (size_t)n + 4 * (size_t)cap + 4; }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "wbc_device.h"
+#include "wbc_track.h"
 
 extern "C" __global__ void wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
                                            uint64_t seed, uint64_t step, StepOut so);
@@ -398,7 +399,13 @@ extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
 // reference's extras["episode"] is only rebuilt inside reset_idx when env_ids is non-empty (WG:705-706, 742-750).
 static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* __restrict__ ep_done, const float* __restrict__ met_done,
                                                                   const int64_t* __restrict__ reset_buf, int n, float scale,
-                                                                  const float* __restrict__ prev, float* __restrict__ out) {
+                                                                  const float* __restrict__ prev, float* __restrict__ out,
+                                                                  const float* __restrict__ rew, const float* __restrict__ arm_rew,
+                                                                  float* __restrict__ track_state, int track_cap) {
+  if (blockIdx.x == WBC_NREW + WBC_NMETRIC) {       // the extra workgroup (only launched with a tracker state): wbc_track.h
+    track_episodes_block<256>(rew, arm_rew, reset_buf, n, track_cap, track_state);
+    return;
+  }
   // one block per column. Thread t sums envs t, t + 256, ... in ascending order; flag and value are loaded together (the value
   // unconditionally: a dependent second load would double the number of memory round trips), 8 envs in flight per thread.
   // Then a fixed butterfly per wavefront and the four wave sums in wave order: deterministic.
@@ -429,12 +436,18 @@ static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* 
   }
 }
 
-extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, const float* prev, float* out, void* stream) {
+extern "C" int wbc_sim_episode_stats_track(wbc_sim* s, float scale, const float* prev, float* out, float* track_state, int track_cap,
+                                           void* stream) {
   if (!s || !out) return fail(-1, "wbc_sim_episode_stats: null argument");
+  if (track_state && track_cap <= 0) return fail(-1, "wbc_sim_episode_stats_track: cap must be positive");
   DeviceGuard dg(s->device);
-  hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC), dim3(256), 0, (hipStream_t)stream, s->T.ep_sums_done, s->T.met_sums_done,
-                     s->T.reset_buf, s->n, scale, prev, out);
+  hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC + (track_state ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, s->T.ep_sums_done,
+                     s->T.met_sums_done, s->T.reset_buf, s->n, scale, prev, out, s->T.rew, s->T.arm_rew, track_state, track_cap);
   return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
+}
+
+extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, const float* prev, float* out, void* stream) {
+  return wbc_sim_episode_stats_track(s, scale, prev, out, nullptr, 0, stream);
 }
 
 // internal (wbc_arm_kernel.hip): the tensors the arm-dynamics pre-pass reads

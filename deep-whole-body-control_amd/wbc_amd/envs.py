@@ -151,7 +151,7 @@ class WidowGo1(LeggedRobot):
         self.async_episode_stats = False
         self._stats_stream = None
         self._stats_pending = False
-        self.stats_hooks = []            # callables launched right after the episode statistics, on the same (side) stream
+        self._track = (None, 0)          # (state, cap) of attach_episode_tracker: advanced by the statistics launch
         # cfg.env.reference_stale_time_outs: publish extras['time_outs'] the way the reference does (quirk Q9). The fused step's
         # in-kernel reward bootstrap uses the CURRENT mask, so with the option on the reward / done slots are filled by
         # wbc_rollout_store from the published (possibly stale) mask instead.
@@ -382,14 +382,10 @@ class WidowGo1(LeggedRobot):
                 side = self._stats_stream
                 side.wait_stream(torch.cuda.current_stream(self.device))                # after the step kernel's writes
                 with torch.cuda.stream(side):
-                    stv = self.sim.episode_stats(1.0 / self.max_episode_length_s)
-                    for hook in self.stats_hooks:                                       # e.g. the runner's episode deques (one launch)
-                        hook()
+                    stv = self.sim.episode_stats(1.0 / self.max_episode_length_s, *self._track)
                 self._stats_pending = True                                              # the next step() waits for it (it rewrites the inputs)
             else:
-                stv = self.sim.episode_stats(1.0 / self.max_episode_length_s)
-                for hook in self.stats_hooks:
-                    hook()
+                stv = self.sim.episode_stats(1.0 / self.max_episode_length_s, *self._track)
             st = stv.unbind(0)                                                           # one launch, 31 scalar views
             ep = EpisodeInfo()
             ep.vector, ep.vector_index = stv, self._episode_vector_index                 # the same numbers as ONE device tensor
@@ -403,9 +399,6 @@ class WidowGo1(LeggedRobot):
             ep["coeff_ang_vel_yaw_lower_bound"] = self.ang_vel_yaw_ranges[0]
             ep["coeff_tracking_ang_vel_yaw_exp"] = self.reward_scales.get("tracking_ang_vel_yaw_exp", 0.0)
             self.extras["episode"] = ep
-        elif self.stats_hooks:
-            for hook in self.stats_hooks:
-                hook()
         if self.cfg.env.send_timeouts:
             if self._stale_time_outs_on:                 # opt-in quirk Q9; at construction the reference binds the all-False initial mask
                 prev = self._stale_mask if self._stale_mask is not None and not start else torch.zeros_like(self.time_out_buf)
@@ -560,6 +553,12 @@ class WidowGo1(LeggedRobot):
         self._sim_env_origins.copy_(new)
         self.root_states[:, :3] += delta
         self.box_root_state[:, 1] += delta[:, 1]
+
+    def attach_episode_tracker(self, state, cap):
+        """The training loop's episode deques (OnPolicyRunner.learn, OPR:140-154) ride on the per-step statistics launch as one
+        extra workgroup (wbc_sim_episode_stats_track): `state` = wbc_runner_track_state_floats(num_envs, cap) zeroed floats on the
+        sim device, or None to detach. Needs collect_episode_stats (the launch it rides on). Effective from the next step()."""
+        self._track = (state, int(cap)) if state is not None else (None, 0)
 
     def restore_terrain_levels(self, levels, arena_restored=False):
         """Checkpoint resume (OnPolicyRunner.load): adopt saved terrain levels. env_origins and the sim's ENV_ORIGINS are

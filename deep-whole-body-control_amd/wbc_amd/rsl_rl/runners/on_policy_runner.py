@@ -41,13 +41,11 @@ class _EpisodeTracker:
         self._check, self._L = check, lib()
         self.n, self.device = n, device
         self.state = torch.zeros(self._L.wbc_runner_track_state_floats(n, self.CAP), device=device)
-        # An env that computes extras['episode'] on a side stream (WidowGo1.stats_hooks) launches the bookkeeping there too, right
-        # behind its statistics kernel: it overlaps the next policy inference and costs the loop no stream hop of its own.
-        self._hooked_env, self._hook = None, None
-        hooks = getattr(env, "stats_hooks", None)
-        if hooks is not None and all(hasattr(env, a) for a in ("rew_buf", "arm_rew_buf", "reset_buf")):
-            self._hook = lambda: self._launch(env.rew_buf, env.arm_rew_buf, env.reset_buf)
-            hooks.append(self._hook)
+        # An env that publishes extras['episode'] with one launch per step (WidowGo1.attach_episode_tracker) carries the
+        # bookkeeping in that launch as an extra workgroup: no launch and no stream hop of its own.
+        self._hooked_env = None
+        if hasattr(env, "attach_episode_tracker") and getattr(env, "collect_episode_stats", False):
+            env.attach_episode_tracker(self.state, self.CAP)
             self._hooked_env = env
 
     def _launch(self, rewards, arm_rewards, dones):
@@ -56,16 +54,16 @@ class _EpisodeTracker:
                     "wbc_runner_track_episodes")
 
     def step(self, rewards, arm_rewards, dones):
-        """Account for the env step that has just produced these tensors. With a hooked env the launch was issued inside its
-        step() already -- but only from the step AFTER the hook was installed, so the very first call launches here."""
+        """Account for the env step that has just produced these tensors. With an attached env its step() has done it already --
+        but only from the step AFTER the attachment, so the very first call launches here."""
         if self._hooked_env is None or not self._armed:
             self._launch(rewards, arm_rewards, dones)
             self._armed = True
     _armed = False
 
     def close(self):
-        if self._hooked_env is not None and self._hook in self._hooked_env.stats_hooks:
-            self._hooked_env.stats_hooks.remove(self._hook)
+        if self._hooked_env is not None:
+            self._hooked_env.attach_episode_tracker(None, 0)
         self._hooked_env = None
 
     def summary(self):
@@ -231,19 +229,23 @@ class OnPolicyRunner:
                            ("mean_episode_length", "Mean episode length:"), ("dones", "Dones:")):
             if key in rec:
                 lines.append(f"{label:>{pad}} {rec[key]:.4f}")
-        std = self.alg.actor_critic.std.detach()
-        lines.append(f"{'Leg mean action noise std:':>{pad}} {std[:, :12].mean().item():.2f}")
-        lines.append(f"{'Arm mean action noise std:':>{pad}} {std[:, 12:].mean().item():.2f}")
+        ep_means = None
+        first = ep_infos[0] if ep_infos else None
+        index = getattr(first, "vector_index", None)
+        std = self.alg.actor_critic.std.detach().reshape(-1)
+        if index is not None and all(getattr(i, "vector", None) is not None for i in ep_infos):
+            # every tensor entry of every step's extras['episode'] AND the two noise levels: ONE device-to-host copy
+            packed = torch.cat([torch.stack([i.vector for i in ep_infos]).mean(0), std[:12].mean().reshape(1), std[12:].mean().reshape(1)]).cpu()
+            ep_means, leg_std, arm_std = packed[:-2], packed[-2].item(), packed[-1].item()
+        else:
+            leg_std, arm_std = std[:12].mean().item(), std[12:].mean().item()
+        lines.append(f"{'Leg mean action noise std:':>{pad}} {leg_std:.2f}")
+        lines.append(f"{'Arm mean action noise std:':>{pad}} {arm_std:.2f}")
         if ep_infos:
-            first = ep_infos[0]
-            index = getattr(first, "vector_index", None)
-            means = None
-            if index is not None and all(getattr(i, "vector", None) is not None for i in ep_infos):
-                means = torch.stack([i.vector for i in ep_infos]).mean(0).cpu()      # every tensor entry of every step: one host copy
             for key in first:
-                if means is not None and key in index:
-                    val = means[index[key]].item()
-                elif means is not None and not torch.is_tensor(first[key]):
+                if ep_means is not None and key in index:
+                    val = ep_means[index[key]].item()
+                elif ep_means is not None and not torch.is_tensor(first[key]):
                     val = sum(float(info[key]) for info in ep_infos) / len(ep_infos)
                 else:                                    # the reference's way (OPR:214-226): one cat + mean + item per key
                     vals = [torch.as_tensor(info[key], dtype=torch.float32, device=self.device).reshape(-1) for info in ep_infos]

@@ -146,13 +146,15 @@ class WbcSim:
         check(self.L.wbc_sim_arm_dynamics(self.h, rb, ms, mm.data_ptr(), jac.data_ptr(), gt.data_ptr(), self._stream()), "wbc_sim_arm_dynamics")
         return mm, jac, gt
 
-    def episode_stats(self, scale: float) -> torch.Tensor:
+    def episode_stats(self, scale: float, track_state: torch.Tensor = None, track_cap: int = 0) -> torch.Tensor:
         """Means over the envs that reset in the last step of their finished episode's reward sums [NREW] and metric
-        sums [NMETRIC], times `scale`, as one fresh device tensor (WG:743-754 without a host sync)."""
+        sums [NMETRIC], times `scale`, as one fresh device tensor (WG:743-754 without a host sync). With `track_state`
+        (wbc_runner_track_state_floats(n, cap) floats) the launch also advances the runner's episode deques (OPR:140-154)."""
         out = torch.empty(abi.NREW + abi.NMETRIC, dtype=torch.float32, device=self.device)
         prev = self.__dict__.get("_last_episode_stats")         # a step without resets re-publishes the previous values (WG:705-706)
-        check(self.L.wbc_sim_episode_stats(self.h, float(scale), prev.data_ptr() if prev is not None else None, out.data_ptr(),
-                                           self._stream()), "wbc_sim_episode_stats")
+        check(self.L.wbc_sim_episode_stats_track(self.h, float(scale), prev.data_ptr() if prev is not None else None, out.data_ptr(),
+                                                 track_state.data_ptr() if track_state is not None else None, int(track_cap),
+                                                 self._stream()), "wbc_sim_episode_stats")
         self._last_episode_stats = out
         return out
 

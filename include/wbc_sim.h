@@ -382,6 +382,10 @@ int wbc_sim_arm_dynamics(wbc_sim* sim, const int* link_rb9, const float* link_ma
  * the reference does not touch extras["episode"] (reset_idx returns early, widowGo1.py:705-706), i.e. the previous values
  * stay published: out = prev then (prev: the previous call's output, or NULL = zeros). */
 int wbc_sim_episode_stats(wbc_sim* sim, float scale, const float* prev, float* out, void* stream);
+/* The same launch with one more workgroup that does wbc_runner_track_episodes' work (below) on this sim's reward / reset
+ * buffers: the logged training loop's episode bookkeeping at no launch of its own. track_state == NULL: wbc_sim_episode_stats. */
+int wbc_sim_episode_stats_track(wbc_sim* sim, float scale, const float* prev, float* out, float* track_state, int track_cap,
+                                void* stream);
 
 /* PPO.process_env_step's tensor work (rsl_rl/algorithms/ppo.py:129-141 + rollout_storage.py:70-72) in one launch:
  * out_rewards[n] = (rew[n], arm_rew[n]) + gamma * values[n] * time_outs[n], out_dones[n] = dones[n] != 0.

@@ -1,0 +1,41 @@
+"""What a process group costs the loop on ONE GPU, separated: (a) no group; (b) a 1-rank RCCL group exists but the learner does
+not use it (watchdog / heartbeat threads only); (c) the learner uses it (parameter broadcast, 20 gradient all-reduces + 1
+statistics all-reduce per iteration). Prints mean collection / learn ms over the non-DAgger iterations of each leg."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd"))
+import torch
+import torch.distributed as dist
+from wbc_amd.config import WidowGo1RoughCfg, WidowGo1RoughCfgPPO, class_to_dict
+from wbc_amd.envs import WidowGo1
+from wbc_amd.rsl_rl.runners import OnPolicyRunner
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+
+
+def leg(tag, group):
+    cfg = WidowGo1RoughCfg(); cfg.env.num_envs = N; cfg.terrain.mesh_type = "plane"
+    tc = WidowGo1RoughCfgPPO(); torch.manual_seed(tc.seed)
+    env = WidowGo1(cfg, sim_device="cuda:0", seed=tc.seed)
+    runner = OnPolicyRunner(env, class_to_dict(tc), log_dir=None, device="cuda:0", dist_group=group)
+    env.collect_episode_stats = True
+    runner.learn(2, init_at_random_ep_len=True)
+    runner.learn(4)
+    torch.cuda.synchronize()
+    runner.history.clear()
+    runner.learn(13)                                   # iterations 6..18: no DAgger iteration among them
+    c = sum(h["collection_time"] for h in runner.history) / len(runner.history) * 1e3
+    l = sum(h["learn_time"] for h in runner.history) / len(runner.history) * 1e3
+    print(f"{tag:34s} collect {c:6.3f} ms  learn {l:6.3f} ms  sum {c + l:6.3f} ms", flush=True)
+    env.sim.close()
+
+
+leg("(a) no process group", None)
+leg("(a') no process group, repeated", None)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+dist.all_reduce(torch.zeros(4, device="cuda:0")); torch.cuda.synchronize()
+leg("(b) 1-rank RCCL group, unused", None)
+leg("(c) 1-rank RCCL group, used", dist.group.WORLD)
+leg("(a'') no group use again", None)
+dist.destroy_process_group()

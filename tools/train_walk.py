@@ -1,0 +1,108 @@
+"""Train the widowGo1 task from scratch (non-RESUME schedules of widowGo1_config.py:359,366) and record what the task is about:
+command tracking (metric tracking_lin_vel_x_l1, WG:1427-1430), EE-goal tracking (metric tracking_ee_sphere, WG:1352-1358),
+episode length, both reward channels; then evaluate teacher (privileged latent) and student (history latent after DAgger).
+usage: python tools/train_walk.py ITERS [key=value ...]  (keys: survive, z, envs, lin_l1, out)"""
+import json
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd"))
+import torch
+from wbc_amd.config import WidowGo1RoughCfg, WidowGo1RoughCfgPPO, class_to_dict
+from wbc_amd.envs import WidowGo1
+from wbc_amd.rsl_rl.runners import OnPolicyRunner
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+kv = dict(a.split("=", 1) for a in sys.argv[2:])
+n = int(kv.get("envs", 4096))
+cfg = WidowGo1RoughCfg()
+cfg.env.num_envs = n
+cfg.terrain.mesh_type = "plane"
+cfg.termination.z_threshold = float(kv.get("z", 0.25))
+cfg.rewards.scales.survive = float(kv.get("survive", 2.0))
+if "lin_l1" in kv:
+    cfg.rewards.scales.tracking_lin_vel_x_l1 = float(kv["lin_l1"])
+if "contacts_z" in kv:
+    cfg.rewards.scales.foot_contacts_z = float(kv["contacts_z"])
+train = class_to_dict(WidowGo1RoughCfgPPO())
+torch.manual_seed(train["seed"])
+env = WidowGo1(cfg, sim_device="cuda:0", seed=train["seed"])
+runner = OnPolicyRunner(env, train, log_dir=None, device="cuda:0")
+dev = "cuda:0"
+K = ("rew", "arm", "resets", "len", "vx_err", "cmd_abs", "vx", "ee_err", "yaw_err")
+acc = {k: torch.zeros((), device=dev) for k in K}
+cnt = {"steps": 0}
+raw_step = env.step
+
+
+def ee_sphere_error():
+    """WG:1352-1357 on the env's views (what metric tracking_ee_sphere accumulates)."""
+    from wbc_amd.envs import _yaw_quat
+    yq = _yaw_quat(env.base_quat)
+    rel = env.ee_pos - torch.cat([env.root_states[:, :2], env.z_invariant_offset], dim=1)
+    x, y, z, w = (-yq[:, 0], -yq[:, 1], -yq[:, 2], yq[:, 3])       # inverse yaw rotation
+    s, c = 2 * w * z, 1 - 2 * z * z
+    loc = torch.stack([c * rel[:, 0] - s * rel[:, 1], s * rel[:, 0] + c * rel[:, 1], rel[:, 2]], 1)
+    l = loc.norm(dim=1)
+    sph = torch.stack([l, torch.atan2(loc[:, 2], loc[:, :2].norm(dim=1)), torch.atan2(loc[:, 1], loc[:, 0])], 1)
+    return (sph - env.curr_ee_goal_sphere).abs().sum(1)
+
+
+def step(a):
+    ep_before = env.episode_length_buf.clone()
+    out = raw_step(a)
+    m = env.reset_buf > 0
+    live = ~m
+    nl = live.sum().clamp(min=1).float()
+    acc["rew"] += env.rew_buf.mean(); acc["arm"] += env.arm_rew_buf.mean(); acc["resets"] += m.float().mean()
+    acc["len"] += ((ep_before + 1) * m).sum().float() / m.sum().clamp(min=1).float()
+    acc["vx_err"] += ((env.commands[:, 0] - env.base_lin_vel[:, 0]).abs() * live).sum() / nl
+    acc["cmd_abs"] += (env.commands[:, 0].abs() * live).sum() / nl
+    acc["vx"] += (env.base_lin_vel[:, 0] * live).sum() / nl
+    acc["yaw_err"] += ((env.commands[:, 2] - env.base_ang_vel[:, 2]).abs() * live).sum() / nl
+    acc["ee_err"] += (ee_sphere_error() * live).sum() / nl
+    cnt["steps"] += 1
+    return out
+
+
+env.step = step
+rows = []
+t0 = time.time()
+every = max(1, iters // 60)
+for it in range(0, iters, every):
+    for k in K:
+        acc[k].zero_()
+    cnt["steps"] = 0
+    runner.learn(min(every, iters - it), init_at_random_ep_len=(it == 0))
+    s = cnt["steps"]
+    rows.append(dict(it=it + every, **{k: round(acc[k].item() / s, 5) for k in K},
+                     lin_vel_x_range=[float(x) for x in env.lin_vel_x_ranges], mixing=runner.history[-1]["value_mixing_ratio"],
+                     hist_loss=runner.history[-1]["mean_hist_latent_loss"], std_leg=float(runner.alg.actor_critic.std[:, :12].mean()),
+                     std_arm=float(runner.alg.actor_critic.std[:, 12:].mean())))
+    print(json.dumps(rows[-1]), flush=True)
+wall = time.time() - t0
+
+
+def evaluate(hist, steps=500):
+    """Deterministic (mean-action) rollout: teacher = privileged latent, student = history latent."""
+    ac = runner.alg.actor_critic
+    for k in K:
+        acc[k].zero_()
+    cnt["steps"] = 0
+    obs = env.get_observations()
+    with torch.inference_mode():
+        for _ in range(steps):
+            a = ac.act_inference(obs, hist_encoding=hist)
+            obs = env.step(a)[0]
+    s = cnt["steps"]
+    return {k: round(acc[k].item() / s, 5) for k in K}
+
+
+summary = {"iterations": iters, "envs": n, "wall_s": round(wall, 1), "env_steps": iters * n * runner.num_steps_per_env,
+           "config": {"survive": cfg.rewards.scales.survive, "z_threshold": cfg.termination.z_threshold,
+                      "tracking_lin_vel_x_l1": cfg.rewards.scales.tracking_lin_vel_x_l1, "foot_contacts_z": cfg.rewards.scales.foot_contacts_z},
+           "teacher_eval": evaluate(False), "student_eval": evaluate(True)}
+print(json.dumps(summary), flush=True)
+if "out" in kv:
+    runner.save(kv["out"])
