@@ -43,7 +43,7 @@ static const TensorSpec kSpecs[WBC_T_COUNT] = {
     {{4, 18, 0}, 2, WBC_F32}, {{18, 0, 0}, 1, WBC_F32}, {{18, 0, 0}, 1, WBC_F32},  {{20, 0, 0}, 1, WBC_F32},
     {{6, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{24, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},
     {{0, 0, 0}, 0, WBC_F32},  {{0, 0, 0}, 0, WBC_I64},  {{0, 0, 0}, 0, WBC_U8},    {{0, 0, 0}, 0, WBC_I64},
-    {{21, 0, 0}, 1, WBC_F32}, {{10, 0, 0}, 1, WBC_F32}, {{21, 0, 0}, 1, WBC_F32},  {{10, 0, 0}, 1, WBC_F32},
+    {{WBC_NREW, 0, 0}, 1, WBC_F32}, {{WBC_NMETRIC, 0, 0}, 1, WBC_F32}, {{WBC_NREW, 0, 0}, 1, WBC_F32},  {{WBC_NMETRIC, 0, 0}, 1, WBC_F32},
     {{3, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{5, 0, 0}, 1, WBC_F32},   {{0, 0, 0}, 0, WBC_F32},
     {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32},
     {{2, 0, 0}, 1, WBC_F32}};
@@ -73,6 +73,14 @@ struct wbc_sim {
 
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
 
+// Per-env shape / dtype of tensor `id` without a sim (and without a GPU): lets a binding check its own table.
+extern "C" int wbc_tensor_spec(int id, int64_t* dims3, int* ndim, int* dtype) {
+  if (id < 0 || id >= WBC_T_COUNT || !dims3 || !ndim || !dtype) return -1;
+  for (int i = 0; i < 3; ++i) dims3[i] = kSpecs[id].dims[i];
+  *ndim = kSpecs[id].ndim; *dtype = kSpecs[id].dtype;
+  return 0;
+}
+
 extern "C" size_t wbc_sim_arena_bytes(int num_envs) {
   size_t off = 0;
   for (int t = 0; t < WBC_T_COUNT; ++t) off = align_up(off + spec_elems(kSpecs[t]) * dtype_bytes(kSpecs[t].dtype) * (size_t)num_envs, 256);
@@ -100,13 +108,36 @@ static int build_chains(DevConst& hc) {
     hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
   }
   if (nchain != WBC_NCHAIN) return -1;
-  for (int k = 0; k < WBC_NCP; ++k) {
-    hc.cp_foot[k] = -1;
-    for (int f = 0; f < WBC_NFEET; ++f) if (k < m.ncp && m.feet_rb[f] == m.cp_rb[k]) hc.cp_foot[k] = f;
-    if (m.cp_body[k] < 0 || m.cp_body[k] >= WBC_NB) return -1;
-    hc.cp_depth[k] = hc.body_depth[m.cp_body[k]];
+  // collision set: every contact has a sphere on a moving body; a self-collision pair also a partner body
+  static_assert(WBC_NCP <= 32 && WBC_NRB_ENV <= 32, "contact sets are 32-bit masks (one lane per contact, ballot of the active ones)");
+  if (m.ncp < WBC_NFEET || m.ncp > WBC_NCP) return -1;
+  for (int d = 0; d <= WBC_MAX_DEPTH; ++d) hc.depth_cp_mask[d] = 0;
+  for (int r = 0; r < 32; ++r) hc.out_cp_mask[r] = hc.out_cp2_mask[r] = 0;
+  for (int i = 0; i < WBC_NB; ++i) hc.body_cp_mask[i] = hc.body_cp2_mask[i] = 0;
+  for (int f = 0; f < WBC_NFEET; ++f) hc.foot_cp[f] = -1;
+  for (int k = 0; k < m.ncp; ++k) {
+    const int b = m.cp_body[k], kind = m.cp_kind[k];
+    if (b < 0 || b >= WBC_NB || m.cp_rb[k] < 0 || m.cp_rb[k] >= WBC_NRB) return -1;
+    if (kind != WBC_CP_TERRAIN && kind != WBC_CP_BOX && kind != WBC_CP_CAPSULE) return -1;
+    int depth = hc.body_depth[b];
+    hc.body_cp_mask[b] |= 1u << k;
+    hc.out_cp_mask[m.cp_rb[k]] |= 1u << k;
+    if (kind != WBC_CP_TERRAIN) {
+      const int b2 = m.cp_body2[k];
+      if (b2 < 0 || b2 >= WBC_NB || b2 == b || m.cp_rb2[k] < 0 || m.cp_rb2[k] >= WBC_NRB) return -1;
+      depth = hc.body_depth[b2] > depth ? hc.body_depth[b2] : depth;
+      hc.body_cp2_mask[b2] |= 1u << k;
+      hc.out_cp2_mask[m.cp_rb2[k]] |= 1u << k;
+    } else {
+      for (int f = 0; f < WBC_NFEET; ++f) if (m.feet_rb[f] == m.cp_rb[k]) {
+        if (hc.foot_cp[f] >= 0) return -1;          // one sphere per foot: the sensor reads that contact
+        hc.foot_cp[f] = k;
+      }
+    }
+    hc.depth_cp_mask[depth] |= 1u << k;
   }
-  static_assert(WBC_NB <= 31 && WBC_NDOF <= 32 && WBC_MAX_DEPTH * 5 <= 32 && WBC_NCP + 7 <= 32, "bit packing of the chain tables");
+  for (int f = 0; f < WBC_NFEET; ++f) if (hc.foot_cp[f] < 0) return -1;
+  static_assert(WBC_NB <= 31 && WBC_NDOF <= 32 && WBC_MAX_DEPTH * 5 <= 32, "bit packing of the chain tables");
   for (int c = 0; c <= WBC_NCHAIN; ++c) {
     uint32_t pb = 0, pd = 0, pa = 0;
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
@@ -118,24 +149,15 @@ static int build_chains(DevConst& hc) {
     }
     hc.chain_pack_body[c] = pb; hc.chain_pack_dof[c] = pd; hc.chain_pack_ax[c] = pa;
   }
-  static_assert(WBC_NRB_ENV <= 32, "out_cp_mask layout");
-  for (int r = 0; r < 32 + WBC_NFEET; ++r) hc.out_cp_mask[r] = 0;
-  for (int k = 0; k < WBC_NCP; ++k) {
-    if (m.cp_rb[k] >= 0 && m.cp_rb[k] < WBC_NRB_ENV) hc.out_cp_mask[m.cp_rb[k]] |= 1u << k;
-    if (hc.cp_foot[k] >= 0) hc.out_cp_mask[32 + hc.cp_foot[k]] |= 1u << k;
-  }
-  for (int i = 0; i < WBC_NB; ++i) {
-    uint32_t mask = 0;
-    for (int k = 0; k < WBC_NCP; ++k) if (m.cp_body[k] == i) mask |= 1u << k;
-    hc.body_pack[i] = (uint32_t)(m.axis[i] < 0 ? 0 : m.axis[i]) | (uint32_t)(m.dof[i] < 0 ? 0 : m.dof[i]) << 2 | mask << 7;
-  }
+  for (int i = 0; i < WBC_NB; ++i)
+    hc.body_pack[i] = (uint32_t)(m.axis[i] < 0 ? 0 : m.axis[i]) | (uint32_t)(m.dof[i] < 0 ? 0 : m.dof[i]) << 2;
   return 0;
 }
 
 extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, int num_envs, int hip_device, uint64_t seed, void* arena,
                               size_t arena_bytes, wbc_sim** out) {
   if (!model || !cfg || !out || num_envs <= 0) return fail(-1, "wbc_sim_create: bad arguments");
-  if (model->ncp != WBC_NCP) return fail(-1, "wbc_sim_create: model.ncp must equal WBC_NCP");
+  if (model->ncp < WBC_NFEET || model->ncp > WBC_NCP) return fail(-1, "wbc_sim_create: model.ncp must be in [4, WBC_NCP]");
   DeviceGuard dg(hip_device);
   wbc_sim* s = new wbc_sim();
   s->n = num_envs; s->device = hip_device; s->seed = seed;

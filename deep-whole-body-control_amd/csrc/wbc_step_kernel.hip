@@ -65,6 +65,11 @@ struct __align__(16) Smem {
   union {
     float IA[WBC_NB][36];        // articulated inertia; reused as K (inverse articulated inertia)
     PostBuf post;
+    struct {                     // contact iterations: K of the bodies 1.. is dead once every active contact has built its Delassus
+      float K0[36];              // block (the sweeps only apply the root's K), so the per-contact data the owning lane re-reads in
+      float cW[WBC_NCP][9];      // every iteration lives there instead of in ~12 more registers per lane
+      float cdv[WBC_NCP][3];
+    } ctc;
   };
   float E[WBC_NB][9];
   float pos[WBC_NB][3];
@@ -74,9 +79,10 @@ struct __align__(16) Smem {
   float q[WBC_NDOF], qd[WBC_NDOF], tau[WBC_NDOF], act[WBC_NACT];
   float root[13], box[13], R[9], wb[3], vb[3], gF[3];
   float bp[20], motor[WBC_NACT];
-  float cxc[WBC_NCP][3], cn[WBC_NCP][3], cW[WBC_NCP][9], cvfree[WBC_NCP][3], clam[WBC_NCP][3], cdv[WBC_NCP][3];
-  float cvtgt[WBC_NCP];
-  int cactive[WBC_NCP];
+  // contacts (one per lane): only what OTHER lanes read lives here -- the contact point and the impulse (gathered per body).
+  // Normal, Delassus block, free velocity, sweep response and velocity target stay in the owning lane's registers; the set of
+  // active contacts is a wavefront ballot.
+  float cxc[WBC_NCP][3], clam[WBC_NCP][3];
   float out_contact[WBC_NRB_ENV][3];
   float out_sensor[WBC_NFEET][6];
   float goal[24], cmd[3], blv[3], bav[3];
@@ -92,6 +98,7 @@ struct __align__(16) Smem {
   uint32_t k_body[WBC_NB];               // DevConst::body_pack
   float k_qdlim[WBC_NDOF];
   float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];   // joint armature at (chain, depth); row WBC_NCHAIN is the idle row
+  uint32_t k_gm1[WBC_NB], k_gm2[WBC_NB];         // DevConst::body_cp_mask / body_cp2_mask
 };
 
 // aliases: pD lives in pA, aD in c (both dead once pass 3 has run); g (pass 3 only) also lives in pA:
@@ -227,7 +234,11 @@ __device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restri
 // One physics substep on the LDS-resident state (oracle: physics_substep).
 __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, const int chain, const int k,
                                 const bool want_outputs) {
-  const int lane = threadIdx.x;
+  // the lane index as a value the optimiser cannot see through: everything derived from it (LDS / constant-table addresses of the
+  // one-body / one-DoF / one-contact-per-lane phases) is then recomputed inside each substep (a few integer operations) instead
+  // of being computed once before the substep loop and held in ~20 VGPRs across it (the kernel is compiled for 128)
+  int lane = threadIdx.x;
+  asm volatile("" : "+v"(lane));
   const float dt = C->cfg.sim_dt;
   const float idt = 1.f / dt;
   // constants of the one-body-per-lane phases: issued here, consumed after the kinematics (latency hidden)
@@ -435,13 +446,18 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   WSYNC();
   STAMP(5);
   // contact-sphere constants of this lane: issued before pass 3, consumed after it
-  int cpb = 0;
+  // (a laundered copy of C for the lane-indexed constant loads of the contact phase: left alone, the compiler computes their
+  // 64-bit addresses once before the substep loop and keeps ~10 of them alive in VGPR pairs across it -- spilled to scratch)
+  const DevConst* Cc = C;
+  asm volatile("" : "+s"(Cc));
+  int cpb = 0, cpkind = -1;
   float cpp[3] = {0.f, 0.f, 0.f}, cpr = 0.f;
-  if (lane < WBC_NCP) {
-    cpb = C->model.cp_body[lane];
+  if (lane < Cc->model.ncp) {
+    cpb = Cc->model.cp_body[lane];
+    cpkind = Cc->model.cp_kind[lane];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) cpp[j] = C->model.cp_pos[lane][j];
-    cpr = C->model.cp_radius[lane];
+    for (int j = 0; j < 3; ++j) cpp[j] = Cc->model.cp_pos[lane][j];
+    cpr = Cc->model.cp_radius[lane];
   }
   // pass 3 and inverse articulated inertias, outward: the parent's K entries (K3) and acceleration component (apr)
   // travel down the chain in registers; one LDS hand-over per level (g = K_p U / D and the terms of U.(a_p + c)).
@@ -487,49 +503,117 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   }
   WSYNC();
   STAMP(6);
-  // contacts: one contact sphere per lane
-  if (lane < WBC_NCP) {
-    const int kc = lane;
-    const int b = cpb;
-    const f3 xk = ld3(s.pos[b]) + mat_mul(s.E[b], mk3(cpp[0], cpp[1], cpp[2]));
+  // contacts: one contact per lane (spheres against the terrain, then the self-collision pairs: a sphere against a box or a
+  // capsule riding on another body). Narrow phase first; only lanes with an ACTIVE contact build a Delassus block.
+  // constants first needed after the terrain branch below (their latency hides behind it): the partner of a self-collision pair
+  int cpb2 = -1;                                                         // stays -1 for terrain contacts
+  float cpa[3] = {0.f, 0.f, 0.f}, cpe[3] = {0.f, 0.f, 0.f}, cpr2 = 0.f;
+  if (cpkind > WBC_CP_TERRAIN) {
+    cpb2 = Cc->model.cp_body2[lane];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { cpa[j] = Cc->model.cp_a[lane][j]; cpe[j] = Cc->model.cp_b[lane][j]; }
+    cpr2 = Cc->model.cp_radius2[lane];
+  }
+  f3 cn = mk3(0.f, 0.f, 1.f), cxcr = mk3(0.f, 0.f, 0.f);
+  float cgap = 1e30f;
+  if (cpkind == WBC_CP_TERRAIN) {
+    const f3 xk = ld3(s.pos[cpb]) + mat_mul(s.E[cpb], mk3(cpp[0], cpp[1], cpp[2]));
     const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
     float h; f3 nw;
     terrain_query(C, Xw.x, Xw.y, &h, &nw);
-    const float rad = cpr;
-    const float gap = (Xw.z - h) * nw.z - rad;
-    const int active = gap < C->cfg.contact_margin;
-    s.cactive[kc] = active;
+    cgap = (Xw.z - h) * nw.z - cpr;
+    cn = matT_mul(s.R, nw);
+    cxcr = xk - cn * cpr;
+  } else if (cpkind > WBC_CP_TERRAIN) {
+    const f3 xk = ld3(s.pos[cpb]) + mat_mul(s.E[cpb], mk3(cpp[0], cpp[1], cpp[2]));
+    const f3 pl = matT_mul(s.E[cpb2], xk - ld3(s.pos[cpb2]));           // sphere centre in the partner's frame
+    const f3 A = mk3(cpa[0], cpa[1], cpa[2]), B = mk3(cpe[0], cpe[1], cpe[2]);
+    f3 ql, nl;
+    float dist;
+    if (cpkind == WBC_CP_BOX) {                                          // box: centre A, half extents B
+      const f3 r = pl - A;
+      const f3 cl = mk3(clampf(r.x, -B.x, B.x), clampf(r.y, -B.y, B.y), clampf(r.z, -B.z, B.z));
+      const bool inside = cl.x == r.x && cl.y == r.y && cl.z == r.z;
+      if (!inside) {
+        ql = A + cl;
+        nl = r - cl;
+        dist = __builtin_amdgcn_sqrtf(dot(nl, nl));
+        nl = nl * (1.f / dist);
+      } else {                                                           // leave through the nearest face
+        const float dx = B.x - fabsf(r.x), dy = B.y - fabsf(r.y), dz = B.z - fabsf(r.z);
+        int ax = 0; float best = dx;
+        if (dy < best) { best = dy; ax = 1; }
+        if (dz < best) { best = dz; ax = 2; }
+        const float rv = ax == 0 ? r.x : (ax == 1 ? r.y : r.z), sg = rv >= 0.f ? 1.f : -1.f;
+        nl = mk3(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
+        ql = A + mk3(ax == 0 ? sg * B.x : cl.x, ax == 1 ? sg * B.y : cl.y, ax == 2 ? sg * B.z : cl.z);
+        dist = -best;
+      }
+      cgap = dist - cpr;
+    } else {                                                             // capsule: segment A..B, radius cpr2
+      const f3 ab = B - A, ap = pl - A;
+      const float tt = clampf(dot(ap, ab) / dot(ab, ab), 0.f, 1.f);
+      ql = A + ab * tt;
+      nl = pl - ql;
+      dist = __builtin_amdgcn_sqrtf(dot(nl, nl));
+      nl = dist > 1e-9f ? nl * (1.f / dist) : mk3(1.f, 0.f, 0.f);
+      ql = ql + nl * cpr2;
+      cgap = dist - cpr - cpr2;
+    }
+    cn = mat_mul(s.E[cpb2], nl);
+    cxcr = ld3(s.pos[cpb2]) + mat_mul(s.E[cpb2], ql);                    // on the partner's surface
+  }
+  const bool cact = cgap < C->cfg.contact_margin;
+  const uint32_t abits = (uint32_t)__ballot(cact);                      // the active set (WBC_NCP <= 32 lanes)
+  f3 cvfree = mk3(0.f, 0.f, 0.f), clamr = mk3(0.f, 0.f, 0.f);
+  float cvtgt = 0.f;
+  if (cact) {
+    const int kc = lane;
+    float cW[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    st3(s.cxc[kc], cxcr);
     s.clam[kc][0] = s.clam[kc][1] = s.clam[kc][2] = 0.f;
-    s.cdv[kc][0] = s.cdv[kc][1] = s.cdv[kc][2] = 0.f;
-    if (active) {
-      const f3 n = matT_mul(s.R, nw);
-      const f3 xc = xk - n * rad;
-      st3(s.cn[kc], n); st3(s.cxc[kc], xc);
-      s.cvtgt[kc] = (gap >= 0.f) ? -gap * idt : fminf(C->cfg.contact_erp * (-gap) * idt, C->cfg.max_depenetration_vel);
-      // W = J K J^T with J = [-[xc]x  I] (point velocity = v + omega x xc): for any 6-vector (a; l), J-row products are
-      // l + a x xc, so K J^T has rows Kl_r + Ka_r x xc and W's columns are L_c + U_c x xc (54 FMAs instead of 162)
+    cvtgt = (cgap >= 0.f) ? -cgap * idt : fminf(C->cfg.contact_erp * (-cgap) * idt, C->cfg.max_depenetration_vel);
+    const f3 xc = cxcr;
+    // W = J K J^T with J = [-[xc]x  I] (point velocity = v + omega x xc): for any 6-vector (a; l), J-row products are
+    // l + a x xc, so K J^T has rows Kl_r + Ka_r x xc and W's columns are L_c + U_c x xc (54 FMAs instead of 162). A
+    // self-collision pair sums the blocks of its two bodies (their coupling through the tree is left to the sweeps).
+    const int nside = cpkind == WBC_CP_TERRAIN ? 1 : 2;
+#pragma unroll 1
+    for (int side = 0; side < nside; ++side) {
+      const int b = side == 0 ? cpb : cpb2;
       const float* K = s.IA[b];
-      f3 kj[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) kj[r] = ld3(&K[r * 6 + 3]) + cross(ld3(&K[r * 6]), xc);
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        const f3 up = mk3(cc == 0 ? kj[0].x : (cc == 1 ? kj[0].y : kj[0].z), cc == 0 ? kj[1].x : (cc == 1 ? kj[1].y : kj[1].z),
-                          cc == 0 ? kj[2].x : (cc == 1 ? kj[2].y : kj[2].z));
-        const f3 lo = mk3(cc == 0 ? kj[3].x : (cc == 1 ? kj[3].y : kj[3].z), cc == 0 ? kj[4].x : (cc == 1 ? kj[4].y : kj[4].z),
-                          cc == 0 ? kj[5].x : (cc == 1 ? kj[5].y : kj[5].z));
-        const f3 wc = lo + cross(up, xc);
-        s.cW[kc][0 * 3 + cc] = wc.x + (cc == 0 ? 1e-6f : 0.f);
-        s.cW[kc][1 * 3 + cc] = wc.y + (cc == 1 ? 1e-6f : 0.f);
-        s.cW[kc][2 * 3 + cc] = wc.z + (cc == 2 ? 1e-6f : 0.f);
+      // rows of K J^T: kj_r = Kl_r + Ka_r x xc. W row r' = kj_{3+r'} + (column-wise) (kj_0, kj_1, kj_2) x xc, i.e.
+      // W0 = kj3 + kj1 xc.z - kj2 xc.y, W1 = kj4 + kj2 xc.x - kj0 xc.z, W2 = kj5 + kj0 xc.y - kj1 xc.x (12 live values, not 27)
+      const f3 k0 = ld3(&K[3]) + cross(ld3(&K[0]), xc), k1 = ld3(&K[9]) + cross(ld3(&K[6]), xc), k2 = ld3(&K[15]) + cross(ld3(&K[12]), xc);
+      {
+        const f3 k3 = ld3(&K[21]) + cross(ld3(&K[18]), xc);
+        const f3 w0 = k3 + (k1 * xc.z - k2 * xc.y);
+        cW[0] += w0.x; cW[1] += w0.y; cW[2] += w0.z;
+      }
+      {
+        const f3 k4 = ld3(&K[27]) + cross(ld3(&K[24]), xc);
+        const f3 w1 = k4 + (k2 * xc.x - k0 * xc.z);
+        cW[3] += w1.x; cW[4] += w1.y; cW[5] += w1.z;
+      }
+      {
+        const f3 k5 = ld3(&K[33]) + cross(ld3(&K[30]), xc);
+        const f3 w2 = k5 + (k0 * xc.y - k1 * xc.x);
+        cW[6] += w2.x; cW[7] += w2.y; cW[8] += w2.z;
       }
       const f3 w = ld3(&s.v[b][0]);
       const f3 vp = ld3(&s.v[b][3]) + cross(w, xc);
       const f3 ab_a = ld3(&s.a[b][0]);
       const f3 ab_l = ld3(&s.a[b][3]) + ld3(s.gF);
       const f3 apnt = ab_l + cross(ab_a, xc) + cross(w, vp);
-      st3(s.cvfree[kc], vp + apnt * dt);
+      const f3 vf = vp + apnt * dt;
+      cvfree = side == 0 ? vf : cvfree - vf;
     }
+    cW[0] += 1e-6f; cW[4] += 1e-6f; cW[8] += 1e-6f;
+    // every lane's reads of K are done (one wavefront, LDS operations in program order; the lanes of a self-collision pair have
+    // left the two-sided loop): the blocks go where K_1.. was
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s.ctc.cW[kc][j] = cW[j];
+    s.ctc.cdv[kc][0] = s.ctc.cdv[kc][1] = s.ctc.cdv[kc][2] = 0.f;
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
   if (lane < 6) AD(s)[0][lane] = 0.f;
@@ -537,37 +621,42 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(7);
   // dmax: deepest chain level that carries an active contact. Deeper levels see no contact wrench, so the inward
   // sweep skips them exactly; the outward sweep needs them only in the last iteration (joint accelerations).
-  int any = 0, dmax = 1;
+  const int any = abits != 0u;
+  int dmax = 1;
 #pragma unroll
-  for (int kc = 0; kc < WBC_NCP; ++kc) {
-    const int a = s.cactive[kc];
-    any |= a;
-    dmax = max(dmax, a ? C->cp_depth[kc] : 0);
-  }
+  for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
+  float com = 1.f;
+  if (cact) com = 1.f / (float)__popc(abits & s.k_gm1[cpb]);
   if (any) {
     const int iters = C->cfg.contact_iters;
     for (int it = 0; it < iters; ++it) {
-      if (lane < WBC_NCP && s.cactive[lane]) {
-        const int kc = lane;
-        const f3 own = mat_mul(s.cW[kc], ld3(s.clam[kc]));
-        const f3 vref = ld3(s.cvfree[kc]) + ld3(s.cdv[kc]) - own;
+      if (cact) {
+        float cW[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) cW[j] = s.ctc.cW[lane][j];
+        const f3 own = mat_mul(cW, clamr);
+        const f3 vref = cvfree + ld3(s.ctc.cdv[lane]) - own;
+        const float cmu = cpb2 < 0 ? s.mu : fmaxf(s.friction, 0.f);
         float lam[3];
-        contact_solve(s.cW[kc], ld3(s.cn[kc]), s.cvtgt[kc], s.mu, vref, lam);
-        s.clam[kc][0] = lam[0]; s.clam[kc][1] = lam[1]; s.clam[kc][2] = lam[2];
+        contact_solve(cW, cn, cvtgt, cmu, vref, lam);
+        // damped block-Jacobi: the active contacts of spheres on the same body share the correction (relaxation 1 / their number)
+        clamr = clamr + (mk3(lam[0], lam[1], lam[2]) - clamr) * com;
+        st3(s.clam[lane], clamr);
       }
       WSYNC();
-      // gather contact wrenches per body (fixed order), pD = -f_ext
+      // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a self-collision pair
+      // receives the opposite wrench
       if (lane < WBC_NB) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        uint32_t mask = s.k_body[lane] >> 7;       // the contact spheres on this body, ascending
+        const uint32_t gmask1 = s.k_gm1[lane];
+        uint32_t mask = (gmask1 | s.k_gm2[lane]) & abits;
         while (mask) {
           const int kc = __ffs(mask) - 1;
           mask &= mask - 1;
-          if (s.cactive[kc]) {
-            const f3 f = ld3(s.clam[kc]) * idt;
-            const f3 mom = cross(ld3(s.cxc[kc]), f);
-            acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
-          }
+          const float sg = ((gmask1 >> kc) & 1u) ? idt : -idt;
+          const f3 f = ld3(s.clam[kc]) * sg;
+          const f3 mom = cross(ld3(s.cxc[kc]), f);
+          acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
@@ -603,7 +692,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
           for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][j];
           pd0[j] = acc;
         }
-        AD(s)[0][lane] = -dot6(&s.IA[0][lane * 6], pd0);
+        AD(s)[0][lane] = -dot6(&s.ctc.K0[lane * 6], pd0);
       }
       WSYNC();
       const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
@@ -625,10 +714,11 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         }
         WSYNC();
       }
-      if (it < iters - 1 && lane < WBC_NCP && s.cactive[lane]) {      // the last sweep's contact-point response is not used
-        const int kc = lane, b = cpb;
-        const f3 t = cross(ld3(&AD(s)[b][0]), ld3(s.cxc[kc]));
-        st3(s.cdv[kc], (ld3(&AD(s)[b][3]) + t) * dt);
+      if (it < iters - 1 && cact) {      // the last sweep's contact-point response is not used
+        const f3 xc = ld3(s.cxc[lane]);
+        f3 dvv = (ld3(&AD(s)[cpb][3]) + cross(ld3(&AD(s)[cpb][0]), xc)) * dt;
+        if (cpb2 >= 0) dvv = dvv - (ld3(&AD(s)[cpb2][3]) + cross(ld3(&AD(s)[cpb2][0]), xc)) * dt;
+        st3(s.ctc.cdv[lane], dvv);
       }
       WSYNC();
     }
@@ -636,29 +726,30 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(8);
   // contact force outputs (world-frame net force per rigid body, foot-frame sensor wrench)
   if (want_outputs) {
-    // lanes 0..27: net force on rigid body `lane`; lanes 32..35: sensor wrench of foot lane-32 (contact masks, ascending)
-    uint32_t mask = C->out_cp_mask[lane < 32 + WBC_NFEET ? lane : 0];
+    // the foot sensors read the normal of their (single) contact from its owning lane; all lanes take part in the shuffles
+    const int src = (lane >= 32 && lane < 32 + WBC_NFEET) ? Cc->foot_cp[lane - 32] : lane;
+    const f3 nsrc = mk3(__shfl(cn.x, src), __shfl(cn.y, src), __shfl(cn.z, src));
+    // lanes 0..27: net force on rigid body `lane` (+ as the sphere's body, - as the partner of a self-collision pair)
     if (lane < WBC_NRB_ENV) {
+      const uint32_t m1 = Cc->out_cp_mask[lane], m2 = Cc->out_cp2_mask[lane];
+      uint32_t mask = (m1 | m2) & abits;
       f3 acc = mk3(0.f, 0.f, 0.f);
       while (mask) {
         const int kc = __ffs(mask) - 1;
         mask &= mask - 1;
-        if (s.cactive[kc]) acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * idt);
+        const float sg = ((m1 >> kc) & 1u) ? idt : -idt;
+        acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * sg);
       }
       st3(s.out_contact[lane], acc);
     } else if (lane >= 32 && lane < 32 + WBC_NFEET) {
-      const int ft = lane - 32;
+      const int ft = lane - 32, kc = src;
       f3 fa = mk3(0.f, 0.f, 0.f), ta = mk3(0.f, 0.f, 0.f);
-      while (mask) {
-        const int kc = __ffs(mask) - 1;
-        mask &= mask - 1;
-        if (s.cactive[kc]) {
-          const int b = C->model.cp_body[kc];
-          const f3 f = ld3(s.clam[kc]) * idt;
-          const f3 arm = ld3(s.cn[kc]) * (-C->model.cp_radius[kc]);
-          fa = fa + matT_mul(s.E[b], f);
-          ta = ta + matT_mul(s.E[b], cross(arm, f));
-        }
+      if ((abits >> kc) & 1u) {
+        const int b = Cc->model.cp_body[kc];
+        const f3 f = ld3(s.clam[kc]) * idt;
+        const f3 arm = nsrc * (-Cc->model.cp_radius[kc]);
+        fa = matT_mul(s.E[b], f);
+        ta = matT_mul(s.E[b], cross(arm, f));
       }
       st3(&s.out_sensor[ft][0], fa); st3(&s.out_sensor[ft][3], ta);
     }
@@ -822,7 +913,7 @@ __device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
     /* FOOT_CONTACTS_Z */ {WBC_REW_FOOT_CONTACTS_Z, -1}};
 
 // compute_reward of the oracle, executed by lane 0 on LDS state
-__device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq) {
+__device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq, const float ncol) {
   const wbc_task_cfg& cf = C->cfg;
   const float inv_sig = 1.f / cf.tracking_sigma, inv_ee_sig = 1.f / cf.tracking_ee_sigma;
   float term[WBC_NREW], met_src[WBC_NREW];
@@ -881,6 +972,7 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   term[WBC_REW_TRACKING_LIN_VEL_Y_L2] = dy * dy;
   term[WBC_REW_TRACKING_LIN_VEL_Z_L2] = dz * dz;
   term[WBC_REW_TORQUES] = tq2;
+  term[WBC_REW_COLLISION] = ncol;
   met_src[WBC_REW_ENERGY_SQUARE] = sq; met_src[WBC_REW_TRACKING_LIN_VEL_X_L1] = ex; met_src[WBC_REW_TRACKING_LIN_VEL_X_EXP] = ex;
   met_src[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = eyaw; met_src[WBC_REW_HIP_ACTION_L2] = hip; met_src[WBC_REW_LEG_ACTION_L2] = act_leg;
   met_src[WBC_REW_FOOT_CONTACTS_Z] = fz; met_src[WBC_REW_TRACKING_EE_SPHERE] = es; met_src[WBC_REW_TRACKING_EE_CART] = ec;
@@ -951,7 +1043,7 @@ __device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restric
 __device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
   const int lane = threadIdx.x;
   if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = (&C->model.joint_xyz[0][0])[lane];
-  if (lane < WBC_NB) s.k_body[lane] = C->body_pack[lane];
+  if (lane < WBC_NB) { s.k_body[lane] = C->body_pack[lane]; s.k_gm1[lane] = C->body_cp_mask[lane]; s.k_gm2[lane] = C->body_cp2_mask[lane]; }
   if (lane < WBC_NDOF) s.k_qdlim[lane] = C->model.qd_limit[lane];
   if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
     const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
@@ -1137,11 +1229,18 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
   STAMP(13);
+  // Everything after the substeps reads its tensor / constant pointers through laundered copies of the two kernel arguments: the
+  // compiler otherwise hoists those (invariant) scalar loads above the substep loop, where the ~40 pointers and constants it
+  // keeps alive across the loop exhaust the SGPR file and end up spilled to scratch memory through VGPRs.
+  const DevTensors* Tq = Tp;
+  const DevConst* Cq = C;
+  asm volatile("" : "+s"(Tq), "+s"(Cq));
+  const DevTensors& T2 = *Tq;
   // the observation's history block (obs_history_buf before this step's update, WG:992): 12 coalesced loads per lane, consumed by
   // observe_and_store at the very end
   float hist_in[12];
   {
-    const float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
+    const float* hist = T2.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
       const int idx = lane + r * LANES;
@@ -1150,9 +1249,16 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   }
   // post_physics_step (WG:865-915)
   float rsc_leg = 0.f, rsc_arm = 0.f;             // this lane's reward scales (consumed after the lane-0 task logic)
-  if (lane < WBC_NREW) { rsc_leg = C->cur.leg_reward_scale[lane]; rsc_arm = C->cur.arm_reward_scale[lane]; }
-  rigid_body_pass(s, C, cr, chain, k);
+  if (lane < WBC_NREW) { rsc_leg = Cq->cur.leg_reward_scale[lane]; rsc_arm = Cq->cur.arm_reward_scale[lane]; }
+  rigid_body_pass(s, Cq, cr, chain, k);
   STAMP(14);
+  // check_termination's contact list (WG:940) and _reward_collision (LR:865-867): |net contact force| of every rigid body on its
+  // own lane, the two conditions as wavefront ballots
+  float cnrm = 0.f;
+  if (lane < WBC_NRB) { const f3 f = ld3(s.out_contact[lane]); cnrm = sqrtf(dot(f, f)); }
+  const uint32_t rb_bit = lane < WBC_NRB ? 1u << lane : 0u;
+  const int c_term = __ballot((Cq->cfg.term_contact_rb_mask & rb_bit) != 0u && cnrm > 1.0f) != 0ull;
+  const float ncol = (float)__popcll(__ballot((Cq->cfg.penalize_contact_rb_mask & rb_bit) != 0u && cnrm > 0.1f));
   float base_yaw = 0.f;
   if (lane == 0) {
     s.ep_len += 1;
@@ -1170,34 +1276,34 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     for (int j = 0; j < 3; ++j) s.goal[G_CURR + j] = lerp_torch(s.goal[G_START + j], s.goal[G_GOAL + j], tt);
     st3(&s.goal[G_CURR_CART], sphere2cart(ld3(&s.goal[G_CURR])));
     s.goal[G_TIMER] += 1.f;
-    if (s.goal[G_TIMER] > s.goal[G_TOTAL]) resample_ee_goal(s, C, seed, env, step, SLOT_GOAL_ORN, SLOT_GOAL_SPHERE, base_yaw);
-    if (s.ep_len % C->cfg.resample_interval == 0) resample_commands(s, C, seed, env, step, SLOT_CMD);
-    if (C->cfg.push_interval > 0 && (step % (uint64_t)C->cfg.push_interval) == 0) {
-      const float px = rng_range(-C->cfg.max_push_vel, C->cfg.max_push_vel, seed, env, step, SLOT_PUSH);
-      const float py = rng_range(-C->cfg.max_push_vel, C->cfg.max_push_vel, seed, env, step, SLOT_PUSH + 1);
+    if (s.goal[G_TIMER] > s.goal[G_TOTAL]) resample_ee_goal(s, Cq, seed, env, step, SLOT_GOAL_ORN, SLOT_GOAL_SPHERE, base_yaw);
+    if (s.ep_len % Cq->cfg.resample_interval == 0) resample_commands(s, Cq, seed, env, step, SLOT_CMD);
+    if (Cq->cfg.push_interval > 0 && (step % (uint64_t)Cq->cfg.push_interval) == 0) {
+      const float px = rng_range(-Cq->cfg.max_push_vel, Cq->cfg.max_push_vel, seed, env, step, SLOT_PUSH);
+      const float py = rng_range(-Cq->cfg.max_push_vel, Cq->cfg.max_push_vel, seed, env, step, SLOT_PUSH + 1);
       const float kk = ((s.cmd[0] + s.cmd[1] + s.cmd[2]) == 0.f) ? 2.5f : 1.f;
       s.root[7] = px * kk; s.root[8] = py * kk;
     }
-    const float r = rpy.x, p = rpy.y, z = s.root[2], th = C->cfg.term_rp_threshold;
+    const float r = rpy.x, p = rpy.y, z = s.root[2], th = Cq->cfg.term_rp_threshold;
     const int r_term = ((r > th) && (s.goal[G_CURR + 2] >= 0.f)) || ((r < -th) && (s.goal[G_CURR + 2] <= 0.f));
     const int p_term = ((p > th) && (s.goal[G_CURR + 1] >= 0.f)) || ((p < -th) && (s.goal[G_CURR + 1] <= 0.f));
-    const int z_term = z < C->cfg.term_z_threshold;
-    s.time_out = s.ep_len > C->cfg.max_episode_length;
-    s.reset_flag = r_term | p_term | z_term | s.time_out;
-    compute_reward(s, C, yq);
+    const int z_term = z < Cq->cfg.term_z_threshold;
+    s.time_out = s.ep_len > Cq->cfg.max_episode_length;
+    s.reset_flag = c_term | r_term | p_term | z_term | s.time_out;
+    compute_reward(s, Cq, yq, ncol);
   }
   WSYNC();
-  reward_accumulate(s, C, rsc_leg, rsc_arm);
+  reward_accumulate(s, Cq, rsc_leg, rsc_arm);
   WSYNC();
   STAMP(15);
   const bool do_reset = s.reset_flag != 0;
-  if (do_reset) reset_env(s, T, C, seed, env, step, 0, s.base_yaw);
+  if (do_reset) reset_env(s, T2, Cq, seed, env, step, 0, s.base_yaw);
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
-    T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
-    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
+    T2.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
+    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T2.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
   }
   STAMP(16);
-  observe_and_store(s, T, C, env, do_reset, so, hist_in);
+  observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
   STAMP(17);
 }
 

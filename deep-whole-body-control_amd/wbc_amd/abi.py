@@ -12,8 +12,9 @@ import numpy as np
 
 from .urdf_model import RobotModel, merge_piece
 
-NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 10
-NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 21, 10
+NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 32
+CP_TERRAIN, CP_BOX, CP_CAPSULE = 0, 1, 2
+NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 22, 10
 
 f32, i32 = C.c_float, C.c_int32
 
@@ -22,7 +23,7 @@ REWARD_TERMS = [
     "foot_contacts_z", "tracking_ee_sphere", "arm_energy_abs_sum", "tracking_ee_cart", "tracking_ee_orn",
     "tracking_ee_orn_ry", "leg_energy_abs_sum", "leg_energy_sum_abs", "leg_action_l2", "leg_energy",
     "tracking_lin_vel", "tracking_lin_vel_x_exp", "tracking_ang_vel_yaw_l1", "tracking_lin_vel_y_l2",
-    "tracking_lin_vel_z_l2", "torques"]
+    "tracking_lin_vel_z_l2", "torques", "collision"]
 METRIC_NAMES = ["leg_energy_abs_sum", "tracking_lin_vel_x_l1", "tracking_ang_vel_yaw_exp", "tracking_ee_cart",
                 "tracking_ee_sphere", "tracking_ee_orn", "leg_action_l2", "torque", "energy_square",
                 "foot_contacts_z"]   # WG:165
@@ -35,7 +36,8 @@ class WbcModel(C.Structure):
         ("q_lower", f32 * NDOF), ("q_upper", f32 * NDOF), ("qd_limit", f32 * NDOF), ("effort", f32 * NDOF),
         ("rb_body", i32 * NRB), ("rb_offset", (f32 * 3) * NRB), ("feet_rb", i32 * NFEET), ("gripper_rb", i32),
         ("ncp", i32), ("cp_body", i32 * NCP), ("cp_pos", (f32 * 3) * NCP), ("cp_radius", f32 * NCP),
-        ("cp_rb", i32 * NCP),
+        ("cp_rb", i32 * NCP), ("cp_kind", i32 * NCP), ("cp_body2", i32 * NCP), ("cp_rb2", i32 * NCP),
+        ("cp_a", (f32 * 3) * NCP), ("cp_b", (f32 * 3) * NCP), ("cp_radius2", f32 * NCP),
         ("base_piece_mass", f32), ("base_piece_com", f32 * 3), ("base_piece_inertia", f32 * 6),
         ("base_rest_mass", f32), ("base_rest_com", f32 * 3), ("base_rest_inertia", f32 * 6),
         ("gripper_body", i32),
@@ -54,6 +56,7 @@ class WbcTaskCfg(C.Structure):
         ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32), ("obs_scale_dof_vel", f32), ("clip_obs", f32),
         ("commands_scale", f32 * 3),
         ("max_episode_length", i32), ("term_rp_threshold", f32), ("term_z_threshold", f32),
+        ("term_contact_rb_mask", C.c_uint32), ("penalize_contact_rb_mask", C.c_uint32),
         ("resample_interval", i32), ("push_interval", i32), ("max_push_vel", f32),
         ("lin_vel_x_clip", f32), ("ang_vel_yaw_clip", f32),
         ("goal_collision_lower", f32 * 3), ("goal_collision_upper", f32 * 3), ("goal_underground_limit", f32),
@@ -89,8 +92,8 @@ TENSOR_SHAPES = {
     "FORCE_SENSOR": (4, 6), "TORQUES": (20,), "OBS_BUF": (860,), "OBS_HISTORY": (10, 76),
     "ACTION_HISTORY": (4, 18), "ACTIONS": (18,), "LAST_ACTIONS": (18,), "LAST_DOF_VEL": (20,),
     "LAST_ROOT_VEL": (6,), "COMMANDS": (3,), "GOAL_STATE": (24,), "REW_BUF": (), "ARM_REW_BUF": (),
-    "RESET_BUF": (), "TIME_OUT_BUF": (), "EPISODE_LENGTH": (), "EPISODE_SUMS": (21,), "METRIC_SUMS": (10,),
-    "EPISODE_SUMS_DONE": (21,), "METRIC_SUMS_DONE": (10,), "BASE_LIN_VEL": (3,), "BASE_ANG_VEL": (3,),
+    "RESET_BUF": (), "TIME_OUT_BUF": (), "EPISODE_LENGTH": (), "EPISODE_SUMS": (NREW,), "METRIC_SUMS": (10,),
+    "EPISODE_SUMS_DONE": (NREW,), "METRIC_SUMS_DONE": (10,), "BASE_LIN_VEL": (3,), "BASE_ANG_VEL": (3,),
     "MASS_PARAMS": (5,), "FRICTION": (), "MOTOR_STRENGTH": (18,), "ENV_ORIGINS": (3,), "BOX_DELTA_Y": (),
     "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,)}
 TENSOR_DTYPES = {name: "f32" for name in TENSOR_IDS}
@@ -115,11 +118,66 @@ def _seti(arr, values):
     view[...] = np.asarray(values, dtype=np.int64).reshape(view.shape)
 
 
+# The URDF's <collision> blocks (legged_gym/resources/robots/widowGo1/urdf/widowGo1.urdf) as this framework's primitives.
+TRUNK_HALF = (0.3762 / 2, 0.0935 / 2, 0.114 / 2)        # <link name="trunk"> box
+THIGH_LEN, THIGH_RADIUS = 0.213, 0.017                   # thigh box 0.213 x 0.0245 x 0.034, long axis -z of the thigh frame
+CORNER_RADIUS = 0.01
+
+
+def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True):
+    """The contact list of this framework's physics spec, as dicts with the wbc_model cp_* fields.
+    Sphere-swept stand-ins for the URDF's collision geometry:
+      terrain contacts -- 4 feet (the URDF's r = 0.02 spheres), 4 knees (calf box upper ends = thigh box lower ends), gripper
+        tip, elbow, wrist (the arm-link meshes), 4 thigh tops (thigh box upper ends), 8 trunk-box corners;
+      self-collision pairs (asset.self_collisions = 0 means enabled, widowGo1_config.py:180) -- gripper / wrist / elbow spheres
+        against the trunk box, gripper / wrist against the two front thighs (capsules): what bounds the arm's workspace."""
+    rbn = m.rb_names
+    feet = [i for i, n in enumerate(rbn) if foot_name in n]
+    grip_rb = rbn.index(gripper_name)
+    cps = []
+
+    def sphere(rb, pos, rad):
+        cps.append(dict(body=int(m.rb_body[rb]), pos=np.asarray(m.rb_offset[rb], dtype=np.float64) + np.asarray(pos, dtype=np.float64),
+                        radius=rad, rb=rb, kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0))
+        return len(cps) - 1
+    for rb in feet:
+        sphere(rb, np.zeros(3), 0.02)
+    for rb in feet:                                                         # knees = calf origins
+        sphere(rb - 1, np.zeros(3), 0.02)
+    k_grip = sphere(grip_rb, np.zeros(3), 0.012)
+    k_elbow = sphere(rbn.index("wx250s/upper_forearm_link"), np.zeros(3), 0.025)
+    k_wrist = sphere(rbn.index("wx250s/wrist_link"), np.zeros(3), 0.025)
+    thighs = [rb - 2 for rb in feet]
+    for rb in thighs:
+        assert "thigh" in rbn[rb]
+        sphere(rb, np.zeros(3), THIGH_RADIUS)
+    trunk_rb = rbn.index("trunk")
+    hx, hy, hz = (h - CORNER_RADIUS for h in TRUNK_HALF)
+    for sx in (1, -1):
+        for sy in (1, -1):
+            for sz in (-1, 1):
+                sphere(trunk_rb, np.array([sx * hx, sy * hy, sz * hz]), CORNER_RADIUS)
+    if self_collisions:
+        def pair(k, kind, rb2, a, b, radius2):
+            c = dict(cps[k])
+            c.update(kind=kind, body2=int(m.rb_body[rb2]), rb2=rb2, a=np.asarray(a, dtype=np.float64) + np.asarray(m.rb_offset[rb2]),
+                     b=np.asarray(b, dtype=np.float64), radius2=radius2)
+            if kind == CP_CAPSULE:
+                c["b"] = c["b"] + np.asarray(m.rb_offset[rb2])
+            cps.append(c)
+        for k in (k_grip, k_wrist, k_elbow):
+            pair(k, CP_BOX, trunk_rb, np.zeros(3), np.array(TRUNK_HALF), 0.0)
+        front = [rb for rb in thighs if rbn[rb].startswith("F")]
+        for k in (k_grip, k_wrist):
+            for rb in front:
+                pair(k, CP_CAPSULE, rb, np.zeros(3), np.array([0.0, 0.0, -THIGH_LEN]), THIGH_RADIUS)
+    assert len(cps) <= NCP
+    return cps
+
+
 def fill_model(m: RobotModel, foot_name: str = "foot",
-               gripper_name: str = "wx250s/ee_gripper_link") -> WbcModel:
-    """RobotModel -> wbc_model, adding the contact spheres of this framework's physics spec:
-    4 feet (URDF collision spheres r=0.02 at the foot links), 4 knees (calf origins), the gripper
-    tip and the elbow. Mesh collision of the arm links and self-collision are not modelled."""
+               gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True) -> WbcModel:
+    """RobotModel -> wbc_model, with the collision set of this framework's physics spec (collision_set)."""
     assert m.nb == NB and m.num_dofs == NDOF and m.num_rigid_bodies == NRB
     out = WbcModel()
     _seti(out.parent, m.parent)
@@ -140,23 +198,16 @@ def fill_model(m: RobotModel, foot_name: str = "foot",
     assert len(feet) == NFEET
     _seti(out.feet_rb, feet)
     out.gripper_rb = m.rb_names.index(gripper_name)                         # WG:318
-    cps = []
-    for rb in feet:                                                         # foot spheres
-        cps.append((m.rb_body[rb], m.rb_offset[rb], 0.02, rb))
-    for rb in feet:                                                         # knees = calf origins
-        calf_rb = rb - 1
-        cps.append((m.rb_body[calf_rb], np.zeros(3), 0.02, calf_rb))
-    cps.append((m.rb_body[out.gripper_rb], m.rb_offset[out.gripper_rb], 0.012, out.gripper_rb))
-    elbow_rb = m.rb_names.index("wx250s/upper_forearm_link")
-    cps.append((m.rb_body[elbow_rb], np.zeros(3), 0.025, elbow_rb))
-    assert len(cps) == NCP
-    out.ncp = NCP
-    for k, (b, pos, rad, rb) in enumerate(cps):
-        out.cp_body[k] = int(b)
+    cps = collision_set(m, foot_name, gripper_name, self_collisions)
+    out.ncp = len(cps)
+    for k in range(NCP):
+        out.cp_body2[k] = out.cp_rb2[k] = -1
+    for k, c in enumerate(cps):
+        out.cp_body[k], out.cp_rb[k], out.cp_kind[k] = c["body"], c["rb"], c["kind"]
+        out.cp_body2[k], out.cp_rb2[k] = c["body2"], c["rb2"]
+        out.cp_radius[k], out.cp_radius2[k] = c["radius"], c["radius2"]
         for j in range(3):
-            out.cp_pos[k][j] = float(pos[j])
-        out.cp_radius[k] = rad
-        out.cp_rb[k] = int(rb)
+            out.cp_pos[k][j], out.cp_a[k][j], out.cp_b[k][j] = float(c["pos"][j]), float(c["a"][j]), float(c["b"][j])
     bp, gp = m.base_piece, m.gripper_piece
     out.base_piece_mass = bp["mass"]
     _set(out.base_piece_com, bp["com"])
@@ -211,6 +262,15 @@ def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None) -> WbcTask
     out.max_episode_length = int(math.ceil(cfg.env.episode_length_s / policy_dt))   # WG:117-118
     out.term_rp_threshold = 0.2                                              # WG:945-946 (hard-coded)
     out.term_z_threshold = float(cfg.termination.z_threshold)
+    def rb_mask(names):                                                       # WG:299-306: substring match on the body names
+        mask = 0
+        for name in names:
+            for i, rbn in enumerate(m.rb_names):
+                if name in rbn:
+                    mask |= 1 << i
+        return mask
+    out.term_contact_rb_mask = rb_mask(cfg.asset.terminate_after_contacts_on)
+    out.penalize_contact_rb_mask = rb_mask(cfg.asset.penalize_contacts_on)
     out.resample_interval = int(cfg.commands.resampling_time / policy_dt)    # WG:922
     out.push_interval = int(math.ceil(cfg.domain_rand.push_interval_s / policy_dt)) if cfg.domain_rand.push_robots else 0
     out.max_push_vel = float(cfg.domain_rand.max_push_vel_xy)

@@ -10,7 +10,7 @@ from . import abi
 # reward names the reference's config knows but the fused step does not implement (all zero in the
 # shipped widowGo1 config); a non-zero scale for one of these is an error, not a silent drop
 UNIMPLEMENTED_REWARDS = {"termination", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_vel", "dof_acc",
-                         "base_height", "feet_air_time", "collision", "feet_stumble", "action_rate", "stand_still",
+                         "base_height", "feet_air_time", "feet_stumble", "action_rate", "stand_still",
                          "arm_orientation"}
 
 

@@ -161,7 +161,8 @@ class WidowGo1(LeggedRobot):
     # ---- construction ----------------------------------------------------------------------
     def create_sim(self):                                                           # WG:230-237, 255-429
         cfg, m, n = self.cfg, self.robot_model, self.num_envs
-        self.wmodel = abi.fill_model(m, foot_name=cfg.asset.foot_name)
+        # asset.self_collisions is Isaac Gym's collision FILTER: 0 = self-collision enabled (widowGo1_config.py:180)
+        self.wmodel = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(getattr(cfg.asset, "self_collisions", 0)) == 0)
         self.tcfg = abi.fill_task_cfg(cfg, m, sim_dt=self._sim_dt)
         self.sim = WbcSim(self.wmodel, self.tcfg, n, self.device, seed=self._seed)
         self.num_dofs, self.num_bodies = m.num_dofs, m.num_rigid_bodies
@@ -176,9 +177,6 @@ class WidowGo1(LeggedRobot):
         pen = [i for name in cfg.asset.penalize_contacts_on for i, s in enumerate(self.body_names) if name in s]
         self.penalized_contact_indices = torch.tensor(pen, dtype=torch.long, device=dev)
         term = [i for name in cfg.asset.terminate_after_contacts_on for i, s in enumerate(self.body_names) if name in s]
-        if term:
-            raise NotImplementedError("terminate_after_contacts_on is empty in the widowGo1 config; contact termination "
-                                      "is not part of the fused step")
         self.termination_contact_indices = torch.tensor(term, dtype=torch.long, device=dev)
         self._terrain_setup()
         self._randomise()

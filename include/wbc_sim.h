@@ -35,13 +35,13 @@ extern "C" {
 #define WBC_NRB 27       /* robot rigid bodies as the importer lists them */
 #define WBC_NRB_ENV 28   /* + the free box actor (WG:384,542,546) */
 #define WBC_NFEET 4
-#define WBC_NCP 10       /* contact points per robot */
+#define WBC_NCP 32       /* contact slots per robot: spheres vs terrain, then self-collision pairs (one wavefront lane each) */
 #define WBC_NPROP 76     /* num_proprio (widowGo1_config.py:122) */
 #define WBC_NPRIV 24     /* num_priv */
 #define WBC_HIST 10      /* history_len */
 #define WBC_NOBS 860     /* num_observations */
 #define WBC_ADELAY_LEN 4 /* action_delay + 2 (WG:540) */
-#define WBC_NREW 21      /* reward terms implemented (enum wbc_reward_term) */
+#define WBC_NREW 22      /* reward terms implemented (enum wbc_reward_term) */
 #define WBC_NMETRIC 10   /* episode_metric_sums (WG:165) */
 #define WBC_MAX_DEPTH 6
 
@@ -62,11 +62,24 @@ typedef struct {
   float rb_offset[WBC_NRB][3];
   int32_t feet_rb[WBC_NFEET];   /* rigid-body indices of the feet, importer order FL,FR,RL,RR */
   int32_t gripper_rb;           /* wx250s/ee_gripper_link (WG:318) */
+  /* Collision set (the URDF's <collision> blocks as sphere-swept primitives): ncp contacts in use.
+   * Every contact has a sphere (centre cp_pos in the frame of moving body cp_body, radius cp_radius, riding on importer
+   * rigid body cp_rb) and a partner selected by cp_kind:
+   *   WBC_CP_TERRAIN  the terrain (plane or height grid);
+   *   WBC_CP_BOX      a box fixed to moving body cp_body2 (rigid body cp_rb2): centre cp_a, half extents cp_b, its frame;
+   *   WBC_CP_CAPSULE  a capsule on cp_body2: segment cp_a..cp_b, radius cp_radius2.
+   * The last two are the robot's self-collision pairs (asset.self_collisions = 0 = enabled, widowGo1_config.py:180): the
+   * impulse acts on both bodies with opposite signs. Terrain contacts come first (the force sensors read contacts 0..3). */
   int32_t ncp;
-  int32_t cp_body[WBC_NCP];     /* contact spheres: body, centre (body frame), radius */
+  int32_t cp_body[WBC_NCP];
   float cp_pos[WBC_NCP][3];
   float cp_radius[WBC_NCP];
   int32_t cp_rb[WBC_NCP];       /* rigid body whose net_contact_force row receives the force */
+  int32_t cp_kind[WBC_NCP];
+  int32_t cp_body2[WBC_NCP];    /* -1 for terrain contacts */
+  int32_t cp_rb2[WBC_NCP];      /* rigid body that receives the opposite force, -1 for terrain contacts */
+  float cp_a[WBC_NCP][3], cp_b[WBC_NCP][3];
+  float cp_radius2[WBC_NCP];
   /* pieces for per-env mass randomisation (WG:431-456) */
   float base_piece_mass, base_piece_com[3], base_piece_inertia[6];
   float base_rest_mass, base_rest_com[3], base_rest_inertia[6];
@@ -75,7 +88,9 @@ typedef struct {
   float grip_rest_mass, grip_rest_com[3], grip_rest_inertia[6];
 } wbc_model;
 
-enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) */
+enum wbc_contact_kind { WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1, WBC_CP_CAPSULE = 2 };
+
+enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) + the base class's _reward_collision (LR:865-867) */
   WBC_REW_ENERGY_SQUARE = 0, WBC_REW_SURVIVE, WBC_REW_TRACKING_LIN_VEL_X_L1,
   WBC_REW_TRACKING_ANG_VEL_YAW_EXP, WBC_REW_HIP_ACTION_L2, WBC_REW_FOOT_CONTACTS_Z,
   WBC_REW_TRACKING_EE_SPHERE, WBC_REW_ARM_ENERGY_ABS_SUM,
@@ -83,7 +98,7 @@ enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) */
   WBC_REW_LEG_ENERGY_ABS_SUM, WBC_REW_LEG_ENERGY_SUM_ABS, WBC_REW_LEG_ACTION_L2,
   WBC_REW_LEG_ENERGY, WBC_REW_TRACKING_LIN_VEL, WBC_REW_TRACKING_LIN_VEL_X_EXP,
   WBC_REW_TRACKING_ANG_VEL_YAW_L1, WBC_REW_TRACKING_LIN_VEL_Y_L2,
-  WBC_REW_TRACKING_LIN_VEL_Z_L2, WBC_REW_TORQUES
+  WBC_REW_TRACKING_LIN_VEL_Z_L2, WBC_REW_TORQUES, WBC_REW_COLLISION
 };
 
 enum wbc_metric {        /* WG:165 order */
@@ -121,6 +136,9 @@ typedef struct {
   int32_t max_episode_length;   /* 500 */
   float term_rp_threshold;      /* 0.2, hard-coded at WG:945-946 */
   float term_z_threshold;       /* 0.325 */
+  uint32_t term_contact_rb_mask;     /* bit rb: rigid body rb is in asset.terminate_after_contacts_on (WG:305-306,940: |net force| > 1 N
+                                        ends the episode); shipped config: empty */
+  uint32_t penalize_contact_rb_mask; /* asset.penalize_contacts_on (WG:299-300; _reward_collision counts |net force| > 0.1 N, LR:865-867) */
   int32_t resample_interval;    /* int(3.0/0.02)=150 (WG:922) */
   int32_t push_interval;        /* 150 (WG:119); <=0 disables */
   float max_push_vel;
@@ -404,6 +422,9 @@ int wbc_rollout_store(const float* rew, const float* arm_rew, const int64_t* don
 int wbc_runner_track_episodes(const float* rew, const float* arm_rew, const int64_t* dones, int n, int cap, float* state,
                               void* stream);
 size_t wbc_runner_track_state_floats(int n, int cap);
+
+/* Per-env shape (up to 3 dims; the leading N is implied), ndim and dtype (0 f32, 1 i64, 2 u8) of tensor `id`, without a sim. */
+int wbc_tensor_spec(int id, int64_t* dims3, int* ndim, int* dtype);
 
 /* sizeof(wbc_model), sizeof(wbc_task_cfg), sizeof(wbc_curriculum): lets a binding check its mirrors. */
 void wbc_abi_sizes(int* out3);

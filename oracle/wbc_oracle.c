@@ -280,7 +280,7 @@ static void solve3(const REAL* W, const REAL* b, REAL* x) { /* symmetric 3x3, co
 }
 
 typedef struct {
-  int active;
+  int active, nshare;      /* nshare: active contacts whose sphere rides on the same body (>= 1 when active) */
   REAL xc[3], n[3], W[9], vfree[3], vn_tgt, mu, lam[3];
 } contact_t;
 
@@ -418,51 +418,118 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc)
       w->K[i][r * 6 + cc] = w->K[p][r * 6 + cc] - g[r] * w->S[i][cc] - w->S[i][r] * g[cc] + gam * w->S[i][r] * w->S[i][cc];
   }
-  /* contacts */
+  /* contacts: spheres against the terrain, then the self-collision pairs (sphere against a box / capsule of another body) */
   contact_t ct[WBC_NCP];
   REAL mu = (REAL)0.5 * (e->friction + (REAL)cf->terrain_friction);   /* PhysX default combine: average */
   if (mu < 0) mu = 0;
+  REAL mu_self = e->friction < 0 ? 0 : e->friction;                   /* both shapes carry the robot's material */
   int any = 0;
   for (int k = 0; k < md->ncp; ++k) {
     contact_t* c = &ct[k];
-    int b = md->cp_body[k];
-    REAL o[3] = {md->cp_pos[k][0], md->cp_pos[k][1], md->cp_pos[k][2]}, xk[3], t[3], Xw[3];
+    int b = md->cp_body[k], kind = md->cp_kind[k], b2 = md->cp_body2[k];
+    REAL o[3] = {md->cp_pos[k][0], md->cp_pos[k][1], md->cp_pos[k][2]}, xk[3], t[3];
     mat3_mul_vec(w->E[b], o, t);
     for (int j = 0; j < 3; ++j) xk[j] = w->pos[b][j] + t[j];
-    mat3_mul_vec(R, xk, t);
-    for (int j = 0; j < 3; ++j) Xw[j] = e->root[0][j] + t[j];
-    REAL h, nw[3];
-    terrain_query(s, Xw[0], Xw[1], &h, nw);
-    REAL rad = md->cp_radius[k];
-    REAL gap = (Xw[2] - h) * nw[2] - rad;
-    c->active = gap < (REAL)cf->contact_margin;
+    REAL rad = md->cp_radius[k], gap;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
-    if (!c->active) continue;
+    if (kind == WBC_CP_TERRAIN) {
+      REAL Xw[3], h, nw[3];
+      mat3_mul_vec(R, xk, t);
+      for (int j = 0; j < 3; ++j) Xw[j] = e->root[0][j] + t[j];
+      terrain_query(s, Xw[0], Xw[1], &h, nw);
+      gap = (Xw[2] - h) * nw[2] - rad;
+      c->active = gap < (REAL)cf->contact_margin;
+      if (!c->active) continue;
+      mat3T_mul_vec(R, nw, c->n);
+      for (int j = 0; j < 3; ++j) c->xc[j] = xk[j] - rad * c->n[j];
+      c->mu = mu;
+    } else {
+      /* sphere centre in the partner body's frame */
+      REAL d[3], pl[3], ql[3], nl[3], dist;
+      for (int j = 0; j < 3; ++j) d[j] = xk[j] - w->pos[b2][j];
+      mat3T_mul_vec(w->E[b2], d, pl);
+      const float* A = md->cp_a[k]; const float* B = md->cp_b[k];
+      if (kind == WBC_CP_BOX) {            /* closest point of the box (centre A, half extents B) */
+        int inside = 1;
+        for (int j = 0; j < 3; ++j) {
+          REAL r = pl[j] - (REAL)A[j], hb = (REAL)B[j];
+          REAL cl = r < -hb ? -hb : (r > hb ? hb : r);
+          if (cl != r) inside = 0;
+          ql[j] = (REAL)A[j] + cl;
+        }
+        if (!inside) {
+          for (int j = 0; j < 3; ++j) nl[j] = pl[j] - ql[j];
+          dist = sqrt(dot3(nl, nl));
+          for (int j = 0; j < 3; ++j) nl[j] /= dist;
+        } else {                            /* centre inside the box: leave through the nearest face */
+          int ax = 0; REAL best = 0; 
+          for (int j = 0; j < 3; ++j) {
+            REAL depth = (REAL)B[j] - fabs(pl[j] - (REAL)A[j]);
+            if (j == 0 || depth < best) { best = depth; ax = j; }
+          }
+          for (int j = 0; j < 3; ++j) nl[j] = 0;
+          nl[ax] = (pl[ax] - (REAL)A[ax]) >= 0 ? 1 : -1;
+          ql[ax] = (REAL)A[ax] + nl[ax] * (REAL)B[ax];
+          dist = -best;
+        }
+        gap = dist - rad;
+      } else {                              /* capsule: segment A..B, radius cp_radius2 */
+        REAL ab[3], ap[3];
+        for (int j = 0; j < 3; ++j) { ab[j] = (REAL)B[j] - (REAL)A[j]; ap[j] = pl[j] - (REAL)A[j]; }
+        REAL tt = dot3(ap, ab) / dot3(ab, ab);
+        tt = clampr(tt, 0, 1);
+        for (int j = 0; j < 3; ++j) { ql[j] = (REAL)A[j] + tt * ab[j]; nl[j] = pl[j] - ql[j]; }
+        dist = sqrt(dot3(nl, nl));
+        if (dist > (REAL)1e-9) { for (int j = 0; j < 3; ++j) nl[j] /= dist; }
+        else { nl[0] = 1; nl[1] = 0; nl[2] = 0; }
+        REAL r2 = md->cp_radius2[k];
+        for (int j = 0; j < 3; ++j) ql[j] += r2 * nl[j];
+        gap = dist - rad - r2;
+      }
+      c->active = gap < (REAL)cf->contact_margin;
+      if (!c->active) continue;
+      mat3_mul_vec(w->E[b2], nl, c->n);
+      mat3_mul_vec(w->E[b2], ql, t);
+      for (int j = 0; j < 3; ++j) c->xc[j] = w->pos[b2][j] + t[j];     /* on the partner's surface */
+      c->mu = mu_self;
+    }
     any = 1;
-    mat3T_mul_vec(R, nw, c->n);
-    for (int j = 0; j < 3; ++j) c->xc[j] = xk[j] - rad * c->n[j];
-    c->mu = mu;
     c->vn_tgt = (gap >= 0) ? -gap / dt : fmin((REAL)cf->contact_erp * (-gap) / dt, (REAL)cf->max_depenetration_vel);
-    /* W = J K J^T, J = [-xc x, 1] */
-    const REAL* K = w->K[b];
+    /* W = J K J^T, J = [-xc x, 1], summed over the two bodies of a self-collision pair (their cross coupling through the
+     * tree is left to the block-Jacobi sweeps, as the coupling between different contacts is) */
     REAL X[9] = {0, -c->xc[2], c->xc[1], c->xc[2], 0, -c->xc[0], -c->xc[1], c->xc[0], 0};
     REAL J[18];
     for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) { J[r * 6 + cc] = -X[r * 3 + cc]; J[r * 6 + 3 + cc] = (r == cc) ? 1 : 0; }
-    REAL KJt[18];
-    for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc) KJt[r * 3 + cc] = dot6(K + r * 6, J + cc * 6);
-    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
-      REAL a = 0; for (int j = 0; j < 6; ++j) a += J[r * 6 + j] * KJt[j * 3 + cc];
-      c->W[r * 3 + cc] = a + ((r == cc) ? (REAL)1e-6 : 0);
+    for (int r = 0; r < 9; ++r) c->W[r] = 0;
+    for (int side = 0; side < (kind == WBC_CP_TERRAIN ? 1 : 2); ++side) {
+      const REAL* K = w->K[side == 0 ? b : b2];
+      REAL KJt[18];
+      for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc) KJt[r * 3 + cc] = dot6(K + r * 6, J + cc * 6);
+      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+        REAL a = 0; for (int j = 0; j < 6; ++j) a += J[r * 6 + j] * KJt[j * 3 + cc];
+        c->W[r * 3 + cc] += a;
+      }
     }
-    REAL vp[3], ab[6], apnt[3], t2[3];
-    cross3(w->v[b], c->xc, t);
-    for (int j = 0; j < 3; ++j) vp[j] = w->v[b][3 + j] + t[j];
-    for (int j = 0; j < 3; ++j) { ab[j] = w->a[b][j]; ab[3 + j] = w->a[b][3 + j] + gF[j]; }
-    cross3(ab, c->xc, t);
-    cross3(w->v[b], vp, t2);
-    for (int j = 0; j < 3; ++j) { apnt[j] = ab[3 + j] + t[j] + t2[j]; c->vfree[j] = vp[j] + dt * apnt[j]; }
+    for (int r = 0; r < 3; ++r) c->W[r * 3 + r] += (REAL)1e-6;
+    /* velocity of the contact point after the unconstrained step (relative to the partner body's point for a pair) */
+    for (int j = 0; j < 3; ++j) c->vfree[j] = 0;
+    for (int side = 0; side < (kind == WBC_CP_TERRAIN ? 1 : 2); ++side) {
+      int bb = side == 0 ? b : b2;
+      REAL sgn = side == 0 ? 1 : -1;
+      REAL vp[3], ab[6], apnt[3], t2[3];
+      cross3(w->v[bb], c->xc, t);
+      for (int j = 0; j < 3; ++j) vp[j] = w->v[bb][3 + j] + t[j];
+      for (int j = 0; j < 3; ++j) { ab[j] = w->a[bb][j]; ab[3 + j] = w->a[bb][3 + j] + gF[j]; }
+      cross3(ab, c->xc, t);
+      cross3(w->v[bb], vp, t2);
+      for (int j = 0; j < 3; ++j) { apnt[j] = ab[3 + j] + t[j] + t2[j]; c->vfree[j] += sgn * (vp[j] + dt * apnt[j]); }
+    }
   }
   REAL qddD[WBC_NB] = {0}, aD0[6] = {0};
+  for (int k = 0; k < md->ncp; ++k) {
+    ct[k].nshare = 0;
+    if (ct[k].active) for (int j = 0; j < md->ncp; ++j) ct[k].nshare += ct[j].active && md->cp_body[j] == md->cp_body[k];
+  }
   if (any) {
     REAL dv[WBC_NCP][3];
     memset(dv, 0, sizeof(dv));
@@ -471,10 +538,15 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       for (int k = 0; k < md->ncp; ++k) {
         contact_t* c = &ct[k];
         if (!c->active) continue;
-        REAL vref[3], own[3];
+        REAL vref[3], own[3], ln[3];
         mat3_mul_vec(c->W, c->lam, own);
         for (int j = 0; j < 3; ++j) vref[j] = c->vfree[j] + dv[k][j] - own[j];
-        contact_solve(c, vref, c->lam);
+        contact_solve(c, vref, ln);
+        /* damped block-Jacobi: contacts of spheres on the SAME body see (almost) the same inverse inertia, so each of the m
+         * active ones would remove the whole approach velocity on its own; they share it instead (relaxation 1/m; a convex
+         * combination of two impulses inside the friction cone stays inside it). m = 1 for a lone foot: plain block-Jacobi. */
+        REAL om = 1 / (REAL)c->nshare;
+        for (int j = 0; j < 3; ++j) c->lam[j] += om * (ln[j] - c->lam[j]);
       }
       /* response of the whole tree to all contact impulses */
       REAL pD[WBC_NB][6], uD[WBC_NB];
@@ -484,8 +556,10 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
         if (!c->active) continue;
         REAL f[3] = {c->lam[0] / dt, c->lam[1] / dt, c->lam[2] / dt}, mom[3];
         cross3(c->xc, f, mom);
-        int b = md->cp_body[k];
+        int b = md->cp_body[k], b2 = md->cp_body2[k];
         for (int j = 0; j < 3; ++j) { pD[b][j] -= mom[j]; pD[b][3 + j] -= f[j]; }
+        if (md->cp_kind[k] != WBC_CP_TERRAIN)            /* the partner body receives the opposite wrench */
+          for (int j = 0; j < 3; ++j) { pD[b2][j] += mom[j]; pD[b2][3 + j] += f[j]; }
       }
       for (int i = WBC_NB - 1; i >= 1; --i) {
         int p = md->parent[i];
@@ -504,10 +578,14 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       for (int k = 0; k < md->ncp; ++k) {
         contact_t* c = &ct[k];
         if (!c->active) continue;
-        int b = md->cp_body[k];
+        int b = md->cp_body[k], b2 = md->cp_body2[k];
         REAL t[3];
         cross3(aD[b], c->xc, t);
         for (int j = 0; j < 3; ++j) dv[k][j] = dt * (aD[b][3 + j] + t[j]);
+        if (md->cp_kind[k] != WBC_CP_TERRAIN) {
+          cross3(aD[b2], c->xc, t);
+          for (int j = 0; j < 3; ++j) dv[k][j] -= dt * (aD[b2][3 + j] + t[j]);
+        }
       }
     }
     for (int r = 0; r < 6; ++r) aD0[r] = aD[0][r];
@@ -522,6 +600,10 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     mat3_mul_vec(R, f, fw);
     int rb = md->cp_rb[k];
     for (int j = 0; j < 3; ++j) e->contact_force[rb][j] += fw[j];
+    if (md->cp_kind[k] != WBC_CP_TERRAIN) {              /* PhysX reports self-collision forces in net_contact_force too */
+      for (int j = 0; j < 3; ++j) e->contact_force[md->cp_rb2[k]][j] -= fw[j];
+      continue;
+    }
     for (int ft = 0; ft < WBC_NFEET; ++ft) if (md->feet_rb[ft] == rb) {
       int b = md->cp_body[k];
       REAL fl[3], arm[3], tq[3], tl[3];
@@ -766,11 +848,15 @@ static void compute_reward(const ora_sim* s, ora_env* e, const REAL* base_yaw_qu
   term[WBC_REW_TRACKING_LIN_VEL_Y_L2] = (e->commands[1] - e->base_lin_vel[1]) * (e->commands[1] - e->base_lin_vel[1]); /* WG:1446-1447 */
   term[WBC_REW_TRACKING_LIN_VEL_Z_L2] = (e->commands[2] - e->base_lin_vel[2]) * (e->commands[2] - e->base_lin_vel[2]); /* WG:1449-1450 */
   term[WBC_REW_TORQUES] = tq2;                                                            /* WG:1460-1464 */
+  REAL ncol = 0;                                                                          /* LR:865-867 (base class) */
+  for (int rb = 0; rb < WBC_NRB; ++rb)
+    if ((cf->penalize_contact_rb_mask >> rb) & 1u) ncol += (sqrt(dot3(e->contact_force[rb], e->contact_force[rb])) > (REAL)0.1) ? 1 : 0;
+  term[WBC_REW_COLLISION] = ncol;
   /* metric side effects of the reward functions, applied once per ACTIVE call */
   static const int met_of[WBC_NREW] = {
     WBC_MET_ENERGY_SQUARE, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, WBC_MET_TRACKING_ANG_VEL_YAW_EXP, WBC_MET_LEG_ACTION_L2,
     WBC_MET_FOOT_CONTACTS_Z, WBC_MET_TRACKING_EE_SPHERE, -1, WBC_MET_TRACKING_EE_CART, -1, WBC_MET_TRACKING_EE_ORN,
-    WBC_MET_LEG_ENERGY_ABS_SUM, -1, WBC_MET_LEG_ACTION_L2, -1, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, -1, -1, -1, WBC_MET_TORQUE};
+    WBC_MET_LEG_ENERGY_ABS_SUM, -1, WBC_MET_LEG_ACTION_L2, -1, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, -1, -1, -1, WBC_MET_TORQUE, -1};
   REAL met_src[WBC_NREW] = {0};
   met_src[WBC_REW_ENERGY_SQUARE] = sq; met_src[WBC_REW_TRACKING_LIN_VEL_X_L1] = ex; met_src[WBC_REW_TRACKING_LIN_VEL_X_EXP] = ex;
   met_src[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = eyaw; met_src[WBC_REW_HIP_ACTION_L2] = hip; met_src[WBC_REW_LEG_ACTION_L2] = act_leg;
@@ -878,13 +964,16 @@ static void env_step(const ora_sim* s, ora_env* e, int env, const REAL* actions_
     REAL k = ((e->commands[0] + e->commands[1] + e->commands[2]) == 0) ? (REAL)2.5 : 1;
     e->root[0][7] = px * k; e->root[0][8] = py * k;
   }
-  /* check_termination, WG:937-963 (contact list empty, widowGo1_config.py:179) */
+  /* check_termination, WG:937-963 (the shipped contact list is empty, widowGo1_config.py:179) */
+  int c_term = 0;                                                                         /* WG:940 */
+  for (int rb = 0; rb < WBC_NRB; ++rb)
+    if ((cf->term_contact_rb_mask >> rb) & 1u) c_term |= sqrt(dot3(e->contact_force[rb], e->contact_force[rb])) > (REAL)1.0;
   REAL r = rpy[0], p = rpy[1], z = e->root[0][2], th = (REAL)cf->term_rp_threshold;
   int r_term = ((r > th) && (e->goal[G_CURR + 2] >= 0)) || ((r < -th) && (e->goal[G_CURR + 2] <= 0));
   int p_term = ((p > th) && (e->goal[G_CURR + 1] >= 0)) || ((p < -th) && (e->goal[G_CURR + 1] <= 0));
   int z_term = z < (REAL)cf->term_z_threshold;
   e->time_out = e->episode_length > cf->max_episode_length;
-  e->reset_buf = r_term | p_term | z_term | e->time_out;
+  e->reset_buf = c_term | r_term | p_term | z_term | e->time_out;
   compute_reward(s, e, yq);                                                               /* WG:897 */
   if (e->reset_buf) reset_env(s, e, env, step, 0, base_yaw);                              /* WG:898-899 */
   compute_observations(s, e);                                                             /* WG:900 */

@@ -233,6 +233,74 @@ def test_action_clip_timeout_and_episode_boundaries(robot):
     g.close()
 
 
+def test_collision_set_matches_oracle(robot):
+    """The URDF's collision geometry beyond feet and knees: trunk-box corners and thigh tops against the
+    ground, arm spheres against the trunk box and the front thighs (self-collision pairs: the impulse acts on both bodies).
+    Robots dropped on their bellies with the legs folded away, robots lying on a side, robots whose arm starts inside the
+    trunk / a thigh: HIP vs the fp64 oracle from a synced state, with terminate_after_contacts_on = thighs and the collision
+    reward on trunk + thighs + calves active. Same active contact set, forces / state to tolerance, masks bit-exact."""
+    import torch
+    n = 384
+    params = helpers.random_env_params(n, seed=61)
+    params["env_origins"] = np.zeros((n, 3), dtype=np.float32)
+    tc = type(robot["tcfg"]).from_buffer_copy(robot["tcfg"])
+    names = robot["model"].rb_names
+    tc.term_z_threshold = 0.02
+    tc.term_contact_rb_mask = sum(1 << i for i, nm in enumerate(names) if "thigh" in nm)
+    tc.penalize_contact_rb_mask = sum(1 << i for i, nm in enumerate(names) if any(k in nm for k in ("thigh", "trunk", "calf")))
+    from wbc_amd.curriculum import make_curriculum
+    cfg = copy.deepcopy(robot["cfg"])
+    cfg.rewards.scales.collision = -1.0
+    cur = make_curriculum(cfg, 1)
+    g = helpers.make_gpu(robot, n, params, tcfg=tc)
+    o = helpers.make_oracle(robot, n, params, "f64", tcfg=tc)
+    g.set_curriculum(cur); o.set_curriculum(cur)
+    g.reset_all()
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(62)
+    root = _t(g, "ROOT_STATES").astype(np.float32)
+    dof = _t(g, "DOF_STATE").astype(np.float32)
+    third = n // 3
+    root[:third, 0, 2] = rng.uniform(0.058, 0.08, third)                     # on the belly, legs folded up
+    for leg in range(4):
+        dof[:third, 3 * leg + 1, 0] = 2.9
+        dof[:third, 3 * leg + 2, 0] = -2.7
+    dof[:third, :, 1] = 0
+    root[third:2 * third, 0, 2] = rng.uniform(0.10, 0.16, third)             # on a side
+    sgn = rng.choice([-1.0, 1.0], third)
+    root[third:2 * third, 0, 3] = 0.7071068 * sgn
+    root[third:2 * third, 0, 6] = 0.7071068
+    lo, hi = np.array(robot["model"].dof_lower[12:18]), np.array(robot["model"].dof_upper[12:18])
+    lo[0], hi[0] = -1.5, 1.5
+    dof[2 * third:, 12:18, 0] = rng.uniform(lo, hi, (n - 2 * third, 6))      # arms anywhere in their joint ranges (standing robots)
+    g.tensor("ROOT_STATES").copy_(torch.from_numpy(root)); g.tensor("DOF_STATE").copy_(torch.from_numpy(dof))
+    seen = np.zeros(27, dtype=np.int64)
+    resets = airborne_arm = 0
+    for step in range(5):
+        helpers.sync_oracle_from_gpu(o, g)
+        a = (0.6 * rng.normal(size=(n, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda()); o.step(a)
+        tag = f"collision set, step {step}"
+        for name in ("RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH"):
+            np.testing.assert_array_equal(_t(g, name), o.get(name), err_msg=f"{tag} {name}")
+        fo, fg = o.get("NET_CONTACT_FORCE"), _t(g, "NET_CONTACT_FORCE")
+        m = o.get("RESET_BUF").astype(bool)
+        live = ~m                                                              # (a reset zeroes nothing here, but its state is re-drawn)
+        strong = np.abs(fo).sum(-1) > 0.5
+        assert ((np.abs(fg).sum(-1) > 0) == (np.abs(fo).sum(-1) > 0))[strong | (np.abs(fo).sum(-1) == 0)].mean() > 0.999, tag
+        _assert_close_bulk(fg, fo, 0.08, 5e-3, f"{tag} NET_CONTACT_FORCE", frac=2e-3)
+        for name, atol, rtol in (("DOF_STATE", 6e-4, 1e-3), ("ROOT_STATES", 4e-4, 5e-4), ("TORQUES", 4e-4, 5e-4),
+                                 ("REW_BUF", 2e-4, 2e-3), ("ARM_REW_BUF", 2e-5, 1e-3), ("OBS_BUF", 3e-3, 1e-3)):
+            _assert_close_bulk(_t(g, name), o.get(name), atol, rtol, f"{tag} {name}", frac=2e-3)
+        np.testing.assert_allclose(_t(g, "EPISODE_SUMS")[live][:, 21], o.get("EPISODE_SUMS")[live][:, 21], atol=1e-6)   # the collision counts
+        seen += (np.abs(fo[:, :27]).sum(-1) > 0).sum(0)
+        resets += int(m.sum())
+        rbz = o.get("RIGID_BODY_STATE")[:, 20:25, 2]
+        airborne_arm += int(((np.abs(fo[:, 20:25]).sum(-1) > 0) & (rbz > 0.08)).sum())
+    assert seen[1] > 100 and seen[[3, 7, 11, 15]].sum() > 20 and airborne_arm > 20 and resets > 50, (seen, airborne_arm, resets)
+    g.close()
+
+
 # ---- BASELINE.json configurations ----------------------------------------------------------------------------------
 def _assert_close_bulk(a, b, atol, rtol, msg, frac=2e-5, slack=10.0):
     """allclose for batches of thousands of envs: every element within slack x the tolerance, and all but a fraction `frac`

@@ -67,6 +67,13 @@ def test_abi_struct_sizes_and_symbols():
         assert hasattr(L, sym), f"{sym} declared in include/wbc_sim.h but not exported"
     assert set(native.EXPORTED_SYMBOLS) <= declared | {"wbc_last_error"}
     assert L.wbc_sim_arena_bytes(4096) > 4096 * 860 * 4
+    # the library's tensor table (shapes, dtypes) against the binding's (abi.TENSOR_SHAPES / TENSOR_DTYPES): a mismatch shifts
+    # every later tensor of the arena
+    for name in abi.TENSOR_IDS:
+        dims, nd, dt = (C.c_int64 * 3)(), C.c_int(), C.c_int()
+        assert L.wbc_tensor_spec(abi.T[name], dims, C.byref(nd), C.byref(dt)) == 0
+        assert tuple(dims[i] for i in range(nd.value)) == abi.TENSOR_SHAPES[name], name
+        assert ["f32", "i64", "u8"][dt.value] == abi.TENSOR_DTYPES[name], name
     import oracle
     o = C.CDLL(os.path.join(HERE, "..", "oracle", "libwbc_oracle_f64.so"))
     o.ora_abi_sizes(sizes)

@@ -214,3 +214,106 @@ def test_static_stance_supports_weight(robot):
     o.refresh_rigid_body_state()
     rb = o.get("RIGID_BODY_STATE")[0]
     assert (rb[feet, 2] - 0.02 > -0.004).all()
+
+
+def _arm_pose_in_self_contact(robot, tc, rng, want_thigh=False):
+    """An arm pose whose gripper / wrist / elbow sphere starts inside the trunk box (or a front thigh capsule): found by trial in
+    the air, where no terrain contact is possible."""
+    model = robot["model"]
+    n = 512
+    o = OracleSim(robot["wmodel"], tc, n)
+    root = np.zeros((n, 2, 13)); root[:, :, 6] = 1; root[:, 0, 2] = 30.0
+    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = np.array(tc.default_dof_pos)[None]
+    lo, hi = np.array(model.dof_lower[12:18]), np.array(model.dof_upper[12:18])
+    lo[0], hi[0] = -1.5, 1.5
+    dof[:, 12:18, 0] = rng.uniform(lo, hi, (n, 6))
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
+    o.simulate()
+    f = o.get("NET_CONTACT_FORCE")
+    hit = np.abs(f[:, [3, 7]]).sum((1, 2)) > 0 if want_thigh else (np.abs(f[:, 1]).sum(1) > 0)
+    assert hit.any()
+    return dof[np.nonzero(hit)[0][0], :, 0]
+
+
+@pytest.mark.parametrize("want_thigh", [False, True])
+def test_self_collision_impulses_are_internal(robot, want_thigh):
+    """Self-collision pairs (arm spheres against the trunk box / the front thighs): the impulse acts on both bodies with opposite
+    signs, so in free fall the robot's linear momentum changes by gravity's impulse only and its angular momentum about the
+    centre of mass not at all; the two net_contact_force rows of a pair cancel; and the contact does separate the bodies."""
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    for j in range(18):
+        tc.joint_armature[j] = 0.0
+    rng = np.random.default_rng(11)
+    q = _arm_pose_in_self_contact(robot, tc, rng, want_thigh)
+    wm = type(robot["wmodel"]).from_buffer_copy(robot["wmodel"])
+    for j in range(20):
+        wm.qd_limit[j] = 0.0                 # the URDF velocity clamp (a non-physical projection) off: this is a conservation test
+    o = OracleSim(wm, tc, 1)
+    root = np.zeros((1, 2, 13))
+    root[0, 0] = [0, 0, 30.0, 0, 0, 0, 1, 0.2, -0.1, 0.05, 0.3, -0.2, 0.1]
+    root[0, 1, 6] = 1
+    o.set("ROOT_STATES", root)
+    o.set("DOF_STATE", np.stack([q, np.zeros(20)], -1)[None])
+    o.set("TORQUES", np.zeros((1, 20)))
+    bp = make_params(model, o.get("BODY_PARAMS")[0])
+    mtot = sum(b[0] for b in bp)
+
+    def momentum():
+        r = o.get("ROOT_STATES")[0, 0]
+        d = o.get("DOF_STATE")[0]
+        tw = body_twists(model, bp, r[:3], r[3:7], d[:, 0], r[7:10], r[10:13], d[:, 1])
+        P = sum(m * vc for m, I, c, vc, om in tw)
+        cm = sum(m * c for m, I, c, vc, om in tw) / mtot
+        L = sum(I @ om + m * np.cross(c - cm, vc) for m, I, c, vc, om in tw)
+        return P, L
+    P0, L0 = momentum()
+    o.simulate()
+    f = o.get("NET_CONTACT_FORCE")[0]
+    rows = np.nonzero(np.abs(f).sum(1) > 0)[0]
+    assert len(rows) >= 2 and np.abs(f).max() > 0.5                     # a pair is pushing
+    np.testing.assert_allclose(f.sum(0), 0, atol=1e-9 * np.abs(f).max())   # ... with equal and opposite forces
+    steps = 1
+    for _ in range(7):
+        o.simulate(); steps += 1
+    P1, L1 = momentum()
+    t = steps * tc.sim_dt
+    np.testing.assert_allclose(P1 - P0, mtot * G * t, atol=1e-3 * mtot)
+    np.testing.assert_allclose(L1, L0, atol=2e-3 * max(1.0, np.abs(L0).max()))
+    for _ in range(60):                                                  # depenetration at <= max_depenetration_velocity: it lets go
+        o.simulate()
+    assert np.abs(o.get("NET_CONTACT_FORCE")[0]).max() < 1e-9 or np.abs(o.get("DOF_STATE")[0, 12:18, 1]).max() < 20.0
+
+
+def test_trunk_and_thighs_rest_on_the_ground(robot):
+    """The trunk box (corner spheres) and the thigh tops carry a robot whose legs are folded away: it comes to rest on them,
+    net_contact_force reports the weight on the trunk / thigh rows (what penalize_contacts_on and terminate_after_contacts_on
+    read), and the trunk does not sink through the ground."""
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    tc.push_interval = 0
+    o = OracleSim(robot["wmodel"], tc, 1)
+    o.set_curriculum(default_curriculum(robot["cfg"]))
+    root = np.zeros((1, 2, 13))
+    root[0, 0, 2], root[0, 0, 6], root[0, 1, 6] = 0.075, 1, 1
+    dof = np.zeros((1, 20, 2))
+    dof[0, :, 0] = np.array(tc.default_dof_pos)
+    for leg in range(4):
+        dof[0, 3 * leg + 1, 0], dof[0, 3 * leg + 2, 0] = 2.9, -2.7          # legs folded up beside the body
+    hold = dof[0, :18, 0] - np.array(tc.default_dof_pos)[:18]
+    o.set("ROOT_STATES", root)
+    o.set("DOF_STATE", dof)
+    sc = np.array(tc.action_scale)
+    act = np.where(sc > 0, hold / np.where(sc > 0, sc, 1.0), 0.0)
+    o.set("ACTIONS", act[None])                                          # PD targets = the folded pose
+    for _ in range(1500):
+        o.compute_torques()
+        o.simulate()
+    r = o.get("ROOT_STATES")[0, 0]
+    f = o.get("NET_CONTACT_FORCE")[0]
+    mtot = sum(b[0] for b in make_params(model, o.get("BODY_PARAMS")[0]))
+    names = model.rb_names
+    trunk, thighs = names.index("trunk"), [i for i, nm in enumerate(names) if "thigh" in nm]
+    assert np.abs(r[7:13]).max() < 2e-2                                   # at rest
+    assert 0.05 < r[2] < 0.08                                             # on its belly (box half height 0.057)
+    np.testing.assert_allclose(f[:, 2].sum(), mtot * 9.81, rtol=5e-3)
+    assert f[trunk, 2] + f[thighs, 2].sum() > 0.5 * mtot * 9.81           # trunk + thigh tops carry most of it
+    assert f[trunk, 2] > 10.0

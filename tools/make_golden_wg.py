@@ -80,6 +80,10 @@ def record_trajectory(env, steps, rng, tag, big_action_envs=()):
     for k, v in env._env_params.items():
         out["param/" + k] = np.asarray(v)
     out["seed"] = np.int64(harness.CTX.seed)
+    tc = env._backend.tcfg                                      # the task constants that differ between the fixtures
+    out["tcfg/term_z_threshold"] = np.float64(tc.term_z_threshold)
+    out["tcfg/term_contact_rb_mask"] = np.int64(tc.term_contact_rb_mask)
+    out["tcfg/penalize_contact_rb_mask"] = np.int64(tc.penalize_contact_rb_mask)
     resets = sum(int(out[f"s{k}/RESET_BUF"].sum()) for k in range(steps))
     tos = sum(int(out[f"s{k}/TIME_OUT_BUF"].sum()) for k in range(steps))
     print(f"[{tag}] {steps} steps x {n} envs: {resets} resets ({tos} time-outs), draws logged: {len(harness.CTX.log)}")
@@ -111,6 +115,28 @@ def stage_events(env, rng):
     env.goal_timer[torch.from_numpy(soon)] = (env.traj_total_timesteps[torch.from_numpy(soon)] - torch.from_numpy(rng.integers(0, 6, int(soon.sum())).astype(np.float32)))
 
 
+def self_contact_arm_poses(backend, count, rng):
+    """Arm joint angles (6) at which an arm sphere touches the trunk box or a front thigh: found by holding robots in the air
+    (no terrain contact possible) in a scratch OracleSim and keeping the poses whose first substep reports a contact force."""
+    from oracle import OracleSim
+    m = backend.model
+    n = 1024
+    o = OracleSim(backend.wmodel, backend.tcfg, n, seed=1, precision="f64")
+    root = np.zeros((n, 2, 13)); root[:, :, 6] = 1; root[:, 0, 2] = 1.0
+    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = np.array(backend.tcfg.default_dof_pos)[None]
+    lo, hi = np.array(m.dof_lower[12:18]), np.array(m.dof_upper[12:18])
+    lo[0], hi[0] = -1.5, 1.5                                       # the waist has no URDF limit
+    dof[:, 12:18, 0] = rng.uniform(lo, hi, (n, 6))
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
+    o.simulate()
+    f = o.get("NET_CONTACT_FORCE")
+    hit = np.abs(f).sum((1, 2)) > 0
+    thigh = np.abs(f[:, [3, 7]]).sum((1, 2)) > 0                   # FL_thigh, FR_thigh rows: a gripper / wrist against a thigh
+    picks = list(np.nonzero(thigh)[0][:max(1, count // 3)]) + list(np.nonzero(hit & ~thigh)[0])
+    assert len(picks) >= count, (hit.sum(), thigh.sum())
+    return dof[picks[:count], 12:18, 0]
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     rng = np.random.default_rng(20260925)
@@ -125,13 +151,13 @@ def main():
         outA = record_trajectory(env, 28, rng, "A1 counter=1", big_action_envs=(3, 11))
     save("wg_reference_counter0.npz", out0)
     save("wg_reference_default.npz", outA)
-    # ---- B: every one of the 21 reward terms of WG:1352-1469 active
+    # ---- B: every one of the 21 reward terms of WG:1352-1469 active, and the base class's _reward_collision (LR:865-867)
     cfg = flat_cfg()
     s, a = cfg.rewards.scales, cfg.rewards.arm_scales
     leg = dict(energy_square=-6e-5, survive=0.2, tracking_lin_vel_x_l1=0.5, tracking_ang_vel_yaw_exp=0.15, hip_action_l2=-0.01,
                foot_contacts_z=-1e-4, leg_energy_abs_sum=-3e-3, leg_energy_sum_abs=-2e-3, leg_action_l2=-0.02, leg_energy=-1e-3,
                tracking_lin_vel=0.3, tracking_lin_vel_x_exp=0.25, tracking_ang_vel_yaw_l1=0.1, tracking_lin_vel_y_l2=-0.4,
-               tracking_lin_vel_z_l2=-0.2, torques=-1e-4)
+               tracking_lin_vel_z_l2=-0.2, torques=-1e-4, collision=-0.7)
     arm = dict(tracking_ee_sphere=0.55, arm_energy_abs_sum=-0.004, tracking_ee_cart=0.35, tracking_ee_orn=0.2, tracking_ee_orn_ry=0.15)
     for k, v in leg.items():
         setattr(s, k, v)                # instance attributes: class_to_dict (helpers.py:41-56) walks dir(obj)
@@ -149,6 +175,45 @@ def main():
     outB["arm_scales"] = np.array([arm.get(nm, 0.0) for nm in __import__("wbc_amd").abi.REWARD_TERMS])
     outB["delta_orn"] = np.array(cfg.goal_ee.ranges.final_delta_orn)
     save("wg_reference_allrewards.npz", outB)
+    # ---- C: the collision set at work. Robots dropped on their trunks (legs folded up), robots on their sides, arms swung into
+    # the trunk and the front thighs by +-3 rad arm targets; episodes end through terminate_after_contacts_on (WG:940),
+    # _reward_collision counts the penalised bodies in contact (LR:865-867). The height termination is moved out of the way.
+    cfg = flat_cfg()
+    cfg.termination.z_threshold = 0.02
+    cfg.asset.terminate_after_contacts_on = ["thigh"]
+    cfg.asset.penalize_contacts_on = ["thigh", "trunk", "calf"]
+    cfg.rewards.scales.collision = -1.0
+    env = make_reference_env(20, seed=13, cfg=cfg)
+    env._backend.ora.set_heightfield(None, 0, 0, 0, 0, 0)
+    with torch.inference_mode():
+        env.reset()
+        env.update_command_curriculum()
+        n = env.num_envs
+        dof = env.dof_state.view(n, 20, 2)
+        low = torch.arange(n) < 7                                 # on the trunk: legs folded up beside the body
+        env.root_states[low, 2] = 0.062
+        env.root_states[low, 7:] = 0
+        for leg in range(4):
+            dof[low, 3 * leg + 1, 0] = 2.9
+            dof[low, 3 * leg + 2, 0] = -2.7
+        dof[low, :, 1] = 0
+        side = (torch.arange(n) >= 7) & (torch.arange(n) < 10)    # on its side: thighs and trunk edges on the ground
+        env.root_states[side, 2] = 0.14
+        env.root_states[side, 3:7] = torch.tensor([0.7071068, 0.0, 0.0, 0.7071068])
+        arm_envs = tuple(range(10, 17))
+        poses = self_contact_arm_poses(env._backend, len(arm_envs), rng)
+        for e, pose in zip(arm_envs, poses):                      # arm spheres start inside the trunk box / a thigh capsule
+            dof[e, 12:18, 0] = torch.from_numpy(pose.astype(np.float32))
+            dof[e, 12:18, 1] = 0
+        outC = record_trajectory(env, 12, rng, "C contacts", big_action_envs=arm_envs[:3])
+    f = np.stack([outC[f"s{k}/NET_CONTACT_FORCE"] for k in range(12)])                     # [steps, n, 28, 3]
+    touching = np.abs(f).sum(-1) > 0
+    names = env._backend.model.rb_names
+    print("   bodies in contact (steps x envs):", {names[i]: int(touching[:, :, i].sum()) for i in range(27) if touching[:, :, i].any()})
+    airborne_arm = touching[:, :, 20:25].any(-1) & (np.stack([outC[f"s{k}/RIGID_BODY_STATE"] for k in range(12)])[:, :, 20:25, 2].min(-1) > 0.08)
+    print("   arm links in contact above the ground (self-collision):", int(airborne_arm.sum()))
+    assert touching[:, :, 1].sum() > 10 and airborne_arm.sum() > 5
+    save("wg_reference_contacts.npz", outC)
 
 
 if __name__ == "__main__":

@@ -454,7 +454,7 @@ class OracleBackend:
         from oracle import OracleSim
         self.n = num_envs
         self.model = abi.load_default_model()
-        self.wmodel = abi.fill_model(self.model, foot_name=cfg.asset.foot_name)
+        self.wmodel = abi.fill_model(self.model, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0)
         self.tcfg = abi.fill_task_cfg(cfg, self.model, sim_dt=sim_dt)
         self.ora = OracleSim(self.wmodel, self.tcfg, num_envs, seed=seed, precision="f64")
         nb = self.model.num_rigid_bodies + 1

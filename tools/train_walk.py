@@ -25,6 +25,12 @@ if "lin_l1" in kv:
     cfg.rewards.scales.tracking_lin_vel_x_l1 = float(kv["lin_l1"])
 if "contacts_z" in kv:
     cfg.rewards.scales.foot_contacts_z = float(kv["contacts_z"])
+if "lin_exp" in kv:
+    cfg.rewards.scales.tracking_lin_vel_x_exp = float(kv["lin_exp"])
+if "energy" in kv:
+    cfg.rewards.scales.energy_square = float(kv["energy"])
+if "hip" in kv:
+    cfg.rewards.scales.hip_action_l2 = float(kv["hip"])
 train = class_to_dict(WidowGo1RoughCfgPPO())
 torch.manual_seed(train["seed"])
 env = WidowGo1(cfg, sim_device="cuda:0", seed=train["seed"])
@@ -101,7 +107,8 @@ def evaluate(hist, steps=500):
 
 summary = {"iterations": iters, "envs": n, "wall_s": round(wall, 1), "env_steps": iters * n * runner.num_steps_per_env,
            "config": {"survive": cfg.rewards.scales.survive, "z_threshold": cfg.termination.z_threshold,
-                      "tracking_lin_vel_x_l1": cfg.rewards.scales.tracking_lin_vel_x_l1, "foot_contacts_z": cfg.rewards.scales.foot_contacts_z},
+                      "tracking_lin_vel_x_l1": cfg.rewards.scales.tracking_lin_vel_x_l1, "foot_contacts_z": cfg.rewards.scales.foot_contacts_z,
+                      "tracking_lin_vel_x_exp": cfg.rewards.scales.tracking_lin_vel_x_exp, "energy_square": cfg.rewards.scales.energy_square},
            "teacher_eval": evaluate(False), "student_eval": evaluate(True)}
 print(json.dumps(summary), flush=True)
 if "out" in kv:
