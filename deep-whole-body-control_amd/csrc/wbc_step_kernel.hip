@@ -459,6 +459,14 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     for (int j = 0; j < 3; ++j) cpp[j] = Cc->model.cp_pos[lane][j];
     cpr = Cc->model.cp_radius[lane];
   }
+  int cpb2 = -1;                                                         // the partner of a self-collision pair; -1 for terrain contacts
+  float cpa[3] = {0.f, 0.f, 0.f}, cpe[3] = {0.f, 0.f, 0.f}, cpr2 = 0.f;
+  if (cpkind > WBC_CP_TERRAIN) {
+    cpb2 = Cc->model.cp_body2[lane];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { cpa[j] = Cc->model.cp_a[lane][j]; cpe[j] = Cc->model.cp_b[lane][j]; }
+    cpr2 = Cc->model.cp_radius2[lane];
+  }
   // pass 3 and inverse articulated inertias, outward: the parent's K entries (K3) and acceleration component (apr)
   // travel down the chain in registers; one LDS hand-over per level (g = K_p U / D and the terms of U.(a_p + c)).
   {
@@ -505,15 +513,6 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(6);
   // contacts: one contact per lane (spheres against the terrain, then the self-collision pairs: a sphere against a box or a
   // capsule riding on another body). Narrow phase first; only lanes with an ACTIVE contact build a Delassus block.
-  // constants first needed after the terrain branch below (their latency hides behind it): the partner of a self-collision pair
-  int cpb2 = -1;                                                         // stays -1 for terrain contacts
-  float cpa[3] = {0.f, 0.f, 0.f}, cpe[3] = {0.f, 0.f, 0.f}, cpr2 = 0.f;
-  if (cpkind > WBC_CP_TERRAIN) {
-    cpb2 = Cc->model.cp_body2[lane];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { cpa[j] = Cc->model.cp_a[lane][j]; cpe[j] = Cc->model.cp_b[lane][j]; }
-    cpr2 = Cc->model.cp_radius2[lane];
-  }
   f3 cn = mk3(0.f, 0.f, 1.f), cxcr = mk3(0.f, 0.f, 0.f);
   float cgap = 1e30f;
   if (cpkind == WBC_CP_TERRAIN) {
@@ -524,9 +523,25 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     cgap = (Xw.z - h) * nw.z - cpr;
     cn = matT_mul(s.R, nw);
     cxcr = xk - cn * cpr;
-  } else if (cpkind > WBC_CP_TERRAIN) {
+  }
+  // self-collision pairs. Broad phase: the sphere against the partner's bounding sphere, generous by 1 mm -- a pair it rejects has
+  // a gap far above the contact margin, so the exact test below (box / capsule closest point, square roots, divisions) could not
+  // have found it active either; with the arm carried above the trunk, as it mostly is, no lane gets past it and the wavefront
+  // skips the exact tests altogether.
+  f3 spl = mk3(0.f, 0.f, 0.f);
+  bool snear = false;
+  if (cpkind > WBC_CP_TERRAIN) {
     const f3 xk = ld3(s.pos[cpb]) + mat_mul(s.E[cpb], mk3(cpp[0], cpp[1], cpp[2]));
-    const f3 pl = matT_mul(s.E[cpb2], xk - ld3(s.pos[cpb2]));           // sphere centre in the partner's frame
+    spl = matT_mul(s.E[cpb2], xk - ld3(s.pos[cpb2]));                    // sphere centre in the partner's frame
+    const f3 A = mk3(cpa[0], cpa[1], cpa[2]), B = mk3(cpe[0], cpe[1], cpe[2]);
+    const bool box = cpkind == WBC_CP_BOX;
+    const f3 ctr = box ? A : (A + B) * 0.5f, ext = box ? B : (B - A) * 0.5f;
+    const float reach = __builtin_amdgcn_sqrtf(dot(ext, ext)) + cpr + cpr2 + C->cfg.contact_margin + 1e-3f;
+    const f3 dc = spl - ctr;
+    snear = dot(dc, dc) < reach * reach;
+  }
+  if (__ballot(snear) != 0ull && snear) {
+    const f3 pl = spl;
     const f3 A = mk3(cpa[0], cpa[1], cpa[2]), B = mk3(cpe[0], cpe[1], cpe[2]);
     f3 ql, nl;
     float dist;
@@ -563,6 +578,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     cn = mat_mul(s.E[cpb2], nl);
     cxcr = ld3(s.pos[cpb2]) + mat_mul(s.E[cpb2], ql);                    // on the partner's surface
   }
+  STAMP(18);
   const bool cact = cgap < C->cfg.contact_margin;
   const uint32_t abits = (uint32_t)__ballot(cact);                      // the active set (WBC_NCP <= 32 lanes)
   f3 cvfree = mk3(0.f, 0.f, 0.f), clamr = mk3(0.f, 0.f, 0.f);
@@ -644,6 +660,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         st3(s.clam[lane], clamr);
       }
       WSYNC();
+      if (it == 0) STAMP(20);
       // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a self-collision pair
       // receives the opposite wrench
       if (lane < WBC_NB) {
@@ -663,6 +680,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         s.uD[lane] = 0.f;                          // levels the inward sweep skips
       }
       WSYNC();
+      if (it == 0) STAMP(21);
       {   // inward. Sweep layout: 8 lanes per chain (sch = lane >> 3, component sk = lane & 7 < 6): lane (sch, sk) carries
           // component sk of the accumulated wrench in a register, the 6-term products S.p are DPP sums (no LDS hand-over)
         const int sch = lane >> 3, sk = lane & 7;
@@ -683,6 +701,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         }
         WSYNC();
       }
+      if (it == 0) STAMP(22);
       if (lane < 6) {       // root: sum of the depth-1 contributions (fixed order), then a0 = -K0 pD0
         float pd0[6];
 #pragma unroll
@@ -695,6 +714,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         AD(s)[0][lane] = -dot6(&s.ctc.K0[lane * 6], pd0);
       }
       WSYNC();
+      if (it == 0) STAMP(23);
       const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
       {   // outward: component sk of the parent's acceleration change travels in a register
         const int sch = lane >> 3, sk = lane & 7;
@@ -714,6 +734,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         }
         WSYNC();
       }
+      if (it == 0) STAMP(24);
       if (it < iters - 1 && cact) {      // the last sweep's contact-point response is not used
         const f3 xc = ld3(s.cxc[lane]);
         f3 dvv = (ld3(&AD(s)[cpb][3]) + cross(ld3(&AD(s)[cpb][0]), xc)) * dt;
@@ -915,7 +936,7 @@ __device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
 // compute_reward of the oracle, executed by lane 0 on LDS state
 __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq, const float ncol) {
   const wbc_task_cfg& cf = C->cfg;
-  const float inv_sig = 1.f / cf.tracking_sigma, inv_ee_sig = 1.f / cf.tracking_ee_sigma;
+  const float inv_sig = rcpf(cf.tracking_sigma), inv_ee_sig = rcpf(cf.tracking_ee_sigma);
   float term[WBC_NREW], met_src[WBC_NREW];
 #pragma unroll
   for (int t = 0; t < WBC_NREW; ++t) met_src[t] = 0.f;
@@ -932,9 +953,9 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   term[WBC_REW_SURVIVE] = 1.f;
   const float ex = fabsf(s.cmd[0] - s.blv[0]);
   term[WBC_REW_TRACKING_LIN_VEL_X_L1] = -ex + fabsf(s.cmd[0]);
-  term[WBC_REW_TRACKING_LIN_VEL_X_EXP] = expf(-ex * inv_sig);
+  term[WBC_REW_TRACKING_LIN_VEL_X_EXP] = fast_expf(-ex * inv_sig);
   const float eyaw = fabsf(s.cmd[2] - s.bav[2]);
-  term[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = expf(-eyaw * inv_sig);
+  term[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = fast_expf(-eyaw * inv_sig);
   term[WBC_REW_TRACKING_ANG_VEL_YAW_L1] = -eyaw + fabsf(s.cmd[2]);
   const float hip = s.act[0] * s.act[0] + s.act[3] * s.act[3] + s.act[6] * s.act[6] + s.act[9] * s.act[9];
   term[WBC_REW_HIP_ACTION_L2] = hip;
@@ -946,11 +967,11 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   const f3 sph = cart2sphere(loc);
   const float es = fabsf(sph.x - s.goal[G_CURR]) * cf.sphere_error_scale[0] + fabsf(sph.y - s.goal[G_CURR + 1]) * cf.sphere_error_scale[1] +
                    fabsf(sph.z - s.goal[G_CURR + 2]) * cf.sphere_error_scale[2];
-  term[WBC_REW_TRACKING_EE_SPHERE] = expf(-es * inv_ee_sig);
+  term[WBC_REW_TRACKING_EE_SPHERE] = fast_expf(-es * inv_ee_sig);
   const float yq_inv[4] = {-yq[0], -yq[1], -yq[2], yq[3]};
   const f3 tw = quat_rotate_inverse(yq_inv, ld3(&s.goal[G_CURR_CART]));
   const float ec = fabsf(ee_pos[0] - (s.root[0] + tw.x)) + fabsf(ee_pos[1] - (s.root[1] + tw.y)) + fabsf(ee_pos[2] - (cf.z_invariant_offset + tw.z));
-  term[WBC_REW_TRACKING_EE_CART] = expf(-ec * inv_ee_sig);
+  term[WBC_REW_TRACKING_EE_CART] = fast_expf(-ec * inv_ee_sig);
   const f3 eul = euler_from_quat(ee_orn);
   const float eu[3] = {eul.x, eul.y, eul.z};
   float eo = 0.f, eo_ry = 0.f;
@@ -960,15 +981,15 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
     eo += fabsf(d) * cf.orn_error_scale[j];
     if (j != 1) eo_ry += fabsf(d * cf.orn_error_scale[j]);
   }
-  term[WBC_REW_TRACKING_EE_ORN] = expf(-eo * inv_ee_sig);
-  term[WBC_REW_TRACKING_EE_ORN_RY] = expf(-eo_ry * inv_ee_sig);
+  term[WBC_REW_TRACKING_EE_ORN] = fast_expf(-eo * inv_ee_sig);
+  term[WBC_REW_TRACKING_EE_ORN_RY] = fast_expf(-eo_ry * inv_ee_sig);
   term[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum;
   term[WBC_REW_LEG_ENERGY_SUM_ABS] = fabsf(sum);
   term[WBC_REW_LEG_ACTION_L2] = act_leg;
   term[WBC_REW_LEG_ENERGY] = sum;
   term[WBC_REW_ARM_ENERGY_ABS_SUM] = arm_abs;
   const float dx = s.cmd[0] - s.blv[0], dy = s.cmd[1] - s.blv[1], dz = s.cmd[2] - s.blv[2];
-  term[WBC_REW_TRACKING_LIN_VEL] = expf(-(dx * dx + dy * dy) * inv_sig);
+  term[WBC_REW_TRACKING_LIN_VEL] = fast_expf(-(dx * dx + dy * dy) * inv_sig);
   term[WBC_REW_TRACKING_LIN_VEL_Y_L2] = dy * dy;
   term[WBC_REW_TRACKING_LIN_VEL_Z_L2] = dz * dz;
   term[WBC_REW_TORQUES] = tq2;
@@ -1272,7 +1293,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     fast_sincosf(0.5f * base_yaw, &sy, &cy);
     const float yq[4] = {0.f, 0.f, sy, cy};
     // update_curr_ee_goal
-    const float tt = clampf(s.goal[G_TIMER] / s.goal[G_TRAJ], 0.f, 1.f);
+    const float tt = clampf(s.goal[G_TIMER] * rcpf(s.goal[G_TRAJ]), 0.f, 1.f);
     for (int j = 0; j < 3; ++j) s.goal[G_CURR + j] = lerp_torch(s.goal[G_START + j], s.goal[G_GOAL + j], tt);
     st3(&s.goal[G_CURR_CART], sphere2cart(ld3(&s.goal[G_CURR])));
     s.goal[G_TIMER] += 1.f;
