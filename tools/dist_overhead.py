@@ -24,10 +24,32 @@ def leg(tag, group):
     runner.learn(4)
     torch.cuda.synchronize()
     runner.history.clear()
+    # where inside a rollout step the time goes: events around the policy inference and around the env step of every 5th step
+    ev = []
+    raw_act, raw_step, k = runner.alg.act, env.step, {"n": 0}
+
+    def act(*a, **kw):
+        k["n"] += 1
+        if k["n"] % 5 == 0:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record(); out = raw_act(*a, **kw); e[1].record()
+            ev.append(e)
+            return out
+        return raw_act(*a, **kw)
+
+    def step(a):
+        out = raw_step(a)
+        if k["n"] % 5 == 0:
+            ev[-1][2].record()
+        return out
+    runner.alg.act, env.step = act, step
     runner.learn(13)                                   # iterations 6..18: no DAgger iteration among them
+    torch.cuda.synchronize()
+    t_act = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev) * 1e3
+    t_step = sum(e[1].elapsed_time(e[2]) for e in ev) / len(ev) * 1e3
     c = sum(h["collection_time"] for h in runner.history) / len(runner.history) * 1e3
     l = sum(h["learn_time"] for h in runner.history) / len(runner.history) * 1e3
-    print(f"{tag:34s} collect {c:6.3f} ms  learn {l:6.3f} ms  sum {c + l:6.3f} ms", flush=True)
+    print(f"{tag:34s} collect {c:6.3f} ms  learn {l:6.3f} ms  sum {c + l:6.3f} ms | per rollout step: act {t_act:6.1f} us, env.step (+ stats) {t_step:6.1f} us", flush=True)
     env.sim.close()
 
 

@@ -32,6 +32,11 @@ if "energy" in kv:
 if "hip" in kv:
     cfg.rewards.scales.hip_action_l2 = float(kv["hip"])
 train = class_to_dict(WidowGo1RoughCfgPPO())
+sched = kv.get("sched", "scratch")         # the shipped file hard-codes RESUME = True (fine-tuning schedules); from scratch: the other branch
+if sched.startswith("scratch"):
+    k = float(sched.split("/")[1]) if "/" in sched else 1.0            # "scratch/5": the same schedules on a 5x shorter clock
+    train["algorithm"]["mixing_schedule"] = [1.0, 0, 3000 / k]                       # widowGo1_config.py:359
+    train["algorithm"]["priv_reg_coef_schedual"] = [0, 0.1, 3000 / k, 7000 / k]      # widowGo1_config.py:366
 torch.manual_seed(train["seed"])
 env = WidowGo1(cfg, sim_device="cuda:0", seed=train["seed"])
 runner = OnPolicyRunner(env, train, log_dir=None, device="cuda:0")
@@ -84,7 +89,7 @@ for it in range(0, iters, every):
     s = cnt["steps"]
     rows.append(dict(it=it + every, **{k: round(acc[k].item() / s, 5) for k in K},
                      lin_vel_x_range=[float(x) for x in env.lin_vel_x_ranges], mixing=runner.history[-1]["value_mixing_ratio"],
-                     hist_loss=runner.history[-1]["mean_hist_latent_loss"], std_leg=float(runner.alg.actor_critic.std[:, :12].mean()),
+                     hist_loss=runner.history[-1]["mean_hist_latent_loss"], priv_reg_coef=runner.history[-1]["priv_reg_coef"], std_leg=float(runner.alg.actor_critic.std[:, :12].mean()),
                      std_arm=float(runner.alg.actor_critic.std[:, 12:].mean())))
     print(json.dumps(rows[-1]), flush=True)
 wall = time.time() - t0
@@ -106,6 +111,7 @@ def evaluate(hist, steps=500):
 
 
 summary = {"iterations": iters, "envs": n, "wall_s": round(wall, 1), "env_steps": iters * n * runner.num_steps_per_env,
+           "schedules": {"mixing_schedule": train["algorithm"]["mixing_schedule"], "priv_reg_coef_schedual": train["algorithm"]["priv_reg_coef_schedual"]},
            "config": {"survive": cfg.rewards.scales.survive, "z_threshold": cfg.termination.z_threshold,
                       "tracking_lin_vel_x_l1": cfg.rewards.scales.tracking_lin_vel_x_l1, "foot_contacts_z": cfg.rewards.scales.foot_contacts_z,
                       "tracking_lin_vel_x_exp": cfg.rewards.scales.tracking_lin_vel_x_exp, "energy_square": cfg.rewards.scales.energy_square},
