@@ -137,8 +137,10 @@ class OnPolicyRunner:
         tot_iter = self.current_learning_iteration + num_learning_iterations
         redirect_obs = hasattr(env, "set_obs_output") and hasattr(alg, "next_observation_slot") and getattr(alg, "fused_rollout", False)
         store_in_step = hasattr(env, "set_rollout_output") and hasattr(alg, "rollout_slots") and getattr(alg, "fused_rollout", False)
-        if hasattr(env, "async_episode_stats"):
-            env.async_episode_stats = True               # every read of infos['episode'] below comes after a device synchronisation
+        # (WidowGo1.async_episode_stats -- extras['episode'] computed on a side stream under the next policy inference -- stays off:
+        # measured on the MI355X (tools/dist_overhead.py), the two cross-stream hand-overs per env step cost more than the 8 us
+        # kernel they hide (151 vs 155 us per rollout step), and with RCCL's streams in the process the extra stream can end up
+        # sharing a hardware queue with the compute stream: +16 us per step)
         tracker = None                                   # device-side deques (wbc_runner_track_episodes), set up on the first logged step
         try:
             for it in range(self.current_learning_iteration, tot_iter):
@@ -208,11 +210,10 @@ class OnPolicyRunner:
                         self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
                 self.history.append(rec)
                 ep_infos.clear()
-        finally:                                         # also on an exception / KeyboardInterrupt: later callers of env.step()
+        finally:                                         # also on an exception / KeyboardInterrupt
             if tracker:
                 tracker.close()
-            if hasattr(env, "async_episode_stats"):      # must not read side-stream results unsynchronised
-                env.async_episode_stats = False
+            if getattr(env, "async_episode_stats", False):   # a caller-enabled side stream: its results are complete from here on
                 sync()
         self.current_learning_iteration += num_learning_iterations
         if logging:
