@@ -362,6 +362,13 @@ def main():
             torch.cuda.synchronize()
             allreduce_us = (time.perf_counter() - tw) * 1e6 / 50
 
+    checkpoint_ms = None
+    if args.log and rank == 0:         # what the one end-of-learn() checkpoint (OPR:182) inside the timed region cost
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        runner.save(os.path.join(log_dir, "bench_probe.pt"))
+        torch.cuda.synchronize()
+        checkpoint_ms = (time.perf_counter() - tc0) * 1e3
     if rank == 0:
         hist = runner.history[-args.steps:]
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
@@ -393,7 +400,7 @@ def main():
                                        if use_dist else "single GPU"),
                        "rccl_ranks": dist.get_world_size(group) if use_dist and args.backend == "nccl" else 0,
                        "backend": args.backend if use_dist else None, "same_device": bool(args.same_device),
-                       "logged": bool(args.log),
+                       "logged": bool(args.log), "end_of_learn_checkpoint_ms": checkpoint_ms,
                        "grad_allreduce_us": allreduce_us,
                        "collection_ms": 1e3 * sum(h["collection_time"] for h in hist) / len(hist),
                        "learn_ms": 1e3 * sum(h["learn_time"] for h in hist) / len(hist)},

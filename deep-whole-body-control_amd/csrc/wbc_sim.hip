@@ -419,41 +419,45 @@ extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
 // episode's reward sums [WBC_NREW] and metric sums [WBC_NMETRIC], times `scale` (1 / max_episode_length_s).
 // One block per column, fixed-order tree: deterministic. No reset in this step -> the previously published value (prev), as the
 // reference's extras["episode"] is only rebuilt inside reset_idx when env_ids is non-empty (WG:705-706, 742-750).
-static __global__ void __launch_bounds__(256) episode_stats_kernel(const float* __restrict__ ep_done, const float* __restrict__ met_done,
-                                                                  const int64_t* __restrict__ reset_buf, int n, float scale,
-                                                                  const float* __restrict__ prev, float* __restrict__ out,
-                                                                  const float* __restrict__ rew, const float* __restrict__ arm_rew,
-                                                                  float* __restrict__ track_state, int track_cap) {
+#define STATS_THREADS 1024
+static __global__ void __launch_bounds__(STATS_THREADS) episode_stats_kernel(const float* __restrict__ ep_done, const float* __restrict__ met_done,
+                                                                            const int64_t* __restrict__ reset_buf, int n, float scale,
+                                                                            const float* __restrict__ prev, float* __restrict__ out,
+                                                                            const float* __restrict__ rew, const float* __restrict__ arm_rew,
+                                                                            float* __restrict__ track_state, int track_cap) {
   if (blockIdx.x == WBC_NREW + WBC_NMETRIC) {       // the extra workgroup (only launched with a tracker state): wbc_track.h
-    track_episodes_block<256>(rew, arm_rew, reset_buf, n, track_cap, track_state);
+    track_episodes_block<STATS_THREADS>(rew, arm_rew, reset_buf, n, track_cap, track_state);
     return;
   }
-  // one block per column. Thread t sums envs t, t + 256, ... in ascending order; flag and value are loaded together (the value
-  // unconditionally: a dependent second load would double the number of memory round trips), 8 envs in flight per thread.
-  // Then a fixed butterfly per wavefront and the four wave sums in wave order: deterministic.
-  __shared__ float sh[4], shc[4];
+  // one block per column. Thread t sums envs t, t + 1024, ... in ascending order; flag and value are loaded together (the value
+  // unconditionally: a dependent second load would double the number of memory round trips), 4 envs in flight per thread (one
+  // round at 4096 envs: the launch is two memory round trips long). Then a fixed butterfly per wavefront and the sixteen wave
+  // sums in wave order: deterministic.
+  __shared__ float sh[STATS_THREADS / 64], shc[STATS_THREADS / 64];
   const int col = blockIdx.x, tid = threadIdx.x;
   const float* src = col < WBC_NREW ? ep_done + col : met_done + (col - WBC_NREW);
   const int width = col < WBC_NREW ? WBC_NREW : WBC_NMETRIC;
   float acc = 0.f, cnt = 0.f;
-  for (int base = 0; base < n; base += 256 * 8) {
-    float v[8];
-    int d[8];
+  for (int base = 0; base < n; base += STATS_THREADS * 4) {
+    float v[4];
+    int d[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + 256 * u + tid, ic = i < n ? i : n - 1;
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + STATS_THREADS * u + tid, ic = i < n ? i : n - 1;
       d[u] = (i < n) && reset_buf[ic] != 0;
       v[u] = src[(size_t)ic * width];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { acc += d[u] ? v[u] : 0.f; cnt += d[u] ? 1.f : 0.f; }
+    for (int u = 0; u < 4; ++u) { acc += d[u] ? v[u] : 0.f; cnt += d[u] ? 1.f : 0.f; }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { acc += __shfl_xor(acc, off); cnt += __shfl_xor(cnt, off); }
   if ((tid & 63) == 0) { sh[tid >> 6] = acc; shc[tid >> 6] = cnt; }
   __syncthreads();
   if (tid == 0) {
-    const float a = ((sh[0] + sh[1]) + sh[2]) + sh[3], c = ((shc[0] + shc[1]) + shc[2]) + shc[3];
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int w = 0; w < STATS_THREADS / 64; ++w) { a += sh[w]; c += shc[w]; }
     out[col] = c > 0.f ? a / c * scale : (prev ? prev[col] : 0.f);
   }
 }
@@ -463,7 +467,7 @@ extern "C" int wbc_sim_episode_stats_track(wbc_sim* s, float scale, const float*
   if (!s || !out) return fail(-1, "wbc_sim_episode_stats: null argument");
   if (track_state && track_cap <= 0) return fail(-1, "wbc_sim_episode_stats_track: cap must be positive");
   DeviceGuard dg(s->device);
-  hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC + (track_state ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, s->T.ep_sums_done,
+  hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC + (track_state ? 1 : 0)), dim3(STATS_THREADS), 0, (hipStream_t)stream, s->T.ep_sums_done,
                      s->T.met_sums_done, s->T.reset_buf, s->n, scale, prev, out, s->T.rew, s->T.arm_rew, track_state, track_cap);
   return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
 }

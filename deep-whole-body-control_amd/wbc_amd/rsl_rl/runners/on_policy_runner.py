@@ -66,13 +66,18 @@ class _EpisodeTracker:
             self._hooked_env.attach_episode_tracker(None, 0)
         self._hooked_env = None
 
-    def summary(self):
+    def device_tail(self):
+        """The rings and their header as one device tensor (4 cap + 4 floats), for a caller that packs several read-backs into one copy."""
+        return self.state[3 * self.n:]
+
+    def summary(self, tail=None):
         """{mean_reward, mean_arm_reward, mean_episode_length, dones} over the rings (empty before the first finished episode,
-        as the reference's `if len(rewbuffer) > 0`). The caller has synchronised the device."""
-        tail = self.state[3 * self.n:].cpu()
+        as the reference's `if len(rewbuffer) > 0`). `tail`: a host copy of device_tail(); default: copy it now. The caller has
+        synchronised the device."""
+        tail = self.device_tail().cpu() if tail is None else tail
         cap = self.CAP
         ring, done_ring = tail[:3 * cap].view(cap, 3).double(), tail[3 * cap:4 * cap].double()
-        hdr = tail[4 * cap:4 * cap + 4].view(torch.int32)
+        hdr = tail[4 * cap:4 * cap + 4].contiguous().view(torch.int32)
         fill, dfill = int(hdr[1]), int(hdr[3])
         if fill == 0:
             return {}
@@ -200,12 +205,10 @@ class OnPolicyRunner:
                 self.tot_timesteps += self.num_steps_per_env * n
                 self.tot_time += collection_time + learn_time
                 if logging:
-                    if tracker:
-                        rec.update(tracker.summary())         # one small device-to-host copy per iteration
-                    elif len(rewbuffer) > 0:
+                    if not tracker and len(rewbuffer) > 0:
                         rec.update(mean_reward=statistics.mean(rewbuffer), mean_arm_reward=statistics.mean(armrewbuffer),
                                    mean_episode_length=statistics.mean(lenbuffer), dones=statistics.mean(donebuffer))
-                    self.log(rec, ep_infos, tot_iter)
+                    self.log(rec, ep_infos, tot_iter, tracker=tracker or None)     # (the tracker's rings travel in log()'s one host copy)
                     if it % self.save_interval == 0:
                         self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
                 self.history.append(rec)
@@ -219,7 +222,27 @@ class OnPolicyRunner:
         if logging:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 
-    def log(self, rec, ep_infos, tot_iter, width=80, pad=35):
+    def log(self, rec, ep_infos, tot_iter, width=80, pad=35, tracker=None):
+        """OPR:187-274 without its ~40 device synchronisations per line: everything the line needs from the device -- the means of
+        extras['episode'] over the rollout, the two noise levels, the episode deques -- comes over in ONE copy."""
+        first = ep_infos[0] if ep_infos else None
+        index = getattr(first, "vector_index", None)
+        std = self.alg.actor_critic.std.detach().reshape(-1)
+        parts = [std[:12].mean().reshape(1), std[12:].mean().reshape(1)]
+        vectorised = index is not None and all(getattr(i, "vector", None) is not None for i in ep_infos)
+        if vectorised:
+            parts.append(torch.stack([i.vector for i in ep_infos]).mean(0))
+        if tracker is not None:
+            parts.append(tracker.device_tail())
+        host = torch.cat(parts).cpu()
+        leg_std, arm_std = host[0].item(), host[1].item()
+        off = 2
+        ep_means = None
+        if vectorised:
+            ep_means = host[off:off + first.vector.numel()]
+            off += first.vector.numel()
+        if tracker is not None:
+            rec.update(tracker.summary(host[off:]))
         lines = ["#" * width, f" Learning iteration {rec['it']}/{tot_iter} ".center(width), ""]
         lines.append(f"{'Computation:':>{pad}} {rec['fps']:.0f} steps/s (collection: {rec['collection_time']:.3f}s, "
                      f"learning {rec['learn_time']:.3f}s)")
@@ -230,16 +253,6 @@ class OnPolicyRunner:
                            ("mean_episode_length", "Mean episode length:"), ("dones", "Dones:")):
             if key in rec:
                 lines.append(f"{label:>{pad}} {rec[key]:.4f}")
-        ep_means = None
-        first = ep_infos[0] if ep_infos else None
-        index = getattr(first, "vector_index", None)
-        std = self.alg.actor_critic.std.detach().reshape(-1)
-        if index is not None and all(getattr(i, "vector", None) is not None for i in ep_infos):
-            # every tensor entry of every step's extras['episode'] AND the two noise levels: ONE device-to-host copy
-            packed = torch.cat([torch.stack([i.vector for i in ep_infos]).mean(0), std[:12].mean().reshape(1), std[12:].mean().reshape(1)]).cpu()
-            ep_means, leg_std, arm_std = packed[:-2], packed[-2].item(), packed[-1].item()
-        else:
-            leg_std, arm_std = std[:12].mean().item(), std[12:].mean().item()
         lines.append(f"{'Leg mean action noise std:':>{pad}} {leg_std:.2f}")
         lines.append(f"{'Arm mean action noise std:':>{pad}} {arm_std:.2f}")
         if ep_infos:
