@@ -10,6 +10,7 @@
 // Grid = (row tiles, 2): blockIdx.y = 0 runs the actor (9 layers), 1 the critic (7 layers), so that 4096 envs give
 // 256 workgroups (one per CU) and the dependent layer chain per workgroup is half as long.
 #include "wbc_mlp.h"
+#include "wbc_stats.h"
 #include "wbc_stream_guard.h"
 
 // ==== 16-row tiles (v_mfma_f32_16x16x4_f32) =====================================================================
@@ -41,7 +42,13 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
                                                                                 const float* __restrict__ bias, const float* __restrict__ obs,
                                                                                 const float* __restrict__ latent, const float* __restrict__ eps,
                                                                                 float* __restrict__ actions, float* __restrict__ mean_out,
-                                                                                float* __restrict__ logp_out, float* __restrict__ value_out, int num_rows) {
+                                                                                float* __restrict__ logp_out, float* __restrict__ value_out, int num_rows,
+                                                                                int tiles, wbc_side_job job) {
+  // workgroups past the row tiles carry a side job (the env step's episode statistics: wbc_stats.h) next to the inference
+  if ((int)blockIdx.x >= tiles) {
+    if (blockIdx.y == 0) side_job_block<PT_THREADS>(job, (int)blockIdx.x - tiles);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float smem[T_END];
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R16;
@@ -132,13 +139,22 @@ extern "C" int wbc_policy_pack(const void* const* params, float* wpack, void* st
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* latent, const float* eps,
-                              float* actions, float* mean, float* logp, float* values, int num_rows, void* stream) {
+extern "C" int wbc_policy_act_job(const void* const* params, const float* wpack, const float* obs, const float* latent, const float* eps,
+                                  float* actions, float* mean, float* logp, float* values, int num_rows, const wbc_side_job* job, void* stream) {
   StreamDeviceGuard sdg(stream);
   PolicyParams P;
   if (!params || !wpack || !obs || !actions || !mean || !logp || !values || num_rows <= 0 || fill_params(params, &P)) return -1;
   static const Tab16 T16 = make_tab16();
-  hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3((num_rows + R16 - 1) / R16, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
-                     wpack + WPACK16_OFF, wpack + WPACK16_OFF + WPACK16_BIAS_OFF, obs, latent, eps, actions, mean, logp, values, num_rows);
+  wbc_side_job J;
+  if (job) J = *job; else { J = wbc_side_job(); J.nblocks = 0; }
+  if (J.nblocks < 0 || (J.nblocks > 0 && !J.out)) return -1;
+  const int tiles = (num_rows + R16 - 1) / R16;
+  hipLaunchKernelGGL(wbc_policy_act16_kernel, dim3(tiles + J.nblocks, 2), dim3(PT_THREADS), 0, (hipStream_t)stream, P, T16,
+                     wpack + WPACK16_OFF, wpack + WPACK16_OFF + WPACK16_BIAS_OFF, obs, latent, eps, actions, mean, logp, values, num_rows, tiles, J);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* latent, const float* eps,
+                              float* actions, float* mean, float* logp, float* values, int num_rows, void* stream) {
+  return wbc_policy_act_job(params, wpack, obs, latent, eps, actions, mean, logp, values, num_rows, nullptr, stream);
 }

@@ -11,7 +11,8 @@
 #include <vector>
 
 #include "wbc_device.h"
-#include "wbc_track.h"
+#include "wbc_stats.h"
+#include "wbc_stream_guard.h"
 
 extern "C" __global__ void wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
                                            uint64_t seed, uint64_t step, StepOut so);
@@ -415,61 +416,35 @@ extern "C" int wbc_sim_refresh_rigid_body_state(wbc_sim* s, void* stream) {
   return 0;
 }
 
-// extras["episode"] of reset_idx (WG:743-754): mean over the envs that reset in the last step of their finished
-// episode's reward sums [WBC_NREW] and metric sums [WBC_NMETRIC], times `scale` (1 / max_episode_length_s).
-// One block per column, fixed-order tree: deterministic. No reset in this step -> the previously published value (prev), as the
-// reference's extras["episode"] is only rebuilt inside reset_idx when env_ids is non-empty (WG:705-706, 742-750).
+// extras["episode"] of reset_idx (WG:743-754) + the runner's episode deques as a side job (wbc_stats.h): one workgroup per
+// statistics column (+ 1 for the tracker), here as a launch of its own.
 #define STATS_THREADS 1024
-static __global__ void __launch_bounds__(STATS_THREADS) episode_stats_kernel(const float* __restrict__ ep_done, const float* __restrict__ met_done,
-                                                                            const int64_t* __restrict__ reset_buf, int n, float scale,
-                                                                            const float* __restrict__ prev, float* __restrict__ out,
-                                                                            const float* __restrict__ rew, const float* __restrict__ arm_rew,
-                                                                            float* __restrict__ track_state, int track_cap) {
-  if (blockIdx.x == WBC_NREW + WBC_NMETRIC) {       // the extra workgroup (only launched with a tracker state): wbc_track.h
-    track_episodes_block<STATS_THREADS>(rew, arm_rew, reset_buf, n, track_cap, track_state);
-    return;
-  }
-  // one block per column. Thread t sums envs t, t + 1024, ... in ascending order; flag and value are loaded together (the value
-  // unconditionally: a dependent second load would double the number of memory round trips), 4 envs in flight per thread (one
-  // round at 4096 envs: the launch is two memory round trips long). Then a fixed butterfly per wavefront and the sixteen wave
-  // sums in wave order: deterministic.
-  __shared__ float sh[STATS_THREADS / 64], shc[STATS_THREADS / 64];
-  const int col = blockIdx.x, tid = threadIdx.x;
-  const float* src = col < WBC_NREW ? ep_done + col : met_done + (col - WBC_NREW);
-  const int width = col < WBC_NREW ? WBC_NREW : WBC_NMETRIC;
-  float acc = 0.f, cnt = 0.f;
-  for (int base = 0; base < n; base += STATS_THREADS * 4) {
-    float v[4];
-    int d[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = base + STATS_THREADS * u + tid, ic = i < n ? i : n - 1;
-      d[u] = (i < n) && reset_buf[ic] != 0;
-      v[u] = src[(size_t)ic * width];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { acc += d[u] ? v[u] : 0.f; cnt += d[u] ? 1.f : 0.f; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { acc += __shfl_xor(acc, off); cnt += __shfl_xor(cnt, off); }
-  if ((tid & 63) == 0) { sh[tid >> 6] = acc; shc[tid >> 6] = cnt; }
-  __syncthreads();
-  if (tid == 0) {
-    float a = 0.f, c = 0.f;
-#pragma unroll
-    for (int w = 0; w < STATS_THREADS / 64; ++w) { a += sh[w]; c += shc[w]; }
-    out[col] = c > 0.f ? a / c * scale : (prev ? prev[col] : 0.f);
-  }
+static __global__ void __launch_bounds__(STATS_THREADS) episode_stats_kernel(wbc_side_job J) { side_job_block<STATS_THREADS>(J, blockIdx.x); }
+
+extern "C" int wbc_sim_episode_stats_job(wbc_sim* s, float scale, const float* prev, float* out, float* track_state, int track_cap,
+                                         wbc_side_job* job) {
+  if (!s || !out || !job) return fail(-1, "wbc_sim_episode_stats_job: null argument");
+  if (track_state && track_cap <= 0) return fail(-1, "wbc_sim_episode_stats_job: cap must be positive");
+  job->ep_done = s->T.ep_sums_done; job->met_done = s->T.met_sums_done; job->reset_buf = s->T.reset_buf; job->prev = prev;
+  job->rew = s->T.rew; job->arm_rew = s->T.arm_rew; job->out = out; job->track_state = track_state;
+  job->n = s->n; job->track_cap = track_cap; job->nblocks = WBC_NREW + WBC_NMETRIC + (track_state ? 1 : 0); job->scale = scale;
+  return 0;
+}
+
+extern "C" int wbc_side_job_run(const wbc_side_job* job, void* stream) {
+  StreamDeviceGuard sdg(stream);
+  if (!job || !job->out || job->nblocks <= 0) return fail(-1, "wbc_side_job_run: empty job");
+  hipLaunchKernelGGL(episode_stats_kernel, dim3(job->nblocks), dim3(STATS_THREADS), 0, (hipStream_t)stream, *job);
+  return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
 }
 
 extern "C" int wbc_sim_episode_stats_track(wbc_sim* s, float scale, const float* prev, float* out, float* track_state, int track_cap,
                                            void* stream) {
-  if (!s || !out) return fail(-1, "wbc_sim_episode_stats: null argument");
-  if (track_state && track_cap <= 0) return fail(-1, "wbc_sim_episode_stats_track: cap must be positive");
+  wbc_side_job job;
+  const int rc = wbc_sim_episode_stats_job(s, scale, prev, out, track_state, track_cap, &job);
+  if (rc) return rc;
   DeviceGuard dg(s->device);
-  hipLaunchKernelGGL(episode_stats_kernel, dim3(WBC_NREW + WBC_NMETRIC + (track_state ? 1 : 0)), dim3(STATS_THREADS), 0, (hipStream_t)stream, s->T.ep_sums_done,
-                     s->T.met_sums_done, s->T.reset_buf, s->n, scale, prev, out, s->T.rew, s->T.arm_rew, track_state, track_cap);
-  return hipGetLastError() == hipSuccess ? 0 : fail(-2, "episode_stats_kernel launch failed");
+  return wbc_side_job_run(&job, stream);
 }
 
 extern "C" int wbc_sim_episode_stats(wbc_sim* s, float scale, const float* prev, float* out, void* stream) {

@@ -78,6 +78,13 @@ class WbcCurriculum(C.Structure):
     ]
 
 
+class WbcSideJob(C.Structure):
+    """wbc_side_job (include/wbc_sim.h): a per-step reduction another launch carries as extra workgroups."""
+    _fields_ = [("ep_done", C.c_void_p), ("met_done", C.c_void_p), ("reset_buf", C.c_void_p), ("prev", C.c_void_p),
+                ("rew", C.c_void_p), ("arm_rew", C.c_void_p), ("out", C.c_void_p), ("track_state", C.c_void_p),
+                ("n", i32), ("track_cap", i32), ("nblocks", i32), ("scale", f32)]
+
+
 # enum wbc_tensor_id, same order as the header
 TENSOR_IDS = [
     "ROOT_STATES", "DOF_STATE", "NET_CONTACT_FORCE", "RIGID_BODY_STATE", "FORCE_SENSOR", "TORQUES", "OBS_BUF",

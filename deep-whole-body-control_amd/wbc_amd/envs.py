@@ -152,6 +152,12 @@ class WidowGo1(LeggedRobot):
         self._stats_stream = None
         self._stats_pending = False
         self._track = (None, 0)          # (state, cap) of attach_episode_tracker: advanced by the statistics launch
+        # opt-in (OnPolicyRunner.learn sets it): step() does not launch the episode statistics itself but leaves them as a side job
+        # (take_stats_job) that the policy inference following every rollout step carries as a few extra workgroups -- one launch
+        # and one inter-kernel dependency stall less per env step. extras['episode'] is then complete once that launch has run;
+        # a job nobody takes is executed by the next step() / flush_stats_job().
+        self.defer_episode_stats = False
+        self._stats_job = None
         # cfg.env.reference_stale_time_outs: publish extras['time_outs'] the way the reference does (quirk Q9). The fused step's
         # in-kernel reward bootstrap uses the CURRENT mask, so with the option on the reward / done slots are filled by
         # wbc_rollout_store from the published (possibly stale) mask instead.
@@ -374,16 +380,20 @@ class WidowGo1(LeggedRobot):
     def _fill_extras(self, start=False):
         """extras['episode'] / extras['time_outs'] of WG:743-754, 902-906, without host syncs."""
         if self.collect_episode_stats:
-            if self.async_episode_stats and self.device.type == "cuda":
+            scale = 1.0 / self.max_episode_length_s
+            self.flush_stats_job()                       # a deferred job nobody took: its inputs are about to be overwritten
+            if self.defer_episode_stats and not start:   # the launch is left to whoever takes the job (the next policy inference)
+                stv, self._stats_job = self.sim.episode_stats_job(scale, *self._track)
+            elif self.async_episode_stats and self.device.type == "cuda":
                 if self._stats_stream is None:
                     self._stats_stream = torch.cuda.Stream(self.device)
                 side = self._stats_stream
                 side.wait_stream(torch.cuda.current_stream(self.device))                # after the step kernel's writes
                 with torch.cuda.stream(side):
-                    stv = self.sim.episode_stats(1.0 / self.max_episode_length_s, *self._track)
+                    stv = self.sim.episode_stats(scale, *self._track)
                 self._stats_pending = True                                              # the next step() waits for it (it rewrites the inputs)
             else:
-                stv = self.sim.episode_stats(1.0 / self.max_episode_length_s, *self._track)
+                stv = self.sim.episode_stats(scale, *self._track)
             st = stv.unbind(0)                                                           # one launch, 31 scalar views
             ep = EpisodeInfo()
             ep.vector, ep.vector_index = stv, self._episode_vector_index                 # the same numbers as ONE device tensor
@@ -450,6 +460,7 @@ class WidowGo1(LeggedRobot):
         store, self._store_output = self._store_output, None
         if self._stale_time_outs_on:
             store = None                              # the learner's process_env_step bootstraps from extras['time_outs']
+        self.flush_stats_job()                        # deferred statistics of the previous step that nobody carried
         if self._stats_pending:                       # the side-stream statistics of the previous step read what this step overwrites
             torch.cuda.current_stream(self.device).wait_stream(self._stats_stream)
             self._stats_pending = False
@@ -551,6 +562,16 @@ class WidowGo1(LeggedRobot):
         self._sim_env_origins.copy_(new)
         self.root_states[:, :3] += delta
         self.box_root_state[:, 1] += delta[:, 1]
+
+    def take_stats_job(self):
+        """The deferred statistics of the last step (sim.SideJob) or None; the taker executes it before the next step()."""
+        job, self._stats_job = self._stats_job, None
+        return job
+
+    def flush_stats_job(self):
+        job = self.take_stats_job()
+        if job is not None:
+            job.run(torch.cuda.current_stream(self.device).cuda_stream)
 
     def attach_episode_tracker(self, state, cap):
         """The training loop's episode deques (OnPolicyRunner.learn, OPR:140-154) ride on the per-step statistics launch as one

@@ -69,7 +69,9 @@ class PPO:
         self.actor_critic.train()
 
     # ---- rollout side ----------------------------------------------------------------------
-    def act(self, obs, critic_obs, hist_encoding=False):
+    def act(self, obs, critic_obs, hist_encoding=False, side_job=None):
+        """`side_job` (sim.SideJob, optional): work the policy launch carries along (WidowGo1.take_stats_job); executed stand-alone
+        when the fused inference kernel is not the path taken."""
         tr, ac = self.transition, self.actor_critic
         if (self.fused_rollout and critic_obs is obs and not torch.is_grad_enabled() and ac.fused_act_supported(obs)
                 and (not hist_encoding or ac.actor._fused_hist_supported(obs))):
@@ -87,7 +89,7 @@ class PPO:
                 i = st.step                       # write straight into this step's storage slots
                 out = (st.actions[i], st.mu[i], st.actions_log_prob[i], st.values[i])
             latent = ac.actor.infer_hist_latent(obs) if hist_encoding else None      # student rollouts (DAgger iterations)
-            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps, out, latent)
+            tr.actions, tr.action_mean, tr.actions_log_prob, tr.values = ac.fused_act(obs, eps, out, latent, side_job)
             if out is not None:                   # std is constant over a rollout: fill the storage's sigma slab once, not per step
                 if st.step == 0:
                     st.sigma.copy_(ac.std.detach().reshape(1, 1, -1).expand_as(st.sigma))
@@ -95,6 +97,8 @@ class PPO:
             else:
                 tr.action_sigma = ac.std.detach().expand_as(tr.action_mean)
         else:
+            if side_job is not None:
+                side_job.run(torch.cuda.current_stream(obs.device).cuda_stream)
             tr.actions = ac.act(obs, hist_encoding).detach()
             tr.values = ac.evaluate(critic_obs).detach()
             tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
@@ -175,12 +179,14 @@ class PPO:
         tr.clear()
         self.actor_critic.reset(dones)
 
-    def compute_returns(self, last_critic_obs):
+    def compute_returns(self, last_critic_obs, side_job=None):
         ac = self.actor_critic
         if self.fused_rollout and not torch.is_grad_enabled() and ac.fused_act_supported(last_critic_obs):
             ac.mark_params_changed()       # a version compare; re-packs only if somebody stepped the weights since the rollout's first act()
-            last_values = ac.fused_act(last_critic_obs)[3]          # the critic half of the inference kernel (one launch)
+            last_values = ac.fused_act(last_critic_obs, side_job=side_job)[3]     # the critic half of the inference kernel (one launch)
         else:
+            if side_job is not None:
+                side_job.run(torch.cuda.current_stream(last_critic_obs.device).cuda_stream)
             last_values = ac.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 

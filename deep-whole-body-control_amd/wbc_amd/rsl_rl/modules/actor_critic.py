@@ -337,11 +337,12 @@ class ActorCritic(nn.Module):
             assert p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda
         return (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
 
-    def fused_act(self, observations, eps=None, out=None, latent=None):
+    def fused_act(self, observations, eps=None, out=None, latent=None, side_job=None):
         """PPO.act's policy side in one launch: returns (actions, mean, log_prob[.,2], values[.,2]).
         `eps` = standard normals [B,18] (drawn by the caller from torch's generator); None acts on the mean.
         `out`: optional 4-tuple of contiguous float32 destination tensors (e.g. rollout-storage slots).
-        `latent` [B,20]: student path (hist_encoding=True), replaces the privileged encoder's output."""
+        `latent` [B,20]: student path (hist_encoding=True), replaces the privileged encoder's output.
+        `side_job` (sim.SideJob): a small reduction the launch carries as extra workgroups (the env step's episode statistics)."""
         from ...native import check, lib
         table = self.fused_param_table()
         dev = observations.device
@@ -364,9 +365,14 @@ class ActorCritic(nn.Module):
             values = torch.empty(n, 2, device=dev)
         if latent is not None:
             assert latent.is_cuda and latent.dtype == torch.float32 and latent.is_contiguous() and latent.shape == (n, 20)
-        check(lib().wbc_policy_act(table, self._wpack.data_ptr(), observations.data_ptr(), latent.data_ptr() if latent is not None else None,
-                                   eps.data_ptr() if eps is not None else None,
-                                   actions.data_ptr(), mean.data_ptr(), logp.data_ptr(), values.data_ptr(), n, stream), "wbc_policy_act")
+        import ctypes as C
+        carried = side_job is not None and not side_job.done
+        check(lib().wbc_policy_act_job(table, self._wpack.data_ptr(), observations.data_ptr(), latent.data_ptr() if latent is not None else None,
+                                       eps.data_ptr() if eps is not None else None,
+                                       actions.data_ptr(), mean.data_ptr(), logp.data_ptr(), values.data_ptr(), n,
+                                       C.byref(side_job.c) if carried else None, stream), "wbc_policy_act")
+        if carried:
+            side_job.done = True
         return actions, mean, logp, values
 
     def act_inference(self, observations, hist_encoding=False):

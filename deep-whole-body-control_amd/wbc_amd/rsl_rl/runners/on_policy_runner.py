@@ -147,6 +147,11 @@ class OnPolicyRunner:
         # kernel they hide (151 vs 155 us per rollout step), and with RCCL's streams in the process the extra stream can end up
         # sharing a hardware queue with the compute stream: +16 us per step)
         tracker = None                                   # device-side deques (wbc_runner_track_episodes), set up on the first logged step
+        # the env's per-step episode statistics ride on the policy inference that follows each step (extra workgroups of that launch)
+        carry = (hasattr(env, "take_stats_job") and getattr(alg, "fused_rollout", False) and is_cuda
+                 and "side_job" in alg.act.__code__.co_varnames and "side_job" in alg.compute_returns.__code__.co_varnames)
+        if carry:
+            env.defer_episode_stats = True
         try:
             for it in range(self.current_learning_iteration, tot_iter):
                 env.update_command_curriculum()
@@ -155,7 +160,7 @@ class OnPolicyRunner:
                 hist_encoding = it % self.dagger_update_freq == 0
                 with torch.inference_mode():
                     for _ in range(self.num_steps_per_env):
-                        actions = alg.act(obs, critic_obs, hist_encoding)
+                        actions = alg.act(obs, critic_obs, hist_encoding, side_job=env.take_stats_job()) if carry else alg.act(obs, critic_obs, hist_encoding)
                         slot = alg.next_observation_slot() if redirect_obs else None
                         if slot is not None:
                             env.set_obs_output(slot)              # the env writes the next observation where act() would copy it
@@ -190,7 +195,10 @@ class OnPolicyRunner:
                     stop = time.time()
                     collection_time = stop - start
                     start = stop
-                    alg.compute_returns(critic_obs)
+                    if carry:
+                        alg.compute_returns(critic_obs, side_job=env.take_stats_job())    # the last step's statistics ride on this inference
+                    else:
+                        alg.compute_returns(critic_obs)
                 if hist_encoding:
                     loss_stats["mean_hist_latent_loss"] = alg.update_dagger()
                 else:
@@ -214,6 +222,9 @@ class OnPolicyRunner:
                 self.history.append(rec)
                 ep_infos.clear()
         finally:                                         # also on an exception / KeyboardInterrupt
+            if carry:
+                env.defer_episode_stats = False
+                env.flush_stats_job()
             if tracker:
                 tracker.close()
             if getattr(env, "async_episode_stats", False):   # a caller-enabled side stream: its results are complete from here on

@@ -17,6 +17,19 @@ from .native import check, lib
 _TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "u8": torch.uint8}
 
 
+class SideJob:
+    """A wbc_side_job plus the tensors it points into (kept alive until it has run)."""
+
+    def __init__(self, L, keep):
+        self.L, self.keep, self.c, self.done = L, keep, abi.WbcSideJob(), False
+
+    def run(self, stream: int) -> None:
+        """Stand-alone execution (nobody carried it)."""
+        if not self.done:
+            check(self.L.wbc_side_job_run(C.byref(self.c), stream), "wbc_side_job_run")
+            self.done = True
+
+
 class WbcSim:
     def __init__(self, model: abi.WbcModel, cfg: abi.WbcTaskCfg, num_envs: int, device: torch.device, seed: int = 1):
         device = torch.device(device)
@@ -157,6 +170,18 @@ class WbcSim:
                                                  self._stream()), "wbc_sim_episode_stats")
         self._last_episode_stats = out
         return out
+
+    def episode_stats_job(self, scale: float, track_state: torch.Tensor = None, track_cap: int = 0):
+        """episode_stats without the launch: (out tensor, SideJob). Whoever takes the job executes it -- as extra workgroups of the
+        policy inference that follows (ActorCritic.fused_act(side_job=...)) or stand-alone (SideJob.run) -- before the next step."""
+        out = torch.empty(abi.NREW + abi.NMETRIC, dtype=torch.float32, device=self.device)
+        prev = self.__dict__.get("_last_episode_stats")
+        job = SideJob(self.L, (out, prev, track_state))
+        check(self.L.wbc_sim_episode_stats_job(self.h, float(scale), prev.data_ptr() if prev is not None else None, out.data_ptr(),
+                                               track_state.data_ptr() if track_state is not None else None, int(track_cap),
+                                               C.byref(job.c)), "wbc_sim_episode_stats_job")
+        self._last_episode_stats = out
+        return out, job
 
     def set_dof_forces(self, torques: torch.Tensor) -> None:
         assert torques.is_cuda and torques.dtype == torch.float32 and torques.is_contiguous()

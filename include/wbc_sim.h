@@ -309,6 +309,21 @@ int wbc_gae_normalize(float* advantages, const double* stats_dev, int64_t total,
 /* Number of doubles stats_dev must hold for N envs (3 statistics + per-block partials). */
 int wbc_gae_workspace_doubles(int N);
 
+/* Side jobs: a small per-step reduction that ANOTHER launch carries as a few extra workgroups instead of being a launch (and an
+ * inter-kernel dependency stall) of its own. wbc_sim_episode_stats_job describes the work of wbc_sim_episode_stats_track without
+ * launching it; wbc_policy_act_job (the policy inference that follows every env step in a rollout anyway) executes it next to
+ * its own workgroups, wbc_side_job_run executes it stand-alone. The job holds device pointers into the sim's tensors: it must be
+ * executed before the sim's next step. */
+typedef struct {
+  const float* ep_done; const float* met_done; const int64_t* reset_buf; const float* prev; const float* rew; const float* arm_rew;
+  float* out; float* track_state;
+  int32_t n, track_cap, nblocks;     /* nblocks: workgroups the job needs (one per statistics column + 1 with a tracker state) */
+  float scale;
+} wbc_side_job;
+int wbc_sim_episode_stats_job(wbc_sim* sim, float scale, const float* prev, float* out, float* track_state, int track_cap,
+                              wbc_side_job* job);
+int wbc_side_job_run(const wbc_side_job* job, void* stream);
+
 /* The policy side of one rollout step, PPO.act (rsl_rl/algorithms/ppo.py:115-127) with the privileged
  * latent: Actor.forward (actor_critic.py:204-221), Critic.forward (:281-286), the action sample
  * mean + std * eps (Normal.sample, :337-339) and get_actions_log_prob (:341-345) in ONE launch on fp32
@@ -325,6 +340,10 @@ int wbc_policy_pack(const void* const* params, float* wpack, void* stream);
 int wbc_policy_act(const void* const* params, const float* wpack, const float* obs, const float* latent,
                    const float* eps, float* actions, float* mean, float* logp, float* values, int num_rows,
                    void* stream);
+/* wbc_policy_act + a side job (may be NULL) executed by extra workgroups of the same launch. */
+int wbc_policy_act_job(const void* const* params, const float* wpack, const float* obs, const float* latent,
+                       const float* eps, float* actions, float* mean, float* logp, float* values, int num_rows,
+                       const wbc_side_job* job, void* stream);
 
 /* StateHistoryEncoder forward without gradient (rsl_rl/modules/actor_critic.py:39-84, tsteps = 10), the regulariser
  * target of PPO.update (ppo.py:174-176). params: 8 device pointers (encoder.0.weight [30,76], .bias,

@@ -290,3 +290,53 @@ def test_stale_time_outs_option_goes_through_the_learner():
     for t in range(12):                                   # PPO:133-134 with the PUBLISHED mask, stale or not
         want = rews[t] + gamma * kept["values"][t, :, 0] * masks[t].float()
         np.testing.assert_allclose(kept["rewards"][t, :, 0].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_episode_statistics_carried_by_the_policy_launch_equal_the_stand_alone_launch():
+    """WidowGo1.defer_episode_stats + ActorCritic.fused_act(side_job=...): the env step's extras['episode'] reduction (and the
+    runner's episode deques) executed by extra workgroups of the policy inference that follows, against the stand-alone launch
+    of an identically seeded env; the inference outputs do not depend on carrying a job; a job nobody takes is run by the next step."""
+    from wbc_amd.rsl_rl.modules import ActorCritic
+    from wbc_amd.rsl_rl.runners.on_policy_runner import _EpisodeTracker
+    cfg = _cfg(n=700)                                     # not a multiple of the 16-row tiles, nor of 256
+    cfg.env.episode_length_s = 0.3                        # 15-step episodes: resets (hence statistics) in most steps
+    train = class_to_dict(WidowGo1RoughCfgPPO())
+    torch.manual_seed(2)
+    ac = ActorCritic(76, 76, 18, **train["policy"], num_priv=24, num_hist=10, num_prop=76).cuda()
+    envs = [WidowGo1(cfg, sim_device="cuda:0", seed=6) for _ in range(2)]
+    for e in envs:
+        e.reset()
+        e.episode_length_buf = torch.randint(0, 15, (700,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    zeros = torch.zeros(700, dtype=torch.int64, device="cuda")
+    trackers = [_EpisodeTracker.create(e, e.rew_buf, e.arm_rew_buf, zeros) for e in envs]     # both envs publish statistics: attached
+    assert all(t._hooked_env is not None for t in trackers)
+    envs[1].defer_episode_stats = True
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = [e.get_observations() for e in envs]
+    with torch.inference_mode():
+        for step in range(24):
+            eps = torch.randn(700, 18, device="cuda", generator=g)
+            job = envs[1].take_stats_job()
+            assert (job is not None) == (step > 0)
+            if step == 7:                                  # nobody carries this one: the next env.step() must run it
+                envs[1]._stats_job, job = job, None
+            a0 = ac.fused_act(obs[0], eps)
+            a1 = ac.fused_act(obs[1], eps, side_job=job)
+            for x, y in zip(a0, a1):
+                assert torch.equal(x, y)
+            out0 = envs[0].step(a0[0])
+            out1 = envs[1].step(a1[0])
+            obs = [out0[0], out1[0]]
+            assert torch.equal(out0[0], out1[0]) and torch.equal(out0[4], out1[4])
+            if step > 0:
+                np.testing.assert_allclose(prev1.vector.cpu().numpy(), prev0.vector.cpu().numpy(), rtol=2e-6, atol=1e-7)
+            prev0, prev1 = out0[5]["episode"], out1[5]["episode"]
+    envs[1].flush_stats_job()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(prev1.vector.cpu().numpy(), prev0.vector.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    s0, s1 = trackers[0].summary(), trackers[1].summary()
+    assert s0["mean_episode_length"] > 0 and s0.keys() == s1.keys()
+    for k in s0:
+        assert s0[k] == pytest.approx(s1[k], rel=1e-6), k
+    for t in trackers:
+        t.close()
