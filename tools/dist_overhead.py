@@ -30,14 +30,14 @@ def leg(tag, group):
     ev = []
     raw_act, raw_step, k = runner.alg.act, env.step, {"n": 0}
 
-    def act(*a, **kw):
+    def act(obs, critic_obs, hist_encoding=False, side_job=None):       # (the runner looks for the side_job parameter)
         k["n"] += 1
         if k["n"] % 5 == 0:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record(); out = raw_act(*a, **kw); e[1].record()
+            e[0].record(); out = raw_act(obs, critic_obs, hist_encoding, side_job=side_job); e[1].record()
             ev.append(e)
             return out
-        return raw_act(*a, **kw)
+        return raw_act(obs, critic_obs, hist_encoding, side_job=side_job)
 
     def step(a):
         out = raw_step(a)

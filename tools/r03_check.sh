@@ -1,12 +1,22 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_env_runner.py tests/test_gpu_policy_kernel.py tests/test_wg_golden.py -m gpu -q -x --timeout 180 2>&1 | tail -25
+timeout 900 python -m pytest tests -m gpu -q --timeout 300 -rs 2>&1 | tail -4
 b() { name=$1; shift; timeout 400 python bench.py "$@" > gpurun_out/r03x_bench_$name.json 2> gpurun_out/r03x_bench_$name.err || { echo "bench $name FAILED rc=$?"; tail -5 gpurun_out/r03x_bench_$name.err; }; }
-b unlogged_a --no-cpu-baseline
-b logged_a --no-cpu-baseline --log
-b unlogged_b --no-cpu-baseline
+b default
+b logged_200 --no-cpu-baseline --log --steps 200
+b unlogged_200 --no-cpu-baseline --steps 200
+b logged_50 --no-cpu-baseline --log
+b unlogged_50 --no-cpu-baseline
+b 2048 --no-cpu-baseline --envs-per-gpu 2048
+b 1024 --no-cpu-baseline --envs-per-gpu 1024
+b cfg2_8192_grid --no-cpu-baseline --envs-per-gpu 8192 --terrain grid --steps 30
+b 16384_flat --no-cpu-baseline --envs-per-gpu 16384 --steps 20
+b gloo2_same_device --no-cpu-baseline --gpus 2 --backend gloo --same-device --steps 20
+b rccl_1rank --no-cpu-baseline --force-dist --steps 30
 for f in gpurun_out/r03x_bench_*.json; do python -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[0]); c=d['config']
-print('$f'.split('bench_')[1], round(d['value']), 'env-steps/s', round(d['ms_per_step'],3), 'ms; collect', round(c['collection_ms'],2), 'learn', round(c['learn_ms'],2), '| step', round(d['roofline']['launch_ms']*1e3,1))
+print('$f'.split('bench_')[1], round(d['value']), 'env-steps/s', round(d['ms_per_step'],3), 'ms; collect', round(c['collection_ms'],2), 'learn', round(c['learn_ms'],2), '| step', round(d['roofline']['launch_ms']*1e3,1), 'frac', round(d['roofline']['frac'],4), '| upd', round(d['roofline_update']['launch_ms']*1e3,1), round(d['roofline_update']['frac'],4), '| ar', c.get('grad_allreduce_us'), 'ckpt', c.get('end_of_learn_checkpoint_ms'))
 " 2>&1 | tail -1; done
+bash tools/prof_bench.sh r03 > gpurun_out/r03x_prof.log 2>&1; head -14 gpurun_out/kernel_stats_r03.csv | cut -c1-150
+timeout 300 python tools/dist_overhead.py 2>&1 | grep "^(" | tee gpurun_out/r03x_dist_overhead.txt
