@@ -61,7 +61,7 @@ struct DevTensors {
   int64_t* reset_buf;
   uint8_t* time_out;
   int64_t* ep_len;
-  float* ep_sums;     // [N,21]
+  float* ep_sums;     // [N,WBC_NREW]
   float* met_sums;    // [N,10]
   float* ep_sums_done;
   float* met_sums_done;

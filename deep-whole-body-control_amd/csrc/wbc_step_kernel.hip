@@ -998,13 +998,13 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   met_src[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = eyaw; met_src[WBC_REW_HIP_ACTION_L2] = hip; met_src[WBC_REW_LEG_ACTION_L2] = act_leg;
   met_src[WBC_REW_FOOT_CONTACTS_Z] = fz; met_src[WBC_REW_TRACKING_EE_SPHERE] = es; met_src[WBC_REW_TRACKING_EE_CART] = ec;
   met_src[WBC_REW_TRACKING_EE_ORN_RY] = eo_ry; met_src[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum; met_src[WBC_REW_TORQUES] = tq2;
-  // the per-term scaling / episode sums / metrics are done by lanes t < 21 (reward_accumulate)
+  // the per-term scaling / episode sums / metrics are done by lanes t < WBC_NREW (reward_accumulate)
 #pragma unroll
   for (int t = 0; t < WBC_NREW; ++t) { s.post.term[t] = term[t]; s.post.msrc[t] = met_src[t]; }
 }
 
 // rew_buf / arm_rew_buf, episode sums and metric sums from the raw terms: lane t owns term t, lane m metric slot m.
-// lsc / asc = this lane's leg / arm reward scale (lanes >= 21: 0). A term is evaluated when its function is in the list the
+// lsc / asc = this lane's leg / arm reward scale (lanes >= WBC_NREW: 0). A term is evaluated when its function is in the list the
 // reference builds at construction (cur.*_active_mask, WG:128-157), whatever its current (scheduled) scale. Per slot the
 // order of additions is the reference's (leg channel then arm channel, terms ascending); the two reward totals are
 // butterfly sums over the wavefront.

@@ -394,7 +394,7 @@ class WidowGo1(LeggedRobot):
                 self._stats_pending = True                                              # the next step() waits for it (it rewrites the inputs)
             else:
                 stv = self.sim.episode_stats(scale, *self._track)
-            st = stv.unbind(0)                                                           # one launch, 31 scalar views
+            st = stv.unbind(0)                                                           # one launch (or side job), 32 scalar views
             ep = EpisodeInfo()
             ep.vector, ep.vector_index = stv, self._episode_vector_index                 # the same numbers as ONE device tensor
             for i, name in self._active_terms:

@@ -199,9 +199,9 @@ enum wbc_tensor_id {
   WBC_T_RESET_BUF,         /* i64 [N]                                        (BT:74) */
   WBC_T_TIME_OUT_BUF,      /* u8  [N]  (bool)                                (BT:76) */
   WBC_T_EPISODE_LENGTH,    /* i64 [N]                                        (BT:75) */
-  WBC_T_EPISODE_SUMS,      /* f32 [N,21] per-term sums, zeroed on reset      (WG:162) */
+  WBC_T_EPISODE_SUMS,      /* f32 [N,22] per-term sums (WBC_NREW), zeroed on reset (WG:162) */
   WBC_T_METRIC_SUMS,       /* f32 [N,10]                                     (WG:166) */
-  WBC_T_EPISODE_SUMS_DONE, /* f32 [N,21] sums at the moment of reset (for extras) (WG:743-746) */
+  WBC_T_EPISODE_SUMS_DONE, /* f32 [N,22] sums at the moment of reset (for extras) (WG:743-746) */
   WBC_T_METRIC_SUMS_DONE,  /* f32 [N,10]                                     (WG:748-750) */
   WBC_T_BASE_LIN_VEL,      /* f32 [N,3]                                      (WG:880) */
   WBC_T_BASE_ANG_VEL,      /* f32 [N,3]                                      (WG:881) */
