@@ -21,7 +21,9 @@
  *   - PHYSICS (what WG:1183-1187 hands to Isaac Gym / PhysX, closed source and absent) is this
  *     framework's own specification: Featherstone articulated-body algorithm for the floating
  *     base + 18 revolute joints, velocity-level contact impulses from per-body inverse
- *     articulated inertias, semi-implicit Euler. PARITY UNPINNED for physics: no reference
+ *     articulated inertias (the URDF's collision geometry as spheres against the terrain plus
+ *     sphere-vs-box / sphere-vs-capsule self-collision pairs acting on both bodies, damped
+ *     block-Jacobi sweeps through the tree: DESIGN.md section 3), semi-implicit Euler. PARITY UNPINNED for physics: no reference
  *     output exists to pin it; tests/test_oracle_physics.py pins it
  *     instead against an independent composite-rigid-body/Newton-Euler formulation and
  *     conservation laws.
