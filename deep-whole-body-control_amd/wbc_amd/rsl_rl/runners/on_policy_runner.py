@@ -24,6 +24,14 @@ _POLICIES = {"ActorCritic": ActorCritic}
 _ALGORITHMS = {"PPO": PPO}
 
 
+def _accepts(fn, name) -> bool:
+    import inspect
+    try:
+        return name in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class _EpisodeTracker:
     """learn()'s episode bookkeeping (OPR:140-154) as device state: running (reward, arm reward, length) per env and the
     deque(maxlen=100) trio + the done-fraction deque as device rings, advanced by one launch per env step
@@ -149,7 +157,7 @@ class OnPolicyRunner:
         tracker = None                                   # device-side deques (wbc_runner_track_episodes), set up on the first logged step
         # the env's per-step episode statistics ride on the policy inference that follows each step (extra workgroups of that launch)
         carry = (hasattr(env, "take_stats_job") and getattr(alg, "fused_rollout", False) and is_cuda
-                 and "side_job" in alg.act.__code__.co_varnames and "side_job" in alg.compute_returns.__code__.co_varnames)
+                 and _accepts(alg.act, "side_job") and _accepts(alg.compute_returns, "side_job"))
         if carry:
             env.defer_episode_stats = True
         try:
