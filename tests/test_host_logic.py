@@ -202,3 +202,37 @@ def test_rollout_slot_hand_over_is_cuda_only_and_storage_skips_filled_slots():
         alg.storage.add_transitions(alg.transition, torque_supervision=False)
     assert st.step == 1 and (st.rewards[0] == 3.5).all() and (st.dones[0] == 1).all()
     assert torch.equal(st.observations[0], obs) and torch.isfinite(st.values[0]).all() and (st.sigma[0] > 0).all()
+
+
+def test_collision_set_follows_the_urdf_collision_blocks():
+    """abi.collision_set: the URDF's <collision> geometry (urdf/widowGo1.urdf) as the contact list of the physics spec: one sphere
+    per foot first (the force sensors read contacts 0..3), trunk-box corners on the box surface, thigh tops / knees on the thigh
+    and calf rows, arm spheres; self-collision pairs last, each naming a partner body different from its own; fits WBC_NCP."""
+    m = abi.load_default_model()
+    cps = abi.collision_set(m)
+    names = m.rb_names
+    assert len(cps) == 30 <= abi.NCP
+    feet = [i for i, n in enumerate(names) if "foot" in n]
+    assert [c["rb"] for c in cps[:4]] == feet and all(c["kind"] == abi.CP_TERRAIN and c["radius"] == 0.02 for c in cps[:4])
+    terrain = [c for c in cps if c["kind"] == abi.CP_TERRAIN]
+    pairs = [c for c in cps if c["kind"] != abi.CP_TERRAIN]
+    assert len(terrain) == 23 and cps[:23] == terrain and len(pairs) == 7
+    corners = [c for c in terrain if names[c["rb"]] == "trunk"]
+    assert len(corners) == 8
+    for c in corners:                                    # sphere surface = the URDF box 0.3762 x 0.0935 x 0.114
+        np.testing.assert_allclose(np.abs(c["pos"]) + c["radius"], np.array([0.3762, 0.0935, 0.114]) / 2, atol=1e-9)
+    assert sorted(names[c["rb"]] for c in terrain if "thigh" in names[c["rb"]]) == ["FL_thigh", "FR_thigh", "RL_thigh", "RR_thigh"]
+    assert sum("calf" in names[c["rb"]] for c in terrain) == 4
+    arm = {names[c["rb"]] for c in terrain if "wx250s" in names[c["rb"]]}
+    assert arm == {"wx250s/ee_gripper_link", "wx250s/upper_forearm_link", "wx250s/wrist_link"}
+    for c in pairs:
+        assert c["body2"] >= 0 and c["body2"] != c["body"] and "wx250s" in names[c["rb"]]
+        assert names[c["rb2"]] in ("trunk", "FL_thigh", "FR_thigh")
+        assert (c["kind"] == abi.CP_BOX) == (names[c["rb2"]] == "trunk")
+    assert abi.fill_model(m, self_collisions=False).ncp == 23
+    # rigid-body masks of the task config (WG:299-306: substring match)
+    cfg = WidowGo1RoughCfg()
+    cfg.asset.terminate_after_contacts_on = ["wx250", "base"]        # the list the reference keeps commented out (widowGo1_config.py:179)
+    tc = abi.fill_task_cfg(cfg, m)
+    assert tc.penalize_contact_rb_mask == sum(1 << i for i, n in enumerate(names) if "thigh" in n or "trunk" in n)
+    assert tc.term_contact_rb_mask == sum(1 << i for i, n in enumerate(names) if "wx250" in n or "base" in n)
