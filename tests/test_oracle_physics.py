@@ -317,3 +317,76 @@ def test_trunk_and_thighs_rest_on_the_ground(robot):
     np.testing.assert_allclose(f[:, 2].sum(), mtot * 9.81, rtol=5e-3)
     assert f[trunk, 2] + f[thighs, 2].sum() > 0.5 * mtot * 9.81           # trunk + thigh tops carry most of it
     assert f[trunk, 2] > 10.0
+
+
+def test_self_collision_geometry_against_brute_force(robot):
+    """The narrow phase of the self-collision pairs (closest point of the trunk box / of a thigh capsule to an arm sphere) against
+    a brute-force search: for random arm poses of a robot at rest in free fall, a pair reports a contact force when the sphere
+    penetrates a dense point sampling of the partner's surface (a separating velocity is demanded), none when it is clear of the
+    contact margin (in between the contact is speculative: active, but bodies at relative rest need no impulse), and the force on
+    the sphere's body points away from the partner (along the line from the nearest sampled surface point to the sphere centre)."""
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    wm = robot["wmodel"]
+    n = 600
+    rng = np.random.default_rng(23)
+    o = OracleSim(wm, tc, n)
+    root = np.zeros((n, 2, 13)); root[:, :, 6] = 1; root[:, 0, 2] = 40.0
+    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = np.array(tc.default_dof_pos)[None]
+    lo, hi = np.array(model.dof_lower[12:18]), np.array(model.dof_upper[12:18])
+    lo[0], hi[0] = -1.5, 1.5
+    dof[:, 12:18, 0] = rng.uniform(lo, hi, (n, 6))
+    dof[:, [1, 4], 0] = rng.uniform(0.3, 1.4, (n, 2))                 # front thighs swung as well
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
+    o.refresh_rigid_body_state()
+    rb = o.get("RIGID_BODY_STATE")                                     # world poses of the rigid bodies BEFORE the substep
+    o.simulate()
+    f = o.get("NET_CONTACT_FORCE")
+    names = model.rb_names
+
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    # surface samplings in the partner's frame
+    hx, hy, hz = 0.3762 / 2, 0.0935 / 2, 0.114 / 2
+    g = np.linspace(-1, 1, 41)
+    u, v = np.meshgrid(g, g, indexing="ij")
+    box = np.concatenate([np.stack([s * hx * np.ones_like(u), hy * u, hz * v], -1).reshape(-1, 3) for s in (-1, 1)] +
+                         [np.stack([hx * u, s * hy * np.ones_like(u), hz * v], -1).reshape(-1, 3) for s in (-1, 1)] +
+                         [np.stack([hx * u, hy * v, s * hz * np.ones_like(u)], -1).reshape(-1, 3) for s in (-1, 1)])
+    ang = np.linspace(0, 2 * np.pi, 48, endpoint=False)
+    zs = np.linspace(-0.213, 0.0, 60)
+    cyl = np.stack([0.017 * np.cos(ang)[None] * np.ones((60, 1)), 0.017 * np.sin(ang)[None] * np.ones((60, 1)), zs[:, None] * np.ones((1, 48))], -1).reshape(-1, 3)
+    th, ph = np.meshgrid(np.linspace(0, np.pi / 2, 12), ang, indexing="ij")
+    cap = np.stack([0.017 * np.sin(th) * np.cos(ph), 0.017 * np.sin(th) * np.sin(ph), 0.017 * np.cos(th)], -1).reshape(-1, 3)
+    caps = np.concatenate([cyl, cap, cap * [1, 1, -1] + [0, 0, -0.213]])
+    checked = hits = 0
+    pair_ids = [k for k in range(wm.ncp) if wm.cp_kind[k] != abi.CP_TERRAIN]
+    for rb1 in sorted({wm.cp_rb[k] for k in pair_ids}):               # per arm sphere: its net_contact_force row sums its pairs
+        mine = [k for k in pair_ids if wm.cp_rb[k] == rb1]
+        rad = wm.cp_radius[mine[0]]
+        off1 = np.array(wm.cp_pos[mine[0]]) - np.array(model.rb_offset[rb1])
+        for e in range(n):
+            c = rb[e, rb1, :3] + rot(rb[e, rb1, 3:7]) @ off1
+            gaps, aways, inside_box = [], [], False
+            for k in mine:
+                rb2 = wm.cp_rb2[k]
+                R2 = rot(rb[e, rb2, 3:7])
+                surf = box if names[rb2] == "trunk" else caps
+                pts = rb[e, rb2, :3] + surf @ R2.T
+                d = np.linalg.norm(pts - c, axis=1)
+                gaps.append(d.min() - rad)
+                aways.append((c - pts[d.argmin()]) / d.min())
+                inside_box |= names[rb2] == "trunk" and bool(np.all(np.abs(R2.T @ (c - rb[e, rb2, :3])) < [hx, hy, hz]))
+            pushing = np.abs(f[e, rb1]).sum() > 0
+            if inside_box or min(gaps) < -4e-3:
+                assert pushing, (names[rb1], e, gaps)
+                hits += 1
+                near = [i for i, gp in enumerate(gaps) if gp < tc.contact_margin + 4e-3]
+                if not inside_box and len(near) == 1 and gaps[near[0]] > -0.5 * rad:
+                    assert np.dot(f[e, rb1], aways[near[0]]) > 0.5 * np.linalg.norm(f[e, rb1]), (names[rb1], e)     # (normal + friction)
+            elif min(gaps) > tc.contact_margin + 4e-3:
+                assert not pushing, (names[rb1], e, gaps)
+            checked += 1
+    assert checked > 1500 and hits > 20, (checked, hits)
