@@ -5,13 +5,15 @@
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one PPO iteration of the hot path: T=40 fused rollout steps over the env batch
-(policy inference + the HIP step kernel: 4 physics substeps + post-physics each), GAE, and
+(two launches each: the policy inference -- which also carries the previous step's episode statistics as a
+side job -- and the HIP step kernel: 4 physics substeps with the URDF's collision set + post-physics), GAE, and
 PPO.update() (5 epochs x 4 minibatches; every 20th iteration is the DAgger update instead, as in
 the reference's learn loop, on_policy_runner.py:129,166-169). Workload = BASELINE.json configs[1]:
 widowGo1, flat terrain, 4096 envs per GPU, fp32, domain randomisation as shipped. The metric is the
 reference's own fps definition (on_policy_runner.py:206), aggregated over ranks (weak scaling: 4096
 envs per GPU, one gradient all-reduce per minibatch and one 3-scalar advantage-statistics all-reduce
-per iteration over RCCL).
+per iteration over RCCL). --log runs the loop as train.py does (log_dir set); --backend gloo --same-device
+puts all ranks on cuda:0 (the sharded learner with world_size > 1 on a 1-GPU box).
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the fused step kernel: launch
 durations measured live with HIP events on torch's current stream over the timed region) and, at
