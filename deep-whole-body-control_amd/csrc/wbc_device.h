@@ -17,16 +17,17 @@ struct DevConst {
   int32_t chain_len[WBC_NCHAIN];
   int32_t body_chain[WBC_NB];                      // chain of each body (-1 root)
   int32_t body_depth[WBC_NB];                      // 0 root, 1.. along the chain
-  int32_t foot_cp[WBC_NFEET];                      // the (single) contact whose force foot sensor f reports
-  uint32_t depth_cp_mask[WBC_MAX_DEPTH + 1];       // contacts whose deepest body (sphere's or partner's) sits at chain depth d
+  int32_t foot_cp[WBC_NFEET];                      // the contacts whose forces foot sensor f reports: the foot sphere against the terrain
+  int32_t foot_cp2[WBC_NFEET];                     // ... and against the free box (-1: none)
+  uint64_t depth_cp_mask[WBC_MAX_DEPTH + 1];       // contacts whose deepest TREE body (sphere's or partner's) sits at chain depth d
   // bit-packed copies the step kernel keeps in registers / LDS (built by build_chains)
   uint32_t chain_pack_body[WBC_NCHAIN + 1];        // 6 x 5 bits: body at depth d (31 = none); row WBC_NCHAIN = idle lanes
   uint32_t chain_pack_dof[WBC_NCHAIN + 1];         // 6 x 5 bits: dof of that body
   uint32_t chain_pack_ax[WBC_NCHAIN + 1];          // 6 x 2 bits: joint axis
-  uint32_t out_cp_mask[32];                        // [rb]: contacts whose force net_contact_force row rb receives ...
-  uint32_t out_cp2_mask[32];                       // ... and those it receives with the opposite sign (partner of a self-collision pair)
-  uint32_t body_cp_mask[WBC_NB];                   // the same two sets per moving body (the sweeps' wrench gather)
-  uint32_t body_cp2_mask[WBC_NB];
+  uint64_t out_cp_mask[32];                        // [rb]: contacts whose force net_contact_force row rb receives ...
+  uint64_t out_cp2_mask[32];                       // ... and those it receives with the opposite sign (partner of a pair)
+  uint64_t body_cp_mask[WBC_NB + 1];               // the same two sets per moving body (the sweeps' wrench gather); entry
+  uint64_t body_cp2_mask[WBC_NB + 1];              // WBC_BOX_BODY is the free box actor
   uint32_t body_pack[WBC_NB];                      // axis | dof << 2
   // heightfield (optional)
   const int16_t* hf;
@@ -74,6 +75,7 @@ struct DevTensors {
   float* box_dy;      // [N]
   float* body_params; // [N,20]
   float* reset_travel; // [N,2]
+  float* box_mass;    // [N]
 };
 
 #define WBC_PI 3.14159265358979323846f

@@ -47,7 +47,7 @@ static const TensorSpec kSpecs[WBC_T_COUNT] = {
     {{WBC_NREW, 0, 0}, 1, WBC_F32}, {{WBC_NMETRIC, 0, 0}, 1, WBC_F32}, {{WBC_NREW, 0, 0}, 1, WBC_F32},  {{WBC_NMETRIC, 0, 0}, 1, WBC_F32},
     {{3, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{5, 0, 0}, 1, WBC_F32},   {{0, 0, 0}, 0, WBC_F32},
     {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32},
-    {{2, 0, 0}, 1, WBC_F32}};
+    {{2, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32}};
 
 static size_t spec_elems(const TensorSpec& s) {
   size_t n = 1;
@@ -109,33 +109,41 @@ static int build_chains(DevConst& hc) {
     hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
   }
   if (nchain != WBC_NCHAIN) return -1;
-  // collision set: every contact has a sphere on a moving body; a self-collision pair also a partner body
-  static_assert(WBC_NCP <= 32 && WBC_NRB_ENV <= 32, "contact sets are 32-bit masks (one lane per contact, ballot of the active ones)");
+  // collision set: every contact has a sphere on a moving body (or on the free box actor); a pair also a partner body
+  static_assert(WBC_NCP <= 64 && WBC_NRB_ENV <= 32, "contact sets are 64-bit masks (one lane per contact, ballot of the active ones)");
   if (m.ncp < WBC_NFEET || m.ncp > WBC_NCP) return -1;
   for (int d = 0; d <= WBC_MAX_DEPTH; ++d) hc.depth_cp_mask[d] = 0;
   for (int r = 0; r < 32; ++r) hc.out_cp_mask[r] = hc.out_cp2_mask[r] = 0;
-  for (int i = 0; i < WBC_NB; ++i) hc.body_cp_mask[i] = hc.body_cp2_mask[i] = 0;
-  for (int f = 0; f < WBC_NFEET; ++f) hc.foot_cp[f] = -1;
+  for (int i = 0; i <= WBC_NB; ++i) hc.body_cp_mask[i] = hc.body_cp2_mask[i] = 0;
+  for (int f = 0; f < WBC_NFEET; ++f) hc.foot_cp[f] = hc.foot_cp2[f] = -1;
   for (int k = 0; k < m.ncp; ++k) {
     const int b = m.cp_body[k], kind = m.cp_kind[k];
-    if (b < 0 || b >= WBC_NB || m.cp_rb[k] < 0 || m.cp_rb[k] >= WBC_NRB) return -1;
+    const uint64_t bit = 1ull << k;
+    if (b < 0 || b > WBC_NB || m.cp_rb[k] < 0 || m.cp_rb[k] >= WBC_NRB_ENV) return -1;
+    if ((b == WBC_BOX_BODY) != (m.cp_rb[k] == WBC_BOX_RB)) return -1;
     if (kind != WBC_CP_TERRAIN && kind != WBC_CP_BOX && kind != WBC_CP_CAPSULE) return -1;
-    int depth = hc.body_depth[b];
-    hc.body_cp_mask[b] |= 1u << k;
-    hc.out_cp_mask[m.cp_rb[k]] |= 1u << k;
+    int depth = b == WBC_BOX_BODY ? 0 : hc.body_depth[b];       // the box is not part of the tree: its contacts need no sweep level
+    hc.body_cp_mask[b] |= bit;
+    hc.out_cp_mask[m.cp_rb[k]] |= bit;
     if (kind != WBC_CP_TERRAIN) {
       const int b2 = m.cp_body2[k];
-      if (b2 < 0 || b2 >= WBC_NB || b2 == b || m.cp_rb2[k] < 0 || m.cp_rb2[k] >= WBC_NRB) return -1;
-      depth = hc.body_depth[b2] > depth ? hc.body_depth[b2] : depth;
-      hc.body_cp2_mask[b2] |= 1u << k;
-      hc.out_cp2_mask[m.cp_rb2[k]] |= 1u << k;
+      if (b2 < 0 || b2 > WBC_NB || b2 == b || m.cp_rb2[k] < 0 || m.cp_rb2[k] >= WBC_NRB_ENV) return -1;
+      if ((b2 == WBC_BOX_BODY) != (m.cp_rb2[k] == WBC_BOX_RB)) return -1;
+      if (b2 == WBC_BOX_BODY && kind != WBC_CP_BOX) return -1;
+      if (b2 != WBC_BOX_BODY) depth = hc.body_depth[b2] > depth ? hc.body_depth[b2] : depth;
+      hc.body_cp2_mask[b2] |= bit;
+      hc.out_cp2_mask[m.cp_rb2[k]] |= bit;
+      if (b2 == WBC_BOX_BODY) for (int f = 0; f < WBC_NFEET; ++f) if (m.feet_rb[f] == m.cp_rb[k]) {
+        if (hc.foot_cp2[f] >= 0) return -1;
+        hc.foot_cp2[f] = k;                          // the foot sphere against the box: its sensor sees that force too
+      }
     } else {
       for (int f = 0; f < WBC_NFEET; ++f) if (m.feet_rb[f] == m.cp_rb[k]) {
         if (hc.foot_cp[f] >= 0) return -1;          // one sphere per foot: the sensor reads that contact
         hc.foot_cp[f] = k;
       }
     }
-    hc.depth_cp_mask[depth] |= 1u << k;
+    hc.depth_cp_mask[depth] |= bit;
   }
   for (int f = 0; f < WBC_NFEET; ++f) if (hc.foot_cp[f] < 0) return -1;
   static_assert(WBC_NB <= 31 && WBC_NDOF <= 32 && WBC_MAX_DEPTH * 5 <= 32, "bit packing of the chain tables");
@@ -159,6 +167,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
                               size_t arena_bytes, wbc_sim** out) {
   if (!model || !cfg || !out || num_envs <= 0) return fail(-1, "wbc_sim_create: bad arguments");
   if (model->ncp < WBC_NFEET || model->ncp > WBC_NCP) return fail(-1, "wbc_sim_create: model.ncp must be in [4, WBC_NCP]");
+  if (!(model->box_half > 0.f) || !(model->box_mass > 0.f)) return fail(-1, "wbc_sim_create: the box actor needs a positive size and mass");
   DeviceGuard dg(hip_device);
   wbc_sim* s = new wbc_sim();
   s->n = num_envs; s->device = hip_device; s->seed = seed;
@@ -194,10 +203,12 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   T.base_ang_vel = (float*)s->ptr[WBC_T_BASE_ANG_VEL]; T.mass_params = (float*)s->ptr[WBC_T_MASS_PARAMS]; T.friction = (float*)s->ptr[WBC_T_FRICTION];
   T.motor = (float*)s->ptr[WBC_T_MOTOR_STRENGTH]; T.origins = (float*)s->ptr[WBC_T_ENV_ORIGINS]; T.box_dy = (float*)s->ptr[WBC_T_BOX_DELTA_Y];
   T.body_params = (float*)s->ptr[WBC_T_BODY_PARAMS]; T.reset_travel = (float*)s->ptr[WBC_T_RESET_TRAVEL];
+  T.box_mass = (float*)s->ptr[WBC_T_BOX_MASS];
   // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
   {
     const int n = num_envs;
     std::vector<float> root((size_t)n * 26, 0.f), fr(n, 1.f), ms((size_t)n * WBC_NACT, 1.f), bp((size_t)n * 20), goal((size_t)n * 24, 0.f);
+    std::vector<float> bm(n, model->box_mass);
     const int g = model->gripper_body;
     for (int i = 0; i < n; ++i) {
       root[(size_t)i * 26 + 6] = 1.f; root[(size_t)i * 26 + 19] = 1.f;
@@ -215,6 +226,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
     HIP_OK(hipMemcpy(T.motor, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(T.body_params, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(T.goal, goal.data(), goal.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(T.box_mass, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
   }
   HIP_OK(hipMalloc((void**)&s->dT, sizeof(DevTensors)));
   HIP_OK(hipMemcpy(s->dT, &s->T, sizeof(DevTensors), hipMemcpyHostToDevice));
@@ -262,7 +274,8 @@ static void merge2(double m1, const double* c1, const double* I1, double m2, con
 
 extern "C" int wbc_sim_set_env_params(wbc_sim* s, const float* friction, const float* base_dmass, const float* base_dcom,
                                       const float* gripper_dmass, const float* motor_strength, const float* env_origins,
-                                      const float* box_delta_y, const float* traj_timesteps, const float* traj_total_timesteps) {
+                                      const float* box_delta_y, const float* traj_timesteps, const float* traj_total_timesteps,
+                                      const float* box_dmass) {
   if (!s) return fail(-1, "wbc_sim_set_env_params: null sim");
   DeviceGuard dg(s->device);
   const int n = s->n;
@@ -271,6 +284,14 @@ extern "C" int wbc_sim_set_env_params(wbc_sim* s, const float* friction, const f
   if (motor_strength) HIP_OK(hipMemcpy(s->T.motor, motor_strength, (size_t)n * WBC_NACT * 4, hipMemcpyHostToDevice));
   if (env_origins) HIP_OK(hipMemcpy(s->T.origins, env_origins, (size_t)n * 3 * 4, hipMemcpyHostToDevice));
   if (box_delta_y) HIP_OK(hipMemcpy(s->T.box_dy, box_delta_y, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (box_dmass) {
+    std::vector<float> bm(n);
+    for (int i = 0; i < n; ++i) {
+      bm[i] = m.box_mass + box_dmass[i];
+      if (!(bm[i] > 0.f)) return fail(-1, "wbc_sim_set_env_params: box mass must stay positive");
+    }
+    HIP_OK(hipMemcpy(s->T.box_mass, bm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  }
   if (base_dmass || base_dcom || gripper_dmass) {
     std::vector<float> bp((size_t)n * 20), mp((size_t)n * 5);
     for (int i = 0; i < n; ++i) {

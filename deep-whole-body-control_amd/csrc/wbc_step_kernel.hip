@@ -15,6 +15,7 @@
 #include "wbc_device.h"
 
 #define LANES 64
+static_assert(LANES == 64, "one wavefront per robot: cross-lane hand-overs rest on wavefront-scope ordering");
 
 // development aid: phase timestamps of block 0 (tools/time_step.py builds a variant with -DWBC_STEP_TIMING)
 __device__ long long* g_step_dbg = nullptr;
@@ -66,29 +67,38 @@ struct __align__(16) Smem {
     float IA[WBC_NB][36];        // articulated inertia; reused as K (inverse articulated inertia)
     PostBuf post;
     struct {                     // contact iterations: K of the bodies 1.. is dead once every active contact has built its Delassus
-      float K0[36];              // block (the sweeps only apply the root's K), so the per-contact data the owning lane re-reads in
-      float cW[WBC_NCP][9];      // every iteration lives there instead of in ~12 more registers per lane
-      float cdv[WBC_NCP][3];
+      float K0[36];              // block (the sweeps only apply the root's K), so the per-contact data of the iterations lives there:
+      float cW[WBC_NCP][6];      // the Delassus block (upper triangle 00 01 02 11 12 22) and the sweep response, re-read by the owning
+      float cdv[WBC_NCP][3];     // lane in every iteration, and the impulse, gathered per body by other lanes
+      float clam[WBC_NCP][3];
     } ctc;
   };
   float E[WBC_NB][9];
   float pos[WBC_NB][3];
-  float S[WBC_NB][6], v[WBC_NB][6], c[WBC_NB][6], pA[WBC_NB][6], U[WBC_NB][6], a[WBC_NB][6];
+  float S[WBC_NB][6], v[WBC_NB][6], c[WBC_NB][6], pA[WBC_NB][6], a[WBC_NB][6];
+  union {
+    float U[WBC_NB][6];
+    struct {                     // the step's contact outputs: written after the last substep's contact iterations (U is dead then:
+      float out_contact[WBC_NRB_ENV][3];   // integration reads a, c, qdd, qddD only) and read by the post-physics phases
+      float out_sensor[WBC_NFEET][6];
+    };
+  };
   float iD[WBC_NB], u[WBC_NB], uD[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];   // iD = 1/D
   float pa1[WBC_NCHAIN][6];      // depth-1 contributions to the root, summed in fixed order
   float q[WBC_NDOF], qd[WBC_NDOF], tau[WBC_NDOF], act[WBC_NACT];
   float root[13], box[13], R[9], wb[3], vb[3], gF[3];
   float bp[20], motor[WBC_NACT];
-  // contacts (one per lane): only what OTHER lanes read lives here -- the contact point and the impulse (gathered per body).
-  // Normal, Delassus block, free velocity, sweep response and velocity target stay in the owning lane's registers; the set of
-  // active contacts is a wavefront ballot.
-  float cxc[WBC_NCP][3], clam[WBC_NCP][3];
-  float out_contact[WBC_NRB_ENV][3];
-  float out_sensor[WBC_NFEET][6];
+  // the free box actor in frame F (oracle: box_ws): rotation of the box in the world, then centre / axes / centre velocity / spin in F,
+  // 1/m and 1/Ic, and its response to the contact impulses of the current sweep (centre acceleration, angular acceleration)
+  float bxRb[9], bxc[3], bxE[9], bxv[3], bxw[3], bxim, bxiI, bxa[6];
+  // contacts (one per lane): only what OTHER lanes read lives here -- the contact point (the impulse: ctc.clam).
+  // Normal, free velocity and velocity target stay in the owning lane's registers; the set of active contacts is a wavefront ballot.
+  float cxc[WBC_NCP][3];
   float goal[24], cmd[3], blv[3], bav[3];
   float act_last[WBC_NACT];      // newest (undelayed) action, sim order
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
-  float rew, arm_rew, base_yaw, mu, friction;
+  float rew, arm_rew, base_yaw, friction;
+  float mu[4];                   // friction coefficients: robot-terrain, robot-robot, box-terrain, robot-box
   float rp[2];                   // base roll / pitch of the state the observation is built from (post-physics, or post-reset)
   int reset_flag, time_out, ep_len;
   float sq[WBC_NDOF], cq[WBC_NDOF];      // sin/cos of the joint angles of this substep
@@ -98,7 +108,7 @@ struct __align__(16) Smem {
   uint32_t k_body[WBC_NB];               // DevConst::body_pack
   float k_qdlim[WBC_NDOF];
   float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];   // joint armature at (chain, depth); row WBC_NCHAIN is the idle row
-  uint32_t k_gm1[WBC_NB], k_gm2[WBC_NB];         // DevConst::body_cp_mask / body_cp2_mask
+  uint64_t k_gm1[WBC_NB + 1], k_gm2[WBC_NB + 1]; // DevConst::body_cp_mask / body_cp2_mask (entry WBC_BOX_BODY: the free box)
 };
 
 // aliases: pD lives in pA, aD in c (both dead once pass 3 has run); g (pass 3 only) also lives in pA:
@@ -156,17 +166,21 @@ __device__ __forceinline__ void fk_pass(Smem& s, const DevConst* __restrict__ C,
   }
 }
 
-// contact_solve of the oracle, one contact per lane
+// symmetric 3x3 (upper triangle 00 01 02 11 12 22) times vector
+__device__ __forceinline__ f3 sym_mul(const float* W, f3 v) {
+  return mk3(W[0] * v.x + W[1] * v.y + W[2] * v.z, W[1] * v.x + W[3] * v.y + W[4] * v.z, W[2] * v.x + W[4] * v.y + W[5] * v.z);
+}
+// contact_solve of the oracle, one contact per lane; W = the Delassus block's upper triangle
 __device__ __forceinline__ void contact_solve(const float* W, f3 n, float vn_tgt, float mu, f3 vref, float* lam) {
   const float vn = dot(n, vref);
   lam[0] = lam[1] = lam[2] = 0.f;
   if (vn >= vn_tgt) return;
-  const f3 Wn = mat_mul(W, n);
+  const f3 Wn = sym_mul(W, n);
   const float nWn = dot(n, Wn);
   const float lam_fl = (vn_tgt - vn) * rcpf(nWn);
   const f3 rhs = n * vn_tgt - vref;
   // symmetric 3x3 solve by cofactors
-  const float a = W[0], b = W[1], c = W[2], d = W[4], e = W[5], f = W[8];
+  const float a = W[0], b = W[1], c = W[2], d = W[3], e = W[4], f = W[5];
   const float c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
   const float det = a * c00 + b * c01 + c * c02;
   const float c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
@@ -177,13 +191,17 @@ __device__ __forceinline__ void contact_solve(const float* W, f3 n, float vn_tgt
   const f3 lt = st - n * ln;
   const float ltn = __builtin_amdgcn_sqrtf(dot(lt, lt));
   if (ln > 0.f && ltn <= mu * ln) { lam[0] = st.x; lam[1] = st.y; lam[2] = st.z; return; }
-  if (ln <= 0.f || ltn <= 1e-12f) { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
-  const f3 dir = n + lt * (mu * rcpf(ltn));
-  const f3 Wd = mat_mul(W, dir);
+  // sliding: friction mu * (normal impulse) against the tangential velocity of the point (the stick impulse's direction if it has none)
+  const f3 vt = vref - n * vn;
+  const float vtn = __builtin_amdgcn_sqrtf(dot(vt, vt));
+  f3 dir;
+  if (vtn > 1e-6f) dir = n - vt * (mu * rcpf(vtn));
+  else if (ltn > 1e-12f) dir = n + lt * (mu * rcpf(ltn));
+  else { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
+  const f3 Wd = sym_mul(W, dir);
   const float den = dot(n, Wd);
   if (den <= 0.05f * nWn) { lam[0] = n.x * lam_fl; lam[1] = n.y * lam_fl; lam[2] = n.z * lam_fl; return; }
-  float l = (vn_tgt - vn) * rcpf(den);
-  l = fmaxf(l, 0.f);
+  const float l = (vn_tgt - vn) * rcpf(den);
   lam[0] = dir.x * l; lam[1] = dir.y * l; lam[2] = dir.z * l;
 }
 
@@ -250,9 +268,9 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
 #pragma unroll
     for (int j = 0; j < 6; ++j) bI6[j] = C->model.inertia[lane][j];
   }
-  // root-frame quantities
+  // root-frame quantities (lane 1, in the same instructions: the rotation of the free box actor)
+  if (lane < 2) quat_to_mat(lane == 0 ? &s.root[3] : &s.box[3], lane == 0 ? s.R : s.bxRb);
   if (lane == 0) {
-    quat_to_mat(&s.root[3], s.R);
     st3(s.wb, matT_mul(s.R, ld3(&s.root[10])));
     st3(s.vb, matT_mul(s.R, ld3(&s.root[7])));
     st3(s.gF, matT_mul(s.R, ld3(C->cfg.gravity)));
@@ -261,6 +279,21 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(0);
   fk_pass(s, C, cr, chain, k);   // begins with a barrier after the identity write, ends with one
   STAMP(1);
+  // the free box in frame F (oracle: box_ws), 18 entries on otherwise idle lanes: out = sum_j R[j][r] x_j with x = a column of the
+  // box's rotation (bxE = R^T Rb), its position relative to the base, its velocity, its spin
+  if (lane >= 44 && lane < 62) {
+    const int e = lane - 44;
+    const bool isE = e < 9;
+    const int r = isE ? e / 3 : (e - 9) % 3, which = isE ? 0 : (e - 9) / 3;
+    const float* X = isE ? &s.bxRb[e % 3] : &s.box[which == 0 ? 0 : (which == 1 ? 7 : 10)];
+    const int stp = isE ? 3 : 1;
+    const bool rel = !isE && which == 0;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc += s.R[3 * j + r] * (X[j * stp] - (rel ? s.root[j] : 0.f));
+    float* dst = isE ? &s.bxE[e] : (which == 0 ? &s.bxc[r] : (which == 1 ? &s.bxv[r] : &s.bxw[r]));
+    *dst = acc;
+  }
   // joint screws S for all 18 joints: 108 entries
   for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
     // component m of the axis (kk < 3) or of pos x axis (kk >= 3): only the operands of that component are read
@@ -511,12 +544,18 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   }
   WSYNC();
   STAMP(6);
-  // contacts: one contact per lane (spheres against the terrain, then the self-collision pairs: a sphere against a box or a
-  // capsule riding on another body). Narrow phase first; only lanes with an ACTIVE contact build a Delassus block.
+  // contacts: one contact per lane (spheres against the terrain -- the robot's, then the free box's corners -- then the pairs: a
+  // sphere against a box or a capsule riding on another body of the robot, or against the free box). Narrow phase first; only
+  // lanes with an ACTIVE contact build a Delassus block.
+  const bool onbox = cpb == WBC_BOX_BODY, p2box = cpb2 == WBC_BOX_BODY;
+  const float* Eb = onbox ? s.bxE : s.E[onbox ? 0 : cpb];
+  const float* pb = onbox ? s.bxc : s.pos[onbox ? 0 : cpb];
+  const float* E2 = p2box ? s.bxE : s.E[cpb2 < 0 || p2box ? 0 : cpb2];
+  const float* p2 = p2box ? s.bxc : s.pos[cpb2 < 0 || p2box ? 0 : cpb2];
   f3 cn = mk3(0.f, 0.f, 1.f), cxcr = mk3(0.f, 0.f, 0.f);
   float cgap = 1e30f;
   if (cpkind == WBC_CP_TERRAIN) {
-    const f3 xk = ld3(s.pos[cpb]) + mat_mul(s.E[cpb], mk3(cpp[0], cpp[1], cpp[2]));
+    const f3 xk = ld3(pb) + mat_mul(Eb, mk3(cpp[0], cpp[1], cpp[2]));
     const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
     float h; f3 nw;
     terrain_query(C, Xw.x, Xw.y, &h, &nw);
@@ -524,15 +563,15 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     cn = matT_mul(s.R, nw);
     cxcr = xk - cn * cpr;
   }
-  // self-collision pairs. Broad phase: the sphere against the partner's bounding sphere, generous by 1 mm -- a pair it rejects has
+  // pairs. Broad phase: the sphere against the partner's bounding sphere, generous by 1 mm -- a pair it rejects has
   // a gap far above the contact margin, so the exact test below (box / capsule closest point, square roots, divisions) could not
-  // have found it active either; with the arm carried above the trunk, as it mostly is, no lane gets past it and the wavefront
-  // skips the exact tests altogether.
+  // have found it active either; with the arm carried above the trunk and the box out of reach, as they mostly are, no lane gets
+  // past it and the wavefront skips the exact tests altogether.
   f3 spl = mk3(0.f, 0.f, 0.f);
   bool snear = false;
   if (cpkind > WBC_CP_TERRAIN) {
-    const f3 xk = ld3(s.pos[cpb]) + mat_mul(s.E[cpb], mk3(cpp[0], cpp[1], cpp[2]));
-    spl = matT_mul(s.E[cpb2], xk - ld3(s.pos[cpb2]));                    // sphere centre in the partner's frame
+    const f3 xk = ld3(pb) + mat_mul(Eb, mk3(cpp[0], cpp[1], cpp[2]));
+    spl = matT_mul(E2, xk - ld3(p2));                                    // sphere centre in the partner's frame
     const f3 A = mk3(cpa[0], cpa[1], cpa[2]), B = mk3(cpe[0], cpe[1], cpe[2]);
     const bool box = cpkind == WBC_CP_BOX;
     const f3 ctr = box ? A : (A + B) * 0.5f, ext = box ? B : (B - A) * 0.5f;
@@ -575,109 +614,138 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       ql = ql + nl * cpr2;
       cgap = dist - cpr - cpr2;
     }
-    cn = mat_mul(s.E[cpb2], nl);
-    cxcr = ld3(s.pos[cpb2]) + mat_mul(s.E[cpb2], ql);                    // on the partner's surface
+    cn = mat_mul(E2, nl);
+    cxcr = ld3(p2) + mat_mul(E2, ql);                                    // on the partner's surface
   }
   STAMP(18);
   const bool cact = cgap < C->cfg.contact_margin;
-  const uint32_t abits = (uint32_t)__ballot(cact);                      // the active set (WBC_NCP <= 32 lanes)
+  const uint64_t abits = __ballot(cact);                                // the active set (WBC_NCP <= 64 lanes)
+  // friction coefficient of this contact: robot-terrain, box-terrain, robot-robot, robot-box
+  const float cmu = s.mu[cpkind == WBC_CP_TERRAIN ? (onbox ? 2 : 0) : (p2box ? 3 : 1)];
   f3 cvfree = mk3(0.f, 0.f, 0.f), clamr = mk3(0.f, 0.f, 0.f);
   float cvtgt = 0.f;
+  float cW[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (cact) {
-    const int kc = lane;
-    float cW[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    st3(s.cxc[kc], cxcr);
-    s.clam[kc][0] = s.clam[kc][1] = s.clam[kc][2] = 0.f;
+    st3(s.cxc[lane], cxcr);
     cvtgt = (cgap >= 0.f) ? -cgap * idt : fminf(C->cfg.contact_erp * (-cgap) * idt, C->cfg.max_depenetration_vel);
     const f3 xc = cxcr;
     // W = J K J^T with J = [-[xc]x  I] (point velocity = v + omega x xc): for any 6-vector (a; l), J-row products are
     // l + a x xc, so K J^T has rows Kl_r + Ka_r x xc and W's columns are L_c + U_c x xc (54 FMAs instead of 162). A
-    // self-collision pair sums the blocks of its two bodies (their coupling through the tree is left to the sweeps).
+    // pair sums the blocks of its two bodies (their coupling through the tree is left to the sweeps). The free box contributes the
+    // closed form of a rigid body with isotropic inertia about its centre: 1/m + (|r|^2 1 - r r^T) / Ic, r = xc - centre.
     const int nside = cpkind == WBC_CP_TERRAIN ? 1 : 2;
 #pragma unroll 1
     for (int side = 0; side < nside; ++side) {
       const int b = side == 0 ? cpb : cpb2;
-      const float* K = s.IA[b];
-      // rows of K J^T: kj_r = Kl_r + Ka_r x xc. W row r' = kj_{3+r'} + (column-wise) (kj_0, kj_1, kj_2) x xc, i.e.
-      // W0 = kj3 + kj1 xc.z - kj2 xc.y, W1 = kj4 + kj2 xc.x - kj0 xc.z, W2 = kj5 + kj0 xc.y - kj1 xc.x (12 live values, not 27)
-      const f3 k0 = ld3(&K[3]) + cross(ld3(&K[0]), xc), k1 = ld3(&K[9]) + cross(ld3(&K[6]), xc), k2 = ld3(&K[15]) + cross(ld3(&K[12]), xc);
-      {
-        const f3 k3 = ld3(&K[21]) + cross(ld3(&K[18]), xc);
-        const f3 w0 = k3 + (k1 * xc.z - k2 * xc.y);
-        cW[0] += w0.x; cW[1] += w0.y; cW[2] += w0.z;
+      f3 vf;
+      if (b == WBC_BOX_BODY) {
+        const f3 r = xc - ld3(s.bxc);
+        const float rr = dot(r, r), im = s.bxim, iI = s.bxiI;
+        cW[0] += (im + rr * iI) - r.x * r.x * iI; cW[1] -= r.x * r.y * iI; cW[2] -= r.x * r.z * iI;
+        cW[3] += (im + rr * iI) - r.y * r.y * iI; cW[4] -= r.y * r.z * iI;
+        cW[5] += (im + rr * iI) - r.z * r.z * iI;
+        // free motion: the centre falls with gravity, the spin is constant (isotropic inertia)
+        const f3 w = ld3(s.bxw);
+        const f3 wr = cross(w, r);
+        vf = (ld3(s.bxv) + wr) + (ld3(s.gF) + cross(w, wr)) * dt;
+      } else {
+        const float* K = s.IA[b];
+        // rows of K J^T: kj_r = Kl_r + Ka_r x xc. W row r' = kj_{3+r'} + (column-wise) (kj_0, kj_1, kj_2) x xc, i.e.
+        // W0 = kj3 + kj1 xc.z - kj2 xc.y, W1 = kj4 + kj2 xc.x - kj0 xc.z, W2 = kj5 + kj0 xc.y - kj1 xc.x; the upper triangle is kept
+        const f3 k0 = ld3(&K[3]) + cross(ld3(&K[0]), xc), k1 = ld3(&K[9]) + cross(ld3(&K[6]), xc), k2 = ld3(&K[15]) + cross(ld3(&K[12]), xc);
+        {
+          const f3 k3 = ld3(&K[21]) + cross(ld3(&K[18]), xc);
+          const f3 w0 = k3 + (k1 * xc.z - k2 * xc.y);
+          cW[0] += w0.x; cW[1] += w0.y; cW[2] += w0.z;
+        }
+        {
+          const f3 k4 = ld3(&K[27]) + cross(ld3(&K[24]), xc);
+          const f3 w1 = k4 + (k2 * xc.x - k0 * xc.z);
+          cW[3] += w1.y; cW[4] += w1.z;
+        }
+        {
+          const f3 k5 = ld3(&K[33]) + cross(ld3(&K[30]), xc);
+          const f3 w2 = k5 + (k0 * xc.y - k1 * xc.x);
+          cW[5] += w2.z;
+        }
+        const f3 w = ld3(&s.v[b][0]);
+        const f3 vp = ld3(&s.v[b][3]) + cross(w, xc);
+        const f3 ab_a = ld3(&s.a[b][0]);
+        const f3 ab_l = ld3(&s.a[b][3]) + ld3(s.gF);
+        const f3 apnt = ab_l + cross(ab_a, xc) + cross(w, vp);
+        vf = vp + apnt * dt;
       }
-      {
-        const f3 k4 = ld3(&K[27]) + cross(ld3(&K[24]), xc);
-        const f3 w1 = k4 + (k2 * xc.x - k0 * xc.z);
-        cW[3] += w1.x; cW[4] += w1.y; cW[5] += w1.z;
-      }
-      {
-        const f3 k5 = ld3(&K[33]) + cross(ld3(&K[30]), xc);
-        const f3 w2 = k5 + (k0 * xc.y - k1 * xc.x);
-        cW[6] += w2.x; cW[7] += w2.y; cW[8] += w2.z;
-      }
-      const f3 w = ld3(&s.v[b][0]);
-      const f3 vp = ld3(&s.v[b][3]) + cross(w, xc);
-      const f3 ab_a = ld3(&s.a[b][0]);
-      const f3 ab_l = ld3(&s.a[b][3]) + ld3(s.gF);
-      const f3 apnt = ab_l + cross(ab_a, xc) + cross(w, vp);
-      const f3 vf = vp + apnt * dt;
       cvfree = side == 0 ? vf : cvfree - vf;
     }
-    cW[0] += 1e-6f; cW[4] += 1e-6f; cW[8] += 1e-6f;
-    // every lane's reads of K are done (one wavefront, LDS operations in program order; the lanes of a self-collision pair have
-    // left the two-sided loop): the blocks go where K_1.. was
+    cW[0] += 1e-6f; cW[3] += 1e-6f; cW[5] += 1e-6f;
+  }
+  // every lane's reads of K are done before the blocks go where K_1.. was (the two-sided loop above has a divergent trip count:
+  // the barrier makes the order explicit instead of resting on reconvergence)
+  WSYNC();
+  if (cact) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) s.ctc.cW[kc][j] = cW[j];
-    s.ctc.cdv[kc][0] = s.ctc.cdv[kc][1] = s.ctc.cdv[kc][2] = 0.f;
+    for (int j = 0; j < 6; ++j) s.ctc.cW[lane][j] = cW[j];
+    s.ctc.cdv[lane][0] = s.ctc.cdv[lane][1] = s.ctc.cdv[lane][2] = 0.f;
+    s.ctc.clam[lane][0] = s.ctc.clam[lane][1] = s.ctc.clam[lane][2] = 0.f;
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
-  if (lane < 6) AD(s)[0][lane] = 0.f;
+  if (lane < 6) { AD(s)[0][lane] = 0.f; s.bxa[lane] = 0.f; }
   WSYNC();
   STAMP(7);
   // dmax: deepest chain level that carries an active contact. Deeper levels see no contact wrench, so the inward
   // sweep skips them exactly; the outward sweep needs them only in the last iteration (joint accelerations).
-  const int any = abits != 0u;
+  const int any = abits != 0ull;
   int dmax = 1;
 #pragma unroll
   for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
+  // damped block-Jacobi: relaxation 1 / (number of active contacts acting on the busier of the contact's two bodies)
   float com = 1.f;
-  if (cact) com = 1.f / (float)__popc(abits & s.k_gm1[cpb]);
+  if (cact) {
+    int cnt = __popcll(abits & (s.k_gm1[cpb] | s.k_gm2[cpb]));
+    if (cpb2 >= 0) cnt = max(cnt, (int)__popcll(abits & (s.k_gm1[cpb2] | s.k_gm2[cpb2])));
+    com = 1.f / (float)cnt;
+  }
   if (any) {
     const int iters = C->cfg.contact_iters;
     for (int it = 0; it < iters; ++it) {
       if (cact) {
-        float cW[9];
+        float W6[6];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) cW[j] = s.ctc.cW[lane][j];
-        const f3 own = mat_mul(cW, clamr);
+        for (int j = 0; j < 6; ++j) W6[j] = s.ctc.cW[lane][j];
+        const f3 own = sym_mul(W6, clamr);
         const f3 vref = cvfree + ld3(s.ctc.cdv[lane]) - own;
-        const float cmu = cpb2 < 0 ? s.mu : fmaxf(s.friction, 0.f);
         float lam[3];
-        contact_solve(cW, cn, cvtgt, cmu, vref, lam);
-        // damped block-Jacobi: the active contacts of spheres on the same body share the correction (relaxation 1 / their number)
+        contact_solve(W6, cn, cvtgt, cmu, vref, lam);
+        // damped block-Jacobi: the active contacts acting on one body share the correction
         clamr = clamr + (mk3(lam[0], lam[1], lam[2]) - clamr) * com;
-        st3(s.clam[lane], clamr);
+        st3(s.ctc.clam[lane], clamr);
       }
       WSYNC();
       if (it == 0) STAMP(20);
-      // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a self-collision pair
-      // receives the opposite wrench
-      if (lane < WBC_NB) {
+      // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a pair receives the opposite
+      // wrench. Lane WBC_BOX_BODY does the same sum for the free box and turns it into the box's response right away.
+      if (lane <= WBC_NB) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const uint32_t gmask1 = s.k_gm1[lane];
-        uint32_t mask = (gmask1 | s.k_gm2[lane]) & abits;
+        const uint64_t gmask1 = s.k_gm1[lane];
+        uint64_t mask = (gmask1 | s.k_gm2[lane]) & abits;
+        // moments about F's origin for the tree's bodies, about its own centre for the box (3 m away: no cancellation in fp32)
+        const f3 org = lane < WBC_NB ? mk3(0.f, 0.f, 0.f) : ld3(s.bxc);
         while (mask) {
-          const int kc = __ffs(mask) - 1;
+          const int kc = __ffsll((long long)mask) - 1;
           mask &= mask - 1;
-          const float sg = ((gmask1 >> kc) & 1u) ? idt : -idt;
-          const f3 f = ld3(s.clam[kc]) * sg;
-          const f3 mom = cross(ld3(s.cxc[kc]), f);
+          const float sg = ((gmask1 >> kc) & 1ull) ? idt : -idt;
+          const f3 f = ld3(s.ctc.clam[kc]) * sg;
+          const f3 mom = cross(ld3(s.cxc[kc]) - org, f);
           acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
         }
+        if (lane < WBC_NB) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
-        s.uD[lane] = 0.f;                          // levels the inward sweep skips
+          for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
+          s.uD[lane] = 0.f;                        // levels the inward sweep skips
+        } else {
+          // the box's response: angular acceleration n / Ic, centre acceleration F / m
+          st3(&s.bxa[0], mk3(-acc[0], -acc[1], -acc[2]) * s.bxiI); st3(&s.bxa[3], mk3(-acc[3], -acc[4], -acc[5]) * s.bxim);
+        }
       }
       WSYNC();
       if (it == 0) STAMP(21);
@@ -737,8 +805,16 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       if (it == 0) STAMP(24);
       if (it < iters - 1 && cact) {      // the last sweep's contact-point response is not used
         const f3 xc = ld3(s.cxc[lane]);
-        f3 dvv = (ld3(&AD(s)[cpb][3]) + cross(ld3(&AD(s)[cpb][0]), xc)) * dt;
-        if (cpb2 >= 0) dvv = dvv - (ld3(&AD(s)[cpb2][3]) + cross(ld3(&AD(s)[cpb2][0]), xc)) * dt;
+        // response of a body at the contact point: (angular; linear) acceleration change, lever from F's origin (tree) / from the
+        // box centre (free box)
+        const float* ad1 = onbox ? s.bxa : AD(s)[onbox ? 0 : cpb];
+        const f3 lv1 = onbox ? xc - ld3(s.bxc) : xc;
+        f3 dvv = (ld3(ad1 + 3) + cross(ld3(ad1), lv1)) * dt;
+        if (cpb2 >= 0) {
+          const float* ad2 = p2box ? s.bxa : AD(s)[p2box ? 0 : cpb2];
+          const f3 lv2 = p2box ? xc - ld3(s.bxc) : xc;
+          dvv = dvv - (ld3(ad2 + 3) + cross(ld3(ad2), lv2)) * dt;
+        }
         st3(s.ctc.cdv[lane], dvv);
       }
       WSYNC();
@@ -747,32 +823,42 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   STAMP(8);
   // contact force outputs (world-frame net force per rigid body, foot-frame sensor wrench)
   if (want_outputs) {
-    // the foot sensors read the normal of their (single) contact from its owning lane; all lanes take part in the shuffles
-    const int src = (lane >= 32 && lane < 32 + WBC_NFEET) ? Cc->foot_cp[lane - 32] : lane;
-    const f3 nsrc = mk3(__shfl(cn.x, src), __shfl(cn.y, src), __shfl(cn.z, src));
-    // lanes 0..27: net force on rigid body `lane` (+ as the sphere's body, - as the partner of a self-collision pair)
+    // a foot's sensor reads the normals of its sphere's contacts (the terrain's, the free box's) from their owning lanes; all lanes
+    // take part in the shuffles
+    const int ftl = lane - 32;
+    const bool isft = ftl >= 0 && ftl < WBC_NFEET;
+    const int kc1 = isft ? Cc->foot_cp[ftl] : lane;
+    const int kc2 = isft ? Cc->foot_cp2[ftl] : -1;
+    const int src2 = kc2 >= 0 ? kc2 : lane;
+    const f3 n1 = mk3(__shfl(cn.x, kc1), __shfl(cn.y, kc1), __shfl(cn.z, kc1));
+    const f3 n2 = mk3(__shfl(cn.x, src2), __shfl(cn.y, src2), __shfl(cn.z, src2));
+    // lanes 0..27: net force on rigid body `lane` (+ as the sphere's body, - as the partner of a pair); row 27 is the box actor
     if (lane < WBC_NRB_ENV) {
-      const uint32_t m1 = Cc->out_cp_mask[lane], m2 = Cc->out_cp2_mask[lane];
-      uint32_t mask = (m1 | m2) & abits;
+      const uint64_t m1 = Cc->out_cp_mask[lane], m2 = Cc->out_cp2_mask[lane];
+      uint64_t mask = (m1 | m2) & abits;
       f3 acc = mk3(0.f, 0.f, 0.f);
       while (mask) {
-        const int kc = __ffs(mask) - 1;
+        const int kc = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const float sg = ((m1 >> kc) & 1u) ? idt : -idt;
-        acc = acc + mat_mul(s.R, ld3(s.clam[kc]) * sg);
+        const float sg = ((m1 >> kc) & 1ull) ? idt : -idt;
+        acc = acc + mat_mul(s.R, ld3(s.ctc.clam[kc]) * sg);
       }
       st3(s.out_contact[lane], acc);
-    } else if (lane >= 32 && lane < 32 + WBC_NFEET) {
-      const int ft = lane - 32, kc = src;
+    } else if (isft) {
       f3 fa = mk3(0.f, 0.f, 0.f), ta = mk3(0.f, 0.f, 0.f);
-      if ((abits >> kc) & 1u) {
-        const int b = Cc->model.cp_body[kc];
-        const f3 f = ld3(s.clam[kc]) * idt;
-        const f3 arm = nsrc * (-Cc->model.cp_radius[kc]);
+      const int b = Cc->model.cp_body[kc1];
+      const float rad = Cc->model.cp_radius[kc1];
+      if ((abits >> kc1) & 1ull) {
+        const f3 f = ld3(s.ctc.clam[kc1]) * idt;
         fa = matT_mul(s.E[b], f);
-        ta = matT_mul(s.E[b], cross(arm, f));
+        ta = matT_mul(s.E[b], cross(n1 * (-rad), f));
       }
-      st3(&s.out_sensor[ft][0], fa); st3(&s.out_sensor[ft][3], ta);
+      if (kc2 >= 0 && ((abits >> kc2) & 1ull)) {
+        const f3 f = ld3(s.ctc.clam[kc2]) * idt;
+        fa = fa + matT_mul(s.E[b], f);
+        ta = ta + matT_mul(s.E[b], cross(n2 * (-rad), f));
+      }
+      st3(&s.out_sensor[ftl][0], fa); st3(&s.out_sensor[ftl][3], ta);
     }
   }
   STAMP(9);
@@ -788,21 +874,25 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     if (lim > 0.f) qd = fminf(fmaxf(qd, -lim), lim);
     s.qd[dj] = qd;
     s.q[dj] += dt * qd;
-  } else if (lane == 0) {
+  } else if (lane == 0 || lane == WBC_NB) {
+    // the two free bodies, same instructions: lane 0 the robot's root, lane WBC_NB the box actor (gravity + its net contact force)
+    const bool isb = lane != 0;
+    float* st = isb ? s.box : s.root;
     const f3 wb = ld3(s.wb), vb = ld3(s.vb);
-    const f3 accF = mk3(a0[3], a0[4], a0[5]) + ld3(s.gF) + cross(wb, vb);
-    const f3 vw = ld3(&s.root[7]) + mat_mul(s.R, accF) * dt;
-    const f3 ww = ld3(&s.root[10]) + mat_mul(s.R, mk3(a0[0], a0[1], a0[2])) * dt;
-    st3(&s.root[7], vw); st3(&s.root[10], ww);
-    st3(&s.root[0], ld3(&s.root[0]) + vw * dt);
+    const f3 accF = isb ? ld3(s.gF) + ld3(&s.bxa[3]) : mk3(a0[3], a0[4], a0[5]) + ld3(s.gF) + cross(wb, vb);
+    const f3 alF = isb ? ld3(&s.bxa[0]) : mk3(a0[0], a0[1], a0[2]);
+    const f3 vw = ld3(&st[7]) + mat_mul(s.R, accF) * dt;
+    const f3 ww = ld3(&st[10]) + mat_mul(s.R, alF) * dt;
+    st3(&st[7], vw); st3(&st[10], ww);
+    st3(&st[0], ld3(&st[0]) + vw * dt);
     const float om[4] = {ww.x, ww.y, ww.z, 0.f};
     float dq[4], nq[4], nn = 0.f;
-    quat_mul(om, &s.root[3], dq);
+    quat_mul(om, &st[3], dq);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { nq[j] = s.root[3 + j] + 0.5f * dt * dq[j]; nn += nq[j] * nq[j]; }
+    for (int j = 0; j < 4; ++j) { nq[j] = st[3 + j] + 0.5f * dt * dq[j]; nn += nq[j] * nq[j]; }
     nn = __builtin_amdgcn_rsqf(nn);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s.root[3 + j] = nq[j] * nn;
+    for (int j = 0; j < 4; ++j) st[3 + j] = nq[j] * nn;
   }
   WSYNC();
   STAMP(10);
@@ -1056,7 +1146,11 @@ __device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restric
   if (lane < WBC_NMETRIC) s.met_sums[lane] = T.met_sums[(size_t)env * WBC_NMETRIC + lane];
   if (lane == 0) {
     s.friction = T.friction[env];
-    s.mu = fmaxf(0.5f * (s.friction + C->cfg.terrain_friction), 0.f);
+    const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
+    s.mu[0] = fmaxf(0.5f * (s.friction + tf), 0.f); s.mu[1] = fmaxf(s.friction, 0.f);
+    s.mu[2] = fmaxf(0.5f * (bf + tf), 0.f); s.mu[3] = fmaxf(0.5f * (bf + s.friction), 0.f);
+    const float bm = T.box_mass[env], bh = C->model.box_half;
+    s.bxim = 1.f / bm; s.bxiI = 1.f / (bm * (2.f / 3.f) * bh * bh);
     s.ep_len = (int)T.ep_len[env];
   }
 }
@@ -1064,7 +1158,8 @@ __device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restric
 __device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
   const int lane = threadIdx.x;
   if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = (&C->model.joint_xyz[0][0])[lane];
-  if (lane < WBC_NB) { s.k_body[lane] = C->body_pack[lane]; s.k_gm1[lane] = C->body_cp_mask[lane]; s.k_gm2[lane] = C->body_cp2_mask[lane]; }
+  if (lane < WBC_NB) s.k_body[lane] = C->body_pack[lane];
+  if (lane <= WBC_NB) { s.k_gm1[lane] = C->body_cp_mask[lane]; s.k_gm2[lane] = C->body_cp2_mask[lane]; }
   if (lane < WBC_NDOF) s.k_qdlim[lane] = C->model.qd_limit[lane];
   if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
     const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
@@ -1373,7 +1468,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   if (lane < WBC_NDOF) s.tau[lane] = T.torques[(size_t)env * WBC_NDOF + lane];
   WSYNC();
   physics_substep(s, C, cr, chain, k, true);
-  if (lane < 13) T.root[(size_t)env * 26 + lane] = s.root[lane];
+  if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
   if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
   for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) T.contact[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
   if (lane < WBC_NFEET * 6) T.sensor[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
@@ -1395,6 +1490,8 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
+static_assert(sizeof(float) * (36 + WBC_NCP * 12) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
+static_assert(sizeof(float) * (WBC_NRB_ENV * 3 + WBC_NFEET * 6) <= sizeof(float) * WBC_NB * 6, "contact outputs alias U");
 static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");
 
 extern "C" void wbc_debug_set_step_timing(void* dev_buf) {

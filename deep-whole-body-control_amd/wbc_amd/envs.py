@@ -168,7 +168,8 @@ class WidowGo1(LeggedRobot):
     def create_sim(self):                                                           # WG:230-237, 255-429
         cfg, m, n = self.cfg, self.robot_model, self.num_envs
         # asset.self_collisions is Isaac Gym's collision FILTER: 0 = self-collision enabled (widowGo1_config.py:180)
-        self.wmodel = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(getattr(cfg.asset, "self_collisions", 0)) == 0)
+        self.wmodel = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(getattr(cfg.asset, "self_collisions", 0)) == 0,
+                                     box_size=float(cfg.box.box_size))
         self.tcfg = abi.fill_task_cfg(cfg, m, sim_dt=self._sim_dt)
         self.sim = WbcSim(self.wmodel, self.tcfg, n, self.device, seed=self._seed)
         self.num_dofs, self.num_bodies = m.num_dofs, m.num_rigid_bodies
@@ -258,11 +259,12 @@ class WidowGo1(LeggedRobot):
             motor = torch.cat([rand(*dr.leg_motor_strength_range, n, 12), rand(*dr.arm_motor_strength_range, n, 6)], dim=1)
         else:
             motor = torch.ones(n, self.num_torques)
+        box_dmass = nprng.uniform(*cfg.box.added_mass_range, size=n) if cfg.box.randomize_base_mass else np.zeros(n)   # WG:458-466
         traj = rand(cfg.goal_ee.traj_time[0], cfg.goal_ee.traj_time[1], n) / self.dt
         total = traj + rand(cfg.goal_ee.hold_time[0], cfg.goal_ee.hold_time[1], n) / self.dt
         self.sim.set_env_params(friction=friction.numpy(), base_dmass=dmass, base_dcom=dcom, gripper_dmass=gmass,
                                 motor_strength=motor.numpy(), env_origins=origins.numpy(), box_delta_y=box_dy.numpy(),
-                                traj_timesteps=traj.numpy(), traj_total_timesteps=total.numpy())
+                                traj_timesteps=traj.numpy(), traj_total_timesteps=total.numpy(), box_dmass=box_dmass)
         self.sim.set_curriculum(make_curriculum(cfg, max(self.update_counter, 0)))
 
     def _init_buffers(self):

@@ -35,7 +35,7 @@ def lib():
                                      c_void, C.c_size_t, C.POINTER(c_void)]
         L.wbc_sim_destroy.argtypes = [c_void]
         L.wbc_sim_get_tensor.argtypes = [c_void, c_int, C.POINTER(c_void), C.POINTER(C.c_int64), C.POINTER(c_int), C.POINTER(c_int)]
-        L.wbc_sim_set_env_params.argtypes = [c_void] + [c_void] * 9
+        L.wbc_sim_set_env_params.argtypes = [c_void] + [c_void] * 10
         L.wbc_sim_set_heightfield.argtypes = [c_void, c_void, c_int, c_int] + [C.c_float] * 5
         L.wbc_sim_set_curriculum.argtypes = [c_void, C.POINTER(abi.WbcCurriculum)]
         L.wbc_sim_step.argtypes = [c_void, c_void, c_void]

@@ -84,7 +84,7 @@ class WbcSim:
 
     # ---- setup -----------------------------------------------------------------------------
     def set_env_params(self, friction=None, base_dmass=None, base_dcom=None, gripper_dmass=None, motor_strength=None,
-                       env_origins=None, box_delta_y=None, traj_timesteps=None, traj_total_timesteps=None):
+                       env_origins=None, box_delta_y=None, traj_timesteps=None, traj_total_timesteps=None, box_dmass=None):
         n = self.num_envs
         keep = []
 
@@ -97,7 +97,8 @@ class WbcSim:
         torch.cuda.synchronize(self.device)
         check(self.L.wbc_sim_set_env_params(self.h, ptr(friction, 1), ptr(base_dmass, 1), ptr(base_dcom, 3), ptr(gripper_dmass, 1),
                                             ptr(motor_strength, 18), ptr(env_origins, 3), ptr(box_delta_y, 1),
-                                            ptr(traj_timesteps, 1), ptr(traj_total_timesteps, 1)), "wbc_sim_set_env_params")
+                                            ptr(traj_timesteps, 1), ptr(traj_total_timesteps, 1), ptr(box_dmass, 1)),
+              "wbc_sim_set_env_params")
 
     def set_curriculum(self, cur: abi.WbcCurriculum):
         check(self.L.wbc_sim_set_curriculum(self.h, C.byref(cur)), "wbc_sim_set_curriculum")

@@ -35,7 +35,10 @@ extern "C" {
 #define WBC_NRB 27       /* robot rigid bodies as the importer lists them */
 #define WBC_NRB_ENV 28   /* + the free box actor (WG:384,542,546) */
 #define WBC_NFEET 4
-#define WBC_NCP 32       /* contact slots per robot: spheres vs terrain, then self-collision pairs (one wavefront lane each) */
+#define WBC_NCP 48       /* contact slots per env (one wavefront lane each): robot spheres vs terrain, box corners vs terrain,
+                            the robot's self-collision pairs, robot spheres vs the free box */
+#define WBC_BOX_BODY WBC_NB   /* pseudo body index of the free box actor (WG:321-325,384) in cp_body / cp_body2 */
+#define WBC_BOX_RB WBC_NRB    /* its row in the [N,28,...] rigid-body tensors (WG:544-548: the last one) */
 #define WBC_NPROP 76     /* num_proprio (widowGo1_config.py:122) */
 #define WBC_NPRIV 24     /* num_priv */
 #define WBC_HIST 10      /* history_len */
@@ -69,7 +72,10 @@ typedef struct {
    *   WBC_CP_BOX      a box fixed to moving body cp_body2 (rigid body cp_rb2): centre cp_a, half extents cp_b, its frame;
    *   WBC_CP_CAPSULE  a capsule on cp_body2: segment cp_a..cp_b, radius cp_radius2.
    * The last two are the robot's self-collision pairs (asset.self_collisions = 0 = enabled, widowGo1_config.py:180): the
-   * impulse acts on both bodies with opposite signs. Terrain contacts come first (the force sensors read contacts 0..3). */
+   * impulse acts on both bodies with opposite signs. Terrain contacts come first (the force sensors read contacts 0..3).
+   * The free box actor (WG:321-325: a cube, density 1000) takes part under the pseudo body index WBC_BOX_BODY / rigid-body row
+   * WBC_BOX_RB: its eight corner spheres against the terrain (cp_body = WBC_BOX_BODY, cp_pos in the box frame) and robot spheres
+   * against it (kind WBC_CP_BOX with cp_body2 = WBC_BOX_BODY, cp_a = 0, cp_b = box_half). */
   int32_t ncp;
   int32_t cp_body[WBC_NCP];
   float cp_pos[WBC_NCP][3];
@@ -86,6 +92,9 @@ typedef struct {
   int32_t gripper_body;
   float grip_piece_mass, grip_piece_com[3], grip_piece_inertia[6];
   float grip_rest_mass, grip_rest_com[3], grip_rest_inertia[6];
+  /* the free box actor: half edge of the cube (box.box_size / 2, widowGo1_config.py:186), nominal mass (density 1000 x size^3,
+   * WG:322; the per-env total is WBC_T_BOX_MASS), friction of its material (Isaac Gym's shape default 1.0) */
+  float box_half, box_mass, box_friction;
 } wbc_model;
 
 enum wbc_contact_kind { WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1, WBC_CP_CAPSULE = 2 };
@@ -213,6 +222,7 @@ enum wbc_tensor_id {
   WBC_T_BODY_PARAMS,       /* f32 [N,20] per-env composite root + gripper (mass, com, inertia6) */
   WBC_T_RESET_TRAVEL,      /* f32 [N,2]  at the moment of an env's reset: ||root_xy - env_origin_xy|| and ||commands[:2]||,
                               the two quantities _update_terrain_curriculum reads before reset_idx overwrites them (LR:431-435) */
+  WBC_T_BOX_MASS,          /* f32 [N]    total mass of the env's box actor: nominal + box.added_mass_range draw (WG:458-466) */
   WBC_T_COUNT
 };
 enum wbc_dtype { WBC_F32 = 0, WBC_I64 = 1, WBC_U8 = 2 };
@@ -237,12 +247,13 @@ int wbc_sim_get_tensor(wbc_sim* sim, int id, void** dev_ptr, int64_t shape[4], i
 
 /* Batched replacement for the O(N) per-env Python loop that sets shape friction and
  * randomised rigid-body properties (WG:365-389, 431-496) and motor strengths (WG:402-408).
- * Host pointers, N entries each (motor_strength N*18, base_dcom N*3, env_origins N*3). */
+ * Host pointers, N entries each (motor_strength N*18, base_dcom N*3, env_origins N*3); box_dmass = the box actor's added
+ * mass (_box_process_rigid_body_props, WG:458-466), NULL = 0. */
 int wbc_sim_set_env_params(wbc_sim* sim, const float* friction, const float* base_dmass,
                            const float* base_dcom, const float* gripper_dmass,
                            const float* motor_strength, const float* env_origins,
                            const float* box_delta_y, const float* traj_timesteps,
-                           const float* traj_total_timesteps);
+                           const float* traj_total_timesteps, const float* box_dmass);
 
 /* gym.add_triangle_mesh for the regular-grid terrain (WG:242-252): the int16 height samples
  * the trimesh is built from, host pointer, rows*cols; NULL restores the flat plane. */

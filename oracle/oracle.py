@@ -54,6 +54,7 @@ def _lib(precision: str):
         for fn in ("ora_reset_all", "ora_simulate", "ora_refresh_rigid_body_state", "ora_compute_torques"):
             getattr(lib, fn).argtypes = [C.c_void_p]
         lib.ora_debug_aba.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ora_debug_contacts.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _LIBS[precision] = lib
     return _LIBS[precision]
 
@@ -96,7 +97,7 @@ class OracleSim:
         assert rc == 0, name
 
     def set_env_params(self, friction, base_dmass, base_dcom, gripper_dmass, motor_strength, env_origins,
-                       box_delta_y, traj_timesteps, traj_total_timesteps, robot_model) -> None:
+                       box_delta_y, traj_timesteps, traj_total_timesteps, robot_model, box_dmass=None) -> None:
         """Same inputs as wbc_sim_set_env_params; the composite inertias are computed by the shared
         host helper abi.body_params_from_randomisation."""
         n = self.n
@@ -107,6 +108,7 @@ class OracleSim:
         self.set("MOTOR_STRENGTH", np.asarray(motor_strength).reshape(n, 18))
         self.set("ENV_ORIGINS", np.asarray(env_origins).reshape(n, 3))
         self.set("BOX_DELTA_Y", np.asarray(box_delta_y).reshape(n))
+        self.set("BOX_MASS", float(self.model.box_mass) + (0.0 if box_dmass is None else np.asarray(box_dmass, dtype=np.float64).reshape(n)))
         self.set("BODY_PARAMS", abi.body_params_from_randomisation(robot_model, base_dmass, base_dcom, gripper_dmass))
         g = self.get("GOAL_STATE")
         g[:, 22] = np.asarray(traj_timesteps).reshape(n)
@@ -135,6 +137,13 @@ class OracleSim:
 
     def refresh_rigid_body_state(self):
         self.lib.ora_refresh_rigid_body_state(self.h)
+
+    def debug_contacts(self, env: int = 0):
+        """Contact list of one substep run on a copy of env's state: active, nshare, impulses, normals, points (frame F)."""
+        act = np.zeros(abi.NCP, dtype=np.int32); nsh = np.zeros(abi.NCP, dtype=np.int32)
+        lam, n, xc = np.zeros((abi.NCP, 3)), np.zeros((abi.NCP, 3)), np.zeros((abi.NCP, 3))
+        self.lib.ora_debug_contacts(self.h, env, act.ctypes.data, nsh.ctypes.data, lam.ctypes.data, n.ctypes.data, xc.ctypes.data)
+        return dict(active=act.astype(bool), nshare=nsh, lam=lam, n=n, xc=xc)
 
     def debug_aba(self, env: int = 0):
         qdd = np.zeros(20)

@@ -170,6 +170,7 @@ typedef struct {
   REAL env_origin[3], box_delta_y;
   REAL body_params[20];      /* root (m, com3, I6), gripper (m, com3, I6) */
   REAL reset_travel[2];      /* ||root_xy - origin_xy||, ||commands[:2]|| at the moment of reset (LR:431-435) */
+  REAL box_mass;             /* total mass of the box actor (WG:458-466) */
 } ora_env;
 
 /* goal[] slots */
@@ -282,9 +283,13 @@ static void solve3(const REAL* W, const REAL* b, REAL* x) { /* symmetric 3x3, co
 }
 
 typedef struct {
-  int active, nshare;      /* nshare: active contacts whose sphere rides on the same body (>= 1 when active) */
+  int active, nshare;      /* nshare: the larger of the numbers of active contacts acting on the contact's two bodies (>= 1 when active) */
   REAL xc[3], n[3], W[9], vfree[3], vn_tgt, mu, lam[3];
 } contact_t;
+
+/* The free box actor (WG:321-325,384) in frame F: centre, axes, centre velocity, angular velocity; mass and the (isotropic: a
+ * cube) rotational inertia about the centre. It is not part of the tree: its inverse inertia is closed-form about its own centre. */
+typedef struct { REAL c[3], E[9], v[3], w[3], m, Ic; } box_ws;
 
 /* Friction-cone solve of one contact given the velocity the point would have without its own
  * impulse: returns the total impulse. */
@@ -302,16 +307,27 @@ static void contact_solve(const contact_t* c, const REAL* vref, REAL* lam) {
   REAL lt[3] = {st[0] - ln * c->n[0], st[1] - ln * c->n[1], st[2] - ln * c->n[2]};
   REAL ltn = sqrt(dot3(lt, lt));
   if (ln > 0 && ltn <= c->mu * ln) { lam[0] = st[0]; lam[1] = st[1]; lam[2] = st[2]; return; }
-  if (ln <= 0 || ltn <= (REAL)1e-12) { for (int k = 0; k < 3; ++k) lam[k] = c->n[k] * lam_fl; return; }
+  /* sliding: Coulomb friction of magnitude mu * (normal impulse) opposing the tangential velocity of the contact point; the
+   * normal impulse is what the normal-velocity target needs in the presence of that friction. (The stick impulse's own tangential
+   * direction is bent by the anisotropy of W, and its normal part may even be negative for a corner whose friction pitches the
+   * body onto it: four corners of a sliding box then felt half the friction, tests/test_oracle_contact_physics.py.) A point
+   * without tangential velocity slides where the stick impulse points. */
+  REAL vt[3] = {vref[0] - vn * c->n[0], vref[1] - vn * c->n[1], vref[2] - vn * c->n[2]};
+  REAL vtn = sqrt(dot3(vt, vt));
   REAL dir[3];
-  for (int k = 0; k < 3; ++k) dir[k] = c->n[k] + c->mu * lt[k] / ltn;
+  if (vtn > (REAL)1e-6) { for (int k = 0; k < 3; ++k) dir[k] = c->n[k] - c->mu * vt[k] / vtn; }
+  else if (ltn > (REAL)1e-12) { for (int k = 0; k < 3; ++k) dir[k] = c->n[k] + c->mu * lt[k] / ltn; }
+  else { for (int k = 0; k < 3; ++k) lam[k] = c->n[k] * lam_fl; return; }
   REAL Wd[3]; mat3_mul_vec(c->W, dir, Wd);
   REAL den = dot3(c->n, Wd);
   if (den <= (REAL)0.05 * nWn) { for (int k = 0; k < 3; ++k) lam[k] = c->n[k] * lam_fl; return; }
-  REAL l = (c->vn_tgt - vn) / den;
-  if (l < 0) l = 0;
+  REAL l = (c->vn_tgt - vn) / den;                  /* > 0 */
   for (int k = 0; k < 3; ++k) lam[k] = dir[k] * l;
 }
+
+/* diagnostics (tests only): when set, physics_substep copies its contact list here */
+typedef struct { int active[WBC_NCP]; double lam[WBC_NCP][3], n[WBC_NCP][3], xc[WBC_NCP][3], resid[WBC_NCP]; int nshare[WBC_NCP]; } contact_dump;
+static _Thread_local contact_dump* g_dump = NULL;
 
 /* One physics substep (what gym.simulate does at WG:1184), torques already in e->torques. */
 static void physics_substep(const ora_sim* s, ora_env* e) {
@@ -420,20 +436,42 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc)
       w->K[i][r * 6 + cc] = w->K[p][r * 6 + cc] - g[r] * w->S[i][cc] - w->S[i][r] * g[cc] + gam * w->S[i][r] * w->S[i][cc];
   }
-  /* contacts: spheres against the terrain, then the self-collision pairs (sphere against a box / capsule of another body) */
+  /* the free box in frame F */
+  box_ws bx;
+  {
+    REAL Rb[9], d[3];
+    quat_to_mat(e->root[1] + 3, Rb);
+    for (int j = 0; j < 3; ++j) d[j] = e->root[1][j] - e->root[0][j];
+    mat3T_mul_vec(R, d, bx.c);
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+      REAL acc = 0; for (int j = 0; j < 3; ++j) acc += R[j * 3 + r] * Rb[j * 3 + cc]; bx.E[r * 3 + cc] = acc; }
+    mat3T_mul_vec(R, e->root[1] + 7, bx.v);
+    mat3T_mul_vec(R, e->root[1] + 10, bx.w);
+    bx.m = e->box_mass;
+    bx.Ic = bx.m * (REAL)(2.0 / 3.0) * (REAL)md->box_half * (REAL)md->box_half;    /* m (2h)^2 / 6 */
+  }
+  /* contacts: spheres against the terrain (the robot's, then the box's corners), then the pairs (a sphere against a box / capsule
+   * riding on another body of the robot, or against the free box) */
   contact_t ct[WBC_NCP];
   REAL mu = (REAL)0.5 * (e->friction + (REAL)cf->terrain_friction);   /* PhysX default combine: average */
   if (mu < 0) mu = 0;
   REAL mu_self = e->friction < 0 ? 0 : e->friction;                   /* both shapes carry the robot's material */
+  REAL mu_box_terrain = (REAL)0.5 * ((REAL)md->box_friction + (REAL)cf->terrain_friction);
+  REAL mu_box_robot = (REAL)0.5 * ((REAL)md->box_friction + e->friction);
+  if (mu_box_terrain < 0) mu_box_terrain = 0;
+  if (mu_box_robot < 0) mu_box_robot = 0;
   int any = 0;
   for (int k = 0; k < md->ncp; ++k) {
     contact_t* c = &ct[k];
     int b = md->cp_body[k], kind = md->cp_kind[k], b2 = md->cp_body2[k];
+    const REAL* Eb = (b == WBC_BOX_BODY) ? bx.E : w->E[b];
+    const REAL* pb = (b == WBC_BOX_BODY) ? bx.c : w->pos[b];
     REAL o[3] = {md->cp_pos[k][0], md->cp_pos[k][1], md->cp_pos[k][2]}, xk[3], t[3];
-    mat3_mul_vec(w->E[b], o, t);
-    for (int j = 0; j < 3; ++j) xk[j] = w->pos[b][j] + t[j];
+    mat3_mul_vec(Eb, o, t);
+    for (int j = 0; j < 3; ++j) xk[j] = pb[j] + t[j];
     REAL rad = md->cp_radius[k], gap;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
+    c->active = 0;
     if (kind == WBC_CP_TERRAIN) {
       REAL Xw[3], h, nw[3];
       mat3_mul_vec(R, xk, t);
@@ -444,12 +482,14 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       if (!c->active) continue;
       mat3T_mul_vec(R, nw, c->n);
       for (int j = 0; j < 3; ++j) c->xc[j] = xk[j] - rad * c->n[j];
-      c->mu = mu;
+      c->mu = (b == WBC_BOX_BODY) ? mu_box_terrain : mu;
     } else {
       /* sphere centre in the partner body's frame */
+      const REAL* E2 = (b2 == WBC_BOX_BODY) ? bx.E : w->E[b2];
+      const REAL* p2 = (b2 == WBC_BOX_BODY) ? bx.c : w->pos[b2];
       REAL d[3], pl[3], ql[3], nl[3], dist;
-      for (int j = 0; j < 3; ++j) d[j] = xk[j] - w->pos[b2][j];
-      mat3T_mul_vec(w->E[b2], d, pl);
+      for (int j = 0; j < 3; ++j) d[j] = xk[j] - p2[j];
+      mat3T_mul_vec(E2, d, pl);
       const float* A = md->cp_a[k]; const float* B = md->cp_b[k];
       if (kind == WBC_CP_BOX) {            /* closest point of the box (centre A, half extents B) */
         int inside = 1;
@@ -490,34 +530,45 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       }
       c->active = gap < (REAL)cf->contact_margin;
       if (!c->active) continue;
-      mat3_mul_vec(w->E[b2], nl, c->n);
-      mat3_mul_vec(w->E[b2], ql, t);
-      for (int j = 0; j < 3; ++j) c->xc[j] = w->pos[b2][j] + t[j];     /* on the partner's surface */
-      c->mu = mu_self;
+      mat3_mul_vec(E2, nl, c->n);
+      mat3_mul_vec(E2, ql, t);
+      for (int j = 0; j < 3; ++j) c->xc[j] = p2[j] + t[j];             /* on the partner's surface */
+      c->mu = (b2 == WBC_BOX_BODY) ? mu_box_robot : mu_self;
     }
     any = 1;
     c->vn_tgt = (gap >= 0) ? -gap / dt : fmin((REAL)cf->contact_erp * (-gap) / dt, (REAL)cf->max_depenetration_vel);
-    /* W = J K J^T, J = [-xc x, 1], summed over the two bodies of a self-collision pair (their cross coupling through the
-     * tree is left to the block-Jacobi sweeps, as the coupling between different contacts is) */
+    /* W = J K J^T, J = [-xc x, 1], summed over the two bodies of a pair (their cross coupling through the tree is left to the
+     * block-Jacobi sweeps, as the coupling between different contacts is). The free box contributes the closed form of a rigid
+     * body with isotropic inertia about its centre: 1/m + (|r|^2 1 - r r^T) / Ic, r = xc - centre. */
     REAL X[9] = {0, -c->xc[2], c->xc[1], c->xc[2], 0, -c->xc[0], -c->xc[1], c->xc[0], 0};
     REAL J[18];
     for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) { J[r * 6 + cc] = -X[r * 3 + cc]; J[r * 6 + 3 + cc] = (r == cc) ? 1 : 0; }
     for (int r = 0; r < 9; ++r) c->W[r] = 0;
+    for (int j = 0; j < 3; ++j) c->vfree[j] = 0;
     for (int side = 0; side < (kind == WBC_CP_TERRAIN ? 1 : 2); ++side) {
-      const REAL* K = w->K[side == 0 ? b : b2];
+      int bb = side == 0 ? b : b2;
+      REAL sgn = side == 0 ? 1 : -1;
+      if (bb == WBC_BOX_BODY) {
+        REAL r[3] = {c->xc[0] - bx.c[0], c->xc[1] - bx.c[1], c->xc[2] - bx.c[2]};
+        REAL rr = dot3(r, r), im = 1 / bx.m, iI = 1 / bx.Ic;
+        for (int a1 = 0; a1 < 3; ++a1) for (int a2 = 0; a2 < 3; ++a2)
+          c->W[a1 * 3 + a2] += (a1 == a2 ? im + rr * iI : 0) - r[a1] * r[a2] * iI;
+        /* free motion: the centre falls with gravity, the spin is constant (isotropic inertia) */
+        REAL wr[3], vp[3], wwr[3];
+        cross3(bx.w, r, wr);
+        for (int j = 0; j < 3; ++j) vp[j] = bx.v[j] + wr[j];
+        cross3(bx.w, wr, wwr);
+        for (int j = 0; j < 3; ++j) c->vfree[j] += sgn * (vp[j] + dt * (gF[j] + wwr[j]));
+        continue;
+      }
+      const REAL* K = w->K[bb];
       REAL KJt[18];
       for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc) KJt[r * 3 + cc] = dot6(K + r * 6, J + cc * 6);
       for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
         REAL a = 0; for (int j = 0; j < 6; ++j) a += J[r * 6 + j] * KJt[j * 3 + cc];
         c->W[r * 3 + cc] += a;
       }
-    }
-    for (int r = 0; r < 3; ++r) c->W[r * 3 + r] += (REAL)1e-6;
-    /* velocity of the contact point after the unconstrained step (relative to the partner body's point for a pair) */
-    for (int j = 0; j < 3; ++j) c->vfree[j] = 0;
-    for (int side = 0; side < (kind == WBC_CP_TERRAIN ? 1 : 2); ++side) {
-      int bb = side == 0 ? b : b2;
-      REAL sgn = side == 0 ? 1 : -1;
+      /* velocity of the contact point after the unconstrained step (relative to the partner body's point for a pair) */
       REAL vp[3], ab[6], apnt[3], t2[3];
       cross3(w->v[bb], c->xc, t);
       for (int j = 0; j < 3; ++j) vp[j] = w->v[bb][3 + j] + t[j];
@@ -526,11 +577,25 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       cross3(w->v[bb], vp, t2);
       for (int j = 0; j < 3; ++j) { apnt[j] = ab[3 + j] + t[j] + t2[j]; c->vfree[j] += sgn * (vp[j] + dt * apnt[j]); }
     }
+    /* the solver reads the upper triangle (exactly symmetric by construction of the product; the kernel stores six entries) */
+    c->W[3] = c->W[1]; c->W[6] = c->W[2]; c->W[7] = c->W[5];
+    for (int r = 0; r < 3; ++r) c->W[r * 3 + r] += (REAL)1e-6;
   }
   REAL qddD[WBC_NB] = {0}, aD0[6] = {0};
-  for (int k = 0; k < md->ncp; ++k) {
-    ct[k].nshare = 0;
-    if (ct[k].active) for (int j = 0; j < md->ncp; ++j) ct[k].nshare += ct[j].active && md->cp_body[j] == md->cp_body[k];
+  REAL boxF[3] = {0, 0, 0}, boxN[3] = {0, 0, 0};       /* net contact force on the box, its moment about the box centre (frame F) */
+  {
+    /* damped block-Jacobi: how many active contacts act on each body (as the sphere's body or as the partner of a pair) */
+    int cnt[WBC_NB + 1] = {0};
+    for (int k = 0; k < md->ncp; ++k) if (ct[k].active) {
+      cnt[md->cp_body[k]] += 1;
+      if (md->cp_kind[k] != WBC_CP_TERRAIN) cnt[md->cp_body2[k]] += 1;
+    }
+    for (int k = 0; k < md->ncp; ++k) {
+      ct[k].nshare = 0;
+      if (!ct[k].active) continue;
+      ct[k].nshare = cnt[md->cp_body[k]];
+      if (md->cp_kind[k] != WBC_CP_TERRAIN && cnt[md->cp_body2[k]] > ct[k].nshare) ct[k].nshare = cnt[md->cp_body2[k]];
+    }
   }
   if (any) {
     REAL dv[WBC_NCP][3];
@@ -544,24 +609,31 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
         mat3_mul_vec(c->W, c->lam, own);
         for (int j = 0; j < 3; ++j) vref[j] = c->vfree[j] + dv[k][j] - own[j];
         contact_solve(c, vref, ln);
-        /* damped block-Jacobi: contacts of spheres on the SAME body see (almost) the same inverse inertia, so each of the m
-         * active ones would remove the whole approach velocity on its own; they share it instead (relaxation 1/m; a convex
-         * combination of two impulses inside the friction cone stays inside it). m = 1 for a lone foot: plain block-Jacobi. */
+        /* damped block-Jacobi: the contacts acting on ONE body see (almost) the same inverse inertia, so each of the m
+         * active ones would remove the whole approach velocity on its own; they share it instead (relaxation 1/m, m counted on
+         * the busier of the contact's two bodies; a convex combination of two impulses inside the friction cone stays inside
+         * it). m = 1 for a lone foot: plain block-Jacobi. */
         REAL om = 1 / (REAL)c->nshare;
         for (int j = 0; j < 3; ++j) c->lam[j] += om * (ln[j] - c->lam[j]);
       }
-      /* response of the whole tree to all contact impulses */
+      /* response of the whole tree, and of the free box, to all contact impulses */
       REAL pD[WBC_NB][6], uD[WBC_NB];
+      REAL bF[3] = {0, 0, 0}, bN[3] = {0, 0, 0};      /* on the box: force, moment about the box centre */
       memset(pD, 0, sizeof(pD));
       for (int k = 0; k < md->ncp; ++k) {
         contact_t* c = &ct[k];
         if (!c->active) continue;
-        REAL f[3] = {c->lam[0] / dt, c->lam[1] / dt, c->lam[2] / dt}, mom[3];
-        cross3(c->xc, f, mom);
+        REAL f[3] = {c->lam[0] / dt, c->lam[1] / dt, c->lam[2] / dt}, mom[3], momb[3];
+        REAL rb3[3] = {c->xc[0] - bx.c[0], c->xc[1] - bx.c[1], c->xc[2] - bx.c[2]};
+        cross3(c->xc, f, mom);                            /* about F's origin (tree bodies) */
+        cross3(rb3, f, momb);                             /* about the box centre */
         int b = md->cp_body[k], b2 = md->cp_body2[k];
-        for (int j = 0; j < 3; ++j) { pD[b][j] -= mom[j]; pD[b][3 + j] -= f[j]; }
-        if (md->cp_kind[k] != WBC_CP_TERRAIN)            /* the partner body receives the opposite wrench */
-          for (int j = 0; j < 3; ++j) { pD[b2][j] += mom[j]; pD[b2][3 + j] += f[j]; }
+        if (b == WBC_BOX_BODY) { for (int j = 0; j < 3; ++j) { bN[j] += momb[j]; bF[j] += f[j]; } }
+        else for (int j = 0; j < 3; ++j) { pD[b][j] -= mom[j]; pD[b][3 + j] -= f[j]; }
+        if (md->cp_kind[k] != WBC_CP_TERRAIN) {          /* the partner body receives the opposite wrench */
+          if (b2 == WBC_BOX_BODY) { for (int j = 0; j < 3; ++j) { bN[j] -= momb[j]; bF[j] -= f[j]; } }
+          else for (int j = 0; j < 3; ++j) { pD[b2][j] += mom[j]; pD[b2][3 + j] += f[j]; }
+        }
       }
       for (int i = WBC_NB - 1; i >= 1; --i) {
         int p = md->parent[i];
@@ -577,20 +649,39 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
         qddD[i] = qdd;
         for (int k = 0; k < 6; ++k) aD[i][k] = aD[p][k] + w->S[i][k] * qdd;
       }
+      /* the box: centre acceleration F/m, angular acceleration n/Ic */
+      REAL bal[3], baa[3];
+      for (int j = 0; j < 3; ++j) { boxF[j] = bF[j]; boxN[j] = bN[j]; bal[j] = boxF[j] / bx.m; baa[j] = boxN[j] / bx.Ic; }
       for (int k = 0; k < md->ncp; ++k) {
         contact_t* c = &ct[k];
         if (!c->active) continue;
         int b = md->cp_body[k], b2 = md->cp_body2[k];
         REAL t[3];
-        cross3(aD[b], c->xc, t);
-        for (int j = 0; j < 3; ++j) dv[k][j] = dt * (aD[b][3 + j] + t[j]);
-        if (md->cp_kind[k] != WBC_CP_TERRAIN) {
-          cross3(aD[b2], c->xc, t);
-          for (int j = 0; j < 3; ++j) dv[k][j] -= dt * (aD[b2][3 + j] + t[j]);
+        for (int side = 0; side < (md->cp_kind[k] == WBC_CP_TERRAIN ? 1 : 2); ++side) {
+          int bb = side == 0 ? b : b2;
+          REAL sgn = side == 0 ? 1 : -1, resp[3];
+          if (bb == WBC_BOX_BODY) {
+            REAL r[3] = {c->xc[0] - bx.c[0], c->xc[1] - bx.c[1], c->xc[2] - bx.c[2]};
+            cross3(baa, r, t);
+            for (int j = 0; j < 3; ++j) resp[j] = bal[j] + t[j];
+          } else {
+            cross3(aD[bb], c->xc, t);
+            for (int j = 0; j < 3; ++j) resp[j] = aD[bb][3 + j] + t[j];
+          }
+          for (int j = 0; j < 3; ++j) dv[k][j] = (side == 0 ? 0 : dv[k][j]) + sgn * dt * resp[j];
         }
       }
     }
     for (int r = 0; r < 6; ++r) aD0[r] = aD[0][r];
+  }
+  if (g_dump) for (int k = 0; k < WBC_NCP; ++k) {
+    g_dump->active[k] = k < md->ncp && ct[k].active;
+    g_dump->nshare[k] = k < md->ncp ? ct[k].nshare : 0;
+    for (int j = 0; j < 3; ++j) {
+      g_dump->lam[k][j] = g_dump->active[k] ? (double)ct[k].lam[j] : 0;
+      g_dump->n[k][j] = g_dump->active[k] ? (double)ct[k].n[j] : 0;
+      g_dump->xc[k][j] = g_dump->active[k] ? (double)ct[k].xc[j] : 0;
+    }
   }
   /* contact force outputs: world-frame net force per rigid body, foot-frame wrench per sensor */
   memset(e->contact_force, 0, sizeof(e->contact_force));
@@ -602,10 +693,9 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     mat3_mul_vec(R, f, fw);
     int rb = md->cp_rb[k];
     for (int j = 0; j < 3; ++j) e->contact_force[rb][j] += fw[j];
-    if (md->cp_kind[k] != WBC_CP_TERRAIN) {              /* PhysX reports self-collision forces in net_contact_force too */
+    if (md->cp_kind[k] != WBC_CP_TERRAIN)                /* PhysX reports pair forces in net_contact_force too */
       for (int j = 0; j < 3; ++j) e->contact_force[md->cp_rb2[k]][j] -= fw[j];
-      continue;
-    }
+    /* a foot's sensor sees every contact of the foot sphere: the terrain's and the box's */
     for (int ft = 0; ft < WBC_NFEET; ++ft) if (md->feet_rb[ft] == rb) {
       int b = md->cp_body[k];
       REAL fl[3], arm[3], tq[3], tl[3];
@@ -642,6 +732,23 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
   for (int k = 0; k < 4; ++k) { nq[k] = qt[k] + (REAL)0.5 * dt * dq[k]; nn += nq[k] * nq[k]; }
   nn = 1 / sqrt(nn);
   for (int k = 0; k < 4; ++k) qt[k] = nq[k] * nn;
+  /* the box: gravity + its net contact force; same integrator */
+  {
+    REAL accB[3], alB[3];
+    for (int k = 0; k < 3; ++k) { accB[k] = gF[k] + boxF[k] / bx.m; alB[k] = boxN[k] / bx.Ic; }
+    mat3_mul_vec(R, accB, t);
+    for (int k = 0; k < 3; ++k) e->root[1][7 + k] += dt * t[k];
+    mat3_mul_vec(R, alB, t);
+    for (int k = 0; k < 3; ++k) e->root[1][10 + k] += dt * t[k];
+    for (int k = 0; k < 3; ++k) e->root[1][k] += dt * e->root[1][7 + k];
+    REAL* qb = e->root[1] + 3;
+    REAL omb[4] = {e->root[1][10], e->root[1][11], e->root[1][12], 0}, dqb[4];
+    quat_mul(omb, qb, dqb);
+    REAL nb4[4], nnb = 0;
+    for (int k = 0; k < 4; ++k) { nb4[k] = qb[k] + (REAL)0.5 * dt * dqb[k]; nnb += nb4[k] * nb4[k]; }
+    nnb = 1 / sqrt(nnb);
+    for (int k = 0; k < 4; ++k) qb[k] = nb4[k] * nnb;
+  }
 }
 
 /* rigid_body_state of the 27 robot bodies + the box (WG:546-556), world frame. */
@@ -1005,6 +1112,7 @@ ORA_API ora_sim* ora_create(const wbc_model* model, const wbc_task_cfg* cfg, int
     for (int k = 0; k < WBC_NACT; ++k) e->motor_strength[k] = 1;
     e->friction = 1;
     e->goal[G_TRAJ] = 100; e->goal[G_TOTAL] = 150;
+    e->box_mass = model->box_mass;
     e->body_params[0] = model->mass[0];
     for (int k = 0; k < 3; ++k) e->body_params[1 + k] = model->com[0][k];
     for (int k = 0; k < 6; ++k) e->body_params[4 + k] = model->inertia[0][k];
@@ -1059,6 +1167,7 @@ static int field_ptr(ora_env* e, int id, REAL** p, int* n) {
     case WBC_T_BOX_DELTA_Y: *p = &e->box_delta_y; *n = 1; return 0;
     case WBC_T_BODY_PARAMS: *p = e->body_params; *n = 20; return 0;
     case WBC_T_RESET_TRAVEL: *p = e->reset_travel; *n = 2; return 0;
+    case WBC_T_BOX_MASS: *p = &e->box_mass; *n = 1; return 0;
     default: return -1;
   }
 }
@@ -1130,6 +1239,19 @@ ORA_API void ora_refresh_rigid_body_state(ora_sim* s) {
 /* _compute_torques over all envs with the currently stored self.actions */
 ORA_API void ora_compute_torques(ora_sim* s) {
   for (int i = 0; i < s->n; ++i) compute_torques(s, &s->env[i]);
+}
+
+/* Diagnostics: the contact list of one substep of env i run on a COPY of its state (the env is not advanced):
+ * active[NCP], nshare[NCP], lam[NCP][3] (impulses, frame F), n[NCP][3], xc[NCP][3]. */
+ORA_API void ora_debug_contacts(ora_sim* s, int i, int* active, int* nshare, double* lam, double* n, double* xc) {
+  ora_env copy = s->env[i];
+  contact_dump d;
+  memset(&d, 0, sizeof(d));
+  g_dump = &d;
+  physics_substep(s, &copy);
+  g_dump = NULL;
+  memcpy(active, d.active, sizeof(d.active)); memcpy(nshare, d.nshare, sizeof(d.nshare));
+  memcpy(lam, d.lam, sizeof(d.lam)); memcpy(n, d.n, sizeof(d.n)); memcpy(xc, d.xc, sizeof(d.xc));
 }
 
 /* Diagnostics for tests/test_oracle_physics.py: joint accelerations and base spatial

@@ -335,6 +335,89 @@ def _synced_steps(robot, g, o, n, steps, rng, tag, check_travel=False):
     return resets
 
 
+def test_box_actor_matches_oracle(robot):
+    """The free box actor (widowGo1.py:321-325,384,769-771: a 0.1 m cube of 1 kg + its mass draw, eight corner spheres against the
+    terrain, the robot's foot spheres and gripper tip against it). Staged: boxes dropped from their spawn height, boxes thrown and
+    spinning, boxes in the path of a front foot of a robot walking into them, boxes dropped onto the gripper; on the plane and on a
+    height grid. HIP vs the fp64 oracle from a synced state: both rows of ROOT_STATES, the box row of NET_CONTACT_FORCE / of
+    RIGID_BODY_STATE, the foot sensors (a foot against the box shows up there), masks bit-exact."""
+    import torch
+    n = 512
+    params = helpers.random_env_params(n, seed=71)
+    rng = np.random.default_rng(72)
+    params["env_origins"] = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), np.zeros(n)], 1).astype(np.float32)
+    params["box_dmass"] = rng.uniform(-0.001, 0.05, n).astype(np.float32)
+    tc = type(robot["tcfg"]).from_buffer_copy(robot["tcfg"])
+    tc.term_z_threshold = 0.15
+    feet = list(robot["wmodel"].feet_rb)
+    for use_hf in (False, True):
+        g = helpers.make_gpu(robot, n, params, tcfg=tc)
+        o = helpers.make_oracle(robot, n, params, "f64", tcfg=tc)
+        np.testing.assert_allclose(_t(g, "BOX_MASS"), o.get("BOX_MASS"), rtol=1e-6)
+        if use_hf:
+            hf = _make_heightfield(rows=200, cols=200, seed=9)
+            hs, vs = 0.1, 0.005
+            args = (hf, hs, vs, -0.5 * hf.shape[0] * hs, -0.5 * hf.shape[1] * hs, 0.0)
+            g.set_heightfield(*args); o.set_heightfield(*args)
+        g.reset_all()
+        torch.cuda.synchronize()
+        root = _t(g, "ROOT_STATES").astype(np.float32)
+        dof = _t(g, "DOF_STATE").astype(np.float32)
+        q = n // 4
+        ground = root[:, 0, 2] - 0.42                                          # nominal ground height under the robot (spawn height 0.42)
+        A, B, Cc, D = slice(0, q), slice(q, 2 * q), slice(2 * q, 3 * q), slice(3 * q, n)
+        # (a) dropped from the spawn height (WG:769-771 puts the box at world x = 0; here: within a metre of the robot)
+        root[A, 1, 0] = root[A, 0, 0] + rng.uniform(0.5, 1.0, q)
+        root[A, 1, 2] = ground[A] + float(tc.box_origin_z)
+        # (b) thrown and spinning
+        root[B, 1, :3] = root[B, 0, :3] + np.stack([rng.uniform(0.6, 1.2, q), rng.uniform(-0.5, 0.5, q), rng.uniform(-0.3, 0.0, q)], 1)
+        root[B, 1, 7:10] = rng.uniform(-1.5, 1.5, (q, 3))
+        root[B, 1, 10:13] = rng.uniform(-8, 8, (q, 3))
+        ang = rng.normal(size=(q, 4))
+        root[B, 1, 3:7] = ang / np.linalg.norm(ang, axis=1, keepdims=True)
+        # (c) in the path of a front foot (default stance: front feet about 0.19 m ahead and 0.13 m to the side of the base)
+        side = rng.choice([-1.0, 1.0], q)
+        root[Cc, 1, 0] = root[Cc, 0, 0] + 0.19 + 0.05 + rng.uniform(0.0, 0.04, q)
+        root[Cc, 1, 1] = root[Cc, 0, 1] + side * 0.13 + rng.uniform(-0.04, 0.04, q)
+        root[Cc, 1, 2] = ground[Cc] + 0.05 + (0.06 if use_hf else 0.0)
+        root[Cc, 0, 7] = rng.uniform(0.3, 1.0, q)
+        # (d) dropped onto the gripper: the arm stretched out in front of the robot, the box released just above its tip
+        dof[D, 13, 0] = rng.uniform(1.2, 1.6, n - 3 * q)
+        dof[D, 14, 0] = rng.uniform(-0.6, -0.2, n - 3 * q)
+        g.tensor("DOF_STATE").copy_(torch.from_numpy(dof))
+        g.tensor("ROOT_STATES").copy_(torch.from_numpy(root))
+        g.refresh_rigid_body_state()
+        ee = _t(g, "RIGID_BODY_STATE")[D, robot["wmodel"].gripper_rb, :3]
+        root[D, 1, :3] = ee + np.stack([rng.uniform(-0.03, 0.03, n - 3 * q), rng.uniform(-0.03, 0.03, n - 3 * q),
+                                        0.062 + rng.uniform(-0.004, 0.01, n - 3 * q)], 1)
+        g.tensor("ROOT_STATES").copy_(torch.from_numpy(root))
+        foot_hits = grip_hits = box_steps = 0
+        for step in range(6):
+            helpers.sync_oracle_from_gpu(o, g)
+            a = (0.3 * rng.normal(size=(n, 18))).astype(np.float32)
+            g.step(torch.from_numpy(a).cuda()); o.step(a)
+            tag = f"box actor ({'grid' if use_hf else 'plane'}), step {step}"
+            for name in ("RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH"):
+                np.testing.assert_array_equal(_t(g, name), o.get(name), err_msg=f"{tag} {name}")
+            fo, fg = o.get("NET_CONTACT_FORCE"), _t(g, "NET_CONTACT_FORCE")
+            _assert_close_bulk(fg, fo, 0.08, 5e-3, f"{tag} NET_CONTACT_FORCE", frac=4e-3, slack=1e9)
+            ro, rg = o.get("ROOT_STATES"), _t(g, "ROOT_STATES")
+            _assert_close_bulk(rg[:, 0], ro[:, 0], 4e-4, 5e-4, f"{tag} ROOT_STATES robot", frac=2e-3)
+            # the box: 1 kg on 0.1 m -- a corner that touches one substep apart in fp32 moves it visibly: the bulk must be tight
+            _assert_close_bulk(rg[:, 1, :7], ro[:, 1, :7], 4e-4, 5e-4, f"{tag} box pose", frac=1e-2, slack=1e9)
+            _assert_close_bulk(rg[:, 1, 7:10], ro[:, 1, 7:10], 2e-3, 2e-3, f"{tag} box velocity", frac=2e-2, slack=1e9)
+            _assert_close_bulk(rg[:, 1, 10:], ro[:, 1, 10:], 3e-2, 5e-3, f"{tag} box spin", frac=2e-2, slack=1e9)
+            np.testing.assert_allclose(_t(g, "RIGID_BODY_STATE")[:, 27], rg[:, 1], atol=1e-6)
+            for name, atol, rtol in (("DOF_STATE", 6e-4, 1e-3), ("FORCE_SENSOR", 0.08, 5e-3), ("OBS_BUF", 3e-3, 1e-3), ("REW_BUF", 2e-4, 2e-3)):
+                _assert_close_bulk(_t(g, name), o.get(name), atol, rtol, f"{tag} {name}", frac=4e-3, slack=1e9)
+            box_steps += int((np.abs(fo[:, 27]).sum(-1) > 0).sum())
+            # a front foot pushed along x together with the box / the gripper pushed up with the box loaded: the pairs at work
+            foot_hits += int(((np.abs(fo[Cc][:, feet[:2], 0]) > 1.0).any(-1) & (np.abs(fo[Cc][:, 27, 0]) > 1.0)).sum())
+            grip_hits += int(((fo[D][:, robot["wmodel"].gripper_rb, 2] < -0.2) & (fo[D][:, 27, 2] > 0.2)).sum())
+        assert box_steps > n and foot_hits > 20 and grip_hits > 20, (box_steps, foot_hits, grip_hits)
+        g.close()
+
+
 def test_step_at_baseline_config1_4096_flat(robot):
     """BASELINE.json configs[1] (the bench workload): 4096 envs on the plane, the fused step against the fp32 oracle from a
     synced state, after a settling rollout so that the batch holds standing, falling and freshly reset robots."""

@@ -206,30 +206,47 @@ def test_rollout_slot_hand_over_is_cuda_only_and_storage_skips_filled_slots():
 
 def test_collision_set_follows_the_urdf_collision_blocks():
     """abi.collision_set: the URDF's <collision> geometry (urdf/widowGo1.urdf) as the contact list of the physics spec: one sphere
-    per foot first (the force sensors read contacts 0..3), trunk-box corners on the box surface, thigh tops / knees on the thigh
-    and calf rows, arm spheres; self-collision pairs last, each naming a partner body different from its own; fits WBC_NCP."""
+    per foot first (the force sensors read contacts 0..3), trunk-box corners on the box surface, thigh tops / knees / mid-shanks on
+    the thigh and calf rows, arm spheres, the corners of the free box actor (WG:321-325); then the pairs, each naming a partner
+    body different from its own: the robot's self-collision pairs and the robot spheres against the box; fits WBC_NCP."""
     m = abi.load_default_model()
     cps = abi.collision_set(m)
     names = m.rb_names
-    assert len(cps) == 30 <= abi.NCP
+    assert len(cps) == 47 <= abi.NCP
     feet = [i for i, n in enumerate(names) if "foot" in n]
     assert [c["rb"] for c in cps[:4]] == feet and all(c["kind"] == abi.CP_TERRAIN and c["radius"] == 0.02 for c in cps[:4])
     terrain = [c for c in cps if c["kind"] == abi.CP_TERRAIN]
     pairs = [c for c in cps if c["kind"] != abi.CP_TERRAIN]
-    assert len(terrain) == 23 and cps[:23] == terrain and len(pairs) == 7
-    corners = [c for c in terrain if names[c["rb"]] == "trunk"]
+    assert len(terrain) == 35 and cps[:35] == terrain and len(pairs) == 12
+    robot_terrain = [c for c in terrain if c["body"] != abi.BOX_BODY]
+    box_corners = [c for c in terrain if c["body"] == abi.BOX_BODY]
+    assert len(robot_terrain) == 27 and len(box_corners) == 8 and all(c["rb"] == abi.BOX_RB for c in box_corners)
+    for c in box_corners:                                # sphere surface = the 0.1 m cube (box.box_size, widowGo1_config.py:186)
+        np.testing.assert_allclose(np.abs(c["pos"]) + c["radius"], 0.05, atol=1e-9)
+    corners = [c for c in robot_terrain if names[c["rb"]] == "trunk"]
     assert len(corners) == 8
     for c in corners:                                    # sphere surface = the URDF box 0.3762 x 0.0935 x 0.114
         np.testing.assert_allclose(np.abs(c["pos"]) + c["radius"], np.array([0.3762, 0.0935, 0.114]) / 2, atol=1e-9)
-    assert sorted(names[c["rb"]] for c in terrain if "thigh" in names[c["rb"]]) == ["FL_thigh", "FR_thigh", "RL_thigh", "RR_thigh"]
-    assert sum("calf" in names[c["rb"]] for c in terrain) == 4
-    arm = {names[c["rb"]] for c in terrain if "wx250s" in names[c["rb"]]}
+    assert sorted(names[c["rb"]] for c in robot_terrain if "thigh" in names[c["rb"]]) == ["FL_thigh", "FR_thigh", "RL_thigh", "RR_thigh"]
+    calf = [c for c in robot_terrain if "calf" in names[c["rb"]]]
+    assert len(calf) == 8                                # knee (calf origin) + mid-shank (the middle of the calf box, urdf:981)
+    shank = [c for c in calf if c["radius"] == abi.CALF_RADIUS]
+    assert len(shank) == 4
+    for c in shank:
+        np.testing.assert_allclose(c["pos"] - np.asarray(m.rb_offset[c["rb"]]), [0, 0, -0.1065], atol=1e-9)
+    arm = {names[c["rb"]] for c in robot_terrain if "wx250s" in names[c["rb"]]}
     assert arm == {"wx250s/ee_gripper_link", "wx250s/upper_forearm_link", "wx250s/wrist_link"}
-    for c in pairs:
+    self_pairs = [c for c in pairs if c["body2"] != abi.BOX_BODY]
+    box_pairs = [c for c in pairs if c["body2"] == abi.BOX_BODY]
+    assert len(self_pairs) == 7 and len(box_pairs) == 5
+    for c in self_pairs:
         assert c["body2"] >= 0 and c["body2"] != c["body"] and "wx250s" in names[c["rb"]]
         assert names[c["rb2"]] in ("trunk", "FL_thigh", "FR_thigh")
         assert (c["kind"] == abi.CP_BOX) == (names[c["rb2"]] == "trunk")
-    assert abi.fill_model(m, self_collisions=False).ncp == 23
+    for c in box_pairs:
+        assert c["kind"] == abi.CP_BOX and c["rb2"] == abi.BOX_RB and np.allclose(c["b"], 0.05) and np.allclose(c["a"], 0)
+    assert sorted(names[c["rb"]] for c in box_pairs) == sorted([names[i] for i in feet] + ["wx250s/ee_gripper_link"])
+    assert abi.fill_model(m, self_collisions=False).ncp == 35          # no pairs at all: the box actor shares the filter (WG:384)
     # rigid-body masks of the task config (WG:299-306: substring match)
     cfg = WidowGo1RoughCfg()
     cfg.asset.terminate_after_contacts_on = ["wx250", "base"]        # the list the reference keeps commented out (widowGo1_config.py:179)

@@ -193,6 +193,7 @@ def test_static_stance_supports_weight(robot):
     o.set_curriculum(default_curriculum(robot["cfg"]))
     root = np.zeros((1, 2, 13))
     root[0, 0, 2], root[0, 0, 6], root[0, 1, 6] = 0.34, 1, 1
+    root[0, 1, :3] = [2.0, 0.0, 0.05]                         # the box actor rests out of reach
     o.set("ROOT_STATES", root)
     dof = np.zeros((1, 20, 2))
     dof[0, :, 0] = np.array(tc.default_dof_pos)
@@ -202,7 +203,7 @@ def test_static_stance_supports_weight(robot):
         o.compute_torques()
         o.simulate()
     r = o.get("ROOT_STATES")[0, 0]
-    f = o.get("NET_CONTACT_FORCE")[0]
+    f = o.get("NET_CONTACT_FORCE")[0, :27]
     mtot = sum(b[0] for b in make_params(model, o.get("BODY_PARAMS")[0]))
     assert np.abs(r[7:13]).max() < 5e-3                       # at rest
     assert 0.28 < r[2] < 0.34                                 # standing on its feet
@@ -268,7 +269,7 @@ def test_self_collision_impulses_are_internal(robot, want_thigh):
         return P, L
     P0, L0 = momentum()
     o.simulate()
-    f = o.get("NET_CONTACT_FORCE")[0]
+    f = o.get("NET_CONTACT_FORCE")[0, :27]                              # (row 27 is the box actor, resting on the ground far below)
     rows = np.nonzero(np.abs(f).sum(1) > 0)[0]
     assert len(rows) >= 2 and np.abs(f).max() > 0.5                     # a pair is pushing
     np.testing.assert_allclose(f.sum(0), 0, atol=1e-9 * np.abs(f).max())   # ... with equal and opposite forces
@@ -281,7 +282,7 @@ def test_self_collision_impulses_are_internal(robot, want_thigh):
     np.testing.assert_allclose(L1, L0, atol=2e-3 * max(1.0, np.abs(L0).max()))
     for _ in range(60):                                                  # depenetration at <= max_depenetration_velocity: it lets go
         o.simulate()
-    assert np.abs(o.get("NET_CONTACT_FORCE")[0]).max() < 1e-9 or np.abs(o.get("DOF_STATE")[0, 12:18, 1]).max() < 20.0
+    assert np.abs(o.get("NET_CONTACT_FORCE")[0, :27]).max() < 1e-9 or np.abs(o.get("DOF_STATE")[0, 12:18, 1]).max() < 20.0
 
 
 def test_trunk_and_thighs_rest_on_the_ground(robot):
@@ -294,6 +295,7 @@ def test_trunk_and_thighs_rest_on_the_ground(robot):
     o.set_curriculum(default_curriculum(robot["cfg"]))
     root = np.zeros((1, 2, 13))
     root[0, 0, 2], root[0, 0, 6], root[0, 1, 6] = 0.075, 1, 1
+    root[0, 1, :3] = [2.0, 0.0, 0.05]                         # the box actor rests out of reach
     dof = np.zeros((1, 20, 2))
     dof[0, :, 0] = np.array(tc.default_dof_pos)
     for leg in range(4):
@@ -308,7 +310,7 @@ def test_trunk_and_thighs_rest_on_the_ground(robot):
         o.compute_torques()
         o.simulate()
     r = o.get("ROOT_STATES")[0, 0]
-    f = o.get("NET_CONTACT_FORCE")[0]
+    f = o.get("NET_CONTACT_FORCE")[0, :27]
     mtot = sum(b[0] for b in make_params(model, o.get("BODY_PARAMS")[0]))
     names = model.rb_names
     trunk, thighs = names.index("trunk"), [i for i, nm in enumerate(names) if "thigh" in nm]
@@ -362,7 +364,7 @@ def test_self_collision_geometry_against_brute_force(robot):
     cap = np.stack([0.017 * np.sin(th) * np.cos(ph), 0.017 * np.sin(th) * np.sin(ph), 0.017 * np.cos(th)], -1).reshape(-1, 3)
     caps = np.concatenate([cyl, cap, cap * [1, 1, -1] + [0, 0, -0.213]])
     checked = hits = 0
-    pair_ids = [k for k in range(wm.ncp) if wm.cp_kind[k] != abi.CP_TERRAIN]
+    pair_ids = [k for k in range(wm.ncp) if wm.cp_kind[k] != abi.CP_TERRAIN and wm.cp_body2[k] != abi.BOX_BODY]
     for rb1 in sorted({wm.cp_rb[k] for k in pair_ids}):               # per arm sphere: its net_contact_force row sums its pairs
         mine = [k for k in pair_ids if wm.cp_rb[k] == rb1]
         rad = wm.cp_radius[mine[0]]

@@ -129,7 +129,7 @@ def self_contact_arm_poses(backend, count, rng):
     dof[:, 12:18, 0] = rng.uniform(lo, hi, (n, 6))
     o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
     o.simulate()
-    f = o.get("NET_CONTACT_FORCE")
+    f = o.get("NET_CONTACT_FORCE")[:, :27]                         # (row 27: the box actor, resting on the ground below)
     hit = np.abs(f).sum((1, 2)) > 0
     thigh = np.abs(f[:, [3, 7]]).sum((1, 2)) > 0                   # FL_thigh, FR_thigh rows: a gripper / wrist against a thigh
     picks = list(np.nonzero(thigh)[0][:max(1, count // 3)]) + list(np.nonzero(hit & ~thigh)[0])

@@ -139,13 +139,14 @@ def make_reference_env(num_envs, seed=1, cfg=None, quiet=True, heightfield=None)
     dcom = np.array([b.env_mass[e][1] for e in range(n)])
     gmass = np.array([b.env_mass[e][2] for e in range(n)])
     fr = np.array([b.env_friction[e] for e in range(n)])
+    bdm = np.array([b.env_box_dmass.get(e, 0.0) for e in range(n)])
     np.testing.assert_allclose(np.concatenate([dmass[:, None], dcom, gmass[:, None]], 1), env.mass_params_tensor.numpy(), atol=1e-6)
     np.testing.assert_allclose(fr, env.friction_coeffs_tensor.numpy().reshape(n), atol=1e-6)
     env._env_params = dict(friction=fr.astype(np.float32), base_dmass=dmass.astype(np.float32), base_dcom=dcom.astype(np.float32),
                            gripper_dmass=gmass.astype(np.float32), motor_strength=env.motor_strength.numpy().copy(),
                            env_origins=env.env_origins.numpy().copy(), box_delta_y=env.box_env_origins_delta_y.numpy().copy(),
                            traj_timesteps=env.traj_timesteps.numpy().copy(),
-                           traj_total_timesteps=env.traj_total_timesteps.numpy().copy())
+                           traj_total_timesteps=env.traj_total_timesteps.numpy().copy(), box_dmass=bdm.astype(np.float32))
     b.ora.set_env_params(robot_model=b.model, **env._env_params)
     if heightfield is not None:
         b.ora.set_heightfield(*heightfield)

@@ -356,6 +356,7 @@ class FakeGym:
             self.b.env_friction[env] = self.b.pending_friction
             self.b.start_pos[env] = pose.p.tolist()
             return 0
+        self.b.box_start_pos[env] = pose.p.tolist()
         return 1
 
     def set_actor_dof_properties(self, env, actor, props):
@@ -363,7 +364,7 @@ class FakeGym:
 
     def get_actor_rigid_body_properties(self, env, actor):
         if actor == 1:
-            return [RigidBodyProperties(1.0, Vec3())]
+            return [RigidBodyProperties(float(self.b.wmodel.box_mass), Vec3())]       # create_box at density 1000 (WG:322-325)
         m = self.b.model
         return [RigidBodyProperties(float(m.rb_mass[i]), Vec3()) for i in range(m.num_rigid_bodies)]
 
@@ -373,6 +374,8 @@ class FakeGym:
             g = m.rb_names.index("wx250s/ee_gripper_link")
             self.b.env_mass[env] = (float(np.asarray(props[0].mass).reshape(-1)[0]) - float(m.rb_mass[0]), props[0].com.tolist(),
                                     float(np.asarray(props[g].mass).reshape(-1)[0]) - float(m.rb_mass[g]))
+        else:                                    # the box actor: _box_process_rigid_body_props added its mass draw (WG:458-466)
+            self.b.env_box_dmass[env] = float(np.asarray(props[0].mass).reshape(-1)[0]) - float(self.b.wmodel.box_mass)
 
     def get_actor_rigid_body_index(self, env, actor, body, domain):
         nb = self.b.model.num_rigid_bodies + 1
@@ -454,7 +457,8 @@ class OracleBackend:
         from oracle import OracleSim
         self.n = num_envs
         self.model = abi.load_default_model()
-        self.wmodel = abi.fill_model(self.model, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0)
+        self.wmodel = abi.fill_model(self.model, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0,
+                                     box_size=float(cfg.box.box_size))
         self.tcfg = abi.fill_task_cfg(cfg, self.model, sim_dt=sim_dt)
         self.ora = OracleSim(self.wmodel, self.tcfg, num_envs, seed=seed, precision="f64")
         nb = self.model.num_rigid_bodies + 1
@@ -465,7 +469,7 @@ class OracleBackend:
         self.t_rb = torch.zeros(num_envs * nb, 13)
         self.t_sensor = torch.zeros(num_envs * 4, 6)
         self.envs, self.sensor_bodies = [], []
-        self.env_friction, self.start_pos, self.env_mass = {}, {}, {}
+        self.env_friction, self.start_pos, self.env_mass, self.env_box_dmass, self.box_start_pos = {}, {}, {}, {}, {}
         self.pending_friction = 1.0
         self.heightfield = None
 
@@ -479,6 +483,7 @@ class OracleBackend:
         root[:, :, 6] = 1
         for e in range(n):
             root[e, 0, :3] = self.start_pos[e]
+            root[e, 1, :3] = self.box_start_pos[e]
         self.ora.set("ROOT_STATES", root)
         self.ora.refresh_rigid_body_state()
         for k in self._MAP:
