@@ -69,7 +69,13 @@ def random_standing_state(n, tcfg, rng, height=(0.30, 0.45)):
     root[:, 0, 3:7] = q
     root[:, 0, 7:10] = rng.uniform(-0.5, 0.5, (n, 3))
     root[:, 0, 10:13] = rng.uniform(-1, 1, (n, 3))
+    # the free box actor: near the robot, some resting on / dipping into the ground plane, some in the air, a few spinning
     root[:, 1, 6] = 1
+    root[:, 1, 0:2] = root[:, 0, 0:2] + rng.uniform(0.3, 0.8, (n, 2)) * rng.choice([-1.0, 1.0], (n, 2))
+    root[:, 1, 2] = rng.uniform(0.045, 0.15, n)
+    spin = rng.random(n) < 0.25
+    root[spin, 1, 7:10] = rng.uniform(-1, 1, (int(spin.sum()), 3))
+    root[spin, 1, 10:13] = rng.uniform(-5, 5, (int(spin.sum()), 3))
     dof = np.zeros((n, 20, 2), dtype=np.float32)
     dof[:, :, 0] = np.array(tcfg.default_dof_pos)[None] + rng.uniform(-0.25, 0.25, (n, 20))
     dof[:, :, 1] = rng.uniform(-2, 2, (n, 20))

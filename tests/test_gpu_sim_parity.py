@@ -16,6 +16,16 @@ pytestmark = pytest.mark.gpu
 N = 64
 
 
+def _rows_close(a, b, atol, rtol, msg):
+    """assert_allclose for [n, rows, k] tensors that names the offending (env, row) pairs."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    if bad.any():
+        idx = np.argwhere(bad.any(-1))[:8]
+        detail = "; ".join(f"env {e} row {r}: got {np.round(a[e, r], 4)} want {np.round(b[e, r], 4)}" for e, r in idx)
+        raise AssertionError(f"{msg}: {int(bad.any(-1).sum())} rows differ (max err {np.abs(a - b).max():.3e}): {detail}")
+
+
 def _t(g, name):
     import torch
     torch.cuda.synchronize()
@@ -42,7 +52,8 @@ def test_simulate_substep_matches_oracle(robot):
         np.testing.assert_allclose(_t(g, "DOF_STATE"), o.get("DOF_STATE"), atol=3e-4, rtol=1e-4)
         np.testing.assert_allclose(_t(g, "ROOT_STATES")[:, 0], o.get("ROOT_STATES")[:, 0], atol=3e-4, rtol=1e-4)
         fo = o.get("NET_CONTACT_FORCE")
-        np.testing.assert_allclose(_t(g, "NET_CONTACT_FORCE"), fo, atol=0.05, rtol=2e-3)
+        _rows_close(_t(g, "NET_CONTACT_FORCE"), fo, 0.05, 2e-3, f"substep {it} NET_CONTACT_FORCE")
+        _rows_close(_t(g, "ROOT_STATES")[:, 1:, :], o.get("ROOT_STATES")[:, 1:, :], 2e-3, 2e-3, f"substep {it} box state")
         np.testing.assert_allclose(_t(g, "FORCE_SENSOR"), o.get("FORCE_SENSOR"), atol=0.05, rtol=2e-3)
         n_contact += (np.abs(fo).sum(-1) > 0).sum()
         helpers.sync_oracle_from_gpu(o, g, ["ROOT_STATES", "DOF_STATE"])
@@ -175,9 +186,10 @@ def test_heightfield_contact_matches_oracle(robot):
         g.simulate(); o.simulate()
         fo = o.get("NET_CONTACT_FORCE")
         np.testing.assert_array_equal(np.abs(_t(g, "NET_CONTACT_FORCE")).sum(-1) > 0, np.abs(fo).sum(-1) > 0)   # same active set
-        np.testing.assert_allclose(_t(g, "NET_CONTACT_FORCE"), fo, atol=0.08, rtol=3e-3)
+        _rows_close(_t(g, "NET_CONTACT_FORCE"), fo, 0.08, 3e-3, f"heightfield substep {it} NET_CONTACT_FORCE")
         np.testing.assert_allclose(_t(g, "DOF_STATE"), o.get("DOF_STATE"), atol=4e-4, rtol=2e-4)
         np.testing.assert_allclose(_t(g, "ROOT_STATES")[:, 0], o.get("ROOT_STATES")[:, 0], atol=4e-4, rtol=2e-4)
+        _rows_close(_t(g, "ROOT_STATES")[:, 1:, :], o.get("ROOT_STATES")[:, 1:, :], 2e-3, 2e-3, f"heightfield substep {it} box state")
         touched += (np.abs(fo).sum(-1) > 0).sum()
         helpers.sync_oracle_from_gpu(o, g, ["ROOT_STATES", "DOF_STATE"])
     assert touched > n
@@ -291,7 +303,7 @@ def test_collision_set_matches_oracle(robot):
         _assert_close_bulk(fg, fo, 0.08, 5e-3, f"{tag} NET_CONTACT_FORCE", frac=2e-3)
         for name, atol, rtol in (("DOF_STATE", 6e-4, 1e-3), ("ROOT_STATES", 4e-4, 5e-4), ("TORQUES", 4e-4, 5e-4),
                                  ("REW_BUF", 2e-4, 2e-3), ("ARM_REW_BUF", 2e-5, 1e-3), ("OBS_BUF", 3e-3, 1e-3)):
-            _assert_close_bulk(_t(g, name), o.get(name), atol, rtol, f"{tag} {name}", frac=2e-3)
+            _close(name, _t(g, name), o.get(name), atol, rtol, f"{tag} {name}", frac=2e-3)
         np.testing.assert_allclose(_t(g, "EPISODE_SUMS")[live][:, 21], o.get("EPISODE_SUMS")[live][:, 21], atol=1e-6)   # the collision counts
         seen += (np.abs(fo[:, :27]).sum(-1) > 0).sum(0)
         resets += int(m.sum())
@@ -314,6 +326,16 @@ def _assert_close_bulk(a, b, atol, rtol, msg, frac=2e-5, slack=10.0):
     assert bad.mean() <= frac, f"{msg}: {bad.sum()} of {bad.size} outside tolerance (max err {err.max():.3e})"
 
 
+def _close(name, got, want, atol, rtol, msg, **kw):
+    """_assert_close_bulk; ROOT_STATES split into the robot's row (the given tolerance) and the box actor's (a 1 kg cube on corner
+    contacts: a corner that meets a terrain edge one substep apart in fp32 moves it by millimetres per second)."""
+    if name == "ROOT_STATES":
+        _assert_close_bulk(got[:, 0], want[:, 0], atol, rtol, msg + " (robot)", **kw)
+        _assert_close_bulk(got[:, 1], want[:, 1], 2e-3, 2e-3, msg + " (box)", frac=3e-3, slack=1e3)
+    else:
+        _assert_close_bulk(got, want, atol, rtol, msg, **kw)
+
+
 def _synced_steps(robot, g, o, n, steps, rng, tag, check_travel=False):
     import torch
     resets = 0
@@ -329,7 +351,7 @@ def _synced_steps(robot, g, o, n, steps, rng, tag, check_travel=False):
         for name, atol, rtol in (("DOF_STATE", 4e-4, 5e-4), ("ROOT_STATES", 4e-4, 5e-4), ("TORQUES", 4e-4, 5e-4), ("COMMANDS", 1e-6, 1e-6),
                                  ("GOAL_STATE", 2e-5, 2e-5), ("OBS_BUF", 2e-3, 5e-4), ("OBS_HISTORY", 2e-3, 5e-4),
                                  ("REW_BUF", 2e-4, 2e-3), ("ARM_REW_BUF", 2e-5, 1e-3), ("EPISODE_SUMS", 2e-2, 2e-3)):
-            _assert_close_bulk(_t(g, name), o.get(name), atol, rtol, f"{tag} {name}, step {step}")
+            _close(name, _t(g, name), o.get(name), atol, rtol, f"{tag} {name}, step {step}")
         if check_travel and m.any():
             np.testing.assert_allclose(_t(g, "RESET_TRAVEL")[m], o.get("RESET_TRAVEL")[m], atol=4e-4, rtol=1e-4)
     return resets
@@ -532,7 +554,7 @@ def test_step_at_baseline_config2_8192_on_the_terrain_grid_with_curriculum(robot
                                  ("OBS_BUF", 2e-3, 5e-4), ("OBS_HISTORY", 2e-3, 5e-4), ("REW_BUF", 2e-4, 2e-3), ("ARM_REW_BUF", 2e-5, 1e-3),
                                  ("EPISODE_SUMS", 2e-2, 2e-3)):
             _assert_close_bulk(_t(env.sim, name), o.get(name), atol, rtol, f"{tag} {name}", frac=1e-4)
-        _assert_close_bulk(_t(env.sim, "ROOT_STATES"), oroot, 4e-4, 5e-4, f"{tag} ROOT_STATES", frac=1e-4)
+        _close("ROOT_STATES", _t(env.sim, "ROOT_STATES"), oroot, 4e-4, 5e-4, f"{tag} ROOT_STATES", frac=1e-4)
         if m.any():
             np.testing.assert_allclose(_t(env.sim, "RESET_TRAVEL")[m], travel[m], atol=4e-4, rtol=1e-4)
         resets += int(m.sum()); moved += int((got != levels0).sum())
