@@ -28,6 +28,7 @@ struct DevConst {
   uint64_t out_cp2_mask[32];                       // ... and those it receives with the opposite sign (partner of a pair)
   uint64_t body_cp_mask[WBC_NB + 1];               // the same two sets per moving body (the sweeps' wrench gather); entry
   uint64_t body_cp2_mask[WBC_NB + 1];              // WBC_BOX_BODY is the free box actor
+  uint64_t box_corner_mask, box_pair_mask;         // the box's corner contacts; the robot spheres against the box
   uint32_t body_pack[WBC_NB];                      // axis | dof << 2
   // heightfield (optional)
   const int16_t* hf;
@@ -76,6 +77,7 @@ struct DevTensors {
   float* body_params; // [N,20]
   float* reset_travel; // [N,2]
   float* box_mass;    // [N]
+  float* box_timer;   // [N]
 };
 
 #define WBC_PI 3.14159265358979323846f

@@ -47,7 +47,7 @@ static const TensorSpec kSpecs[WBC_T_COUNT] = {
     {{WBC_NREW, 0, 0}, 1, WBC_F32}, {{WBC_NMETRIC, 0, 0}, 1, WBC_F32}, {{WBC_NREW, 0, 0}, 1, WBC_F32},  {{WBC_NMETRIC, 0, 0}, 1, WBC_F32},
     {{3, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{5, 0, 0}, 1, WBC_F32},   {{0, 0, 0}, 0, WBC_F32},
     {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32},
-    {{2, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32}};
+    {{2, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},  {{0, 0, 0}, 0, WBC_F32}};
 
 static size_t spec_elems(const TensorSpec& s) {
   size_t n = 1;
@@ -116,9 +116,15 @@ static int build_chains(DevConst& hc) {
   for (int r = 0; r < 32; ++r) hc.out_cp_mask[r] = hc.out_cp2_mask[r] = 0;
   for (int i = 0; i <= WBC_NB; ++i) hc.body_cp_mask[i] = hc.body_cp2_mask[i] = 0;
   for (int f = 0; f < WBC_NFEET; ++f) hc.foot_cp[f] = hc.foot_cp2[f] = -1;
+  hc.box_corner_mask = hc.box_pair_mask = 0;
   for (int k = 0; k < m.ncp; ++k) {
     const int b = m.cp_body[k], kind = m.cp_kind[k];
     const uint64_t bit = 1ull << k;
+    if (kind == WBC_CP_NONE) continue;                          // unused slot
+    if (b == WBC_BOX_BODY) hc.box_corner_mask |= bit;
+    if (kind != WBC_CP_TERRAIN && m.cp_body2[k] == WBC_BOX_BODY) hc.box_pair_mask |= bit;
+    // layout rule of the step kernel: the contacts that involve the free box fill the 16-lane row 32..47, and only they do
+    if (((hc.box_corner_mask | hc.box_pair_mask) & bit) != 0 ? (k < 32 || k > 47) : (k >= 32 && k <= 47)) return -2;
     if (b < 0 || b > WBC_NB || m.cp_rb[k] < 0 || m.cp_rb[k] >= WBC_NRB_ENV) return -1;
     if ((b == WBC_BOX_BODY) != (m.cp_rb[k] == WBC_BOX_RB)) return -1;
     if (kind != WBC_CP_TERRAIN && kind != WBC_CP_BOX && kind != WBC_CP_CAPSULE) return -1;
@@ -173,7 +179,11 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   s->n = num_envs; s->device = hip_device; s->seed = seed;
   memset(&s->hc, 0, sizeof(DevConst));
   s->hc.model = *model; s->hc.cfg = *cfg;
-  if (build_chains(s->hc) != 0) { delete s; return fail(-1, "wbc_sim_create: topology must be a root with 5 serial chains of depth <= 6"); }
+  if (const int rc = build_chains(s->hc)) {
+    delete s;
+    return fail(-1, rc == -2 ? "wbc_sim_create: contact slots 32..47 are the free box's row (its corners, robot spheres against it) and nothing else"
+                             : "wbc_sim_create: topology must be a root with 5 serial chains of depth <= 6, contacts on valid bodies");
+  }
   const size_t need = wbc_sim_arena_bytes(num_envs);
   if (arena) {
     if (arena_bytes < need) { delete s; return fail(-1, "wbc_sim_create: arena too small"); }
@@ -203,7 +213,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   T.base_ang_vel = (float*)s->ptr[WBC_T_BASE_ANG_VEL]; T.mass_params = (float*)s->ptr[WBC_T_MASS_PARAMS]; T.friction = (float*)s->ptr[WBC_T_FRICTION];
   T.motor = (float*)s->ptr[WBC_T_MOTOR_STRENGTH]; T.origins = (float*)s->ptr[WBC_T_ENV_ORIGINS]; T.box_dy = (float*)s->ptr[WBC_T_BOX_DELTA_Y];
   T.body_params = (float*)s->ptr[WBC_T_BODY_PARAMS]; T.reset_travel = (float*)s->ptr[WBC_T_RESET_TRAVEL];
-  T.box_mass = (float*)s->ptr[WBC_T_BOX_MASS];
+  T.box_mass = (float*)s->ptr[WBC_T_BOX_MASS]; T.box_timer = (float*)s->ptr[WBC_T_BOX_SLEEP_TIMER];
   // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
   {
     const int n = num_envs;

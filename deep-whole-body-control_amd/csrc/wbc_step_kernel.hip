@@ -46,6 +46,16 @@ __device__ __forceinline__ float sum8(float x) {
   return x;
 }
 
+// Inclusive sum along a 16-lane row (DPP row_shr 1, 2, 4, 8 with zero fill): the row's last lane ends up with the row total.
+// Fixed order, VALU speed, no LDS.
+__device__ __forceinline__ float row_scan16(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xF, 0xF, true));    // row_shr:1
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xF, 0xF, true));    // row_shr:2
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xF, 0xF, true));    // row_shr:4
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xF, 0xF, true));    // row_shr:8
+  return x;
+}
+
 // Packed bodies (DevConst::chain_pack_body) of chain `sch` of the 8-lane sweep layout: five scalar loads and a select chain
 // (LDS has no room for another table: 16 robots per CU need <= 10240 B each).
 __device__ __forceinline__ uint32_t sweep_chain_bodies(const DevConst* __restrict__ C, int sch) {
@@ -91,6 +101,7 @@ struct __align__(16) Smem {
   // the free box actor in frame F (oracle: box_ws): rotation of the box in the world, then centre / axes / centre velocity / spin in F,
   // 1/m and 1/Ic, and its response to the contact impulses of the current sweep (centre acceleration, angular acceleration)
   float bxRb[9], bxc[3], bxE[9], bxv[3], bxw[3], bxim, bxiI, bxa[6];
+  int bxtimer;                   // substeps the box has been at rest (asleep from box_sleep_time / sim_dt on)
   // contacts (one per lane): only what OTHER lanes read lives here -- the contact point (the impulse: ctc.clam).
   // Normal, free velocity and velocity target stay in the owning lane's registers; the set of active contacts is a wavefront ballot.
   float cxc[WBC_NCP][3];
@@ -108,7 +119,10 @@ struct __align__(16) Smem {
   uint32_t k_body[WBC_NB];               // DevConst::body_pack
   float k_qdlim[WBC_NDOF];
   float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];   // joint armature at (chain, depth); row WBC_NCHAIN is the idle row
-  uint64_t k_gm1[WBC_NB + 1], k_gm2[WBC_NB + 1]; // DevConst::body_cp_mask / body_cp2_mask (entry WBC_BOX_BODY: the free box)
+  // DevConst::body_cp_mask / body_cp2_mask of the tree's bodies, contact slots 0..31 and 32..63 apart: the per-body loops walk the
+  // two halves separately (32-bit mask arithmetic; the upper half -- mid-shanks, feet / gripper against the box -- is mostly idle).
+  // The free box is not in these loops: its contacts fill one 16-lane row and are summed by a row reduction.
+  uint2 k_gmlo[WBC_NB], k_gmhi[WBC_NB];           // .x: contacts whose sphere rides on the body, .y: contacts it is the partner of
 };
 
 // aliases: pD lives in pA, aD in c (both dead once pass 3 has run); g (pass 3 only) also lives in pA:
@@ -492,7 +506,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     for (int j = 0; j < 3; ++j) cpp[j] = Cc->model.cp_pos[lane][j];
     cpr = Cc->model.cp_radius[lane];
   }
-  int cpb2 = -1;                                                         // the partner of a self-collision pair; -1 for terrain contacts
+  int cpb2 = -1;                                                         // the partner of a pair; -1 for terrain contacts
   float cpa[3] = {0.f, 0.f, 0.f}, cpe[3] = {0.f, 0.f, 0.f}, cpr2 = 0.f;
   if (cpkind > WBC_CP_TERRAIN) {
     cpb2 = Cc->model.cp_body2[lane];
@@ -618,8 +632,27 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     cxcr = ld3(p2) + mat_mul(E2, ql);                                    // on the partner's surface
   }
   STAMP(18);
-  const bool cact = cgap < C->cfg.contact_margin;
-  const uint64_t abits = __ballot(cact);                                // the active set (WBC_NCP <= 64 lanes)
+  bool cact = cgap < C->cfg.contact_margin;
+  uint64_t abits = __ballot(cact);                                      // the active set (WBC_NCP <= 64 lanes)
+  // sleeping box (oracle: box_asleep): at rest for box_sleep_time, on at least three corners, untouched -> frozen this substep
+  bool asleep = false;
+  {
+    const float vs = Cc->model.box_sleep_speed;
+    if (vs > 0.f) {
+      const uint64_t bx_corner_mask = Cc->box_corner_mask, bx_pair_mask = Cc->box_pair_mask;
+      const int bx_nsleep = (int)(Cc->model.box_sleep_time * idt + 0.5f);                      // substeps at rest before it sleeps
+      // slow enough? (every lane evaluates the same broadcast reads of the box's velocities: no hand-over; kept as a scalar)
+      const float bh = Cc->model.box_half;
+      const f3 bv = ld3(&s.box[7]), bw = ld3(&s.box[10]);
+      const int bxslow = __builtin_amdgcn_readfirstlane((int)(dot(bv, bv) < vs * vs && dot(bw, bw) * (bh * bh) < vs * vs));
+      const bool resting = bxslow && __popcll(abits & bx_corner_mask) >= 3 && (abits & bx_pair_mask) == 0ull;
+      const int boxtimer = __builtin_amdgcn_readfirstlane(s.bxtimer);      // (a register carried across the substeps spills the kernel)
+      asleep = resting && boxtimer >= bx_nsleep;
+      if (lane == 0) s.bxtimer = resting ? min(boxtimer + 1, bx_nsleep) : 0;
+      if (asleep) { abits &= ~bx_corner_mask; cact = cact && !onbox; }
+    }
+  }
+  const uint32_t ablo = (uint32_t)abits, abhi = (uint32_t)(abits >> 32);
   // friction coefficient of this contact: robot-terrain, box-terrain, robot-robot, robot-box
   const float cmu = s.mu[cpkind == WBC_CP_TERRAIN ? (onbox ? 2 : 0) : (p2box ? 3 : 1)];
   f3 cvfree = mk3(0.f, 0.f, 0.f), clamr = mk3(0.f, 0.f, 0.f);
@@ -701,8 +734,17 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   // damped block-Jacobi: relaxation 1 / (number of active contacts acting on the busier of the contact's two bodies)
   float com = 1.f;
   if (cact) {
-    int cnt = __popcll(abits & (s.k_gm1[cpb] | s.k_gm2[cpb]));
-    if (cpb2 >= 0) cnt = max(cnt, (int)__popcll(abits & (s.k_gm1[cpb2] | s.k_gm2[cpb2])));
+    // (the free box: every contact of its row acts on it; a scalar count)
+    const int tb1 = onbox ? 0 : cpb, tb2 = (cpb2 < 0 || p2box) ? tb1 : cpb2;
+    const uint2 l1 = s.k_gmlo[tb1], l2 = s.k_gmlo[tb2];
+    int c1 = __popc(ablo & (l1.x | l1.y)), c2 = __popc(ablo & (l2.x | l2.y));
+    if (abhi != 0u) {                                   // (scalar: the upper slots are mostly idle)
+      const uint2 h1 = s.k_gmhi[tb1], h2 = s.k_gmhi[tb2];
+      c1 += __popc(abhi & (h1.x | h1.y)); c2 += __popc(abhi & (h2.x | h2.y));
+    }
+    const int cbox = __popc(abhi & 0xFFFFu);
+    c1 = onbox ? cbox : c1; c2 = p2box ? cbox : (cpb2 < 0 ? 0 : c2);
+    const int cnt = max(c1, c2);
     com = 1.f / (float)cnt;
   }
   if (any) {
@@ -722,30 +764,36 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       }
       WSYNC();
       if (it == 0) STAMP(20);
-      // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a pair receives the opposite
-      // wrench. Lane WBC_BOX_BODY does the same sum for the free box and turns it into the box's response right away.
-      if (lane <= WBC_NB) {
+      // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a pair receives the opposite wrench
+      if (lane < WBC_NB) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const uint64_t gmask1 = s.k_gm1[lane];
-        uint64_t mask = (gmask1 | s.k_gm2[lane]) & abits;
-        // moments about F's origin for the tree's bodies, about its own centre for the box (3 m away: no cancellation in fp32)
-        const f3 org = lane < WBC_NB ? mk3(0.f, 0.f, 0.f) : ld3(s.bxc);
-        while (mask) {
-          const int kc = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          const float sg = ((gmask1 >> kc) & 1ull) ? idt : -idt;
-          const f3 f = ld3(s.ctc.clam[kc]) * sg;
-          const f3 mom = cross(ld3(s.cxc[kc]) - org, f);
-          acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
-        }
-        if (lane < WBC_NB) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
-          s.uD[lane] = 0.f;                        // levels the inward sweep skips
-        } else {
-          // the box's response: angular acceleration n / Ic, centre acceleration F / m
-          st3(&s.bxa[0], mk3(-acc[0], -acc[1], -acc[2]) * s.bxiI); st3(&s.bxa[3], mk3(-acc[3], -acc[4], -acc[5]) * s.bxim);
+        for (int half = 0; half < 2; ++half) {
+          if (half && abhi == 0u) break;                // (scalar) nothing active in the upper slots: the usual case
+          const uint2 gm = half ? s.k_gmhi[lane] : s.k_gmlo[lane];
+          uint32_t mask = (gm.x | gm.y) & (half ? abhi : ablo);
+          while (mask) {
+            const int kb = __ffs(mask) - 1, kc = kb + 32 * half;
+            mask &= mask - 1;
+            const float sg = ((gm.x >> kb) & 1u) ? idt : -idt;
+            const f3 f = ld3(s.ctc.clam[kc]) * sg;
+            const f3 mom = cross(ld3(s.cxc[kc]), f);
+            acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
+          }
         }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
+        s.uD[lane] = 0.f;                          // levels the inward sweep skips
+      }
+      // the free box: its contacts fill the 16-lane row 32..47 (corners: + the impulse; a robot sphere against it: - the impulse);
+      // every lane of the row forms its wrench about the box centre (3 m from F's origin: no cancellation in fp32), a row reduction
+      // sums them, the row's last lane turns the sum into the box's response (angular acceleration n / Ic, centre acceleration F / m)
+      if ((abhi & 0xFFFFu) != 0u && (lane >> 4) == 2) {
+        const f3 f = cact ? clamr * (onbox ? idt : -idt) : mk3(0.f, 0.f, 0.f);
+        const f3 mom = cross((cact ? ld3(s.cxc[lane]) : ld3(s.bxc)) - ld3(s.bxc), f);
+        const float nx = row_scan16(mom.x), ny = row_scan16(mom.y), nz = row_scan16(mom.z);
+        const float fx = row_scan16(f.x), fy = row_scan16(f.y), fz = row_scan16(f.z);
+        if (lane == 47) { st3(&s.bxa[0], mk3(nx, ny, nz) * s.bxiI); st3(&s.bxa[3], mk3(fx, fy, fz) * s.bxim); }
       }
       WSYNC();
       if (it == 0) STAMP(21);
@@ -833,17 +881,24 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     const f3 n1 = mk3(__shfl(cn.x, kc1), __shfl(cn.y, kc1), __shfl(cn.z, kc1));
     const f3 n2 = mk3(__shfl(cn.x, src2), __shfl(cn.y, src2), __shfl(cn.z, src2));
     // lanes 0..27: net force on rigid body `lane` (+ as the sphere's body, - as the partner of a pair); row 27 is the box actor
-    if (lane < WBC_NRB_ENV) {
+    if (lane == WBC_BOX_RB) {                     // the box actor's row: the net force the last sweep's row reduction left (F = m a)
+      st3(s.out_contact[lane], mat_mul(s.R, ld3(&s.bxa[3]) * (1.f / s.bxim)));
+    } else if (lane < WBC_NRB) {
       const uint64_t m1 = Cc->out_cp_mask[lane], m2 = Cc->out_cp2_mask[lane];
-      uint64_t mask = (m1 | m2) & abits;
       f3 acc = mk3(0.f, 0.f, 0.f);
-      while (mask) {
-        const int kc = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const float sg = ((m1 >> kc) & 1ull) ? idt : -idt;
-        acc = acc + mat_mul(s.R, ld3(s.ctc.clam[kc]) * sg);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half && abhi == 0u) break;
+        const uint32_t h1 = (uint32_t)(m1 >> (32 * half));
+        uint32_t mask = (h1 | (uint32_t)(m2 >> (32 * half))) & (half ? abhi : ablo);
+        while (mask) {
+          const int kb = __ffs(mask) - 1, kc = kb + 32 * half;
+          mask &= mask - 1;
+          const float sg = ((h1 >> kb) & 1u) ? idt : -idt;
+          acc = acc + ld3(s.ctc.clam[kc]) * sg;
+        }
       }
-      st3(s.out_contact[lane], acc);
+      st3(s.out_contact[lane], mat_mul(s.R, acc));
     } else if (isft) {
       f3 fa = mk3(0.f, 0.f, 0.f), ta = mk3(0.f, 0.f, 0.f);
       const int b = Cc->model.cp_body[kc1];
@@ -874,6 +929,8 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
     if (lim > 0.f) qd = fminf(fmaxf(qd, -lim), lim);
     s.qd[dj] = qd;
     s.q[dj] += dt * qd;
+  } else if (lane == WBC_NB && asleep) {
+    st3(&s.box[7], mk3(0.f, 0.f, 0.f)); st3(&s.box[10], mk3(0.f, 0.f, 0.f));      // frozen
   } else if (lane == 0 || lane == WBC_NB) {
     // the two free bodies, same instructions: lane 0 the robot's root, lane WBC_NB the box actor (gravity + its net contact force)
     const bool isb = lane != 0;
@@ -1149,6 +1206,7 @@ __device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restric
     const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
     s.mu[0] = fmaxf(0.5f * (s.friction + tf), 0.f); s.mu[1] = fmaxf(s.friction, 0.f);
     s.mu[2] = fmaxf(0.5f * (bf + tf), 0.f); s.mu[3] = fmaxf(0.5f * (bf + s.friction), 0.f);
+    s.bxtimer = (int)T.box_timer[env];
     const float bm = T.box_mass[env], bh = C->model.box_half;
     s.bxim = 1.f / bm; s.bxiI = 1.f / (bm * (2.f / 3.f) * bh * bh);
     s.ep_len = (int)T.ep_len[env];
@@ -1159,7 +1217,10 @@ __device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restri
   const int lane = threadIdx.x;
   if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = (&C->model.joint_xyz[0][0])[lane];
   if (lane < WBC_NB) s.k_body[lane] = C->body_pack[lane];
-  if (lane <= WBC_NB) { s.k_gm1[lane] = C->body_cp_mask[lane]; s.k_gm2[lane] = C->body_cp2_mask[lane]; }
+  if (lane < WBC_NB) {
+    const uint64_t m1 = C->body_cp_mask[lane], m2 = C->body_cp2_mask[lane];
+    s.k_gmlo[lane] = make_uint2((uint32_t)m1, (uint32_t)m2); s.k_gmhi[lane] = make_uint2((uint32_t)(m1 >> 32), (uint32_t)(m2 >> 32));
+  }
   if (lane < WBC_NDOF) s.k_qdlim[lane] = C->model.qd_limit[lane];
   if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
     const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
@@ -1344,6 +1405,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     WSYNC();
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
+  if (lane == 0) T.box_timer[env] = (float)s.bxtimer;
   STAMP(13);
   // Everything after the substeps reads its tensor / constant pointers through laundered copies of the two kernel arguments: the
   // compiler otherwise hoists those (invariant) scalar loads above the substep loop, where the ~40 pointers and constants it
@@ -1469,6 +1531,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   WSYNC();
   physics_substep(s, C, cr, chain, k, true);
   if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane == 0) T.box_timer[env] = (float)s.bxtimer;
   if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
   for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) T.contact[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
   if (lane < WBC_NFEET * 6) T.sensor[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];

@@ -12,9 +12,9 @@ import numpy as np
 
 from .urdf_model import RobotModel, merge_piece
 
-NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 48
+NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 52
 BOX_BODY, BOX_RB = NB, NRB                                # the free box actor's pseudo body index / rigid-body row
-CP_TERRAIN, CP_BOX, CP_CAPSULE = 0, 1, 2
+CP_NONE, CP_TERRAIN, CP_BOX, CP_CAPSULE = -1, 0, 1, 2
 NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 22, 10
 
 f32, i32 = C.c_float, C.c_int32
@@ -44,7 +44,7 @@ class WbcModel(C.Structure):
         ("gripper_body", i32),
         ("grip_piece_mass", f32), ("grip_piece_com", f32 * 3), ("grip_piece_inertia", f32 * 6),
         ("grip_rest_mass", f32), ("grip_rest_com", f32 * 3), ("grip_rest_inertia", f32 * 6),
-        ("box_half", f32), ("box_mass", f32), ("box_friction", f32),
+        ("box_half", f32), ("box_mass", f32), ("box_friction", f32), ("box_sleep_speed", f32), ("box_sleep_time", f32),
     ]
 
 
@@ -93,7 +93,7 @@ TENSOR_IDS = [
     "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_ROOT_VEL", "COMMANDS",
     "GOAL_STATE", "REW_BUF", "ARM_REW_BUF", "RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH", "EPISODE_SUMS",
     "METRIC_SUMS", "EPISODE_SUMS_DONE", "METRIC_SUMS_DONE", "BASE_LIN_VEL", "BASE_ANG_VEL", "MASS_PARAMS",
-    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS", "RESET_TRAVEL", "BOX_MASS"]
+    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS", "RESET_TRAVEL", "BOX_MASS", "BOX_SLEEP_TIMER"]
 T = {name: i for i, name in enumerate(TENSOR_IDS)}
 # per-env shapes (without the leading N) and dtypes, as the header documents them
 TENSOR_SHAPES = {
@@ -104,7 +104,7 @@ TENSOR_SHAPES = {
     "RESET_BUF": (), "TIME_OUT_BUF": (), "EPISODE_LENGTH": (), "EPISODE_SUMS": (NREW,), "METRIC_SUMS": (10,),
     "EPISODE_SUMS_DONE": (NREW,), "METRIC_SUMS_DONE": (10,), "BASE_LIN_VEL": (3,), "BASE_ANG_VEL": (3,),
     "MASS_PARAMS": (5,), "FRICTION": (), "MOTOR_STRENGTH": (18,), "ENV_ORIGINS": (3,), "BOX_DELTA_Y": (),
-    "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,), "BOX_MASS": ()}
+    "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,), "BOX_MASS": (), "BOX_SLEEP_TIMER": ()}
 TENSOR_DTYPES = {name: "f32" for name in TENSOR_IDS}
 TENSOR_DTYPES.update(RESET_BUF="i64", EPISODE_LENGTH="i64", TIME_OUT_BUF="u8")
 
@@ -134,27 +134,33 @@ CORNER_RADIUS = 0.01
 CALF_LEN, CALF_RADIUS = 0.213, 0.008                     # calf box 0.213 x 0.016 x 0.016 (urdf:981), long axis -z of the calf frame
 BOX_CORNER_RADIUS = 0.005
 BOX_DENSITY, BOX_FRICTION = 1000.0, 1.0                  # asset_options.density (WG:322); Isaac Gym's default shape friction
+BOX_SLEEP_SPEED, BOX_SLEEP_TIME = 0.01, 0.4                # m/s, s: a box at rest for 0.4 s is frozen, as PhysX puts resting actors to sleep
 
 
 def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True,
                   box_half: float = 0.05):
-    """The contact list of this framework's physics spec, as dicts with the wbc_model cp_* fields.
-    Sphere-swept stand-ins for the URDF's collision geometry:
+    """The contact list of this framework's physics spec, as dicts with the wbc_model cp_* fields and the
+    contact SLOT (= wavefront lane) each one occupies. Sphere-swept stand-ins for the URDF's collision geometry:
       terrain contacts -- 4 feet (the URDF's r = 0.02 spheres), 4 knees (calf box upper ends = thigh box lower ends), gripper
         tip, elbow, wrist (the arm-link meshes), 4 thigh tops (thigh box upper ends), 8 trunk-box corners, 4 mid-shanks (the
         middle of the calf boxes: what touches a stair edge between knee and foot), the 8 corners of the free box actor;
       self-collision pairs (asset.self_collisions = 0 means enabled, widowGo1_config.py:180) -- gripper / wrist / elbow spheres
         against the trunk box, gripper / wrist against the two front thighs (capsules): what bounds the arm's workspace;
       robot-vs-box pairs (the box actor is created with the same collision filter, WG:384) -- the 4 foot spheres and the
-        gripper tip against the cube."""
+        gripper tip against the cube.
+    Slots (= wavefront lanes): 0..22 the robot's spheres against the terrain, 23..29 its self-collision pairs (the set a walking
+    robot lives in: the kernel's per-body loops over slots < 32); 32..47 everything that involves the free box (its corners, the
+    feet and the gripper tip against it: one 16-lane row, summed by a row reduction instead of a per-body loop); 48..51 the
+    mid-shanks (second loop half, empty unless a shin touches something)."""
     rbn = m.rb_names
     feet = [i for i, n in enumerate(rbn) if foot_name in n]
     grip_rb = rbn.index(gripper_name)
     cps = []
 
-    def sphere(rb, pos, rad):
+    def sphere(rb, pos, rad, slot=None):
         cps.append(dict(body=int(m.rb_body[rb]), pos=np.asarray(m.rb_offset[rb], dtype=np.float64) + np.asarray(pos, dtype=np.float64),
-                        radius=rad, rb=rb, kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0))
+                        radius=rad, rb=rb, kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0,
+                        slot=len(cps) if slot is None else slot))
         return len(cps) - 1
     for rb in feet:
         sphere(rb, np.zeros(3), 0.02)
@@ -173,35 +179,43 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
         for sy in (1, -1):
             for sz in (-1, 1):
                 sphere(trunk_rb, np.array([sx * hx, sy * hy, sz * hz]), CORNER_RADIUS)
-    for rb in feet:                                                         # mid-shank: calf rigid body, half way down the calf box
+    assert len(cps) == 23
+    BOX_ROW, SHANK0 = 32, 48
+    for i, rb in enumerate(feet):                                           # mid-shank: calf rigid body, half way down the calf box
         assert "calf" in rbn[rb - 1]
-        sphere(rb - 1, np.array([0.0, 0.0, -CALF_LEN / 2]), CALF_RADIUS)
+        sphere(rb - 1, np.array([0.0, 0.0, -CALF_LEN / 2]), CALF_RADIUS, slot=SHANK0 + i)
     hb = box_half - BOX_CORNER_RADIUS                                       # the free box: corner spheres inset so that the surface is the cube's
+    hi = BOX_ROW
     for sx in (1, -1):
         for sy in (1, -1):
             for sz in (-1, 1):
                 cps.append(dict(body=BOX_BODY, pos=np.array([sx * hb, sy * hb, sz * hb]), radius=BOX_CORNER_RADIUS, rb=BOX_RB,
-                                kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0))
+                                kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0, slot=hi))
+                hi += 1
     if self_collisions:
-        def pair(k, kind, rb2, a, b, radius2):
+        lo = 23
+
+        def pair(k, kind, body2, rb2, a, b, radius2, slot):
             c = dict(cps[k])
-            c.update(kind=kind, body2=int(m.rb_body[rb2]), rb2=rb2, a=np.asarray(a, dtype=np.float64) + np.asarray(m.rb_offset[rb2]),
-                     b=np.asarray(b, dtype=np.float64), radius2=radius2)
-            if kind == CP_CAPSULE:
-                c["b"] = c["b"] + np.asarray(m.rb_offset[rb2])
+            c.update(kind=kind, body2=body2, rb2=rb2, a=np.asarray(a, dtype=np.float64), b=np.asarray(b, dtype=np.float64), radius2=radius2,
+                     slot=slot)
             cps.append(c)
         for k in (k_grip, k_wrist, k_elbow):
-            pair(k, CP_BOX, trunk_rb, np.zeros(3), np.array(TRUNK_HALF), 0.0)
+            pair(k, CP_BOX, int(m.rb_body[trunk_rb]), trunk_rb, np.asarray(m.rb_offset[trunk_rb]), np.array(TRUNK_HALF), 0.0, lo)
+            lo += 1
         front = [rb for rb in thighs if rbn[rb].startswith("F")]
         for k in (k_grip, k_wrist):
             for rb in front:
-                pair(k, CP_CAPSULE, rb, np.zeros(3), np.array([0.0, 0.0, -THIGH_LEN]), THIGH_RADIUS)
-        for k in list(range(len(feet))) + [k_grip]:                           # robot spheres against the free box
-            c = dict(cps[k])
-            c.update(kind=CP_BOX, body2=BOX_BODY, rb2=BOX_RB, a=np.zeros(3), b=np.full(3, box_half), radius2=0.0)
-            cps.append(c)
-    assert len(cps) <= NCP
-    return cps
+                off = np.asarray(m.rb_offset[rb])
+                pair(k, CP_CAPSULE, int(m.rb_body[rb]), rb, off, off + np.array([0.0, 0.0, -THIGH_LEN]), THIGH_RADIUS, lo)
+                lo += 1
+        assert lo <= 32
+        for k in list(range(len(feet))) + [k_grip]:                           # the foot spheres and the gripper tip against the free box
+            pair(k, CP_BOX, BOX_BODY, BOX_RB, np.zeros(3), np.full(3, box_half), 0.0, hi)
+            hi += 1
+    assert hi <= BOX_ROW + 16
+    assert len({c["slot"] for c in cps}) == len(cps) and max(c["slot"] for c in cps) < NCP
+    return sorted(cps, key=lambda c: c["slot"])
 
 
 def fill_model(m: RobotModel, foot_name: str = "foot",
@@ -229,10 +243,13 @@ def fill_model(m: RobotModel, foot_name: str = "foot",
     out.gripper_rb = m.rb_names.index(gripper_name)                         # WG:318
     cps = collision_set(m, foot_name, gripper_name, self_collisions, box_half=0.5 * box_size)
     out.box_half, out.box_mass, out.box_friction = 0.5 * box_size, BOX_DENSITY * box_size ** 3, BOX_FRICTION
-    out.ncp = len(cps)
+    out.box_sleep_speed, out.box_sleep_time = BOX_SLEEP_SPEED, BOX_SLEEP_TIME
+    out.ncp = max(c["slot"] for c in cps) + 1                              # slots in use: 0 .. ncp-1, unused ones marked kind = -1
     for k in range(NCP):
         out.cp_body2[k] = out.cp_rb2[k] = -1
-    for k, c in enumerate(cps):
+        out.cp_kind[k] = CP_NONE
+    for c in cps:
+        k = c["slot"]
         out.cp_body[k], out.cp_rb[k], out.cp_kind[k] = c["body"], c["rb"], c["kind"]
         out.cp_body2[k], out.cp_rb2[k] = c["body2"], c["rb2"]
         out.cp_radius[k], out.cp_radius2[k] = c["radius"], c["radius2"]

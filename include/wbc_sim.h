@@ -35,7 +35,7 @@ extern "C" {
 #define WBC_NRB 27       /* robot rigid bodies as the importer lists them */
 #define WBC_NRB_ENV 28   /* + the free box actor (WG:384,542,546) */
 #define WBC_NFEET 4
-#define WBC_NCP 48       /* contact slots per env (one wavefront lane each): robot spheres vs terrain, box corners vs terrain,
+#define WBC_NCP 52       /* contact slots per env (one wavefront lane each): robot spheres vs terrain, box corners vs terrain,
                             the robot's self-collision pairs, robot spheres vs the free box */
 #define WBC_BOX_BODY WBC_NB   /* pseudo body index of the free box actor (WG:321-325,384) in cp_body / cp_body2 */
 #define WBC_BOX_RB WBC_NRB    /* its row in the [N,28,...] rigid-body tensors (WG:544-548: the last one) */
@@ -75,7 +75,11 @@ typedef struct {
    * impulse acts on both bodies with opposite signs. Terrain contacts come first (the force sensors read contacts 0..3).
    * The free box actor (WG:321-325: a cube, density 1000) takes part under the pseudo body index WBC_BOX_BODY / rigid-body row
    * WBC_BOX_RB: its eight corner spheres against the terrain (cp_body = WBC_BOX_BODY, cp_pos in the box frame) and robot spheres
-   * against it (kind WBC_CP_BOX with cp_body2 = WBC_BOX_BODY, cp_a = 0, cp_b = box_half). */
+   * against it (kind WBC_CP_BOX with cp_body2 = WBC_BOX_BODY, cp_a = 0, cp_b = box_half).
+   * Slots 0 .. ncp-1 are in use except those marked WBC_CP_NONE. The step kernel's layout rules (checked at wbc_sim_create): every
+   * contact that involves the free box sits in slots 32..47 (one 16-lane row: their wrenches on the box are summed by a row
+   * reduction) and nothing else does; keep what a walking robot normally touches with (feet, knees, trunk, arm) below 32 -- the
+   * per-body loops walk the slots below 32 and those from 48 separately. */
   int32_t ncp;
   int32_t cp_body[WBC_NCP];
   float cp_pos[WBC_NCP][3];
@@ -95,9 +99,15 @@ typedef struct {
   /* the free box actor: half edge of the cube (box.box_size / 2, widowGo1_config.py:186), nominal mass (density 1000 x size^3,
    * WG:322; the per-env total is WBC_T_BOX_MASS), friction of its material (Isaac Gym's shape default 1.0) */
   float box_half, box_mass, box_friction;
+  /* Sleeping (as PhysX puts resting actors to sleep: sleep threshold + wake counter): while the box's speed and (spin x half edge)
+   * are below box_sleep_speed, at least three of its corners are within the contact offset of the terrain and no robot sphere is
+   * within the contact offset of it, a per-env timer (WBC_T_BOX_SLEEP_TIMER) runs, otherwise it is zero; once it has reached
+   * box_sleep_time the box is frozen -- no contacts, no gravity, zero velocity -- until a robot sphere touches it or it loses
+   * its support (reset_idx re-places it in the air). box_sleep_speed <= 0: never sleeps. */
+  float box_sleep_speed, box_sleep_time;
 } wbc_model;
 
-enum wbc_contact_kind { WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1, WBC_CP_CAPSULE = 2 };
+enum wbc_contact_kind { WBC_CP_NONE = -1 /* unused slot */, WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1, WBC_CP_CAPSULE = 2 };
 
 enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) + the base class's _reward_collision (LR:865-867) */
   WBC_REW_ENERGY_SQUARE = 0, WBC_REW_SURVIVE, WBC_REW_TRACKING_LIN_VEL_X_L1,
@@ -223,6 +233,7 @@ enum wbc_tensor_id {
   WBC_T_RESET_TRAVEL,      /* f32 [N,2]  at the moment of an env's reset: ||root_xy - env_origin_xy|| and ||commands[:2]||,
                               the two quantities _update_terrain_curriculum reads before reset_idx overwrites them (LR:431-435) */
   WBC_T_BOX_MASS,          /* f32 [N]    total mass of the env's box actor: nominal + box.added_mass_range draw (WG:458-466) */
+  WBC_T_BOX_SLEEP_TIMER,   /* f32 [N]    substeps the box actor has been at rest (asleep from box_sleep_time / sim_dt on) */
   WBC_T_COUNT
 };
 enum wbc_dtype { WBC_F32 = 0, WBC_I64 = 1, WBC_U8 = 2 };

@@ -171,6 +171,7 @@ typedef struct {
   REAL body_params[20];      /* root (m, com3, I6), gripper (m, com3, I6) */
   REAL reset_travel[2];      /* ||root_xy - origin_xy||, ||commands[:2]|| at the moment of reset (LR:431-435) */
   REAL box_mass;             /* total mass of the box actor (WG:458-466) */
+  REAL box_timer;            /* substeps the box has been at rest (asleep from box_sleep_time / sim_dt on) */
 } ora_env;
 
 /* goal[] slots */
@@ -284,7 +285,7 @@ static void solve3(const REAL* W, const REAL* b, REAL* x) { /* symmetric 3x3, co
 
 typedef struct {
   int active, nshare;      /* nshare: the larger of the numbers of active contacts acting on the contact's two bodies (>= 1 when active) */
-  REAL xc[3], n[3], W[9], vfree[3], vn_tgt, mu, lam[3];
+  REAL xc[3], n[3], W[9], vfree[3], vn_tgt, mu, lam[3], gap;
 } contact_t;
 
 /* The free box actor (WG:321-325,384) in frame F: centre, axes, centre velocity, angular velocity; mass and the (isotropic: a
@@ -472,6 +473,7 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     REAL rad = md->cp_radius[k], gap;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
     c->active = 0;
+    if (kind < 0) continue;                               /* unused slot */
     if (kind == WBC_CP_TERRAIN) {
       REAL Xw[3], h, nw[3];
       mat3_mul_vec(R, xk, t);
@@ -535,6 +537,29 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       for (int j = 0; j < 3; ++j) c->xc[j] = p2[j] + t[j];             /* on the partner's surface */
       c->mu = (b2 == WBC_BOX_BODY) ? mu_box_robot : mu_self;
     }
+    c->gap = gap;
+  }
+  /* sleeping box (as PhysX puts resting actors to sleep): slow, supported by at least three corners, untouched by the robot ->
+   * frozen for this substep: its corner contacts are dropped, its velocity is zero, gravity does not act on it */
+  int box_asleep = 0;
+  if (md->box_sleep_speed > 0) {
+    const REAL vs2 = (REAL)md->box_sleep_speed * (REAL)md->box_sleep_speed, h2 = (REAL)md->box_half * (REAL)md->box_half;
+    int ncorner = 0, touched = 0;
+    for (int k = 0; k < md->ncp; ++k) if (ct[k].active) {
+      if (md->cp_body[k] == WBC_BOX_BODY) ncorner += 1;
+      if (md->cp_kind[k] > WBC_CP_TERRAIN && md->cp_body2[k] == WBC_BOX_BODY) touched = 1;
+    }
+    const int resting = dot3(e->root[1] + 7, e->root[1] + 7) < vs2 && dot3(e->root[1] + 10, e->root[1] + 10) * h2 < vs2 && ncorner >= 3 && !touched;
+    const REAL nsleep = (REAL)(int)(md->box_sleep_time * (1.0f / cf->sim_dt) + 0.5f);   /* the timer counts substeps (exact in fp32) */
+    box_asleep = resting && e->box_timer >= nsleep;
+    e->box_timer = resting ? fmin(e->box_timer + 1, nsleep) : 0;
+    if (box_asleep) for (int k = 0; k < md->ncp; ++k) if (md->cp_body[k] == WBC_BOX_BODY) ct[k].active = 0;
+  }
+  for (int k = 0; k < md->ncp; ++k) {
+    contact_t* c = &ct[k];
+    if (!c->active) continue;
+    int b = md->cp_body[k], kind = md->cp_kind[k], b2 = md->cp_body2[k];
+    REAL gap = c->gap, t[3];
     any = 1;
     c->vn_tgt = (gap >= 0) ? -gap / dt : fmin((REAL)cf->contact_erp * (-gap) / dt, (REAL)cf->max_depenetration_vel);
     /* W = J K J^T, J = [-xc x, 1], summed over the two bodies of a pair (their cross coupling through the tree is left to the
@@ -732,8 +757,10 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
   for (int k = 0; k < 4; ++k) { nq[k] = qt[k] + (REAL)0.5 * dt * dq[k]; nn += nq[k] * nq[k]; }
   nn = 1 / sqrt(nn);
   for (int k = 0; k < 4; ++k) qt[k] = nq[k] * nn;
-  /* the box: gravity + its net contact force; same integrator */
-  {
+  /* the box: gravity + its net contact force; same integrator (asleep: frozen) */
+  if (box_asleep) {
+    for (int k = 7; k < 13; ++k) e->root[1][k] = 0;
+  } else {
     REAL accB[3], alB[3];
     for (int k = 0; k < 3; ++k) { accB[k] = gF[k] + boxF[k] / bx.m; alB[k] = boxN[k] / bx.Ic; }
     mat3_mul_vec(R, accB, t);
@@ -1168,6 +1195,7 @@ static int field_ptr(ora_env* e, int id, REAL** p, int* n) {
     case WBC_T_BODY_PARAMS: *p = e->body_params; *n = 20; return 0;
     case WBC_T_RESET_TRAVEL: *p = e->reset_travel; *n = 2; return 0;
     case WBC_T_BOX_MASS: *p = &e->box_mass; *n = 1; return 0;
+    case WBC_T_BOX_SLEEP_TIMER: *p = &e->box_timer; *n = 1; return 0;
     default: return -1;
   }
 }

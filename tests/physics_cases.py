@@ -189,17 +189,21 @@ def box_drop(robot, height=None, T=1.5):
     o.set("TORQUES", np.zeros((1, 20)))
     dt = tc.sim_dt
     n = int(round(T / dt))
-    z = np.zeros(n); vz = np.zeros(n); f = np.zeros(n)
+    z = np.zeros(n); vz = np.zeros(n); f = np.zeros(n); tm = np.zeros(n)
     for k in range(n):
         o.simulate()
         b = o.get("ROOT_STATES")[0, 1]
         z[k], vz[k] = b[2] - wm.box_half, b[9]
         f[k] = o.get("NET_CONTACT_FORCE")[0, 27, 2]
+        tm[k] = o.get("BOX_SLEEP_TIMER")[0]
     touch = int(np.argmax(z < tc.contact_margin))
     t_fall = np.sqrt(2 * (z0 - wm.box_half) / G)
     quiet = np.nonzero(np.abs(vz) > 1e-3)[0]
+    awake = np.nonzero(f != 0)[0]                                        # asleep (frozen, PhysX-style) it reports no contact force
+    asleep_from = (awake[-1] + 1) * dt if len(awake) and awake[-1] + 1 < n else float("nan")
     return dict(t_touch=touch * dt, t_touch_expected=t_fall, impact_vz=float(vz[touch - 1]), rebound_vz=float(vz[touch:].max()),
-                rest_penetration=float(-z[-1]), rest_force=float(f[-1]), weight=float(o.get("BOX_MASS")[0] * G),
+                rest_penetration=float(-z[-1]), rest_force=float(f[awake[-1]]), weight=float(o.get("BOX_MASS")[0] * G),
+                asleep_from=float(asleep_from), final_speed=float(np.abs(o.get("ROOT_STATES")[0, 1, 7:13]).max()), timer=float(tm[-1]),
                 settle_time=(quiet[-1] + 1) * dt - touch * dt, tilt=float(np.abs(o.get("ROOT_STATES")[0, 1, 3:5]).max()))
 
 

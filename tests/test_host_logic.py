@@ -217,7 +217,18 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     assert [c["rb"] for c in cps[:4]] == feet and all(c["kind"] == abi.CP_TERRAIN and c["radius"] == 0.02 for c in cps[:4])
     terrain = [c for c in cps if c["kind"] == abi.CP_TERRAIN]
     pairs = [c for c in cps if c["kind"] != abi.CP_TERRAIN]
-    assert len(terrain) == 35 and cps[:35] == terrain and len(pairs) == 12
+    assert len(terrain) == 35 and len(pairs) == 12
+    # slots (= wavefront lanes): the robot's terrain spheres and self pairs below 32 (the set a walking robot lives in), everything
+    # that involves the free box in the 16-lane row 32..47 (summed by a row reduction in the kernel), the mid-shanks from 48
+    slots = [c["slot"] for c in cps]
+    assert slots == sorted(slots) and len(set(slots)) == 47 and max(slots) < abi.NCP
+    low = [c for c in cps if c["slot"] < 32]
+    assert [c["slot"] for c in low] == list(range(30)) and all(c["body"] != abi.BOX_BODY and c["body2"] != abi.BOX_BODY for c in low)
+    row = [c for c in cps if 32 <= c["slot"] < 48]
+    assert len(row) == 13 and all(c["body"] == abi.BOX_BODY or c["body2"] == abi.BOX_BODY for c in row)
+    assert [c["slot"] for c in cps if c["radius"] == abi.CALF_RADIUS] == [48, 49, 50, 51]
+    wm = abi.fill_model(m)
+    assert wm.ncp == 52 and wm.cp_kind[31] == abi.CP_NONE and all(wm.cp_kind[c["slot"]] == c["kind"] for c in cps)
     robot_terrain = [c for c in terrain if c["body"] != abi.BOX_BODY]
     box_corners = [c for c in terrain if c["body"] == abi.BOX_BODY]
     assert len(robot_terrain) == 27 and len(box_corners) == 8 and all(c["rb"] == abi.BOX_RB for c in box_corners)
@@ -246,7 +257,8 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     for c in box_pairs:
         assert c["kind"] == abi.CP_BOX and c["rb2"] == abi.BOX_RB and np.allclose(c["b"], 0.05) and np.allclose(c["a"], 0)
     assert sorted(names[c["rb"]] for c in box_pairs) == sorted([names[i] for i in feet] + ["wx250s/ee_gripper_link"])
-    assert abi.fill_model(m, self_collisions=False).ncp == 35          # no pairs at all: the box actor shares the filter (WG:384)
+    wm0 = abi.fill_model(m, self_collisions=False)                      # no pairs at all: the box actor shares the filter (WG:384)
+    assert sum(wm0.cp_kind[k] != abi.CP_NONE for k in range(wm0.ncp)) == 35 and all(wm0.cp_kind[k] <= abi.CP_TERRAIN for k in range(wm0.ncp))
     # rigid-body masks of the task config (WG:299-306: substring match)
     cfg = WidowGo1RoughCfg()
     cfg.asset.terminate_after_contacts_on = ["wx250", "base"]        # the list the reference keeps commented out (widowGo1_config.py:179)

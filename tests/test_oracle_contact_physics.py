@@ -74,8 +74,46 @@ def test_box_drop_has_no_rebound(robot):
     assert r["impact_vz"] < -1.5
     assert r["rebound_vz"] < 0.05 * abs(r["impact_vz"]), r
     assert 0.0 <= r["rest_penetration"] < 1e-3, r
-    np.testing.assert_allclose(r["rest_force"], r["weight"], rtol=1e-4)
+    np.testing.assert_allclose(r["rest_force"], r["weight"], rtol=1e-4)       # the last force reported before it falls asleep
     assert r["settle_time"] < 0.3 and r["tilt"] < 1e-6, r
+    # at rest for box_sleep_time = 0.4 s (PhysX's wake counter) it is frozen: exactly motionless, no contact report
+    assert r["t_touch"] + r["settle_time"] + 0.35 < r["asleep_from"] < r["t_touch"] + r["settle_time"] + 0.55, r
+    assert r["final_speed"] == 0.0 and r["timer"] == 80, r
+
+
+def test_sleeping_box_wakes_when_touched_and_when_it_loses_support(robot):
+    """A sleeping box costs the solver nothing (its corner contacts are dropped); a robot sphere within the contact offset wakes it
+    in the same substep, and so does the loss of its support (reset_idx re-places it in the air, widowGo1.py:769-771)."""
+    from oracle import OracleSim, default_curriculum
+    tc = pc.clone_struct(robot["tcfg"])
+    wm = robot["wmodel"]
+    o = OracleSim(wm, tc, 2)
+    o.set_curriculum(default_curriculum(robot["cfg"]))
+    root = np.zeros((2, 2, 13)); root[:, :, 6] = 1
+    root[:, 0, :3] = [0.0, 0.0, 60.0]
+    root[:, 1, :3] = [3.0, 0.2, wm.box_half]
+    o.set("ROOT_STATES", root)
+    dof = np.zeros((2, 20, 2)); dof[:, :, 0] = np.array(tc.default_dof_pos)
+    o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((2, 20)))
+    for _ in range(120):
+        o.simulate()
+    assert (o.get("BOX_SLEEP_TIMER") == 80).all() and np.abs(o.get("NET_CONTACT_FORCE")[:, 27]).max() == 0.0
+    asleep_pose = o.get("ROOT_STATES")[:, 1].copy()
+    # env 0: the robot's front-left foot sphere set against the box's side; env 1: the box lifted (what a reset does)
+    root = o.get("ROOT_STATES")
+    root[0, 0, :3] = [3.0 - wm.box_half - 0.02 - 0.19 + 0.002, 0.2 - 0.13, 0.40]
+    root[0, 0, 7:13] = 0
+    o.set("ROOT_STATES", root); o.refresh_rigid_body_state()
+    foot = o.get("RIGID_BODY_STATE")[0, wm.feet_rb[0], :3]
+    root[0, 0, :3] += np.array([3.0 - wm.box_half - 0.02 + 0.003, 0.2, 0.05]) - foot       # the sphere 3 mm inside the box's -x face
+    root[1, 1, 2] = 0.21
+    o.set("ROOT_STATES", root)
+    o.simulate()
+    f = o.get("NET_CONTACT_FORCE")
+    assert np.abs(f[0, 27]).max() > 0 and f[0, wm.feet_rb[0], 0] < 0 < f[0, 27, 0]          # awake: pushed along +x, corners report again
+    assert o.get("BOX_SLEEP_TIMER")[0] == 0.0
+    assert o.get("BOX_SLEEP_TIMER")[1] == 0.0 and o.get("ROOT_STATES")[1, 1, 9] < 0          # falling
+    assert np.allclose(asleep_pose[1, :2], o.get("ROOT_STATES")[1, 1, :2])
 
 
 # ---------------------------------------------------------------------------------------------------------------- (c)

@@ -202,4 +202,6 @@ def wbc_state(env):
         COMMANDS=f(env.commands)[:, :3], GOAL_STATE=goal, REW_BUF=f(env.rew_buf), ARM_REW_BUF=f(env.arm_rew_buf),
         RESET_BUF=f(env.reset_buf).astype(np.int64), TIME_OUT_BUF=f(env.time_out_buf).astype(np.uint8),
         EPISODE_LENGTH=f(env.episode_length_buf).astype(np.int64), EPISODE_SUMS=sums, METRIC_SUMS=mets,
-        BASE_LIN_VEL=f(env.base_lin_vel), BASE_ANG_VEL=f(env.base_ang_vel))
+        BASE_LIN_VEL=f(env.base_lin_vel), BASE_ANG_VEL=f(env.base_ang_vel),
+        # physics-internal state the reference never sees (as PhysX keeps its actors' sleep state to itself)
+        BOX_SLEEP_TIMER=env._backend.ora.get("BOX_SLEEP_TIMER").astype(np.float32))

@@ -22,8 +22,8 @@ for var in variants:
     robot = dict(model=m, wmodel=abi.fill_model(m), cfg=cfg, tcfg=tc)
     g = helpers.make_gpu(robot, n, helpers.random_env_params(n, 0))
     g.reset_all()
-    acts = [torch.randn(n, 18, device="cuda") * 0.5 for _ in range(8)]
-    for i in range(20): g.step(acts[i % 8])
+    acts = [torch.randn(n, 18, device="cuda") * float(os.environ.get("WBC_ACT_SCALE", "0.5")) for _ in range(8)]
+    for i in range(int(os.environ.get("WBC_WARM_STEPS", "20"))): g.step(acts[i % 8])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
