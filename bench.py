@@ -75,7 +75,7 @@ def cpu_baseline(runner, sim_sample_envs=512):
     learner has just consumed (its storage copied to the host): compute_returns + update() (median of 3) and
     update_dagger() (once), torch CPU with all cores. `value` = N*T / (returns + update): the learner-only ceiling of a
     CPU run in env-steps/s (the reference has no CPU simulator: Isaac Gym is CUDA-only). For context, `sim_port` times
-    this framework's scalar C oracle of the sim step on one core over a bounded sample."""
+    this framework's scalar C oracle of the sim step (OpenMP over the envs: the thread count is reported) over a bounded sample."""
     import contextlib
     import io
     import statistics
@@ -133,7 +133,7 @@ def cpu_baseline(runner, sim_sample_envs=512):
                      f"{N}x{T} rollout the GPU learner consumed), update_dagger() {t_dag:.2f} s (once); learner only, no CPU sim exists",
            "compute_returns_s": ret_s, "update_s": upd_s, "update_dagger_s": t_dag,
            "sample_epochs_per_s": N * T * 5 / upd_s}
-    # context: this framework's own scalar CPU oracle of the sim step (test infrastructure), one core
+    # context: this framework's own scalar CPU oracle of the sim step (test infrastructure), OpenMP over the envs
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as ora
@@ -152,8 +152,8 @@ def cpu_baseline(runner, sim_sample_envs=512):
         while k < 10 and time.perf_counter() - t0 < 8.0:
             sim.step(0.3 * rng.standard_normal((n, 18)))
             k += 1
-        out["sim_port"] = {"value": n * k / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1,
-                           "sample": f"oracle/wbc_oracle.c (fp64), {n} envs x {k} steps"}
+        out["sim_port"] = {"value": n * k / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": sim.threads,
+                           "sample": f"oracle/wbc_oracle.c (fp64, OpenMP over envs, {sim.threads} threads), {n} envs x {k} steps"}
     except Exception as e:      # the checker is optional here
         out["sim_port"] = {"error": repr(e)}
     return out
@@ -386,7 +386,19 @@ def main():
                 return d.get("hbm_bytes_per_launch")
             except Exception:
                 return None
-        traffic = counter_file("step_kernel_traffic.json") if args.envs_per_gpu == 4096 and args.terrain == "plane" else None
+        # Counter-derived fields are NOT collected by this run (rocprofv3 --pmc needs its own passes): they are read from the
+        # committed summary of the same bench command, and the line says so (roofline.counters_source); null when the summary
+        # does not match this configuration.
+        traffic = active_lanes = valu_per_wave = counters_source = None
+        if args.envs_per_gpu == 4096 and args.terrain == "plane":
+            try:
+                cj = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_counters.json")))
+                sk = cj["step_kernel"]
+                traffic, active_lanes, valu_per_wave = sk["hbm_bytes_per_launch"], sk["active_lanes"], sk["valu_insts_per_wave"]
+                counters_source = {"file": "profiles/step_kernel_counters.json", "collected_with": cj["collected_with"], "date": cj["date"],
+                                   "note": "separate rocprofv3 --pmc passes over the same bench loop; not measured by this run"}
+            except Exception:
+                pass
         strong = bool(args.global_envs)
         out = {
             "metric": "env-steps/sec whole node, widowGo1 4096-env PPO",
@@ -408,7 +420,14 @@ def main():
                        "learn_ms": 1e3 * sum(h["learn_time"] for h in hist) / len(hist)},
             "roofline": {"kernel": "wbc_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(events)},
+                         "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(events),
+                         # what actually bounds this kernel (one wavefront per env, 4 per SIMD at 4096 envs): vector-instruction issue.
+                         # active_lanes = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU; valu_issue_frac = the share of the launch the SIMDs
+                         # spend issuing vector instructions = insts per wave x waves per SIMD x 4 cycles / (launch time x 2.4 GHz)
+                         "active_lanes": active_lanes,
+                         "valu_issue_frac": (valu_per_wave * (args.envs_per_gpu / 1024.0) * 4.0 / (kern_ms * 1e-3 * 2.4e9)
+                                             if valu_per_wave and kern_ms > 0 else None),
+                         "counters_source": counters_source},
         }
         if upd_events:
             upd_ms = sum(a.elapsed_time(b) for a, b in upd_events) / len(upd_events)
@@ -424,6 +443,9 @@ def main():
             note("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(runner)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if log_dir is not None:
+        import shutil
+        shutil.rmtree(log_dir, ignore_errors=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -578,8 +578,10 @@ class WidowGo1(LeggedRobot):
     def attach_episode_tracker(self, state, cap):
         """The training loop's episode deques (OnPolicyRunner.learn, OPR:140-154) ride on the per-step statistics launch as one
         extra workgroup (wbc_sim_episode_stats_track): `state` = wbc_runner_track_state_floats(num_envs, cap) zeroed floats on the
-        sim device, or None to detach. Needs collect_episode_stats (the launch it rides on). Effective from the next step()."""
+        sim device, or None to detach. Needs collect_episode_stats (the launch it rides on). Effective from the next step():
+        returns the value common_step_counter will have after the first step this env accounts for (steps before it are the caller's)."""
         self._track = (state, int(cap)) if state is not None else (None, 0)
+        return int(self.common_step_counter) + 1
 
     def restore_terrain_levels(self, levels, arena_restored=False):
         """Checkpoint resume (OnPolicyRunner.load): adopt saved terrain levels. env_origins and the sim's ENV_ORIGINS are

@@ -182,7 +182,8 @@ class PPO:
     def compute_returns(self, last_critic_obs, side_job=None):
         ac = self.actor_critic
         if self.fused_rollout and not torch.is_grad_enabled() and ac.fused_act_supported(last_critic_obs):
-            ac.mark_params_changed()       # a version compare; re-packs only if somebody stepped the weights since the rollout's first act()
+            # (the weight pack follows ac.param_version: update() / update_dagger() / load_state_dict bump it; nothing steps the
+            # weights between the rollout's first act() and here, so no re-pack is forced)
             last_values = ac.fused_act(last_critic_obs, side_job=side_job)[3]     # the critic half of the inference kernel (one launch)
         else:
             if side_job is not None:

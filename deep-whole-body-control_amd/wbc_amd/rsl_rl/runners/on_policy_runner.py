@@ -51,9 +51,9 @@ class _EpisodeTracker:
         self.state = torch.zeros(self._L.wbc_runner_track_state_floats(n, self.CAP), device=device)
         # An env that publishes extras['episode'] with one launch per step (WidowGo1.attach_episode_tracker) carries the
         # bookkeeping in that launch as an extra workgroup: no launch and no stream hop of its own.
-        self._hooked_env = None
+        self._hooked_env, self._env_from = None, None
         if hasattr(env, "attach_episode_tracker") and getattr(env, "collect_episode_stats", False):
-            env.attach_episode_tracker(self.state, self.CAP)
+            self._env_from = env.attach_episode_tracker(self.state, self.CAP)     # first env step (its common_step_counter) the env accounts for
             self._hooked_env = env
 
     def _launch(self, rewards, arm_rewards, dones):
@@ -62,12 +62,12 @@ class _EpisodeTracker:
                     "wbc_runner_track_episodes")
 
     def step(self, rewards, arm_rewards, dones):
-        """Account for the env step that has just produced these tensors. With an attached env its step() has done it already --
-        but only from the step AFTER the attachment, so the very first call launches here."""
-        if self._hooked_env is None or not self._armed:
+        """Account for the env step that has just produced these tensors. An attached env does it inside its own step() -- from
+        the step index attach_episode_tracker returned on; a step before that (the one during which the tracker was created) is
+        launched here. Gated on the env's step counter, not on call order: no step is counted twice or dropped."""
+        env = self._hooked_env
+        if env is None or self._env_from is None or int(env.common_step_counter) < self._env_from:
             self._launch(rewards, arm_rewards, dones)
-            self._armed = True
-    _armed = False
 
     def close(self):
         if self._hooked_env is not None:
@@ -103,9 +103,14 @@ class OnPolicyRunner:
         actor_critic = policy_cls(e.num_proprio, e.num_proprio, env.num_actions, **self.policy_cfg, num_priv=e.num_priv,
                                   num_hist=e.history_len, num_prop=e.num_proprio).to(self.device)
         self.dist_group = dist_group
-        if dist_group is not None:      # identical initial replicas on every rank
-            for p in actor_critic.parameters():
-                collectives.broadcast(p.data, 0, dist_group)
+        if dist_group is not None:      # identical initial replicas on every rank: ONE flat broadcast (41 tensors, 675 kB), not one per parameter
+            params = list(actor_critic.parameters())
+            flat = torch.cat([p.data.reshape(-1) for p in params])
+            collectives.broadcast(flat, 0, dist_group)
+            off = 0
+            for p in params:
+                p.data.copy_(flat[off:off + p.numel()].view_as(p.data))
+                off += p.numel()
         self.alg: PPO = _ALGORITHMS[self.cfg["algorithm_class_name"]](actor_critic, device=self.device, dist_group=dist_group,
                                                                       **self.alg_cfg)
         if hasattr(self.alg, "warm_up_collectives"):
@@ -318,7 +323,9 @@ class OnPolicyRunner:
 
     def load(self, path, load_optimizer=True, restore_rng=True):
         """OPR:284-290; a checkpoint written by the reference (no 'wbc_extra') loads the same way."""
-        d = torch.load(path, map_location=self.device)
+        # weights_only: a checkpoint is tensors, numbers and plain containers (what save() writes and what the reference writes,
+        # OPR:276-282); nothing in it needs the unpickler to run code
+        d = torch.load(path, map_location=self.device, weights_only=True)
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
         if hasattr(self.alg.actor_critic, "mark_params_changed"):
             self.alg.actor_critic.mark_params_changed()          # the fused kernels re-pack the weights
@@ -339,9 +346,15 @@ class OnPolicyRunner:
                 env.common_step_counter = extra["env_common_step_counter"]
             sim = getattr(env, "sim", None)
             arena_restored = False
-            if "sim_arena" in extra and sim is not None and hasattr(sim, "arena") and sim.arena.shape == extra["sim_arena"].shape:
-                sim.arena.copy_(extra["sim_arena"])
-                arena_restored = True
+            if "sim_arena" in extra and sim is not None and hasattr(sim, "arena"):
+                if sim.arena.shape == extra["sim_arena"].shape:
+                    sim.arena.copy_(extra["sim_arena"])
+                    arena_restored = True
+                else:      # another build's tensor layout (enum wbc_tensor_id / WBC_NREW changed): the env state cannot be adopted
+                    import warnings
+                    warnings.warn(f"checkpoint {path}: its simulator arena ({tuple(extra['sim_arena'].shape)} bytes) does not match this build's "
+                                  f"({tuple(sim.arena.shape)}); networks, optimisers and counters are restored, the env state is NOT "
+                                  f"(robots are re-placed by a reset)", stacklevel=2)
             if "terrain_levels" in extra and torch.is_tensor(getattr(env, "terrain_levels", None)):
                 if hasattr(env, "restore_terrain_levels"):      # origins follow the levels; robots re-placed unless the arena came back
                     env.restore_terrain_levels(extra["terrain_levels"], arena_restored)

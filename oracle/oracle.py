@@ -72,6 +72,11 @@ class OracleSim:
             self.lib.ora_destroy(self.h)
             self.h = None
 
+    @property
+    def threads(self) -> int:
+        """OpenMP threads `step` spreads the envs over."""
+        return int(self.lib.ora_threads())
+
     def set_curriculum(self, cur: abi.WbcCurriculum):
         self.lib.ora_set_curriculum(self.h, C.byref(cur))
 

@@ -40,6 +40,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/wbc_sim.h"
 
@@ -1126,6 +1129,14 @@ static void env_step(const ora_sim* s, ora_env* e, int env, const REAL* actions_
 #endif
 
 ORA_API int ora_real_bytes(void) { return (int)sizeof(REAL); }
+/* threads ora_step spreads the envs over (bench.py reports it with the oracle's throughput) */
+ORA_API int ora_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 /* sizeof of the ABI structs, so the ctypes mirrors in wbc_amd/abi.py can be checked */
 ORA_API void ora_abi_sizes(int* out) { out[0] = (int)sizeof(wbc_model); out[1] = (int)sizeof(wbc_task_cfg); out[2] = (int)sizeof(wbc_curriculum); }
 
