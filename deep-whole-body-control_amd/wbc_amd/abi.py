@@ -272,9 +272,83 @@ def fill_model(m: RobotModel, foot_name: str = "foot",
     return out
 
 
-def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None) -> WbcTaskCfg:
+def _get(cfg, path, default=None):
+    o = cfg
+    for name in path.split("."):
+        if not hasattr(o, name):
+            return default
+        o = getattr(o, name)
+    return o
+
+
+# Config switches the reference READS (WG = envs/widowGo1/widowGo1.py) whose non-default value this framework does not implement:
+# (path, supported value(s), why). Flipping one raises instead of being silently ignored (tests/test_host_logic.py flips each).
+UNSUPPORTED_SWITCHES = [
+    ("control.adaptive_arm_gains", (False,), "dead in the reference as well: step() reorders the actions through an 18-index table (WG:1162, "
+     "raisim2ig_wo_gripper) which drops the six gain columns, then _compute_torques slices actions[:, 18:] = [N, 0] and adds it to the six "
+     "arm gains (WG:1274,1285: a shape error); action_history_buf is [N, 4, 18] (WG:540)"),
+    ("env.reorder_dofs", (True,), "the fused step hard-wires the policy <-> simulator joint order of WG:1003-1088"),
+    ("domain_rand.observe_priv", (True,), "dead in the reference as well: obs_buf is only ever assigned inside `if observe_priv` (WG:986-992), so "
+     "without it the policy sees the zero-initialised buffer forever (profiles/r04_reference_switches.txt)"),
+    ("goal_ee.command_mode", ("sphere",), "'cart' rebinds curr_ee_goal to the Cartesian goal (WG:589-593): observations [70:73] and the goal-sign tests of "
+     "check_termination (WG:945-946) would read Cartesian coordinates; the fused step implements the shipped spherical mode"),
+    ("asset.fix_base_link", (False,), "the physics spec is a floating base (DESIGN.md section 3)"),
+    ("asset.disable_gravity", (False,), "not modelled; set sim.gravity instead"),
+    ("asset.collapse_fixed_joints", (True,), "the rigid-body list (27 bodies, quirk Q1) is the collapsed one"),
+    ("asset.default_dof_drive_mode", (3,), "the task drives joints by effort (WG:1183); position / velocity drive modes are not modelled"),
+    ("asset.linear_damping", (0.0,), "body damping is not modelled"),
+    ("asset.angular_damping", (0.0,), "body damping is not modelled"),
+    ("terrain.restitution", (0.0,), "contacts are inelastic (restitution 0, tests/test_oracle_contact_physics.py)"),
+    ("sim.substeps", (1,), "one solver step per gym.simulate (LRC:184)"),
+    ("sim.up_axis", (1,), "z is up (LRC:186)"),
+]
+# Switches the reference reads but that have NO effect in its widowGo1 task either (the code that would use them is commented out or
+# overridden): ignoring them is the faithful behaviour. (path, where the reference drops it)
+REFERENCE_NO_OPS = [
+    ("noise.add_noise", "WG:63 stores it, WG:616 builds noise_scale_vec, compute_observations (WG:966-1001) never applies either"),
+    ("commands.heading_command", "WG:927-930 commented out"),
+    ("commands.curriculum", "WG:711-712 commented out (update_command_curriculum is called by the runner instead, OPR:126)"),
+    ("domain_rand.randomize_arm_ema", "WG:410-413,1170 commented out"),
+    ("control.control_type", "WidowGo1._compute_torques (WG:1262-1295) is a PD law whatever the value; only the base class reads it"),
+    ("box.box_pos_obs_range", "update_target_ee_base commented out (WG:1244-1259)"),
+    ("arm.grasp_offset", "update_target_ee_base commented out (WG:1244-1259)"),
+    ("arm.init_target_ee_base", "update_target_ee_base commented out (WG:1244-1259)"),
+    ("termination.r_threshold", "check_termination hard-codes 0.2 rad (WG:945-946)"),
+    ("termination.p_threshold", "check_termination hard-codes 0.2 rad (WG:945-946)"),
+    ("asset.flip_visual_attachments", "visual only"),
+    ("asset.max_linear_velocity", "1000 m/s: never reached"),
+    ("asset.max_angular_velocity", "1000 rad/s: never reached (URDF joint velocity limits are enforced, DESIGN.md section 3)"),
+    ("asset.thickness", "PhysX shape-thickness hint of the importer; the contact offset is sim.physx.contact_offset"),
+    ("asset.density", "the URDF gives every link its mass"),
+    ("asset.replace_cylinder_with_capsule", "the collision set uses sphere-swept primitives throughout"),
+    ("env.env_spacing", "custom origins (WG:207-224)"),
+    ("viewer.pos", "headless"), ("viewer.lookat", "headless"),
+]
+
+
+def unsupported_switches(cfg):
+    """[(path, value, reason)] for every switch of UNSUPPORTED_SWITCHES that `cfg` flips away from what is implemented."""
+    bad = []
+    for path, ok, why in UNSUPPORTED_SWITCHES:
+        v = _get(cfg, path, ok[0])
+        if isinstance(v, bool) or isinstance(ok[0], bool):
+            v = bool(v)
+        if v not in ok:
+            bad.append((path, v, why))
+    t = getattr(cfg, "terrain", None)
+    if t is not None and float(getattr(t, "dynamic_friction", getattr(t, "static_friction", 1.0))) != float(getattr(t, "static_friction", 1.0)):
+        bad.append(("terrain.dynamic_friction", t.dynamic_friction, "one Coulomb coefficient per contact (static = dynamic), DESIGN.md section 3"))
+    return bad
+
+
+def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None, check: bool = True) -> WbcTaskCfg:
     """WidowGo1RoughCfg (+ LeggedRobotCfg.sim) -> wbc_task_cfg, resolving names to numbers the way
-    WidowGo1._parse_cfg / _init_buffers do (WG:78-121, 498-672)."""
+    WidowGo1._parse_cfg / _init_buffers do (WG:78-121, 498-672). Raises NotImplementedError for a switch the reference reads
+    and this framework does not implement (UNSUPPORTED_SWITCHES): nothing is silently ignored."""
+    bad = unsupported_switches(cfg) if check else []      # (check=False: the reference harness, whose physics backend ignores the task switches)
+    if bad:
+        raise NotImplementedError("config switches this framework does not implement: " +
+                                  "; ".join(f"{p} = {v!r} ({why})" for p, v, why in bad))
     out = WbcTaskCfg()
     dt = float(cfg.sim.dt if sim_dt is None else sim_dt)
     out.sim_dt = dt
@@ -296,7 +370,7 @@ def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None) -> WbcTask
             if key in names[i]:
                 kp, kd = cfg.control.stiffness[key], cfg.control.damping[key]
         out.p_gains[i], out.d_gains[i] = kp, kd
-        out.joint_armature[i] = dt * kd + dt * dt * kp
+        out.joint_armature[i] = dt * kd + dt * dt * kp + float(_get(cfg, "asset.armature", 0.0))   # + the importer's armature (LRC:115)
     for i in range(NDOF):                                                    # WG:642-646
         out.default_dof_pos[i] = float(cfg.init_state.default_joint_angles[names[i]])
         out.torque_limits[i] = float(m.dof_effort[i])                        # LR:294-299

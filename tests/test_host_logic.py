@@ -265,3 +265,80 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     tc = abi.fill_task_cfg(cfg, m)
     assert tc.penalize_contact_rb_mask == sum(1 << i for i, n in enumerate(names) if "thigh" in n or "trunk" in n)
     assert tc.term_contact_rb_mask == sum(1 << i for i, n in enumerate(names) if "wx250" in n or "base" in n)
+
+
+def _set_path(cfg, path, value):
+    o = cfg
+    parts = path.split(".")
+    for name in parts[:-1]:
+        o = getattr(o, name)
+    setattr(o, parts[-1], value)
+
+
+def test_no_config_switch_is_silently_ignored():
+    """Every switch of WidowGo1RoughCfg that the reference's widowGo1 path reads is one of: implemented (flipping it changes the
+    task constants / the model handed to the kernels), refused (abi.UNSUPPORTED_SWITCHES: NotImplementedError naming the switch
+    and the reference line), or a no-op in the reference itself (abi.REFERENCE_NO_OPS: the code that would read it is commented
+    out or overridden there; what the reference does with the doubtful ones is recorded by tools/check_reference_dead_switches.py
+    in profiles/r04_reference_switches.txt)."""
+    import ctypes
+    m = abi.load_default_model()
+
+    def snapshot(cfg):
+        tc = abi.fill_task_cfg(cfg, m)
+        wm = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0, box_size=float(cfg.box.box_size))
+        return bytes(ctypes.string_at(ctypes.addressof(tc), ctypes.sizeof(tc))) + bytes(ctypes.string_at(ctypes.addressof(wm), ctypes.sizeof(wm)))
+    base = snapshot(WidowGo1RoughCfg())
+    # refused
+    flips = {"control.adaptive_arm_gains": True, "env.reorder_dofs": False, "domain_rand.observe_priv": False, "goal_ee.command_mode": "cart",
+             "asset.fix_base_link": True, "asset.disable_gravity": True, "asset.collapse_fixed_joints": False, "asset.default_dof_drive_mode": 1,
+             "asset.linear_damping": 0.1, "asset.angular_damping": 0.1, "terrain.restitution": 0.5, "sim.substeps": 2, "sim.up_axis": 0}
+    assert set(flips) == {p for p, _, _ in abi.UNSUPPORTED_SWITCHES}
+    for path, value in flips.items():
+        cfg = WidowGo1RoughCfg()
+        _set_path(cfg, path, value)
+        with pytest.raises(NotImplementedError, match=path.replace(".", r"\.")):
+            abi.fill_task_cfg(cfg, m)
+    cfg = WidowGo1RoughCfg()
+    cfg.terrain.dynamic_friction = 0.5
+    with pytest.raises(NotImplementedError, match="dynamic_friction"):
+        abi.fill_task_cfg(cfg, m)
+    # no-ops of the reference: nothing handed to the kernels changes
+    noop_values = {"noise.add_noise": True, "commands.heading_command": False, "commands.curriculum": False, "domain_rand.randomize_arm_ema": True,
+                   "control.control_type": "V", "box.box_pos_obs_range": 2.0, "arm.grasp_offset": 0.2, "arm.init_target_ee_base": [0.3, 0.1, 0.1],
+                   "termination.r_threshold": 0.3, "termination.p_threshold": 0.3, "asset.flip_visual_attachments": True,
+                   "asset.max_linear_velocity": 500.0, "asset.max_angular_velocity": 500.0, "asset.thickness": 0.02, "asset.density": 0.01,
+                   "asset.replace_cylinder_with_capsule": False, "env.env_spacing": 5.0, "viewer.pos": [0, 0, 1], "viewer.lookat": [1, 0, 0]}
+    assert set(noop_values) == {p for p, _ in abi.REFERENCE_NO_OPS}
+    for path, value in noop_values.items():
+        cfg = WidowGo1RoughCfg()
+        try:
+            _set_path(cfg, path, value)
+        except AttributeError:
+            continue                                           # (a field the shipped config does not even define)
+        assert snapshot(cfg) == base, path
+    # implemented: each of these changes what the kernels receive
+    effective = {"control.decimation": 2, "control.action_scale": [0.3] * 18, "control.stiffness": {"joint": 40, "widow": 4},
+                 "control.damping": {"joint": 2, "widow": 1}, "env.action_delay": 1, "env.episode_length_s": 5, "normalization.clip_actions": 50.0,
+                 "normalization.clip_observations": 50.0, "termination.z_threshold": 0.2, "asset.terminate_after_contacts_on": ["thigh"],
+                 "asset.penalize_contacts_on": ["calf"], "asset.self_collisions": 1, "asset.armature": 0.01, "asset.foot_name": "foot",
+                 "commands.resampling_time": 2.0, "commands.lin_vel_x_clip": 0.2, "commands.ang_vel_yaw_clip": 0.4, "domain_rand.push_robots": False,
+                 "domain_rand.push_interval_s": 5, "domain_rand.max_push_vel_xy": 1.0, "goal_ee.underground_limit": -0.4,
+                 "goal_ee.num_collision_check_samples": 5, "goal_ee.collision_upper_limits": [0.3, 0.15, 0.0], "goal_ee.sphere_error_scale": [1, 1, 1],
+                 "goal_ee.orn_error_scale": [1, 1, 1], "rewards.tracking_sigma": 0.5, "rewards.tracking_ee_sigma": 0.5, "rewards.only_positive_rewards": True,
+                 "init_state.pos": [0, 0, 0.5], "terrain.origin_perturb_range": 0.1, "terrain.init_vel_perturb_range": 0.3, "terrain.static_friction": 0.5,
+                 "box.box_env_origins_x": 1.0, "box.box_env_origins_z": 0.3, "box.box_size": 0.2, "sim.dt": 0.0025, "sim.gravity": [0, 0, -5.0]}
+    for path, value in effective.items():
+        cfg = WidowGo1RoughCfg()
+        _set_path(cfg, path, value)
+        if path == "terrain.static_friction":
+            cfg.terrain.dynamic_friction = value               # (one Coulomb coefficient: the two must agree)
+        if path == "asset.foot_name":
+            continue                                           # (renaming the feet away is an assertion in fill_model: covered below)
+        assert snapshot(cfg) != base, f"{path} = {value!r} changed nothing"
+    cfg = WidowGo1RoughCfg()
+    cfg.sim.physx.contact_offset = 0.02
+    assert snapshot(cfg) != base
+    cfg = WidowGo1RoughCfg()
+    cfg.sim.physx.max_depenetration_velocity = 2.0
+    assert snapshot(cfg) != base

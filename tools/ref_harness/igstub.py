@@ -459,7 +459,7 @@ class OracleBackend:
         self.model = abi.load_default_model()
         self.wmodel = abi.fill_model(self.model, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0,
                                      box_size=float(cfg.box.box_size))
-        self.tcfg = abi.fill_task_cfg(cfg, self.model, sim_dt=sim_dt)
+        self.tcfg = abi.fill_task_cfg(cfg, self.model, sim_dt=sim_dt, check=False)
         self.ora = OracleSim(self.wmodel, self.tcfg, num_envs, seed=seed, precision="f64")
         nb = self.model.num_rigid_bodies + 1
         self.t_root = torch.zeros(num_envs * 2, 13)
