@@ -78,6 +78,8 @@ struct DevTensors {
   float* reset_travel; // [N,2]
   float* box_mass;    // [N]
   float* box_timer;   // [N]
+  float* feet_air_time; // [N,4]
+  float* last_contacts; // [N,4]
 };
 
 #define WBC_PI 3.14159265358979323846f

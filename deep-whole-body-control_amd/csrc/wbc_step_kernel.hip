@@ -69,8 +69,8 @@ struct PostBuf {                  // post-physics staging; shares LDS with IA (d
   float out_rb[WBC_NRB_ENV][13];
   float quatB[WBC_NB][4], omB[WBC_NB][3], voB[WBC_NB][3];
   float o76[WBC_NPROP];
-  float term[WBC_NREW], msrc[WBC_NREW];      // raw reward terms / metric sources of this step (lane 0 -> lanes t)
 };
+#define WBC_NREW_WG 22             // the terms WG itself defines (the only ones with a metric side effect)
 
 struct __align__(16) Smem {
   union {
@@ -108,6 +108,7 @@ struct __align__(16) Smem {
   float goal[24], cmd[3], blv[3], bav[3];
   float act_last[WBC_NACT];      // newest (undelayed) action, sim order
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
+  float term[WBC_NREW], msrc[WBC_NREW_WG];   // raw reward terms / metric sources of this step (lane 0 -> lanes t)
   float rew, arm_rew, base_yaw, friction;
   float mu[4];                   // friction coefficients: robot-terrain, robot-robot, box-terrain, robot-box
   float rp[2];                   // base roll / pitch of the state the observation is built from (post-physics, or post-reset)
@@ -1081,12 +1082,16 @@ __device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
     /* FOOT_CONTACTS_Z */ {WBC_REW_FOOT_CONTACTS_Z, -1}};
 
 // compute_reward of the oracle, executed by lane 0 on LDS state
-__device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const float* yq, const float ncol) {
+// sums over the DoFs / actions that the base class's reward terms need (computed lane-parallel by base_reward_sums, all lanes)
+struct BaseSums { float dv2, da2, ar2, plim, vlim, tlim, still; };
+
+__device__ void compute_reward(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, const float* yq, const float ncol, const bool base_on,
+                               const BaseSums& bs, int env) {
   const wbc_task_cfg& cf = C->cfg;
   const float inv_sig = rcpf(cf.tracking_sigma), inv_ee_sig = rcpf(cf.tracking_ee_sigma);
-  float term[WBC_NREW], met_src[WBC_NREW];
+  float term[WBC_NREW_WG], met_src[WBC_NREW_WG];
 #pragma unroll
-  for (int t = 0; t < WBC_NREW; ++t) met_src[t] = 0.f;
+  for (int t = 0; t < WBC_NREW_WG; ++t) met_src[t] = 0.f;
   const float* ee_pos = s.post.out_rb[C->model.gripper_rb];
   const float* ee_orn = ee_pos + 3;
   float sq = 0.f, abs_sum = 0.f, sum = 0.f, arm_abs = 0.f, tq2 = 0.f, act_leg = 0.f;
@@ -1147,7 +1152,64 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
   met_src[WBC_REW_TRACKING_EE_ORN_RY] = eo_ry; met_src[WBC_REW_LEG_ENERGY_ABS_SUM] = abs_sum; met_src[WBC_REW_TORQUES] = tq2;
   // the per-term scaling / episode sums / metrics are done by lanes t < WBC_NREW (reward_accumulate)
 #pragma unroll
-  for (int t = 0; t < WBC_NREW; ++t) { s.post.term[t] = term[t]; s.post.msrc[t] = met_src[t]; }
+  for (int t = 0; t < WBC_NREW_WG; ++t) { s.term[t] = term[t]; s.msrc[t] = met_src[t]; }
+  // ---- the base class's terms (legged_robot.py:832-922; oracle: compute_reward), only when a config switches one on ----
+  if (base_on) {
+    s.term[WBC_REW_LIN_VEL_Z] = s.blv[2] * s.blv[2];
+    s.term[WBC_REW_ANG_VEL_XY] = s.bav[0] * s.bav[0] + s.bav[1] * s.bav[1];
+    s.term[WBC_REW_DOF_VEL] = bs.dv2; s.term[WBC_REW_DOF_ACC] = bs.da2; s.term[WBC_REW_ACTION_RATE] = bs.ar2;
+    s.term[WBC_REW_TERMINATION] = (s.reset_flag && !s.time_out) ? 1.f : 0.f;
+    s.term[WBC_REW_DOF_POS_LIMITS] = bs.plim; s.term[WBC_REW_DOF_VEL_LIMITS] = bs.vlim; s.term[WBC_REW_TORQUE_LIMITS] = bs.tlim;
+    s.term[WBC_REW_TRACKING_ANG_VEL] = fast_expf(-(eyaw * eyaw) * inv_sig);
+    const float cmd_xy = __builtin_amdgcn_sqrtf(s.cmd[0] * s.cmd[0] + s.cmd[1] * s.cmd[1]);
+    s.term[WBC_REW_STAND_STILL] = bs.still * (cmd_xy < 0.1f ? 1.f : 0.f);
+    float stumble = 0.f, fcf = 0.f, air = 0.f;
+    const bool air_on = (((C->cur.leg_active_mask | C->cur.arm_active_mask) >> WBC_REW_FEET_AIR_TIME) & 1ull) != 0ull;
+    const float dtp = cf.sim_dt * (float)cf.decimation;
+    for (int f = 0; f < WBC_NFEET; ++f) {
+      const f3 cf3 = ld3(s.out_contact[C->model.feet_rb[f]]);
+      if (__builtin_amdgcn_sqrtf(cf3.x * cf3.x + cf3.y * cf3.y) > 5.f * fabsf(cf3.z)) stumble = 1.f;
+      fcf += fmaxf(__builtin_amdgcn_sqrtf(dot(cf3, cf3)) - cf.max_contact_force, 0.f);
+      if (air_on) {                                   // feet_air_time's state advances only while the function is in a reward list
+        float at = T.feet_air_time[(size_t)env * WBC_NFEET + f];
+        const bool contact = cf3.z > 1.f;
+        const bool filt = contact || T.last_contacts[(size_t)env * WBC_NFEET + f] != 0.f;
+        T.last_contacts[(size_t)env * WBC_NFEET + f] = contact ? 1.f : 0.f;
+        const bool first = at > 0.f && filt;
+        at += dtp;
+        air += first ? at - 0.5f : 0.f;
+        T.feet_air_time[(size_t)env * WBC_NFEET + f] = filt ? 0.f : at;
+      }
+    }
+    s.term[WBC_REW_STUMBLE] = stumble; s.term[WBC_REW_FEET_CONTACT_FORCES] = fcf;
+    s.term[WBC_REW_FEET_AIR_TIME] = air * (cmd_xy > 0.1f ? 1.f : 0.f);
+    const float bh = s.root[2] - cf.base_height_target;
+    s.term[WBC_REW_BASE_HEIGHT] = bh * bh;
+  }
+}
+
+// The base class's per-DoF / per-action sums, one DoF per lane and a butterfly (all lanes; called only when a base term is on).
+__device__ BaseSums base_reward_sums(const Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env) {
+  const int j = threadIdx.x;
+  const wbc_task_cfg& cf = C->cfg;
+  float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j < WBC_NDOF) {
+    const float q = s.q[j], qd = s.qd[j], tau = s.tau[j];
+    const float acc = (T.last_dof_vel[(size_t)env * WBC_NDOF + j] - qd) / (cf.sim_dt * (float)cf.decimation);
+    v[0] = qd * qd; v[1] = acc * acc;
+    v[3] = -fminf(q - cf.soft_dof_lower[j], 0.f) + fmaxf(q - cf.soft_dof_upper[j], 0.f);
+    v[4] = clampf(fabsf(qd) - cf.soft_dof_vel_limit[j], 0.f, 1.f);
+    v[5] = fmaxf(fabsf(tau) - cf.soft_torque_limit[j], 0.f);
+    v[6] = fabsf(q - cf.default_dof_pos[j]);
+  }
+  if (j < WBC_NACT) { const float d = T.last_actions[(size_t)env * WBC_NACT + j] - s.act[j]; v[2] = d * d; }
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+  // (the DoFs sit in lanes 0..19: after the xor 16 .. 1 butterfly every lane below 32 holds the sum over lanes 0..31)
+  BaseSums b; b.dv2 = v[0]; b.da2 = v[1]; b.ar2 = v[2]; b.plim = v[3]; b.vlim = v[4]; b.tlim = v[5]; b.still = v[6];
+  return b;
 }
 
 // rew_buf / arm_rew_buf, episode sums and metric sums from the raw terms: lane t owns term t, lane m metric slot m.
@@ -1157,24 +1219,25 @@ __device__ void compute_reward(Smem& s, const DevConst* __restrict__ C, const fl
 // butterfly sums over the wavefront.
 __device__ __forceinline__ void reward_accumulate(Smem& s, const DevConst* __restrict__ C, float lsc, float asc) {
   const int lane = threadIdx.x;
-  const uint32_t lmask = C->cur.leg_active_mask, amask = C->cur.arm_active_mask;
+  const uint64_t lmask = C->cur.leg_active_mask, amask = C->cur.arm_active_mask;
   float vl = 0.f, va = 0.f;
   if (lane < WBC_NREW) {
-    const float tm = s.post.term[lane];
+    const float tm = s.term[lane];
     float e = s.ep_sums[lane];
-    if ((lmask >> lane) & 1u) { vl = tm * lsc; e += vl; }
-    if ((amask >> lane) & 1u) { va = tm * asc; e += va; }
+    if ((lmask >> lane) & 1ull) { vl = tm * lsc; e += vl; }
+    if ((amask >> lane) & 1ull) { va = tm * asc; e += va; }
     s.ep_sums[lane] = e;
+    if (lane == WBC_REW_TERMINATION) { vl = 0.f; va = 0.f; }        // joins the totals after the only_positive_rewards clip (lane 0 below)
   }
   if (lane < WBC_NMETRIC) {
     float mt = s.met_sums[lane];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const uint32_t mask = ch == 0 ? lmask : amask;
+      const uint64_t mask = ch == 0 ? lmask : amask;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int t = MET_TERMS[lane][j];
-        if (t >= 0 && ((mask >> t) & 1)) mt += s.post.msrc[t];
+        if (t >= 0 && ((mask >> t) & 1ull)) mt += s.msrc[t];
       }
     }
     s.met_sums[lane] = mt;
@@ -1185,6 +1248,11 @@ __device__ __forceinline__ void reward_accumulate(Smem& s, const DevConst* __res
     float r = vl, ra = va;
     if (C->cfg.only_positive_rewards && r < 0.f) r = 0.f;
     if (C->cfg.only_positive_rewards && ra < 0.f) ra = 0.f;
+    if (((lmask | amask) >> WBC_REW_TERMINATION) & 1ull) {           // WG:184-188, 200-203
+      const float tt = s.term[WBC_REW_TERMINATION];
+      if ((lmask >> WBC_REW_TERMINATION) & 1ull) r += tt * C->cur.leg_reward_scale[WBC_REW_TERMINATION];
+      if ((amask >> WBC_REW_TERMINATION) & 1ull) ra += tt * C->cur.arm_reward_scale[WBC_REW_TERMINATION];
+    }
     s.rew = r / 100.f;
     s.arm_rew = ra / 100.f;
   }
@@ -1255,6 +1323,8 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
     s.q[lane] = C->cfg.default_dof_pos[lane] * rng_range(C->cfg.dof_reset_lo, C->cfg.dof_reset_hi, seed, env, step, SLOT_RESET_DOF + lane);
     s.qd[lane] = 0.f;
   }
+  if (lane < WBC_NFEET && (((C->cur.leg_active_mask | C->cur.arm_active_mask) >> WBC_REW_FEET_AIR_TIME) & 1ull))
+    T.feet_air_time[(size_t)env * WBC_NFEET + lane] = 0.f;                              // WG:734 (the state only exists while the term is on)
   if (lane < WBC_NREW) { T.ep_sums_done[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane]; }
   if (lane < WBC_NMETRIC) { T.met_sums_done[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane]; }
   WSYNC();
@@ -1437,6 +1507,10 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const uint32_t rb_bit = lane < WBC_NRB ? 1u << lane : 0u;
   const int c_term = __ballot((Cq->cfg.term_contact_rb_mask & rb_bit) != 0u && cnrm > 1.0f) != 0ull;
   const float ncol = (float)__popcll(__ballot((Cq->cfg.penalize_contact_rb_mask & rb_bit) != 0u && cnrm > 0.1f));
+  // the base class's reward terms (zero-scaled in the shipped config): their per-DoF sums, lane-parallel, only when one is on
+  const bool base_on = ((Cq->cur.leg_active_mask | Cq->cur.arm_active_mask) >> WBC_NREW_WG) != 0ull;
+  BaseSums bsums = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (base_on) bsums = base_reward_sums(s, T2, Cq, env);
   float base_yaw = 0.f;
   if (lane == 0) {
     s.ep_len += 1;
@@ -1468,8 +1542,9 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     const int z_term = z < Cq->cfg.term_z_threshold;
     s.time_out = s.ep_len > Cq->cfg.max_episode_length;
     s.reset_flag = c_term | r_term | p_term | z_term | s.time_out;
-    compute_reward(s, Cq, yq, ncol);
+    compute_reward(s, T2, Cq, yq, ncol, base_on, bsums, env);
   }
+  if (!base_on && lane >= WBC_NREW_WG && lane < WBC_NREW) s.term[lane] = 0.f;
   WSYNC();
   reward_accumulate(s, Cq, rsc_leg, rsc_arm);
   WSYNC();

@@ -15,7 +15,7 @@ from .urdf_model import RobotModel, merge_piece
 NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 52
 BOX_BODY, BOX_RB = NB, NRB                                # the free box actor's pseudo body index / rigid-body row
 CP_NONE, CP_TERRAIN, CP_BOX, CP_CAPSULE = -1, 0, 1, 2
-NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 22, 10
+NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 37, 10
 
 f32, i32 = C.c_float, C.c_int32
 
@@ -24,7 +24,11 @@ REWARD_TERMS = [
     "foot_contacts_z", "tracking_ee_sphere", "arm_energy_abs_sum", "tracking_ee_cart", "tracking_ee_orn",
     "tracking_ee_orn_ry", "leg_energy_abs_sum", "leg_energy_sum_abs", "leg_action_l2", "leg_energy",
     "tracking_lin_vel", "tracking_lin_vel_x_exp", "tracking_ang_vel_yaw_l1", "tracking_lin_vel_y_l2",
-    "tracking_lin_vel_z_l2", "torques", "collision"]
+    "tracking_lin_vel_z_l2", "torques", "collision",
+    # the base class's terms (legged_robot.py:832-922) that work in the widowGo1 task
+    "lin_vel_z", "ang_vel_xy", "dof_vel", "dof_acc", "action_rate", "termination", "dof_pos_limits", "dof_vel_limits", "torque_limits",
+    "tracking_ang_vel", "feet_air_time", "stumble", "stand_still", "feet_contact_forces", "base_height"]
+assert len(REWARD_TERMS) == NREW
 METRIC_NAMES = ["leg_energy_abs_sum", "tracking_lin_vel_x_l1", "tracking_ang_vel_yaw_exp", "tracking_ee_cart",
                 "tracking_ee_sphere", "tracking_ee_orn", "leg_action_l2", "torque", "energy_square",
                 "foot_contacts_z"]   # WG:165
@@ -65,6 +69,8 @@ class WbcTaskCfg(C.Structure):
         ("goal_collision_samples", i32), ("goal_delta_orn_range", (f32 * 2) * 3),
         ("sphere_error_scale", f32 * 3), ("orn_error_scale", f32 * 3), ("z_invariant_offset", f32),
         ("tracking_sigma", f32), ("tracking_ee_sigma", f32), ("only_positive_rewards", i32),
+        ("soft_dof_lower", f32 * NDOF), ("soft_dof_upper", f32 * NDOF), ("soft_dof_vel_limit", f32 * NDOF), ("soft_torque_limit", f32 * NDOF),
+        ("max_contact_force", f32), ("base_height_target", f32),
         ("base_init_state", f32 * 13), ("origin_perturb_range", f32), ("init_vel_perturb_range", f32),
         ("dof_reset_lo", f32), ("dof_reset_hi", f32), ("box_origin_x", f32), ("box_origin_z", f32),
         ("ground_z", f32),
@@ -76,7 +82,7 @@ class WbcCurriculum(C.Structure):
         ("lin_vel_x_range", f32 * 2), ("ang_vel_yaw_range", f32 * 2),
         ("goal_l_range", f32 * 2), ("goal_p_range", f32 * 2), ("goal_y_range", f32 * 2),
         ("leg_reward_scale", f32 * NREW), ("arm_reward_scale", f32 * NREW),
-        ("leg_active_mask", C.c_uint32), ("arm_active_mask", C.c_uint32),
+        ("leg_active_mask", C.c_uint64), ("arm_active_mask", C.c_uint64),
     ]
 
 
@@ -93,7 +99,7 @@ TENSOR_IDS = [
     "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_ROOT_VEL", "COMMANDS",
     "GOAL_STATE", "REW_BUF", "ARM_REW_BUF", "RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH", "EPISODE_SUMS",
     "METRIC_SUMS", "EPISODE_SUMS_DONE", "METRIC_SUMS_DONE", "BASE_LIN_VEL", "BASE_ANG_VEL", "MASS_PARAMS",
-    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS", "RESET_TRAVEL", "BOX_MASS", "BOX_SLEEP_TIMER"]
+    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS", "RESET_TRAVEL", "BOX_MASS", "BOX_SLEEP_TIMER", "FEET_AIR_TIME", "LAST_CONTACTS"]
 T = {name: i for i, name in enumerate(TENSOR_IDS)}
 # per-env shapes (without the leading N) and dtypes, as the header documents them
 TENSOR_SHAPES = {
@@ -104,7 +110,7 @@ TENSOR_SHAPES = {
     "RESET_BUF": (), "TIME_OUT_BUF": (), "EPISODE_LENGTH": (), "EPISODE_SUMS": (NREW,), "METRIC_SUMS": (10,),
     "EPISODE_SUMS_DONE": (NREW,), "METRIC_SUMS_DONE": (10,), "BASE_LIN_VEL": (3,), "BASE_ANG_VEL": (3,),
     "MASS_PARAMS": (5,), "FRICTION": (), "MOTOR_STRENGTH": (18,), "ENV_ORIGINS": (3,), "BOX_DELTA_Y": (),
-    "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,), "BOX_MASS": (), "BOX_SLEEP_TIMER": ()}
+    "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,), "BOX_MASS": (), "BOX_SLEEP_TIMER": (), "FEET_AIR_TIME": (4,), "LAST_CONTACTS": (4,)}
 TENSOR_DTYPES = {name: "f32" for name in TENSOR_IDS}
 TENSOR_DTYPES.update(RESET_BUF="i64", EPISODE_LENGTH="i64", TIME_OUT_BUF="u8")
 
@@ -341,6 +347,20 @@ def unsupported_switches(cfg):
     return bad
 
 
+def set_soft_limits(out: "WbcTaskCfg", m: RobotModel, soft_pos: float, soft_vel: float, soft_torque: float, max_contact_force: float,
+                    base_height_target: float) -> None:
+    """What the base class's limit rewards compare against: LR:294-304 (_process_dof_props: centre +- half range * soft_dof_pos_limit),
+    LR:882 (velocity limit * soft_dof_vel_limit), LR:886 (torque limit * soft_torque_limit), LR:922, LR:848."""
+    for i in range(NDOF):
+        lo, hi = float(m.dof_lower[i]), float(m.dof_upper[i])
+        mid, rng = 0.5 * (lo + hi), hi - lo
+        out.soft_dof_lower[i] = mid - 0.5 * rng * soft_pos
+        out.soft_dof_upper[i] = mid + 0.5 * rng * soft_pos
+        out.soft_dof_vel_limit[i] = float(m.dof_velocity[i]) * soft_vel
+        out.soft_torque_limit[i] = float(m.dof_effort[i]) * soft_torque
+    out.max_contact_force, out.base_height_target = max_contact_force, base_height_target
+
+
 def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None, check: bool = True) -> WbcTaskCfg:
     """WidowGo1RoughCfg (+ LeggedRobotCfg.sim) -> wbc_task_cfg, resolving names to numbers the way
     WidowGo1._parse_cfg / _init_buffers do (WG:78-121, 498-672). Raises NotImplementedError for a switch the reference reads
@@ -409,6 +429,9 @@ def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None, check: boo
     out.tracking_sigma = float(cfg.rewards.tracking_sigma)
     out.tracking_ee_sigma = float(cfg.rewards.tracking_ee_sigma)
     out.only_positive_rewards = int(bool(cfg.rewards.only_positive_rewards))
+    rw = cfg.rewards
+    set_soft_limits(out, m, float(_get(rw, "soft_dof_pos_limit", 1.0)), float(_get(rw, "soft_dof_vel_limit", 1.0)),
+                    float(_get(rw, "soft_torque_limit", 1.0)), float(_get(rw, "max_contact_force", 100.0)), float(_get(rw, "base_height_target", 0.25)))
     st = cfg.init_state
     _set(out.base_init_state, list(st.pos) + list(st.rot) + list(st.lin_vel) + list(st.ang_vel))   # WG:341
     out.origin_perturb_range = float(cfg.terrain.origin_perturb_range)

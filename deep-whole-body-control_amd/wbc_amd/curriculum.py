@@ -7,11 +7,16 @@ import numpy as np
 
 from . import abi
 
-# reward names the reference's config knows but the fused step does not implement (all zero in the
-# shipped widowGo1 config); a non-zero scale for one of these is an error, not a silent drop
-UNIMPLEMENTED_REWARDS = {"termination", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_vel", "dof_acc",
-                         "base_height", "feet_air_time", "feet_stumble", "action_rate", "stand_still",
-                         "arm_orientation"}
+# reward names the reference's config knows that cannot be offered, each with what the REFERENCE does when its scale is non-zero
+# (recorded from its own code by tools/check_reference_dead_switches.py, profiles/r04_reference_switches.txt): a non-zero scale is
+# an error here too, not a silent drop
+UNIMPLEMENTED_REWARDS = {
+    "orientation": "legged_robot.py:841-843 reads self.projected_gravity, which WidowGo1._init_buffers never creates (WG:636,885 commented out): "
+                   "AttributeError on the first compute_reward",
+    "arm_orientation": "no _reward_arm_orientation exists (WG:1417-1420 commented out): AttributeError in _prepare_reward_function",
+    "feet_stumble": "the config key names no method (the method is _reward_stumble: use the scale name 'stumble'): AttributeError in "
+                    "_prepare_reward_function",
+}
 
 
 def _scales(obj) -> dict:
@@ -36,8 +41,13 @@ def make_curriculum(cfg, update_counter: int) -> abi.WbcCurriculum:
     leg, arm = _scales(cfg.rewards.scales), _scales(cfg.rewards.arm_scales)
     for table in (leg, arm):
         for name, val in table.items():
-            if val != 0 and (name in UNIMPLEMENTED_REWARDS or name not in abi.REWARD_TERMS):
-                raise NotImplementedError(f"reward term '{name}' has a non-zero scale but is not implemented by the fused step")
+            if val != 0 and name in UNIMPLEMENTED_REWARDS:
+                raise NotImplementedError(f"reward term '{name}' has a non-zero scale; the reference cannot run it either: {UNIMPLEMENTED_REWARDS[name]}")
+            if val != 0 and name not in abi.REWARD_TERMS:
+                raise NotImplementedError(f"reward term '{name}' has a non-zero scale but no such _reward_ method exists in the reference's widowGo1 task")
+            if val != 0 and name == "base_height" and bool(cfg.terrain.measure_heights):
+                raise NotImplementedError("reward term 'base_height' with terrain.measure_heights = True needs the measured heights inside the fused "
+                                          "step (legged_robot.py:845-848); with measure_heights = False (measured_heights = 0, WG:639) it is implemented")
     # the reward-function lists are fixed at construction from the config's non-zero scales (WG:128-157)
     leg_active = {name for name, val in leg.items() if val != 0}
     arm_active = {name for name, val in arm.items() if val != 0}

@@ -44,7 +44,7 @@ extern "C" {
 #define WBC_HIST 10      /* history_len */
 #define WBC_NOBS 860     /* num_observations */
 #define WBC_ADELAY_LEN 4 /* action_delay + 2 (WG:540) */
-#define WBC_NREW 22      /* reward terms implemented (enum wbc_reward_term) */
+#define WBC_NREW 37      /* reward terms implemented (enum wbc_reward_term) */
 #define WBC_NMETRIC 10   /* episode_metric_sums (WG:165) */
 #define WBC_MAX_DEPTH 6
 
@@ -109,7 +109,10 @@ typedef struct {
 
 enum wbc_contact_kind { WBC_CP_NONE = -1 /* unused slot */, WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1, WBC_CP_CAPSULE = 2 };
 
-enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) + the base class's _reward_collision (LR:865-867) */
+enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469), then the base class's (LR = envs/base/legged_robot.py:832-922)
+                            that work in the widowGo1 task. Not offered: orientation (LR:841-843 reads self.projected_gravity, which
+                            WidowGo1 never creates: AttributeError in the reference, profiles/r04_reference_switches.txt), arm_orientation
+                            (no such method), feet_stumble (the config key names no method; the method is _reward_stumble) */
   WBC_REW_ENERGY_SQUARE = 0, WBC_REW_SURVIVE, WBC_REW_TRACKING_LIN_VEL_X_L1,
   WBC_REW_TRACKING_ANG_VEL_YAW_EXP, WBC_REW_HIP_ACTION_L2, WBC_REW_FOOT_CONTACTS_Z,
   WBC_REW_TRACKING_EE_SPHERE, WBC_REW_ARM_ENERGY_ABS_SUM,
@@ -117,7 +120,14 @@ enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469) + th
   WBC_REW_LEG_ENERGY_ABS_SUM, WBC_REW_LEG_ENERGY_SUM_ABS, WBC_REW_LEG_ACTION_L2,
   WBC_REW_LEG_ENERGY, WBC_REW_TRACKING_LIN_VEL, WBC_REW_TRACKING_LIN_VEL_X_EXP,
   WBC_REW_TRACKING_ANG_VEL_YAW_L1, WBC_REW_TRACKING_LIN_VEL_Y_L2,
-  WBC_REW_TRACKING_LIN_VEL_Z_L2, WBC_REW_TORQUES, WBC_REW_COLLISION
+  WBC_REW_TRACKING_LIN_VEL_Z_L2, WBC_REW_TORQUES, WBC_REW_COLLISION,
+  /* base class */
+  WBC_REW_LIN_VEL_Z, WBC_REW_ANG_VEL_XY, WBC_REW_DOF_VEL, WBC_REW_DOF_ACC, WBC_REW_ACTION_RATE,
+  WBC_REW_TERMINATION,   /* added AFTER the only_positive_rewards clip (WG:184-188, 200-203) */
+  WBC_REW_DOF_POS_LIMITS, WBC_REW_DOF_VEL_LIMITS, WBC_REW_TORQUE_LIMITS, WBC_REW_TRACKING_ANG_VEL,
+  WBC_REW_FEET_AIR_TIME, /* stateful: WBC_T_FEET_AIR_TIME / WBC_T_LAST_CONTACTS, advanced only while the term is active */
+  WBC_REW_STUMBLE, WBC_REW_STAND_STILL, WBC_REW_FEET_CONTACT_FORCES,
+  WBC_REW_BASE_HEIGHT    /* with terrain.measure_heights = False (measured_heights = 0, WG:639): (z - base_height_target)^2 */
 };
 
 enum wbc_metric {        /* WG:165 order */
@@ -172,6 +182,10 @@ typedef struct {
   /* rewards */
   float tracking_sigma, tracking_ee_sigma;
   int32_t only_positive_rewards;
+  /* the base class's terms: soft joint limits (LR:301-304: centre +- half range * rewards.soft_dof_pos_limit), velocity limits
+   * * soft_dof_vel_limit (LR:882), torque limits * soft_torque_limit (LR:886), rewards.max_contact_force, base_height_target */
+  float soft_dof_lower[WBC_NDOF], soft_dof_upper[WBC_NDOF], soft_dof_vel_limit[WBC_NDOF], soft_torque_limit[WBC_NDOF];
+  float max_contact_force, base_height_target;
   /* resets (WG:757-828) */
   float base_init_state[13];
   float origin_perturb_range, init_vel_perturb_range;
@@ -190,7 +204,7 @@ typedef struct {
   /* bit t set = term t's _reward_ function is in the list built at construction from the config's non-zero scales
    * (_prepare_reward_function, WG:128-157): it is evaluated every step -- episode sum += term * current scale, metric side
    * effect applied -- even while a scheduled scale is 0 */
-  uint32_t leg_active_mask, arm_active_mask;
+  uint64_t leg_active_mask, arm_active_mask;
 } wbc_curriculum;
 
 /* Device tensors owned by the sim; ids for wbc_sim_get_tensor. Shapes at N envs. */
@@ -218,9 +232,9 @@ enum wbc_tensor_id {
   WBC_T_RESET_BUF,         /* i64 [N]                                        (BT:74) */
   WBC_T_TIME_OUT_BUF,      /* u8  [N]  (bool)                                (BT:76) */
   WBC_T_EPISODE_LENGTH,    /* i64 [N]                                        (BT:75) */
-  WBC_T_EPISODE_SUMS,      /* f32 [N,22] per-term sums (WBC_NREW), zeroed on reset (WG:162) */
+  WBC_T_EPISODE_SUMS,      /* f32 [N,37] per-term sums (WBC_NREW), zeroed on reset (WG:162) */
   WBC_T_METRIC_SUMS,       /* f32 [N,10]                                     (WG:166) */
-  WBC_T_EPISODE_SUMS_DONE, /* f32 [N,22] sums at the moment of reset (for extras) (WG:743-746) */
+  WBC_T_EPISODE_SUMS_DONE, /* f32 [N,37] sums at the moment of reset (for extras) (WG:743-746) */
   WBC_T_METRIC_SUMS_DONE,  /* f32 [N,10]                                     (WG:748-750) */
   WBC_T_BASE_LIN_VEL,      /* f32 [N,3]                                      (WG:880) */
   WBC_T_BASE_ANG_VEL,      /* f32 [N,3]                                      (WG:881) */
@@ -234,6 +248,8 @@ enum wbc_tensor_id {
                               the two quantities _update_terrain_curriculum reads before reset_idx overwrites them (LR:431-435) */
   WBC_T_BOX_MASS,          /* f32 [N]    total mass of the env's box actor: nominal + box.added_mass_range draw (WG:458-466) */
   WBC_T_BOX_SLEEP_TIMER,   /* f32 [N]    substeps the box actor has been at rest (asleep from box_sleep_time / sim_dt on) */
+  WBC_T_FEET_AIR_TIME,     /* f32 [N,4]  feet_air_time (WG:633, LR:898-909), zeroed on reset (WG:734) */
+  WBC_T_LAST_CONTACTS,     /* f32 [N,4]  last_contacts as 0 / 1 (WG:626, LR:902-903) */
   WBC_T_COUNT
 };
 enum wbc_dtype { WBC_F32 = 0, WBC_I64 = 1, WBC_U8 = 2 };

@@ -175,6 +175,7 @@ typedef struct {
   REAL reset_travel[2];      /* ||root_xy - origin_xy||, ||commands[:2]|| at the moment of reset (LR:431-435) */
   REAL box_mass;             /* total mass of the box actor (WG:458-466) */
   REAL box_timer;            /* substeps the box has been at rest (asleep from box_sleep_time / sim_dt on) */
+  REAL feet_air_time[WBC_NFEET], last_contacts[WBC_NFEET];   /* LR:898-909 (WG:626,633) */
 } ora_env;
 
 /* goal[] slots */
@@ -915,6 +916,7 @@ static void reset_env(const ora_sim* s, ora_env* e, int env, uint64_t step, int 
   resample_ee_goal(s, e, env, step, SLOT_RESET_GOAL_ORN, SLOT_RESET_GOAL_SPHERE, base_yaw); /* WG:729 */
   memset(e->last_actions, 0, sizeof(e->last_actions));                                    /* WG:732-739 */
   memset(e->last_dof_vel, 0, sizeof(e->last_dof_vel));
+  memset(e->feet_air_time, 0, sizeof(e->feet_air_time));                                  /* WG:734 */
   e->episode_length = 0;
   e->reset_buf = 1;
   memset(e->obs_hist, 0, sizeof(e->obs_hist));
@@ -991,11 +993,60 @@ static void compute_reward(const ora_sim* s, ora_env* e, const REAL* base_yaw_qu
   for (int rb = 0; rb < WBC_NRB; ++rb)
     if ((cf->penalize_contact_rb_mask >> rb) & 1u) ncol += (sqrt(dot3(e->contact_force[rb], e->contact_force[rb])) > (REAL)0.1) ? 1 : 0;
   term[WBC_REW_COLLISION] = ncol;
+  /* ---- the base class's terms (LR = legged_gym/envs/base/legged_robot.py) ---- */
+  const REAL dtp = (REAL)cf->sim_dt * (REAL)cf->decimation;                              /* self.dt, WG:80 */
+  term[WBC_REW_LIN_VEL_Z] = e->base_lin_vel[2] * e->base_lin_vel[2];                      /* LR:833-835 */
+  term[WBC_REW_ANG_VEL_XY] = e->base_ang_vel[0] * e->base_ang_vel[0] + e->base_ang_vel[1] * e->base_ang_vel[1];   /* LR:837-839 */
+  REAL dv2 = 0, da2 = 0, ar2 = 0, plim = 0, vlim = 0, tlim = 0, still = 0;
+  for (int j = 0; j < WBC_NDOF; ++j) {
+    dv2 += e->qd[j] * e->qd[j];                                                           /* LR:854-856 */
+    REAL acc = (e->last_dof_vel[j] - e->qd[j]) / dtp;                                     /* LR:858-860 */
+    da2 += acc * acc;
+    REAL below = e->q[j] - (REAL)cf->soft_dof_lower[j], above = e->q[j] - (REAL)cf->soft_dof_upper[j];   /* LR:873-877 */
+    plim += -(below < 0 ? below : 0) + (above > 0 ? above : 0);
+    vlim += clampr(fabs(e->qd[j]) - (REAL)cf->soft_dof_vel_limit[j], 0, 1);               /* LR:879-882 */
+    REAL over = fabs(e->torques[j]) - (REAL)cf->soft_torque_limit[j];                     /* LR:884-886 */
+    tlim += over > 0 ? over : 0;
+    still += fabs(e->q[j] - (REAL)cf->default_dof_pos[j]);                                /* LR:916-918 */
+  }
+  for (int j = 0; j < WBC_NACT; ++j) ar2 += (e->last_actions[j] - e->actions[j]) * (e->last_actions[j] - e->actions[j]);   /* LR:862-864 */
+  term[WBC_REW_DOF_VEL] = dv2; term[WBC_REW_DOF_ACC] = da2; term[WBC_REW_ACTION_RATE] = ar2;
+  term[WBC_REW_TERMINATION] = (e->reset_buf && !e->time_out) ? 1 : 0;                     /* LR:869-871 */
+  term[WBC_REW_DOF_POS_LIMITS] = plim; term[WBC_REW_DOF_VEL_LIMITS] = vlim; term[WBC_REW_TORQUE_LIMITS] = tlim;
+  REAL eyaw2 = (e->commands[2] - e->base_ang_vel[2]) * (e->commands[2] - e->base_ang_vel[2]);
+  term[WBC_REW_TRACKING_ANG_VEL] = exp(-eyaw2 / (REAL)cf->tracking_sigma);                /* LR:893-896 */
+  const REAL cmd_xy = sqrt(e->commands[0] * e->commands[0] + e->commands[1] * e->commands[1]);
+  term[WBC_REW_STAND_STILL] = still * (cmd_xy < (REAL)0.1 ? 1 : 0);
+  REAL stumble = 0, fcf = 0;
+  for (int f = 0; f < WBC_NFEET; ++f) {
+    const REAL* cf3 = e->contact_force[s->model.feet_rb[f]];
+    if (sqrt(cf3[0] * cf3[0] + cf3[1] * cf3[1]) > 5 * fabs(cf3[2])) stumble = 1;          /* LR:911-914 */
+    REAL over = sqrt(dot3(cf3, cf3)) - (REAL)cf->max_contact_force;                       /* LR:920-922 */
+    fcf += over > 0 ? over : 0;
+  }
+  term[WBC_REW_STUMBLE] = stumble; term[WBC_REW_FEET_CONTACT_FORCES] = fcf;
+  { REAL bh = e->root[0][2] - (REAL)cf->base_height_target; term[WBC_REW_BASE_HEIGHT] = bh * bh; }   /* LR:845-848, measured_heights = 0 (WG:639) */
+  /* feet_air_time (LR:898-909): its state advances only when the function is in a reward list */
+  term[WBC_REW_FEET_AIR_TIME] = 0;
+  if (((cu->leg_active_mask | cu->arm_active_mask) >> WBC_REW_FEET_AIR_TIME) & 1u) {
+    REAL rew = 0;
+    for (int f = 0; f < WBC_NFEET; ++f) {
+      const int contact = e->contact_force[s->model.feet_rb[f]][2] > (REAL)1.0;
+      const int filt = contact || (e->last_contacts[f] != 0);
+      e->last_contacts[f] = contact;
+      const int first = (e->feet_air_time[f] > 0) && filt;
+      e->feet_air_time[f] += dtp;
+      rew += (e->feet_air_time[f] - (REAL)0.5) * first;
+      if (filt) e->feet_air_time[f] = 0;
+    }
+    term[WBC_REW_FEET_AIR_TIME] = rew * (cmd_xy > (REAL)0.1 ? 1 : 0);
+  }
   /* metric side effects of the reward functions, applied once per ACTIVE call */
   static const int met_of[WBC_NREW] = {
     WBC_MET_ENERGY_SQUARE, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, WBC_MET_TRACKING_ANG_VEL_YAW_EXP, WBC_MET_LEG_ACTION_L2,
     WBC_MET_FOOT_CONTACTS_Z, WBC_MET_TRACKING_EE_SPHERE, -1, WBC_MET_TRACKING_EE_CART, -1, WBC_MET_TRACKING_EE_ORN,
-    WBC_MET_LEG_ENERGY_ABS_SUM, -1, WBC_MET_LEG_ACTION_L2, -1, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, -1, -1, -1, WBC_MET_TORQUE, -1};
+    WBC_MET_LEG_ENERGY_ABS_SUM, -1, WBC_MET_LEG_ACTION_L2, -1, -1, WBC_MET_TRACKING_LIN_VEL_X_L1, -1, -1, -1, WBC_MET_TORQUE, -1,
+    -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};          /* the base class's terms touch no metric */
   REAL met_src[WBC_NREW] = {0};
   met_src[WBC_REW_ENERGY_SQUARE] = sq; met_src[WBC_REW_TRACKING_LIN_VEL_X_L1] = ex; met_src[WBC_REW_TRACKING_LIN_VEL_X_EXP] = ex;
   met_src[WBC_REW_TRACKING_ANG_VEL_YAW_EXP] = eyaw; met_src[WBC_REW_HIP_ACTION_L2] = hip; met_src[WBC_REW_LEG_ACTION_L2] = act_leg;
@@ -1005,23 +1056,31 @@ static void compute_reward(const ora_sim* s, ora_env* e, const REAL* base_yaw_qu
   REAL r = 0, ra = 0;
   for (int t = 0; t < WBC_NREW; ++t) {
     REAL sc = (REAL)cu->leg_reward_scale[t];
-    if ((cu->leg_active_mask >> t) & 1u) {                                                /* WG:176-180; list built at WG:128-142 */
+    if (t != WBC_REW_TERMINATION && ((cu->leg_active_mask >> t) & 1u)) {                  /* WG:176-180; list built at WG:128-142 */
       REAL v = term[t] * sc;
       r += v; e->episode_sums[t] += v;
       if (met_of[t] >= 0) e->metric_sums[met_of[t]] += met_src[t];
     }
   }
   if (cf->only_positive_rewards && r < 0) r = 0;                                          /* WG:181-182 */
+  if ((cu->leg_active_mask >> WBC_REW_TERMINATION) & 1u) {                                /* after the clip, WG:184-188 */
+    REAL v = term[WBC_REW_TERMINATION] * (REAL)cu->leg_reward_scale[WBC_REW_TERMINATION];
+    r += v; e->episode_sums[WBC_REW_TERMINATION] += v;
+  }
   e->rew = r / 100;                                                                       /* WG:189 */
   for (int t = 0; t < WBC_NREW; ++t) {
     REAL sc = (REAL)cu->arm_reward_scale[t];
-    if ((cu->arm_active_mask >> t) & 1u) {                                                /* WG:192-196; list built at WG:144-157 */
+    if (t != WBC_REW_TERMINATION && ((cu->arm_active_mask >> t) & 1u)) {                  /* WG:192-196; list built at WG:144-157 */
       REAL v = term[t] * sc;
       ra += v; e->episode_sums[t] += v;
       if (met_of[t] >= 0) e->metric_sums[met_of[t]] += met_src[t];
     }
   }
   if (cf->only_positive_rewards && ra < 0) ra = 0;
+  if ((cu->arm_active_mask >> WBC_REW_TERMINATION) & 1u) {                                /* WG:200-203 */
+    REAL v = term[WBC_REW_TERMINATION] * (REAL)cu->arm_reward_scale[WBC_REW_TERMINATION];
+    ra += v; e->episode_sums[WBC_REW_TERMINATION] += v;
+  }
   e->arm_rew = ra / 100;                                                                  /* WG:205 */
 }
 
@@ -1207,6 +1266,8 @@ static int field_ptr(ora_env* e, int id, REAL** p, int* n) {
     case WBC_T_RESET_TRAVEL: *p = e->reset_travel; *n = 2; return 0;
     case WBC_T_BOX_MASS: *p = &e->box_mass; *n = 1; return 0;
     case WBC_T_BOX_SLEEP_TIMER: *p = &e->box_timer; *n = 1; return 0;
+    case WBC_T_FEET_AIR_TIME: *p = e->feet_air_time; *n = WBC_NFEET; return 0;
+    case WBC_T_LAST_CONTACTS: *p = e->last_contacts; *n = WBC_NFEET; return 0;
     default: return -1;
   }
 }

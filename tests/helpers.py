@@ -9,7 +9,7 @@ from wbc_amd import abi
 STATE_TENSORS = ["ROOT_STATES", "DOF_STATE", "TORQUES", "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS",
                  "LAST_DOF_VEL", "LAST_ROOT_VEL", "COMMANDS", "GOAL_STATE", "EPISODE_LENGTH", "EPISODE_SUMS", "METRIC_SUMS",
                  "FORCE_SENSOR", "NET_CONTACT_FORCE", "RIGID_BODY_STATE", "BASE_LIN_VEL", "BASE_ANG_VEL", "TIME_OUT_BUF",
-                 "RESET_BUF", "BOX_SLEEP_TIMER"]
+                 "RESET_BUF", "BOX_SLEEP_TIMER", "FEET_AIR_TIME", "LAST_CONTACTS"]
 
 
 def random_env_params(n, seed=0):

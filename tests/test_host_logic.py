@@ -106,8 +106,25 @@ def test_curriculum_saturates_on_first_call_and_rejects_unimplemented_rewards():
     active = [abi.REWARD_TERMS[i] for i in range(abi.NREW) if c1.leg_reward_scale[i] != 0]
     assert sorted(active) == sorted(["energy_square", "survive", "tracking_lin_vel_x_l1", "tracking_ang_vel_yaw_exp",
                                      "hip_action_l2", "foot_contacts_z"])                 # SURVEY 8a, compute_reward row
+    # the base class's terms (legged_robot.py:832-922) are table entries too: a config subclass that switches one on is drop-in
     cfg.rewards.scales.feet_air_time = 1.0
-    with pytest.raises(NotImplementedError):
+    cfg.rewards.scales.termination = -5.0
+    cfg.rewards.arm_scales.termination = -1.0
+    c2 = make_curriculum(cfg, 1)
+    ia, it = abi.REWARD_TERMS.index("feet_air_time"), abi.REWARD_TERMS.index("termination")
+    assert c2.leg_reward_scale[ia] == 1.0 and (c2.leg_active_mask >> ia) & 1 and not (c2.arm_active_mask >> ia) & 1
+    assert c2.leg_reward_scale[it] == -5.0 and c2.arm_reward_scale[it] == -1.0 and (c2.leg_active_mask >> it) & (c2.arm_active_mask >> it) & 1
+    # ... except the ones the reference itself cannot run (recorded from its own code: profiles/r04_reference_switches.txt)
+    for name, table in (("orientation", "scales"), ("arm_orientation", "arm_scales"), ("feet_stumble", "scales")):
+        cfg = WidowGo1RoughCfg()
+        setattr(getattr(cfg.rewards, table), name, -1.0)
+        with pytest.raises(NotImplementedError, match=name):
+            make_curriculum(cfg, 1)
+    cfg = WidowGo1RoughCfg()
+    cfg.rewards.scales.base_height = -1.0
+    assert (make_curriculum(cfg, 1).leg_active_mask >> abi.REWARD_TERMS.index("base_height")) & 1
+    cfg.terrain.measure_heights = True
+    with pytest.raises(NotImplementedError, match="base_height"):
         make_curriculum(cfg, 1)
 
 

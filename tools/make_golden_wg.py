@@ -27,7 +27,7 @@ GOLD = os.path.join(HERE, "..", "tests", "golden")
 
 INPUT_NAMES = ["ROOT_STATES", "DOF_STATE", "TORQUES", "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL",
                "LAST_ROOT_VEL", "COMMANDS", "GOAL_STATE", "EPISODE_LENGTH", "EPISODE_SUMS", "METRIC_SUMS", "FORCE_SENSOR",
-               "NET_CONTACT_FORCE", "RIGID_BODY_STATE", "BASE_LIN_VEL", "BASE_ANG_VEL", "TIME_OUT_BUF", "RESET_BUF", "BOX_SLEEP_TIMER"]
+               "NET_CONTACT_FORCE", "RIGID_BODY_STATE", "BASE_LIN_VEL", "BASE_ANG_VEL", "TIME_OUT_BUF", "RESET_BUF", "BOX_SLEEP_TIMER", "FEET_AIR_TIME", "LAST_CONTACTS"]
 OUTPUT_NAMES = INPUT_NAMES + ["OBS_BUF", "REW_BUF", "ARM_REW_BUF"]
 
 
@@ -157,8 +157,15 @@ def main():
     leg = dict(energy_square=-6e-5, survive=0.2, tracking_lin_vel_x_l1=0.5, tracking_ang_vel_yaw_exp=0.15, hip_action_l2=-0.01,
                foot_contacts_z=-1e-4, leg_energy_abs_sum=-3e-3, leg_energy_sum_abs=-2e-3, leg_action_l2=-0.02, leg_energy=-1e-3,
                tracking_lin_vel=0.3, tracking_lin_vel_x_exp=0.25, tracking_ang_vel_yaw_l1=0.1, tracking_lin_vel_y_l2=-0.4,
-               tracking_lin_vel_z_l2=-0.2, torques=-1e-4, collision=-0.7)
-    arm = dict(tracking_ee_sphere=0.55, arm_energy_abs_sum=-0.004, tracking_ee_cart=0.35, tracking_ee_orn=0.2, tracking_ee_orn_ry=0.15)
+               tracking_lin_vel_z_l2=-0.2, torques=-1e-4, collision=-0.7,
+               # the base class's terms that work in the widowGo1 task (legged_robot.py:832-922)
+               lin_vel_z=-0.5, ang_vel_xy=-0.05, dof_vel=-1e-4, dof_acc=-1e-7, action_rate=-0.01, termination=-5.0, dof_pos_limits=-1.0,
+               dof_vel_limits=-0.5, torque_limits=-0.01, tracking_ang_vel=0.2, feet_air_time=1.0, stumble=-0.3, stand_still=-0.1,
+               feet_contact_forces=-0.01, base_height=-2.0)
+    arm = dict(tracking_ee_sphere=0.55, arm_energy_abs_sum=-0.004, tracking_ee_cart=0.35, tracking_ee_orn=0.2, tracking_ee_orn_ry=0.15,
+               termination=-1.0)
+    cfg.rewards.soft_dof_pos_limit, cfg.rewards.soft_dof_vel_limit, cfg.rewards.soft_torque_limit = 0.9, 0.1, 0.3     # so that the limit terms bite
+    cfg.rewards.max_contact_force, cfg.rewards.base_height_target = 20.0, 0.3
     for k, v in leg.items():
         setattr(s, k, v)                # instance attributes: class_to_dict (helpers.py:41-56) walks dir(obj)
     for k, v in arm.items():
@@ -174,6 +181,11 @@ def main():
     outB["leg_scales"] = np.array([leg.get(nm, 0.0) for nm in __import__("wbc_amd").abi.REWARD_TERMS])
     outB["arm_scales"] = np.array([arm.get(nm, 0.0) for nm in __import__("wbc_amd").abi.REWARD_TERMS])
     outB["delta_orn"] = np.array(cfg.goal_ee.ranges.final_delta_orn)
+    outB["soft_limits"] = np.array([cfg.rewards.soft_dof_pos_limit, cfg.rewards.soft_dof_vel_limit, cfg.rewards.soft_torque_limit,
+                                    cfg.rewards.max_contact_force, cfg.rewards.base_height_target])
+    base_terms = [i for i, nm in enumerate(__import__("wbc_amd").abi.REWARD_TERMS) if i >= 22]
+    sums = np.stack([outB[f"s{k}/EPISODE_SUMS"] for k in range(10)])
+    print("   base-class terms with a non-zero episode sum somewhere:", [__import__("wbc_amd").abi.REWARD_TERMS[i] for i in base_terms if np.abs(sums[:, :, i]).max() > 0])
     save("wg_reference_allrewards.npz", outB)
     # ---- C: the collision set at work. Robots dropped on their trunks (legs folded up), robots on their sides, arms swung into
     # the trunk and the front thighs by +-3 rad arm targets; episodes end through terminate_after_contacts_on (WG:940),

@@ -172,8 +172,15 @@ def curriculum_struct(env):
     for i, name in enumerate(abi.REWARD_TERMS):
         cur.leg_reward_scale[i] = float(env.reward_scales.get(name, 0.0)) if name in env.reward_names else 0.0
         cur.arm_reward_scale[i] = float(env.arm_reward_scales.get(name, 0.0)) if name in env.arm_reward_names else 0.0
-        lm |= int(name in env.reward_names) << i            # the function lists of _prepare_reward_function (WG:135-157)
-        am |= int(name in env.arm_reward_names) << i
+        # the function lists of _prepare_reward_function (WG:135-157); "termination" is kept out of them and applied from the scale
+        # tables after the clip (WG:184-188, 200-203)
+        on_l = name in env.reward_names or (name == "termination" and "termination" in env.reward_scales)
+        on_a = name in env.arm_reward_names or (name == "termination" and "termination" in env.arm_reward_scales)
+        if name == "termination":
+            cur.leg_reward_scale[i] = float(env.reward_scales.get(name, 0.0))
+            cur.arm_reward_scale[i] = float(env.arm_reward_scales.get(name, 0.0))
+        lm |= int(on_l) << i
+        am |= int(on_a) << i
     cur.leg_active_mask, cur.arm_active_mask = lm, am
     return cur
 
@@ -204,4 +211,5 @@ def wbc_state(env):
         EPISODE_LENGTH=f(env.episode_length_buf).astype(np.int64), EPISODE_SUMS=sums, METRIC_SUMS=mets,
         BASE_LIN_VEL=f(env.base_lin_vel), BASE_ANG_VEL=f(env.base_ang_vel),
         # physics-internal state the reference never sees (as PhysX keeps its actors' sleep state to itself)
-        BOX_SLEEP_TIMER=env._backend.ora.get("BOX_SLEEP_TIMER").astype(np.float32))
+        BOX_SLEEP_TIMER=env._backend.ora.get("BOX_SLEEP_TIMER").astype(np.float32),
+        FEET_AIR_TIME=f(env.feet_air_time), LAST_CONTACTS=f(env.last_contacts).astype(np.float32))
