@@ -729,6 +729,9 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   // dmax: deepest chain level that carries an active contact. Deeper levels see no contact wrench, so the inward
   // sweep skips them exactly; the outward sweep needs them only in the last iteration (joint accelerations).
   const int any = abits != 0ull;
+  // contacts that act on the tree (everything but the box's own corners): without one -- the robot in the air while the box lies
+  // on the ground -- the tree's response is zero and its sweeps are skipped
+  const bool any_tree = (abits & ~Cc->box_corner_mask) != 0ull;
   int dmax = 1;
 #pragma unroll
   for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
@@ -765,27 +768,6 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
       }
       WSYNC();
       if (it == 0) STAMP(20);
-      // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a pair receives the opposite wrench
-      if (lane < WBC_NB) {
-        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          if (half && abhi == 0u) break;                // (scalar) nothing active in the upper slots: the usual case
-          const uint2 gm = half ? s.k_gmhi[lane] : s.k_gmlo[lane];
-          uint32_t mask = (gm.x | gm.y) & (half ? abhi : ablo);
-          while (mask) {
-            const int kb = __ffs(mask) - 1, kc = kb + 32 * half;
-            mask &= mask - 1;
-            const float sg = ((gm.x >> kb) & 1u) ? idt : -idt;
-            const f3 f = ld3(s.ctc.clam[kc]) * sg;
-            const f3 mom = cross(ld3(s.cxc[kc]), f);
-            acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
-        s.uD[lane] = 0.f;                          // levels the inward sweep skips
-      }
       // the free box: its contacts fill the 16-lane row 32..47 (corners: + the impulse; a robot sphere against it: - the impulse);
       // every lane of the row forms its wrench about the box centre (3 m from F's origin: no cancellation in fp32), a row reduction
       // sums them, the row's last lane turns the sum into the box's response (angular acceleration n / Ic, centre acceleration F / m)
@@ -796,59 +778,84 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
         const float fx = row_scan16(f.x), fy = row_scan16(f.y), fz = row_scan16(f.z);
         if (lane == 47) { st3(&s.bxa[0], mk3(nx, ny, nz) * s.bxiI); st3(&s.bxa[3], mk3(fx, fy, fz) * s.bxim); }
       }
-      WSYNC();
-      if (it == 0) STAMP(21);
-      {   // inward. Sweep layout: 8 lanes per chain (sch = lane >> 3, component sk = lane & 7 < 6): lane (sch, sk) carries
-          // component sk of the accumulated wrench in a register, the 6-term products S.p are DPP sums (no LDS hand-over)
-        const int sch = lane >> 3, sk = lane & 7;
-        const uint32_t sbody = sweep_chain_bodies(C, sch);
-        float carry = 0.f;
-#pragma unroll 1
-        for (int d = dmax - 1; d >= 0; --d) {
-          const int i = (sbody >> (5 * d)) & 31;
-          const bool act = i != CH_NONE && sk < 6;
-          float pk = 0.f, t = 0.f;
-          if (act) { pk = PD(s)[i][sk] + carry; t = s.S[i][sk] * pk; }
-          const float uD = -sum8(t);
-          if (act) {
-            if (sk == 0) s.uD[i] = uD;
-            carry = pk + s.U[i][sk] * (uD * s.iD[i]);
-            if (d == 0) s.pa1[sch][sk] = carry;
+      if (any_tree) {
+        // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a pair receives the opposite wrench
+        if (lane < WBC_NB) {
+          float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            if (half && abhi == 0u) break;                // (scalar) nothing active in the upper slots: the usual case
+            const uint2 gm = half ? s.k_gmhi[lane] : s.k_gmlo[lane];
+            uint32_t mask = (gm.x | gm.y) & (half ? abhi : ablo);
+            while (mask) {
+              const int kb = __ffs(mask) - 1, kc = kb + 32 * half;
+              mask &= mask - 1;
+              const float sg = ((gm.x >> kb) & 1u) ? idt : -idt;
+              const f3 f = ld3(s.ctc.clam[kc]) * sg;
+              const f3 mom = cross(ld3(s.cxc[kc]), f);
+              acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
+            }
           }
+#pragma unroll
+          for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
+          s.uD[lane] = 0.f;                          // levels the inward sweep skips
         }
         WSYNC();
-      }
-      if (it == 0) STAMP(22);
-      if (lane < 6) {       // root: sum of the depth-1 contributions (fixed order), then a0 = -K0 pD0
-        float pd0[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          float acc = PD(s)[0][j];
-#pragma unroll
-          for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][j];
-          pd0[j] = acc;
-        }
-        AD(s)[0][lane] = -dot6(&s.ctc.K0[lane * 6], pd0);
-      }
-      WSYNC();
-      if (it == 0) STAMP(23);
-      const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
-      {   // outward: component sk of the parent's acceleration change travels in a register
-        const int sch = lane >> 3, sk = lane & 7;
-        const uint32_t sbody = sweep_chain_bodies(C, sch);
-        float adk = (sk < 6) ? AD(s)[0][sk] : 0.f;
-#pragma unroll 1
-        for (int d = 0; d < dout; ++d) {
-          const int i = (sbody >> (5 * d)) & 31;
-          const bool act = i != CH_NONE && sk < 6;
-          const float ut = sum8(act ? s.U[i][sk] * adk : 0.f);
-          if (act) {
-            const float qdd = (s.uD[i] - ut) * s.iD[i];
-            adk += s.S[i][sk] * qdd;
-            AD(s)[i][sk] = adk;
-            if (sk == 0) s.qddD[i] = qdd;
+        if (it == 0) STAMP(21);
+        {   // inward. Sweep layout: 8 lanes per chain (sch = lane >> 3, component sk = lane & 7 < 6): lane (sch, sk) carries
+            // component sk of the accumulated wrench in a register, the 6-term products S.p are DPP sums (no LDS hand-over)
+          const int sch = lane >> 3, sk = lane & 7;
+          const uint32_t sbody = sweep_chain_bodies(C, sch);
+          float carry = 0.f;
+  #pragma unroll 1
+          for (int d = dmax - 1; d >= 0; --d) {
+            const int i = (sbody >> (5 * d)) & 31;
+            const bool act = i != CH_NONE && sk < 6;
+            float pk = 0.f, t = 0.f;
+            if (act) { pk = PD(s)[i][sk] + carry; t = s.S[i][sk] * pk; }
+            const float uD = -sum8(t);
+            if (act) {
+              if (sk == 0) s.uD[i] = uD;
+              carry = pk + s.U[i][sk] * (uD * s.iD[i]);
+              if (d == 0) s.pa1[sch][sk] = carry;
+            }
           }
+          WSYNC();
         }
+        if (it == 0) STAMP(22);
+        if (lane < 6) {       // root: sum of the depth-1 contributions (fixed order), then a0 = -K0 pD0
+          float pd0[6];
+  #pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            float acc = PD(s)[0][j];
+  #pragma unroll
+            for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][j];
+            pd0[j] = acc;
+          }
+          AD(s)[0][lane] = -dot6(&s.ctc.K0[lane * 6], pd0);
+        }
+        WSYNC();
+        if (it == 0) STAMP(23);
+        const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
+        {   // outward: component sk of the parent's acceleration change travels in a register
+          const int sch = lane >> 3, sk = lane & 7;
+          const uint32_t sbody = sweep_chain_bodies(C, sch);
+          float adk = (sk < 6) ? AD(s)[0][sk] : 0.f;
+  #pragma unroll 1
+          for (int d = 0; d < dout; ++d) {
+            const int i = (sbody >> (5 * d)) & 31;
+            const bool act = i != CH_NONE && sk < 6;
+            const float ut = sum8(act ? s.U[i][sk] * adk : 0.f);
+            if (act) {
+              const float qdd = (s.uD[i] - ut) * s.iD[i];
+              adk += s.S[i][sk] * qdd;
+              AD(s)[i][sk] = adk;
+              if (sk == 0) s.qddD[i] = qdd;
+            }
+          }
+          WSYNC();
+        }
+      } else {
         WSYNC();
       }
       if (it == 0) STAMP(24);

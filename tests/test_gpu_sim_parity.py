@@ -613,13 +613,13 @@ def test_free_running_100_policy_steps(robot):
 
 def test_free_run_statistics_match_the_fp64_oracle(robot):
     """What the trajectory-level free-run test above cannot pin (contact switching decorrelates joint phases within seconds):
-    the STATISTICS of a long free run. 2048 envs x 500 policy steps = 10 s of simulated time each, the same seeds and the same
+    the STATISTICS of a long free run. 4096 envs (the bench size) x 500 policy steps = 10 s of simulated time each, the same seeds and the same
     action stream through the fp32 HIP kernel and the fp64 oracle, nothing synced in between, episodes ending by falls
     (z threshold lowered to 0.22 m so that robots survive landing and fall from the 0.6-sigma action noise instead) and by
     150-step time-outs. Compared: finished episodes, fall rate, time-out count, mean episode length and the mean reward of
     both channels, each within 4 standard errors of the oracle's own estimate plus 2 % -- the stated confidence interval."""
     import torch
-    n, steps = 2048, 500
+    n, steps = 4096, 500
     params = helpers.random_env_params(n, seed=23)
     tc = copy.copy(robot["tcfg"])
     tc.term_z_threshold = 0.22

@@ -217,6 +217,11 @@ def main():
         for e, pose in zip(arm_envs, poses):                      # arm spheres start inside the trunk box / a thigh capsule
             dof[e, 12:18, 0] = torch.from_numpy(pose.astype(np.float32))
             dof[e, 12:18, 1] = 0
+        kick = torch.arange(n) >= 17                               # the free box actor in the path of a front foot, the robot walking into it
+        env.box_root_state[kick, 0] = env.root_states[kick, 0] + 0.19 + 0.05 + 0.02
+        env.box_root_state[kick, 1] = env.root_states[kick, 1] + torch.tensor([0.13, -0.13, 0.10])
+        env.box_root_state[kick, 2] = 0.05
+        env.root_states[kick, 7] = torch.tensor([0.5, 0.8, 0.6])
         outC = record_trajectory(env, 12, rng, "C contacts", big_action_envs=arm_envs[:3])
     f = np.stack([outC[f"s{k}/NET_CONTACT_FORCE"] for k in range(12)])                     # [steps, n, 28, 3]
     touching = np.abs(f).sum(-1) > 0
@@ -224,7 +229,9 @@ def main():
     print("   bodies in contact (steps x envs):", {names[i]: int(touching[:, :, i].sum()) for i in range(27) if touching[:, :, i].any()})
     airborne_arm = touching[:, :, 20:25].any(-1) & (np.stack([outC[f"s{k}/RIGID_BODY_STATE"] for k in range(12)])[:, :, 20:25, 2].min(-1) > 0.08)
     print("   arm links in contact above the ground (self-collision):", int(airborne_arm.sum()))
-    assert touching[:, :, 1].sum() > 10 and airborne_arm.sum() > 5
+    box_pushed = (np.abs(f[:, 17:, 27, :2]).sum(-1) > 0.5).sum()
+    print("   box pushed sideways by a foot (steps x envs):", int(box_pushed))
+    assert touching[:, :, 1].sum() > 10 and airborne_arm.sum() > 5 and box_pushed > 3
     save("wg_reference_contacts.npz", outC)
 
 
