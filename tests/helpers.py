@@ -81,3 +81,43 @@ def random_standing_state(n, tcfg, rng, height=(0.30, 0.45)):
     dof[:, :, 1] = rng.uniform(-2, 2, (n, 20))
     dof[:, 18:, :] = 0
     return root, dof
+
+
+class GpuAsOracle:
+    """The HIP sim (WbcSim, through the C-ABI) behind the OracleSim interface the closed-form physics cases use
+    (tests/physics_cases.py): get / set by tensor name, step, simulate, set_heightfield, set_curriculum."""
+
+    def __init__(self, wmodel, tcfg, n, seed=1):
+        import torch
+        from wbc_amd.sim import WbcSim
+        self.torch = torch
+        self.g = WbcSim(wmodel, tcfg, n, torch.device("cuda:0"), seed=seed)
+        self.n, self.model = n, wmodel
+
+    def get(self, name):
+        self.torch.cuda.synchronize()
+        return self.g.tensor(name).detach().cpu().numpy().astype(np.float64)
+
+    def set(self, name, value):
+        t = self.g.tensor(name)
+        v = np.array(np.broadcast_to(np.asarray(value, dtype=np.float64), tuple(t.shape)))
+        t.copy_(self.torch.from_numpy(v).to(t.dtype))
+
+    def set_curriculum(self, cur):
+        self.g.set_curriculum(cur)
+
+    def set_heightfield(self, heights, hscale=0.0, vscale=0.0, tx=0.0, ty=0.0, tz=0.0):
+        self.g.set_heightfield(heights, hscale, vscale, tx, ty, tz)
+
+    def step(self, actions):
+        a = self.torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n, 18)).cuda()
+        self.g.step(a)
+
+    def simulate(self):
+        self.g.simulate()
+
+    def refresh_rigid_body_state(self):
+        self.g.refresh_rigid_body_state()
+
+    def close(self):
+        self.g.close()

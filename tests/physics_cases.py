@@ -20,6 +20,30 @@ def clone_struct(s):
     return type(s).from_buffer_copy(s)
 
 
+def _oracle_factory(wmodel, tcfg, n, seed=1):
+    return OracleSim(wmodel, tcfg, n, seed=seed)
+
+
+def quiet_task(tc):
+    """Task logic out of the way for cases that advance by whole policy steps (`sim.step`): no pushes, no terminations, no time-outs."""
+    tc.push_interval = 0
+    tc.term_z_threshold = -1e3
+    tc.term_rp_threshold = 1e3
+    tc.max_episode_length = 10 ** 8
+    tc.resample_interval = 10 ** 8
+    return tc
+
+
+POLICY_FROM_SIM = [3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8, 12, 13, 14, 15, 16, 17]
+
+
+def to_policy_order(a_sim):
+    """Actions in simulator joint order -> the policy's order (WG:1070-1088): policy[POLICY_FROM_SIM[j]] = sim[j]."""
+    a = np.zeros_like(np.asarray(a_sim, dtype=np.float64))
+    a[..., POLICY_FROM_SIM] = a_sim
+    return a
+
+
 def folded_pose(tc):
     """Default pose with the four legs folded up beside the body: the robot lies on its trunk box and thigh tops."""
     q = np.array(tc.default_dof_pos, dtype=np.float64)
@@ -49,16 +73,17 @@ def _rot_y(a):
     return np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)])
 
 
-def robot_on_incline(robot, tan_theta, mu_env, terrain_friction=1.0, t_settle=0.3, t_measure=0.5, iters=None, kick=0.0):
+def robot_on_incline(robot, tan_theta, mu_env, terrain_friction=1.0, t_settle=0.3, t_measure=0.5, iters=None, kick=0.0, make_sim=_oracle_factory):
     """The robot on its trunk (legs folded, joints held by the task's PD law) on a plane of slope tan_theta, released at rest
-    (or with a downhill velocity `kick`, so that the contacts are certainly sliding). Returns (down-slope acceleration over the
-    measurement window, closed form g (sin - mu cos) if sliding else 0, mu, speed at the end)."""
-    tc = clone_struct(robot["tcfg"])
-    tc.push_interval = 0
+    (or with a downhill velocity `kick`, so that the contacts are certainly sliding), advanced by whole policy steps. Returns the
+    down-slope acceleration over the measurement window, the closed form g (sin - mu cos) if sliding else 0, mu, the final speed.
+    make_sim: the backend (the fp64 oracle by default; tests/test_gpu_contact_physics.py passes the HIP kernel's)."""
+    tc = quiet_task(clone_struct(robot["tcfg"]))
     tc.terrain_friction = terrain_friction
+    tc.action_delay = -1                                                   # the hold pose acts from the first step
     if iters is not None:
         tc.contact_iters = iters
-    o = OracleSim(robot["wmodel"], tc, 1)
+    o = make_sim(robot["wmodel"], tc, 1)
     o.set_curriculum(default_curriculum(robot["cfg"]))
     o.set("FRICTION", np.array([mu_env]))
     o.set_heightfield(*incline_heightfield(tan_theta))
@@ -78,13 +103,12 @@ def robot_on_incline(robot, tan_theta, mu_env, terrain_friction=1.0, t_settle=0.
     dof = np.zeros((1, 20, 2))
     dof[0, :, 0] = q
     o.set("DOF_STATE", dof)
-    o.set("ACTIONS", hold_actions(tc, q)[None])
-    dt = tc.sim_dt
+    act = to_policy_order(hold_actions(tc, q))[None]
+    dtp = tc.sim_dt * tc.decimation
 
     def run(T):
-        for _ in range(int(round(T / dt))):
-            o.compute_torques()
-            o.simulate()
+        for _ in range(int(round(T / dtp))):
+            o.step(act)
         return o.get("ROOT_STATES")[0, 0, 7:10] @ down
     v0 = run(t_settle)
     v1 = run(t_measure)
@@ -94,13 +118,13 @@ def robot_on_incline(robot, tan_theta, mu_env, terrain_friction=1.0, t_settle=0.
     return dict(acc=(v1 - v0) / t_measure, expect=expect, mu=mu, v_end=v1, sticks_expected=not sliding)
 
 
-def box_on_incline(robot, tan_theta, terrain_friction, t_settle=0.2, t_measure=0.5, kick=0.0):
+def box_on_incline(robot, tan_theta, terrain_friction, t_settle=0.2, t_measure=0.5, kick=0.0, make_sim=_oracle_factory):
     """The free box actor (a 0.1 m cube resting on four corner spheres) on the same incline: a single rigid body, so the closed
     form holds without any joint compliance. mu = (box 1.0 + terrain) / 2."""
     tc = clone_struct(robot["tcfg"])
     tc.terrain_friction = terrain_friction
     wm = robot["wmodel"]
-    o = OracleSim(wm, tc, 1)
+    o = make_sim(wm, tc, 1)
     o.set_curriculum(default_curriculum(robot["cfg"]))
     o.set_heightfield(*incline_heightfield(tan_theta))
     th = np.arctan(tan_theta)
@@ -132,13 +156,13 @@ def box_on_incline(robot, tan_theta, terrain_friction, t_settle=0.2, t_measure=0
     return dict(acc=(v1 - v0) / t_measure, expect=expect, mu=mu, v_end=v1, spin=w_end, sticks_expected=not sliding)
 
 
-def robot_drop(robot, height=0.42, T=3.0):
-    """The default stance released from the spawn height (init_state.pos z, widowGo1_config.py:134): impact with restitution 0,
-    rest penetration, settle time. The legs are PD springs, so the trunk rings; the FEET must not leave the ground again."""
-    tc = clone_struct(robot["tcfg"])
-    tc.push_interval = 0
+def robot_drop(robot, height=0.42, T=3.0, make_sim=_oracle_factory):
+    """The default stance released from the spawn height (init_state.pos z, widowGo1_config.py:134), advanced by whole policy steps with
+    zero actions: impact with restitution 0, rest penetration, settle time. The legs are PD springs, so the trunk rings; the FEET must
+    not leave the ground again (sampled after every policy step)."""
+    tc = quiet_task(clone_struct(robot["tcfg"]))
     wm = robot["wmodel"]
-    o = OracleSim(wm, tc, 1)
+    o = make_sim(wm, tc, 1)
     o.set_curriculum(default_curriculum(robot["cfg"]))
     root = np.zeros((1, 2, 13))
     root[0, :, 6] = 1
@@ -148,35 +172,33 @@ def robot_drop(robot, height=0.42, T=3.0):
     dof = np.zeros((1, 20, 2))
     dof[0, :, 0] = np.array(tc.default_dof_pos)
     o.set("DOF_STATE", dof)
-    o.set("ACTIONS", np.zeros((1, 18)))
     feet = list(wm.feet_rb)
-    dt = tc.sim_dt
-    n = int(round(T / dt))
+    dtp = tc.sim_dt * tc.decimation
+    n = int(round(T / dtp))
     foot_z = np.zeros((n, 4)); foot_vz = np.zeros((n, 4)); speed = np.zeros(n); fz = np.zeros(n)
+    zero = np.zeros((1, 18))
     for k in range(n):
-        o.compute_torques()
-        o.simulate()
-        o.refresh_rigid_body_state()
+        o.step(zero)
         rb = o.get("RIGID_BODY_STATE")[0]
         foot_z[k] = rb[feet, 2] - 0.02                                   # lowest point of the foot sphere
         foot_vz[k] = rb[feet, 9]
         r = o.get("ROOT_STATES")[0, 0]
         speed[k] = max(np.abs(r[7:13]).max(), np.abs(o.get("DOF_STATE")[0, :, 1]).max())
         fz[k] = o.get("NET_CONTACT_FORCE")[0, :27, 2].sum()
-    touch = int(np.argmax((foot_z < tc.contact_margin).all(1)))           # first substep with all four feet in the contact band
+    touch = int(np.argmax((foot_z < tc.contact_margin).all(1)))           # first policy step with all four feet in the contact band
     after = slice(touch + 1, None)
     quiet = np.nonzero(speed > 2e-2)[0]
-    settle = (quiet[-1] + 1) * dt if len(quiet) else 0.0
-    return dict(t_touch=touch * dt, rebound_height=float(foot_z[after].max()), rebound_vz=float(foot_vz[after].max()),
-                impact_vz=float(foot_vz[touch - 1].min()), rest_penetration=float(-foot_z[-1].min()), settle_time=settle - touch * dt,
+    settle = (quiet[-1] + 1) * dtp if len(quiet) else 0.0
+    return dict(t_touch=(touch + 1) * dtp, rebound_height=float(foot_z[after].max()), rebound_vz=float(foot_vz[after].max()),
+                impact_vz=float(foot_vz[max(touch - 1, 0)].min()), rest_penetration=float(-foot_z[-1].min()), settle_time=settle - touch * dtp,
                 rest_force=float(fz[-1]), contact_offset=float(tc.contact_margin))
 
 
-def box_drop(robot, height=None, T=1.5):
+def box_drop(robot, height=None, T=1.5, make_sim=_oracle_factory):
     """The box actor released from its spawn height (box_env_origins_z = 0.21: 0.16 m of free fall, widowGo1_config.py:191)."""
     tc = clone_struct(robot["tcfg"])
     wm = robot["wmodel"]
-    o = OracleSim(wm, tc, 1)
+    o = make_sim(wm, tc, 1)
     o.set_curriculum(default_curriculum(robot["cfg"]))
     z0 = float(tc.box_origin_z) if height is None else height
     root = np.zeros((1, 2, 13))
@@ -436,7 +458,7 @@ def free_flight_energy(robot, T=2.0, seed=0, gravity=True):
                 qd_max=float(np.abs(o.get("DOF_STATE")[0, :, 1]).max()))
 
 
-def robot_kicks_box(robot, seed=0):
+def robot_kicks_box(robot, seed=0, make_sim=_oracle_factory):
     """A foot sphere started inside the box actor, both in free fall far above the ground (no terrain contact, no gravity): the pair
     impulse is internal to the robot + box system, so its total linear momentum and its angular momentum about the common centre
     of mass are conserved while the two separate."""
@@ -450,7 +472,7 @@ def robot_kicks_box(robot, seed=0):
     wm = clone_struct(robot["wmodel"])
     for j in range(20):
         wm.qd_limit[j] = 0.0
-    o = OracleSim(wm, tc, 1)
+    o = make_sim(wm, tc, 1)
     rng = np.random.default_rng(seed)
     q = np.array(tc.default_dof_pos)
     root = np.zeros((1, 2, 13)); root[0, :, 6] = 1

@@ -1,0 +1,64 @@
+"""The closed-form physics cases of tests/test_oracle_contact_physics.py run on the HIP KERNEL itself (wbc_step_kernel /
+wbc_simulate_kernel through the C-ABI), not only on the oracle it is parity-tested against: a body on an incline sticks iff
+tan(theta) < mu and otherwise slides at g (sin - mu cos); drops end without rebound inside the contact offset carrying the weight;
+a foot against the box exchanges momentum with it; the box falls asleep. Same experiments (tests/physics_cases.py), the fp32 kernel
+as the backend; thresholds as on the oracle (a little wider where fp32 shows)."""
+import numpy as np
+import pytest
+
+import helpers
+import physics_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu(wmodel, tcfg, n, seed=1):
+    return helpers.GpuAsOracle(wmodel, tcfg, n, seed=seed)
+
+
+@pytest.mark.parametrize("terrain_friction,tan_theta", [(1.0, 0.5), (0.2, 0.5), (-0.6, 0.1)])
+def test_box_sticks_below_the_friction_angle_on_the_kernel(robot, terrain_friction, tan_theta):
+    r = pc.box_on_incline(robot, tan_theta, terrain_friction, make_sim=gpu)
+    assert r["sticks_expected"] and abs(r["acc"]) < 0.01 and abs(r["v_end"]) < 0.05, r
+
+
+@pytest.mark.parametrize("terrain_friction,tan_theta", [(0.2, 0.7), (0.2, 0.9), (-0.6, 0.3), (-0.6, 0.6), (-1.0, 0.2), (-1.0, 0.7)])
+def test_box_slides_at_the_coulomb_rate_on_the_kernel(robot, terrain_friction, tan_theta):
+    r = pc.box_on_incline(robot, tan_theta, terrain_friction, make_sim=gpu)
+    assert not r["sticks_expected"]
+    assert abs(r["acc"] - r["expect"]) < 0.02 * r["expect"], r
+    assert r["spin"] < 0.05, r
+
+
+@pytest.mark.parametrize("mu_env,terrain_friction,tan_theta", [(-0.5, 1.0, 0.2), (0.0, 1.0, 0.4), (1.0, 1.0, 0.6)])
+def test_robot_on_its_trunk_sticks_on_the_kernel(robot, mu_env, terrain_friction, tan_theta):
+    r = pc.robot_on_incline(robot, tan_theta, mu_env, terrain_friction, t_settle=1.2, t_measure=0.4, make_sim=gpu)
+    assert r["sticks_expected"] and abs(r["acc"]) < 0.03 and abs(r["v_end"]) < 0.04, r
+
+
+@pytest.mark.parametrize("mu_env,terrain_friction,tan_theta", [(-0.5, 1.0, 0.4), (-0.5, 1.0, 0.6), (0.0, 1.0, 0.6), (-0.5, 0.0, 0.1), (-0.5, 0.0, 0.4)])
+def test_robot_on_its_trunk_slides_at_the_coulomb_rate_on_the_kernel(robot, mu_env, terrain_friction, tan_theta):
+    r = pc.robot_on_incline(robot, tan_theta, mu_env, terrain_friction, t_settle=1.2, t_measure=0.4, make_sim=gpu)
+    assert not r["sticks_expected"]
+    assert abs(r["acc"] - r["expect"]) < 0.025 * r["expect"], r
+
+
+def test_drops_on_the_kernel(robot):
+    r = pc.robot_drop(robot, make_sim=gpu)
+    assert r["impact_vz"] < -0.8
+    assert r["rebound_height"] < 0.5 * r["contact_offset"] and r["rebound_vz"] < 0.06 * abs(r["impact_vz"]) + 0.02, r
+    assert -1e-3 < r["rest_penetration"] < r["contact_offset"] and r["settle_time"] < 3.0, r
+    np.testing.assert_allclose(r["rest_force"], 14.151 * 9.81, rtol=5e-3)
+    b = pc.box_drop(robot, make_sim=gpu)
+    assert abs(b["t_touch"] - b["t_touch_expected"]) < 0.015 and b["rebound_vz"] < 0.05 * abs(b["impact_vz"]), b
+    assert 0.0 <= b["rest_penetration"] < 1e-3 and b["tilt"] < 1e-4, b
+    np.testing.assert_allclose(b["rest_force"], b["weight"], rtol=5e-3)      # (the last report before it falls asleep: fp32 jitter 0.2 %)
+    assert b["final_speed"] == 0.0 and b["timer"] == 80, b                # asleep: exactly motionless
+
+
+def test_foot_against_the_box_exchanges_momentum_on_the_kernel(robot):
+    r = pc.robot_kicks_box(robot, make_sim=gpu)
+    assert r["box_force_max"] > 5.0 and r["robot_dP"] > 0.05, r
+    assert r["pair_force_sum"] < 1e-3, r                                   # +f on the foot's row, -f on the box's (fp32 sums)
+    assert r["dP"] < 0.02 * r["robot_dP"] + 2e-3 and r["dL"] < 3e-3 * r["L_scale"], r
+    assert r["separated"], r
