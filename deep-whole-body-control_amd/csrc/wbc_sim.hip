@@ -369,7 +369,7 @@ extern "C" int wbc_sim_step_rollout(wbc_sim* s, const float* actions_dev, float*
     return fail(-1, "wbc_sim_step_rollout: values, out_rewards and out_dones go together");
   s->step_counter += 1;
   const StepOut so{obs_out_dev, values_dev, out_rewards_dev, out_dones_dev, gamma};
-  hipLaunchKernelGGL(wbc_step_kernel, dim3(s->n), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter, so);
+  hipLaunchKernelGGL(wbc_step_kernel, dim3(8 * ((s->n + 7) / 8)), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter, so);
   HIP_OK(hipGetLastError());
   return 0;
 }

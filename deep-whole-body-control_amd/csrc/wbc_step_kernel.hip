@@ -1447,7 +1447,15 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
                                                                     int num_envs, uint64_t seed, uint64_t step, StepOut so) {
   __shared__ Smem s;
   const DevTensors& T = *Tp;        // read on demand through the scalar path: 32 pointers held in SGPRs spilled the kernel
+  // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: XCD x takes the CONTIGUOUS env range
+  // [x per, (x + 1) per), so the sub-64-B rows of neighbouring envs (13-float root rows, 3-float commands, ...) meet in one L2 and
+  // leave it as whole lines instead of as byte-masked partial writes from two L2s (grid = 8 per workgroups, wbc_sim.hip).
+#ifndef WBC_NO_XCD_MAP
+  const int per = (num_envs + 7) >> 3;
+  const int env = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+#else
   const int env = blockIdx.x;
+#endif
   if (env >= num_envs) return;
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
