@@ -14,6 +14,22 @@
 // only describe the lane mapping.
 #include "wbc_device.h"
 
+// The per-sim constant block is never written while a kernel runs: read through the CONSTANT address space, a wave-uniform load of
+// it is a scalar load (s_load into SGPRs) whatever fences surround it; through a generic pointer every load after the first
+// wavefront fence is a vector load plus a v_readfirstlane. The tensor table (wbc_step_kernel reads it from memory, the small
+// kernels take it by value: TT = its type as the caller holds it) likewise. A tensor's base pointer is a GLOBAL pointer: with
+// the address space spelled out its accesses are global_load / global_store with the base in SGPRs and a 32-bit lane offset
+// instead of flat accesses on a 64-bit per-lane address. (The host pass of the compiler only parses the device code: plain types.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) DevConst* CP;
+typedef __attribute__((address_space(4))) DevTensors DevTensorsK;
+template <class X> __device__ __forceinline__ __attribute__((address_space(1))) X* G(X* p) { return (__attribute__((address_space(1))) X*)p; }
+#else
+typedef const DevConst* CP;
+typedef DevTensors DevTensorsK;
+template <class X> __device__ __forceinline__ X* G(X* p) { return p; }
+#endif
+
 #define LANES 64
 static_assert(LANES == 64, "one wavefront per robot: cross-lane hand-overs rest on wavefront-scope ordering");
 
@@ -58,7 +74,7 @@ __device__ __forceinline__ float row_scan16(float x) {
 
 // Packed bodies (DevConst::chain_pack_body) of chain `sch` of the 8-lane sweep layout: five scalar loads and a select chain
 // (LDS has no room for another table: 16 robots per CU need <= 10240 B each).
-__device__ __forceinline__ uint32_t sweep_chain_bodies(const DevConst* __restrict__ C, int sch) {
+__device__ __forceinline__ uint32_t sweep_chain_bodies(CP C, int sch) {
   uint32_t b = C->chain_pack_body[WBC_NCHAIN];
 #pragma unroll
   for (int c = 0; c < WBC_NCHAIN; ++c) b = (sch == c) ? C->chain_pack_body[c] : b;
@@ -146,7 +162,7 @@ __device__ __forceinline__ int ch_par(const ChainRegs& cr, int d) { return d ? (
 __device__ __forceinline__ int ch_dof(const ChainRegs& cr, int d) { return (cr.dof >> (5 * d)) & 31; }
 __device__ __forceinline__ int ch_ax(const ChainRegs& cr, int d) { return (cr.ax >> (2 * d)) & 3; }
 
-__device__ __forceinline__ void fk_pass(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, int chain, int k) {
+__device__ __forceinline__ void fk_pass(Smem& s, CP C, const ChainRegs& cr, int chain, int k) {
   const int lane = threadIdx.x;
   if (lane < 9) s.E[0][lane] = (lane % 4 == 0) ? 1.f : 0.f;
   if (lane < 3) s.pos[0][lane] = 0.f;
@@ -220,7 +236,7 @@ __device__ __forceinline__ void contact_solve(const float* W, f3 n, float vn_tgt
   lam[0] = dir.x * l; lam[1] = dir.y * l; lam[2] = dir.z * l;
 }
 
-__device__ __forceinline__ void terrain_query(const DevConst* __restrict__ C, float x, float y, float* h, f3* n) {
+__device__ __forceinline__ void terrain_query(CP C, float x, float y, float* h, f3* n) {
   if (!C->hf) { *h = C->cfg.ground_z; *n = mk3(0.f, 0.f, 1.f); return; }
   const float fx = (x - C->hf_t[0]) / C->hf_hs, fy = (y - C->hf_t[1]) / C->hf_hs;
   long long ix = (long long)fx, iy = (long long)fy;
@@ -243,7 +259,7 @@ __device__ __forceinline__ void terrain_query(const DevConst* __restrict__ C, fl
 // sin/cos of every joint angle and the joint-limit terms of this substep: lanes 32..51, one DoF each.
 // HALF (post-physics): the limit slots receive sin/cos of the half angles instead (joint quaternions).
 template <bool HALF>
-__device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restrict__ C) {
+__device__ __forceinline__ void joint_pre_pass(Smem& s, CP C) {
   const int j = (int)threadIdx.x - 32;
   if (j >= 0 && j < WBC_NDOF) {
     const float qq = s.q[j], qdv = s.qd[j];
@@ -265,7 +281,7 @@ __device__ __forceinline__ void joint_pre_pass(Smem& s, const DevConst* __restri
 }
 
 // One physics substep on the LDS-resident state (oracle: physics_substep).
-__device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, const int chain, const int k,
+__device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int chain, const int k,
                                 const bool want_outputs) {
   // the lane index as a value the optimiser cannot see through: everything derived from it (LDS / constant-table addresses of the
   // one-body / one-DoF / one-contact-per-lane phases) is then recomputed inside each substep (a few integer operations) instead
@@ -496,7 +512,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
   // contact-sphere constants of this lane: issued before pass 3, consumed after it
   // (a laundered copy of C for the lane-indexed constant loads of the contact phase: left alone, the compiler computes their
   // 64-bit addresses once before the substep loop and keeps ~10 of them alive in VGPR pairs across it -- spilled to scratch)
-  const DevConst* Cc = C;
+  CP Cc = C;
   asm volatile("" : "+s"(Cc));
   int cpb = 0, cpkind = -1;
   float cpp[3] = {0.f, 0.f, 0.f}, cpr = 0.f;
@@ -965,7 +981,7 @@ __device__ void physics_substep(Smem& s, const DevConst* __restrict__ C, const C
 
 // rigid_body_state of the 27 robot bodies + box from the LDS state (oracle: update_rigid_body_state).
 // Needs E/pos of the CURRENT q (fk_pass) and s.R.
-__device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const ChainRegs& cr, const int chain, const int k) {
+__device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int chain, const int k) {
   const int lane = threadIdx.x;
   if (lane == 0) {
     quat_to_mat(&s.root[3], s.R);
@@ -1029,7 +1045,7 @@ __device__ void rigid_body_pass(Smem& s, const DevConst* __restrict__ C, const C
   WSYNC();
 }
 
-__device__ __forceinline__ void resample_commands(Smem& s, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int slot) {
+__device__ __forceinline__ void resample_commands(Smem& s, CP C, uint64_t seed, int env, uint64_t step, int slot) {
   const float cx = rng_range(C->cur.lin_vel_x_range[0], C->cur.lin_vel_x_range[1], seed, env, step, slot);
   const float cy = rng_range(C->cur.ang_vel_yaw_range[0], C->cur.ang_vel_yaw_range[1], seed, env, step, slot + 1);
   const bool keep = (cx > C->cfg.lin_vel_x_clip) || (fabsf(cy) > C->cfg.ang_vel_yaw_clip);
@@ -1039,7 +1055,7 @@ __device__ __forceinline__ void resample_commands(Smem& s, const DevConst* __res
 enum { G_START = 0, G_GOAL = 3, G_GOAL_CART = 6, G_CURR = 9, G_CURR_CART = 12, G_DORN = 15, G_ORN = 18,
        G_TIMER = 21, G_TRAJ = 22, G_TOTAL = 23 };
 
-__device__ int goal_collision(const Smem& s, const DevConst* __restrict__ C) {
+__device__ int goal_collision(const Smem& s, CP C) {
   const int ns = C->cfg.goal_collision_samples;
   int hit = 0;
   for (int kk = 0; kk < ns; ++kk) {
@@ -1057,7 +1073,7 @@ __device__ int goal_collision(const Smem& s, const DevConst* __restrict__ C) {
   return hit;
 }
 
-__device__ void resample_ee_goal(Smem& s, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int slot_orn, int slot_sph, float base_yaw) {
+__device__ void resample_ee_goal(Smem& s, CP C, uint64_t seed, int env, uint64_t step, int slot_orn, int slot_sph, float base_yaw) {
   for (int j = 0; j < 3; ++j) {
     const float d = rng_range(C->cfg.goal_delta_orn_range[j][0], C->cfg.goal_delta_orn_range[j][1], seed, env, step, slot_orn + j);
     s.goal[G_DORN + j] = d;
@@ -1092,7 +1108,7 @@ __device__ const int8_t MET_TERMS[WBC_NMETRIC][2] = {
 // sums over the DoFs / actions that the base class's reward terms need (computed lane-parallel by base_reward_sums, all lanes)
 struct BaseSums { float dv2, da2, ar2, plim, vlim, tlim, still; };
 
-__device__ void compute_reward(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, const float* yq, const float ncol, const bool base_on,
+template <class TT> __device__ void compute_reward(Smem& s, const TT& T, CP C, const float* yq, const float ncol, const bool base_on,
                                const BaseSums& bs, int env) {
   const wbc_task_cfg& cf = C->cfg;
   const float inv_sig = rcpf(cf.tracking_sigma), inv_ee_sig = rcpf(cf.tracking_ee_sigma);
@@ -1178,14 +1194,14 @@ __device__ void compute_reward(Smem& s, const DevTensors& T, const DevConst* __r
       if (__builtin_amdgcn_sqrtf(cf3.x * cf3.x + cf3.y * cf3.y) > 5.f * fabsf(cf3.z)) stumble = 1.f;
       fcf += fmaxf(__builtin_amdgcn_sqrtf(dot(cf3, cf3)) - cf.max_contact_force, 0.f);
       if (air_on) {                                   // feet_air_time's state advances only while the function is in a reward list
-        float at = T.feet_air_time[(size_t)env * WBC_NFEET + f];
+        float at = G(T.feet_air_time)[(size_t)env * WBC_NFEET + f];
         const bool contact = cf3.z > 1.f;
-        const bool filt = contact || T.last_contacts[(size_t)env * WBC_NFEET + f] != 0.f;
-        T.last_contacts[(size_t)env * WBC_NFEET + f] = contact ? 1.f : 0.f;
+        const bool filt = contact || G(T.last_contacts)[(size_t)env * WBC_NFEET + f] != 0.f;
+        G(T.last_contacts)[(size_t)env * WBC_NFEET + f] = contact ? 1.f : 0.f;
         const bool first = at > 0.f && filt;
         at += dtp;
         air += first ? at - 0.5f : 0.f;
-        T.feet_air_time[(size_t)env * WBC_NFEET + f] = filt ? 0.f : at;
+        G(T.feet_air_time)[(size_t)env * WBC_NFEET + f] = filt ? 0.f : at;
       }
     }
     s.term[WBC_REW_STUMBLE] = stumble; s.term[WBC_REW_FEET_CONTACT_FORCES] = fcf;
@@ -1196,20 +1212,20 @@ __device__ void compute_reward(Smem& s, const DevTensors& T, const DevConst* __r
 }
 
 // The base class's per-DoF / per-action sums, one DoF per lane and a butterfly (all lanes; called only when a base term is on).
-__device__ BaseSums base_reward_sums(const Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env) {
+template <class TT> __device__ BaseSums base_reward_sums(const Smem& s, const TT& T, CP C, int env) {
   const int j = threadIdx.x;
   const wbc_task_cfg& cf = C->cfg;
   float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (j < WBC_NDOF) {
     const float q = s.q[j], qd = s.qd[j], tau = s.tau[j];
-    const float acc = (T.last_dof_vel[(size_t)env * WBC_NDOF + j] - qd) / (cf.sim_dt * (float)cf.decimation);
+    const float acc = (G(T.last_dof_vel)[(size_t)env * WBC_NDOF + j] - qd) / (cf.sim_dt * (float)cf.decimation);
     v[0] = qd * qd; v[1] = acc * acc;
     v[3] = -fminf(q - cf.soft_dof_lower[j], 0.f) + fmaxf(q - cf.soft_dof_upper[j], 0.f);
     v[4] = clampf(fabsf(qd) - cf.soft_dof_vel_limit[j], 0.f, 1.f);
     v[5] = fmaxf(fabsf(tau) - cf.soft_torque_limit[j], 0.f);
     v[6] = fabsf(q - cf.default_dof_pos[j]);
   }
-  if (j < WBC_NACT) { const float d = T.last_actions[(size_t)env * WBC_NACT + j] - s.act[j]; v[2] = d * d; }
+  if (j < WBC_NACT) { const float d = G(T.last_actions)[(size_t)env * WBC_NACT + j] - s.act[j]; v[2] = d * d; }
 #pragma unroll
   for (int k = 0; k < 7; ++k)
 #pragma unroll
@@ -1224,7 +1240,7 @@ __device__ BaseSums base_reward_sums(const Smem& s, const DevTensors& T, const D
 // reference builds at construction (cur.*_active_mask, WG:128-157), whatever its current (scheduled) scale. Per slot the
 // order of additions is the reference's (leg channel then arm channel, terms ascending); the two reward totals are
 // butterfly sums over the wavefront.
-__device__ __forceinline__ void reward_accumulate(Smem& s, const DevConst* __restrict__ C, float lsc, float asc) {
+__device__ __forceinline__ void reward_accumulate(Smem& s, CP C, float lsc, float asc) {
   const int lane = threadIdx.x;
   const uint64_t lmask = C->cur.leg_active_mask, amask = C->cur.arm_active_mask;
   float vl = 0.f, va = 0.f;
@@ -1266,29 +1282,29 @@ __device__ __forceinline__ void reward_accumulate(Smem& s, const DevConst* __res
 }
 
 // Load one env's state from HBM into LDS (consecutive lanes read consecutive words).
-__device__ void load_env(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env) {
+template <class TT> __device__ void load_env(Smem& s, const TT& T, CP C, int env) {
   const int lane = threadIdx.x;
-  if (lane < 13) { s.root[lane] = T.root[(size_t)env * 26 + lane]; s.box[lane] = T.root[(size_t)env * 26 + 13 + lane]; }
-  if (lane < 40) { const float v = T.dof[(size_t)env * 40 + lane]; if (lane & 1) s.qd[lane >> 1] = v; else s.q[lane >> 1] = v; }
-  if (lane < 20) s.bp[lane] = T.body_params[(size_t)env * 20 + lane];
-  if (lane < WBC_NACT) s.motor[lane] = T.motor[(size_t)env * WBC_NACT + lane];
-  if (lane < 24) s.goal[lane] = T.goal[(size_t)env * 24 + lane];
-  if (lane < 3) s.cmd[lane] = T.commands[(size_t)env * 3 + lane];
-  if (lane < WBC_NREW) s.ep_sums[lane] = T.ep_sums[(size_t)env * WBC_NREW + lane];
-  if (lane < WBC_NMETRIC) s.met_sums[lane] = T.met_sums[(size_t)env * WBC_NMETRIC + lane];
+  if (lane < 13) { s.root[lane] = G(T.root)[(size_t)env * 26 + lane]; s.box[lane] = G(T.root)[(size_t)env * 26 + 13 + lane]; }
+  if (lane < 40) { const float v = G(T.dof)[(size_t)env * 40 + lane]; if (lane & 1) s.qd[lane >> 1] = v; else s.q[lane >> 1] = v; }
+  if (lane < 20) s.bp[lane] = G(T.body_params)[(size_t)env * 20 + lane];
+  if (lane < WBC_NACT) s.motor[lane] = G(T.motor)[(size_t)env * WBC_NACT + lane];
+  if (lane < 24) s.goal[lane] = G(T.goal)[(size_t)env * 24 + lane];
+  if (lane < 3) s.cmd[lane] = G(T.commands)[(size_t)env * 3 + lane];
+  if (lane < WBC_NREW) s.ep_sums[lane] = G(T.ep_sums)[(size_t)env * WBC_NREW + lane];
+  if (lane < WBC_NMETRIC) s.met_sums[lane] = G(T.met_sums)[(size_t)env * WBC_NMETRIC + lane];
   if (lane == 0) {
-    s.friction = T.friction[env];
+    s.friction = G(T.friction)[env];
     const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
     s.mu[0] = fmaxf(0.5f * (s.friction + tf), 0.f); s.mu[1] = fmaxf(s.friction, 0.f);
     s.mu[2] = fmaxf(0.5f * (bf + tf), 0.f); s.mu[3] = fmaxf(0.5f * (bf + s.friction), 0.f);
-    s.bxtimer = (int)T.box_timer[env];
-    const float bm = T.box_mass[env], bh = C->model.box_half;
+    s.bxtimer = (int)G(T.box_timer)[env];
+    const float bm = G(T.box_mass)[env], bh = C->model.box_half;
     s.bxim = 1.f / bm; s.bxiI = 1.f / (bm * (2.f / 3.f) * bh * bh);
-    s.ep_len = (int)T.ep_len[env];
+    s.ep_len = (int)G(T.ep_len)[env];
   }
 }
 
-__device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restrict__ C, int chain) {
+__device__ void make_chain_regs(Smem& s, ChainRegs& cr, CP C, int chain) {
   const int lane = threadIdx.x;
   if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = (&C->model.joint_xyz[0][0])[lane];
   if (lane < WBC_NB) s.k_body[lane] = C->body_pack[lane];
@@ -1309,7 +1325,7 @@ __device__ void make_chain_regs(Smem& s, ChainRegs& cr, const DevConst* __restri
 }
 
 // _compute_torques (oracle: compute_torques): lanes 0..19
-__device__ __forceinline__ void torque_pass(Smem& s, const DevConst* __restrict__ C) {
+__device__ __forceinline__ void torque_pass(Smem& s, CP C) {
   const int j = threadIdx.x;
   if (j < WBC_NACT) {
     const float a_s = s.act[j] * s.motor[j] * C->cfg.action_scale[j];
@@ -1324,30 +1340,30 @@ __device__ __forceinline__ void torque_pass(Smem& s, const DevConst* __restrict_
 }
 
 // reset_idx for this env (oracle: reset_env); all lanes enter, writes go to LDS
-__device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, uint64_t seed, int env, uint64_t step, int start, float base_yaw) {
+template <class TT> __device__ __forceinline__ void reset_env(Smem& s, const TT& T, CP C, uint64_t seed, int env, uint64_t step, int start, float base_yaw) {
   const int lane = threadIdx.x;
   if (lane < WBC_NDOF) {
     s.q[lane] = C->cfg.default_dof_pos[lane] * rng_range(C->cfg.dof_reset_lo, C->cfg.dof_reset_hi, seed, env, step, SLOT_RESET_DOF + lane);
     s.qd[lane] = 0.f;
   }
   if (lane < WBC_NFEET && (((C->cur.leg_active_mask | C->cur.arm_active_mask) >> WBC_REW_FEET_AIR_TIME) & 1ull))
-    T.feet_air_time[(size_t)env * WBC_NFEET + lane] = 0.f;                              // WG:734 (the state only exists while the term is on)
-  if (lane < WBC_NREW) { T.ep_sums_done[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane]; }
-  if (lane < WBC_NMETRIC) { T.met_sums_done[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane]; }
+    G(T.feet_air_time)[(size_t)env * WBC_NFEET + lane] = 0.f;                              // WG:734 (the state only exists while the term is on)
+  if (lane < WBC_NREW) { G(T.ep_sums_done)[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane]; }
+  if (lane < WBC_NMETRIC) { G(T.met_sums_done)[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane]; }
   WSYNC();
   if (lane < WBC_NREW) s.ep_sums[lane] = 0.f;
   if (lane < WBC_NMETRIC) s.met_sums[lane] = 0.f;
   if (lane == 0) {
     {   // what _update_terrain_curriculum reads of the finished episode (LR:431-435), before root and commands are overwritten
-      const float dx = s.root[0] - T.origins[(size_t)env * 3], dy = s.root[1] - T.origins[(size_t)env * 3 + 1];
-      T.reset_travel[(size_t)env * 2] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-      T.reset_travel[(size_t)env * 2 + 1] = __fsqrt_rn(__fadd_rn(__fmul_rn(s.cmd[0], s.cmd[0]), __fmul_rn(s.cmd[1], s.cmd[1])));
+      const float dx = s.root[0] - G(T.origins)[(size_t)env * 3], dy = s.root[1] - G(T.origins)[(size_t)env * 3 + 1];
+      G(T.reset_travel)[(size_t)env * 2] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      G(T.reset_travel)[(size_t)env * 2 + 1] = __fsqrt_rn(__fadd_rn(__fmul_rn(s.cmd[0], s.cmd[0]), __fmul_rn(s.cmd[1], s.cmd[1])));
     }
     for (int j = 0; j < 13; ++j) s.root[j] = C->cfg.base_init_state[j];
-    for (int j = 0; j < 3; ++j) s.root[j] += T.origins[(size_t)env * 3 + j];
+    for (int j = 0; j < 3; ++j) s.root[j] += G(T.origins)[(size_t)env * 3 + j];
     for (int j = 0; j < 2; ++j) s.root[j] += rng_range(-C->cfg.origin_perturb_range, C->cfg.origin_perturb_range, seed, env, step, SLOT_RESET_XY + j);
     s.box[0] = C->cfg.box_origin_x;
-    s.box[1] = s.root[1] + T.box_dy[env];
+    s.box[1] = s.root[1] + G(T.box_dy)[env];
     s.box[2] = C->cfg.box_origin_z;
     for (int j = 0; j < 6; ++j) s.root[7 + j] = rng_range(-C->cfg.init_vel_perturb_range, C->cfg.init_vel_perturb_range, seed, env, step, SLOT_RESET_VEL + j);
     { const f3 e = euler_from_quat(&s.root[3]); s.rp[0] = e.x; s.rp[1] = e.y; }      // the observation of a reset env shows the new pose
@@ -1360,8 +1376,13 @@ __device__ void reset_env(Smem& s, const DevTensors& T, const DevConst* __restri
   WSYNC();
 }
 
+// The step kernel's copy stays out of line: 13 % of the waves take it, inlined it costs every wave its registers.
+__device__ __attribute__((noinline)) void reset_env_call(Smem& s, const DevTensorsK& T, CP C, uint64_t seed, int env, uint64_t step, float base_yaw) {
+  reset_env(s, T, C, seed, env, step, 0, base_yaw);
+}
+
 // compute_observations (oracle) + the HBM write-out of the step's results.
-__device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* __restrict__ C, int env, bool was_reset, const StepOut& so,
+template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C, int env, bool was_reset, const StepOut& so,
                                   const float (&hist_in)[12]) {
   const int lane = threadIdx.x;
   const wbc_task_cfg& cf = C->cfg;
@@ -1389,8 +1410,8 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   WSYNC();
   // obs_buf = [o76, priv24, old history]; history <- shifted / refilled
   const float clipv = cf.clip_obs;
-  float* obs = (so.obs ? so.obs : T.obs) + (size_t)env * WBC_NOBS;
-  float* hist = T.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
+  auto obs = G(so.obs ? so.obs : T.obs) + (size_t)env * WBC_NOBS;
+  auto hist = G(T.obs_hist) + (size_t)env * (WBC_HIST * WBC_NPROP);
   const bool refill = s.ep_len <= 1;
   // the old history was requested right after the substeps (hist_in: its HBM latency ran under the rigid-body pass and the task
   // logic); every lane's reads were issued long before the first write of the in-place shift below
@@ -1410,43 +1431,45 @@ __device__ void observe_and_store(Smem& s, const DevTensors& T, const DevConst* 
   for (int e = lane; e < WBC_NPROP + WBC_NPRIV; e += LANES) {
     float val;
     if (e < WBC_NPROP) val = s.post.o76[e];
-    else if (e < WBC_NPROP + 5) val = T.mass_params[(size_t)env * 5 + e - WBC_NPROP];
+    else if (e < WBC_NPROP + 5) val = G(T.mass_params)[(size_t)env * 5 + e - WBC_NPROP];
     else if (e == WBC_NPROP + 5) val = s.friction;
     else val = s.motor[e - WBC_NPROP - 6] - 1.f;
     obs[e] = clampf(val, -clipv, clipv);
   }
   // state write-back
-  if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
-  if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
-  if (lane < WBC_NDOF) { T.torques[(size_t)env * WBC_NDOF + lane] = s.tau[lane]; T.last_dof_vel[(size_t)env * WBC_NDOF + lane] = s.qd[lane]; }
-  if (lane < WBC_NACT) { T.actions[(size_t)env * WBC_NACT + lane] = s.act[lane]; T.last_actions[(size_t)env * WBC_NACT + lane] = s.act[lane]; }
-  if (lane < 6) T.last_root_vel[(size_t)env * 6 + lane] = s.root[7 + lane];
-  if (lane < 24) T.goal[(size_t)env * 24 + lane] = s.goal[lane];
-  if (lane < 3) { T.commands[(size_t)env * 3 + lane] = s.cmd[lane]; T.base_lin_vel[(size_t)env * 3 + lane] = s.blv[lane]; T.base_ang_vel[(size_t)env * 3 + lane] = s.bav[lane]; }
-  if (lane < WBC_NREW) T.ep_sums[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane];
-  if (lane < WBC_NMETRIC) T.met_sums[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane];
-  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) T.contact[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
-  if (lane < WBC_NFEET * 6) T.sensor[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
-  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  if (lane < 13) { G(T.root)[(size_t)env * 26 + lane] = s.root[lane]; G(T.root)[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane < 40) G(T.dof)[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  if (lane < WBC_NDOF) { G(T.torques)[(size_t)env * WBC_NDOF + lane] = s.tau[lane]; G(T.last_dof_vel)[(size_t)env * WBC_NDOF + lane] = s.qd[lane]; }
+  if (lane < WBC_NACT) { G(T.actions)[(size_t)env * WBC_NACT + lane] = s.act[lane]; G(T.last_actions)[(size_t)env * WBC_NACT + lane] = s.act[lane]; }
+  if (lane < 6) G(T.last_root_vel)[(size_t)env * 6 + lane] = s.root[7 + lane];
+  if (lane < 24) G(T.goal)[(size_t)env * 24 + lane] = s.goal[lane];
+  if (lane < 3) { G(T.commands)[(size_t)env * 3 + lane] = s.cmd[lane]; G(T.base_lin_vel)[(size_t)env * 3 + lane] = s.blv[lane]; G(T.base_ang_vel)[(size_t)env * 3 + lane] = s.bav[lane]; }
+  if (lane < WBC_NREW) G(T.ep_sums)[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane];
+  if (lane < WBC_NMETRIC) G(T.met_sums)[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane];
+  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) G(T.contact)[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
+  if (lane < WBC_NFEET * 6) G(T.sensor)[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) G(T.rb)[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
   if (lane == 0) {
-    T.rew[env] = s.rew; T.arm_rew[env] = s.arm_rew;
-    T.reset_buf[env] = s.reset_flag; T.time_out[env] = (uint8_t)s.time_out; T.ep_len[env] = s.ep_len;
+    G(T.rew)[env] = s.rew; G(T.arm_rew)[env] = s.arm_rew;
+    G(T.reset_buf)[env] = s.reset_flag; G(T.time_out)[env] = (uint8_t)s.time_out; G(T.ep_len)[env] = s.ep_len;
     if (so.rewards) {                                 // the same arithmetic as rollout_store_kernel (csrc/wbc_gae_kernel.hip)
       const float to = s.time_out ? 1.f : 0.f;
       float r0 = s.rew, r1 = s.arm_rew;
-      r0 += so.gamma * (so.values[2 * (size_t)env] * to); r1 += so.gamma * (so.values[2 * (size_t)env + 1] * to);
-      so.rewards[2 * (size_t)env] = r0; so.rewards[2 * (size_t)env + 1] = r1;
-      so.dones[env] = (uint8_t)(s.reset_flag != 0);
+      r0 += so.gamma * (G(so.values)[2 * (size_t)env] * to); r1 += so.gamma * (G(so.values)[2 * (size_t)env + 1] * to);
+      G(so.rewards)[2 * (size_t)env] = r0; G(so.rewards)[2 * (size_t)env + 1] = r1;
+      G(so.dones)[env] = (uint8_t)(s.reset_flag != 0);
     }
   }
 }
 
 // WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment. so: optional
 // extra outputs (observation rows into the rollout storage slot of the next transition, this transition's reward / done slots).
-extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions,
+extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ Cg, const float* __restrict__ actions,
                                                                     int num_envs, uint64_t seed, uint64_t step, StepOut so) {
+  CP C = (CP)Cg;
   __shared__ Smem s;
-  const DevTensors& T = *Tp;        // read on demand through the scalar path: 32 pointers held in SGPRs spilled the kernel
+  // (the tensor table likewise: never written by a kernel -> constant address space, its pointers arrive by scalar loads on demand)
+  const DevTensorsK& T = *(const DevTensorsK*)Tp;
   // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: XCD x takes the CONTIGUOUS env range
   // [x per, (x + 1) per), so the sub-64-B rows of neighbouring envs (13-float root rows, 3-float commands, ...) meet in one L2 and
   // leave it as whole lines instead of as byte-masked partial writes from two L2s (grid = 8 per workgroups, wbc_sim.hip).
@@ -1467,7 +1490,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   if (lane < WBC_NACT) {
     const float clipa = C->cfg.clip_actions;
     const float a = clampf(actions[(size_t)env * WBC_NACT + POLICY_PERM[lane]], -clipa, clipa);
-    float* ah = T.act_hist + (size_t)env * (WBC_ADELAY_LEN * WBC_NACT);
+    auto ah = G(T.act_hist) + (size_t)env * (WBC_ADELAY_LEN * WBC_NACT);
     float used = a;
     if (C->cfg.action_delay != -1) {
       float h[WBC_ADELAY_LEN];
@@ -1490,20 +1513,20 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     WSYNC();
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
-  if (lane == 0) T.box_timer[env] = (float)s.bxtimer;
+  if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
   STAMP(13);
   // Everything after the substeps reads its tensor / constant pointers through laundered copies of the two kernel arguments: the
   // compiler otherwise hoists those (invariant) scalar loads above the substep loop, where the ~40 pointers and constants it
   // keeps alive across the loop exhaust the SGPR file and end up spilled to scratch memory through VGPRs.
-  const DevTensors* Tq = Tp;
-  const DevConst* Cq = C;
+  const DevTensorsK* Tq = (const DevTensorsK*)Tp;
+  CP Cq = C;
   asm volatile("" : "+s"(Tq), "+s"(Cq));
-  const DevTensors& T2 = *Tq;
+  const DevTensorsK& T2 = *Tq;
   // the observation's history block (obs_history_buf before this step's update, WG:992): 12 coalesced loads per lane, consumed by
   // observe_and_store at the very end
   float hist_in[12];
   {
-    const float* hist = T2.obs_hist + (size_t)env * (WBC_HIST * WBC_NPROP);
+    auto hist = G(T2.obs_hist) + (size_t)env * (WBC_HIST * WBC_NPROP);
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
       const int idx = lane + r * LANES;
@@ -1565,10 +1588,10 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   WSYNC();
   STAMP(15);
   const bool do_reset = s.reset_flag != 0;
-  if (do_reset) reset_env(s, T2, Cq, seed, env, step, 0, s.base_yaw);
+  if (do_reset) reset_env_call(s, T2, Cq, seed, env, step, s.base_yaw);
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
-    T2.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
-    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) T2.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
+    G(T2.act_hist)[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
+    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) G(T2.act_hist)[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
   }
   STAMP(16);
   observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
@@ -1576,7 +1599,8 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
 }
 
 // reset_idx(all envs, start=True) (BT:129): one wave per env
-extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step) {
+extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ Cg, int num_envs, uint64_t seed, uint64_t step) {
+  CP C = (CP)Cg;
   __shared__ Smem s;
   const int env = blockIdx.x;
   if (env >= num_envs) return;
@@ -1593,22 +1617,23 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors 
   reset_env(s, T, C, seed, env, step, 1, s.base_yaw);
   rigid_body_pass(s, C, cr, chain, k);
   // write back what a reset touches
-  if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
-  if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
-  if (lane < 24) T.goal[(size_t)env * 24 + lane] = s.goal[lane];
-  if (lane < 3) T.commands[(size_t)env * 3 + lane] = s.cmd[lane];
-  if (lane < WBC_NREW) T.ep_sums[(size_t)env * WBC_NREW + lane] = 0.f;
-  if (lane < WBC_NMETRIC) T.met_sums[(size_t)env * WBC_NMETRIC + lane] = 0.f;
-  if (lane < WBC_NACT) T.last_actions[(size_t)env * WBC_NACT + lane] = 0.f;
-  if (lane < WBC_NDOF) T.last_dof_vel[(size_t)env * WBC_NDOF + lane] = 0.f;
-  for (int e = lane; e < WBC_HIST * WBC_NPROP; e += LANES) T.obs_hist[(size_t)env * (WBC_HIST * WBC_NPROP) + e] = 0.f;
-  for (int e = lane; e < WBC_ADELAY_LEN * WBC_NACT; e += LANES) T.act_hist[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + e] = 0.f;
-  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
-  if (lane == 0) { T.reset_buf[env] = 1; T.ep_len[env] = 0; }
+  if (lane < 13) { G(T.root)[(size_t)env * 26 + lane] = s.root[lane]; G(T.root)[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane < 40) G(T.dof)[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  if (lane < 24) G(T.goal)[(size_t)env * 24 + lane] = s.goal[lane];
+  if (lane < 3) G(T.commands)[(size_t)env * 3 + lane] = s.cmd[lane];
+  if (lane < WBC_NREW) G(T.ep_sums)[(size_t)env * WBC_NREW + lane] = 0.f;
+  if (lane < WBC_NMETRIC) G(T.met_sums)[(size_t)env * WBC_NMETRIC + lane] = 0.f;
+  if (lane < WBC_NACT) G(T.last_actions)[(size_t)env * WBC_NACT + lane] = 0.f;
+  if (lane < WBC_NDOF) G(T.last_dof_vel)[(size_t)env * WBC_NDOF + lane] = 0.f;
+  for (int e = lane; e < WBC_HIST * WBC_NPROP; e += LANES) G(T.obs_hist)[(size_t)env * (WBC_HIST * WBC_NPROP) + e] = 0.f;
+  for (int e = lane; e < WBC_ADELAY_LEN * WBC_NACT; e += LANES) G(T.act_hist)[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + e] = 0.f;
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) G(T.rb)[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  if (lane == 0) { G(T.reset_buf)[env] = 1; G(T.ep_len)[env] = 0; }
 }
 
 // gym.simulate: one substep with the torques tensor as set (no PD, no post-physics)
-extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs) {
+extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ Cg, int num_envs) {
+  CP C = (CP)Cg;
   __shared__ Smem s;
   const int env = blockIdx.x;
   if (env >= num_envs) return;
@@ -1617,18 +1642,19 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   ChainRegs cr;
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
-  if (lane < WBC_NDOF) s.tau[lane] = T.torques[(size_t)env * WBC_NDOF + lane];
+  if (lane < WBC_NDOF) s.tau[lane] = G(T.torques)[(size_t)env * WBC_NDOF + lane];
   WSYNC();
   physics_substep(s, C, cr, chain, k, true);
-  if (lane < 13) { T.root[(size_t)env * 26 + lane] = s.root[lane]; T.root[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
-  if (lane == 0) T.box_timer[env] = (float)s.bxtimer;
-  if (lane < 40) T.dof[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
-  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) T.contact[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
-  if (lane < WBC_NFEET * 6) T.sensor[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
+  if (lane < 13) { G(T.root)[(size_t)env * 26 + lane] = s.root[lane]; G(T.root)[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
+  if (lane < 40) G(T.dof)[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) G(T.contact)[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
+  if (lane < WBC_NFEET * 6) G(T.sensor)[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
 }
 
 // gym.refresh_rigid_body_state_tensor after a state write: forward kinematics only
-extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs) {
+extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ Cg, int num_envs) {
+  CP C = (CP)Cg;
   __shared__ Smem s;
   const int env = blockIdx.x;
   if (env >= num_envs) return;
@@ -1639,7 +1665,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
   load_env(s, T, C, env);
   WSYNC();
   rigid_body_pass(s, C, cr, chain, k);
-  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) T.rb[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) G(T.rb)[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
