@@ -173,6 +173,7 @@ static int build_chains(DevConst& hc) {
 extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, int num_envs, int hip_device, uint64_t seed, void* arena,
                               size_t arena_bytes, wbc_sim** out) {
   if (!model || !cfg || !out || num_envs <= 0) return fail(-1, "wbc_sim_create: bad arguments");
+  if (num_envs > (1 << 22)) return fail(-1, "wbc_sim_create: num_envs above 2^22 (the kernels index a tensor's rows with 32-bit element offsets)");
   if (model->ncp < WBC_NFEET || model->ncp > WBC_NCP) return fail(-1, "wbc_sim_create: model.ncp must be in [4, WBC_NCP]");
   if (!(model->box_half > 0.f) || !(model->box_mass > 0.f)) return fail(-1, "wbc_sim_create: the box actor needs a positive size and mass");
   DeviceGuard dg(hip_device);

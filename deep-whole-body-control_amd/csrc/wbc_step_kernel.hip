@@ -30,6 +30,9 @@ typedef DevTensors DevTensorsK;
 template <class X> __device__ __forceinline__ X* G(X* p) { return p; }
 #endif
 
+// Row `env` of a per-env tensor: base + env * stride as a wave-uniform 32-bit product on the scalar unit (tensors stay below 2^32
+// elements: wbc_sim_create bounds num_envs), so the lane's access is (SGPR base) + (32-bit lane offset).
+#define ROW(p, env, stride) (G(p) + (uint32_t)(env) * (uint32_t)(stride))
 #define LANES 64
 static_assert(LANES == 64, "one wavefront per robot: cross-lane hand-overs rest on wavefront-scope ordering");
 
@@ -1194,14 +1197,14 @@ template <class TT> __device__ void compute_reward(Smem& s, const TT& T, CP C, c
       if (__builtin_amdgcn_sqrtf(cf3.x * cf3.x + cf3.y * cf3.y) > 5.f * fabsf(cf3.z)) stumble = 1.f;
       fcf += fmaxf(__builtin_amdgcn_sqrtf(dot(cf3, cf3)) - cf.max_contact_force, 0.f);
       if (air_on) {                                   // feet_air_time's state advances only while the function is in a reward list
-        float at = G(T.feet_air_time)[(size_t)env * WBC_NFEET + f];
+        float at = ROW(T.feet_air_time, env, WBC_NFEET)[f];
         const bool contact = cf3.z > 1.f;
-        const bool filt = contact || G(T.last_contacts)[(size_t)env * WBC_NFEET + f] != 0.f;
-        G(T.last_contacts)[(size_t)env * WBC_NFEET + f] = contact ? 1.f : 0.f;
+        const bool filt = contact || ROW(T.last_contacts, env, WBC_NFEET)[f] != 0.f;
+        ROW(T.last_contacts, env, WBC_NFEET)[f] = contact ? 1.f : 0.f;
         const bool first = at > 0.f && filt;
         at += dtp;
         air += first ? at - 0.5f : 0.f;
-        G(T.feet_air_time)[(size_t)env * WBC_NFEET + f] = filt ? 0.f : at;
+        ROW(T.feet_air_time, env, WBC_NFEET)[f] = filt ? 0.f : at;
       }
     }
     s.term[WBC_REW_STUMBLE] = stumble; s.term[WBC_REW_FEET_CONTACT_FORCES] = fcf;
@@ -1218,14 +1221,14 @@ template <class TT> __device__ BaseSums base_reward_sums(const Smem& s, const TT
   float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (j < WBC_NDOF) {
     const float q = s.q[j], qd = s.qd[j], tau = s.tau[j];
-    const float acc = (G(T.last_dof_vel)[(size_t)env * WBC_NDOF + j] - qd) / (cf.sim_dt * (float)cf.decimation);
+    const float acc = (ROW(T.last_dof_vel, env, WBC_NDOF)[j] - qd) / (cf.sim_dt * (float)cf.decimation);
     v[0] = qd * qd; v[1] = acc * acc;
     v[3] = -fminf(q - cf.soft_dof_lower[j], 0.f) + fmaxf(q - cf.soft_dof_upper[j], 0.f);
     v[4] = clampf(fabsf(qd) - cf.soft_dof_vel_limit[j], 0.f, 1.f);
     v[5] = fmaxf(fabsf(tau) - cf.soft_torque_limit[j], 0.f);
     v[6] = fabsf(q - cf.default_dof_pos[j]);
   }
-  if (j < WBC_NACT) { const float d = G(T.last_actions)[(size_t)env * WBC_NACT + j] - s.act[j]; v[2] = d * d; }
+  if (j < WBC_NACT) { const float d = ROW(T.last_actions, env, WBC_NACT)[j] - s.act[j]; v[2] = d * d; }
 #pragma unroll
   for (int k = 0; k < 7; ++k)
 #pragma unroll
@@ -1284,14 +1287,14 @@ __device__ __forceinline__ void reward_accumulate(Smem& s, CP C, float lsc, floa
 // Load one env's state from HBM into LDS (consecutive lanes read consecutive words).
 template <class TT> __device__ void load_env(Smem& s, const TT& T, CP C, int env) {
   const int lane = threadIdx.x;
-  if (lane < 13) { s.root[lane] = G(T.root)[(size_t)env * 26 + lane]; s.box[lane] = G(T.root)[(size_t)env * 26 + 13 + lane]; }
-  if (lane < 40) { const float v = G(T.dof)[(size_t)env * 40 + lane]; if (lane & 1) s.qd[lane >> 1] = v; else s.q[lane >> 1] = v; }
-  if (lane < 20) s.bp[lane] = G(T.body_params)[(size_t)env * 20 + lane];
-  if (lane < WBC_NACT) s.motor[lane] = G(T.motor)[(size_t)env * WBC_NACT + lane];
-  if (lane < 24) s.goal[lane] = G(T.goal)[(size_t)env * 24 + lane];
-  if (lane < 3) s.cmd[lane] = G(T.commands)[(size_t)env * 3 + lane];
-  if (lane < WBC_NREW) s.ep_sums[lane] = G(T.ep_sums)[(size_t)env * WBC_NREW + lane];
-  if (lane < WBC_NMETRIC) s.met_sums[lane] = G(T.met_sums)[(size_t)env * WBC_NMETRIC + lane];
+  if (lane < 13) { s.root[lane] = ROW(T.root, env, 26)[lane]; s.box[lane] = ROW(T.root, env, 26)[13 + lane]; }
+  if (lane < 40) { const float v = ROW(T.dof, env, 40)[lane]; if (lane & 1) s.qd[lane >> 1] = v; else s.q[lane >> 1] = v; }
+  if (lane < 20) s.bp[lane] = ROW(T.body_params, env, 20)[lane];
+  if (lane < WBC_NACT) s.motor[lane] = ROW(T.motor, env, WBC_NACT)[lane];
+  if (lane < 24) s.goal[lane] = ROW(T.goal, env, 24)[lane];
+  if (lane < 3) s.cmd[lane] = ROW(T.commands, env, 3)[lane];
+  if (lane < WBC_NREW) s.ep_sums[lane] = ROW(T.ep_sums, env, WBC_NREW)[lane];
+  if (lane < WBC_NMETRIC) s.met_sums[lane] = ROW(T.met_sums, env, WBC_NMETRIC)[lane];
   if (lane == 0) {
     s.friction = G(T.friction)[env];
     const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
@@ -1347,20 +1350,20 @@ template <class TT> __device__ __forceinline__ void reset_env(Smem& s, const TT&
     s.qd[lane] = 0.f;
   }
   if (lane < WBC_NFEET && (((C->cur.leg_active_mask | C->cur.arm_active_mask) >> WBC_REW_FEET_AIR_TIME) & 1ull))
-    G(T.feet_air_time)[(size_t)env * WBC_NFEET + lane] = 0.f;                              // WG:734 (the state only exists while the term is on)
-  if (lane < WBC_NREW) { G(T.ep_sums_done)[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane]; }
-  if (lane < WBC_NMETRIC) { G(T.met_sums_done)[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane]; }
+    ROW(T.feet_air_time, env, WBC_NFEET)[lane] = 0.f;                              // WG:734 (the state only exists while the term is on)
+  if (lane < WBC_NREW) { ROW(T.ep_sums_done, env, WBC_NREW)[lane] = s.ep_sums[lane]; }
+  if (lane < WBC_NMETRIC) { ROW(T.met_sums_done, env, WBC_NMETRIC)[lane] = s.met_sums[lane]; }
   WSYNC();
   if (lane < WBC_NREW) s.ep_sums[lane] = 0.f;
   if (lane < WBC_NMETRIC) s.met_sums[lane] = 0.f;
   if (lane == 0) {
     {   // what _update_terrain_curriculum reads of the finished episode (LR:431-435), before root and commands are overwritten
-      const float dx = s.root[0] - G(T.origins)[(size_t)env * 3], dy = s.root[1] - G(T.origins)[(size_t)env * 3 + 1];
-      G(T.reset_travel)[(size_t)env * 2] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-      G(T.reset_travel)[(size_t)env * 2 + 1] = __fsqrt_rn(__fadd_rn(__fmul_rn(s.cmd[0], s.cmd[0]), __fmul_rn(s.cmd[1], s.cmd[1])));
+      const float dx = s.root[0] - ROW(T.origins, env, 3)[0], dy = s.root[1] - ROW(T.origins, env, 3)[1];
+      ROW(T.reset_travel, env, 2)[0] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      ROW(T.reset_travel, env, 2)[1] = __fsqrt_rn(__fadd_rn(__fmul_rn(s.cmd[0], s.cmd[0]), __fmul_rn(s.cmd[1], s.cmd[1])));
     }
     for (int j = 0; j < 13; ++j) s.root[j] = C->cfg.base_init_state[j];
-    for (int j = 0; j < 3; ++j) s.root[j] += G(T.origins)[(size_t)env * 3 + j];
+    for (int j = 0; j < 3; ++j) s.root[j] += ROW(T.origins, env, 3)[j];
     for (int j = 0; j < 2; ++j) s.root[j] += rng_range(-C->cfg.origin_perturb_range, C->cfg.origin_perturb_range, seed, env, step, SLOT_RESET_XY + j);
     s.box[0] = C->cfg.box_origin_x;
     s.box[1] = s.root[1] + G(T.box_dy)[env];
@@ -1410,8 +1413,8 @@ template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C
   WSYNC();
   // obs_buf = [o76, priv24, old history]; history <- shifted / refilled
   const float clipv = cf.clip_obs;
-  auto obs = G(so.obs ? so.obs : T.obs) + (size_t)env * WBC_NOBS;
-  auto hist = G(T.obs_hist) + (size_t)env * (WBC_HIST * WBC_NPROP);
+  auto obs = ROW(so.obs ? so.obs : T.obs, env, WBC_NOBS);
+  auto hist = ROW(T.obs_hist, env, (WBC_HIST * WBC_NPROP));
   const bool refill = s.ep_len <= 1;
   // the old history was requested right after the substeps (hist_in: its HBM latency ran under the rigid-body pass and the task
   // logic); every lane's reads were issued long before the first write of the in-place shift below
@@ -1431,32 +1434,32 @@ template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C
   for (int e = lane; e < WBC_NPROP + WBC_NPRIV; e += LANES) {
     float val;
     if (e < WBC_NPROP) val = s.post.o76[e];
-    else if (e < WBC_NPROP + 5) val = G(T.mass_params)[(size_t)env * 5 + e - WBC_NPROP];
+    else if (e < WBC_NPROP + 5) val = ROW(T.mass_params, env, 5)[e - WBC_NPROP];
     else if (e == WBC_NPROP + 5) val = s.friction;
     else val = s.motor[e - WBC_NPROP - 6] - 1.f;
     obs[e] = clampf(val, -clipv, clipv);
   }
   // state write-back
-  if (lane < 13) { G(T.root)[(size_t)env * 26 + lane] = s.root[lane]; G(T.root)[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
-  if (lane < 40) G(T.dof)[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
-  if (lane < WBC_NDOF) { G(T.torques)[(size_t)env * WBC_NDOF + lane] = s.tau[lane]; G(T.last_dof_vel)[(size_t)env * WBC_NDOF + lane] = s.qd[lane]; }
-  if (lane < WBC_NACT) { G(T.actions)[(size_t)env * WBC_NACT + lane] = s.act[lane]; G(T.last_actions)[(size_t)env * WBC_NACT + lane] = s.act[lane]; }
-  if (lane < 6) G(T.last_root_vel)[(size_t)env * 6 + lane] = s.root[7 + lane];
-  if (lane < 24) G(T.goal)[(size_t)env * 24 + lane] = s.goal[lane];
-  if (lane < 3) { G(T.commands)[(size_t)env * 3 + lane] = s.cmd[lane]; G(T.base_lin_vel)[(size_t)env * 3 + lane] = s.blv[lane]; G(T.base_ang_vel)[(size_t)env * 3 + lane] = s.bav[lane]; }
-  if (lane < WBC_NREW) G(T.ep_sums)[(size_t)env * WBC_NREW + lane] = s.ep_sums[lane];
-  if (lane < WBC_NMETRIC) G(T.met_sums)[(size_t)env * WBC_NMETRIC + lane] = s.met_sums[lane];
-  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) G(T.contact)[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
-  if (lane < WBC_NFEET * 6) G(T.sensor)[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
-  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) G(T.rb)[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
+  if (lane < 40) ROW(T.dof, env, 40)[lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  if (lane < WBC_NDOF) { ROW(T.torques, env, WBC_NDOF)[lane] = s.tau[lane]; ROW(T.last_dof_vel, env, WBC_NDOF)[lane] = s.qd[lane]; }
+  if (lane < WBC_NACT) { ROW(T.actions, env, WBC_NACT)[lane] = s.act[lane]; ROW(T.last_actions, env, WBC_NACT)[lane] = s.act[lane]; }
+  if (lane < 6) ROW(T.last_root_vel, env, 6)[lane] = s.root[7 + lane];
+  if (lane < 24) ROW(T.goal, env, 24)[lane] = s.goal[lane];
+  if (lane < 3) { ROW(T.commands, env, 3)[lane] = s.cmd[lane]; ROW(T.base_lin_vel, env, 3)[lane] = s.blv[lane]; ROW(T.base_ang_vel, env, 3)[lane] = s.bav[lane]; }
+  if (lane < WBC_NREW) ROW(T.ep_sums, env, WBC_NREW)[lane] = s.ep_sums[lane];
+  if (lane < WBC_NMETRIC) ROW(T.met_sums, env, WBC_NMETRIC)[lane] = s.met_sums[lane];
+  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) ROW(T.contact, env, (WBC_NRB_ENV * 3))[e] = (&s.out_contact[0][0])[e];
+  if (lane < WBC_NFEET * 6) ROW(T.sensor, env, (WBC_NFEET * 6))[lane] = (&s.out_sensor[0][0])[lane];
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) ROW(T.rb, env, (WBC_NRB_ENV * 13))[e] = (&s.post.out_rb[0][0])[e];
   if (lane == 0) {
     G(T.rew)[env] = s.rew; G(T.arm_rew)[env] = s.arm_rew;
     G(T.reset_buf)[env] = s.reset_flag; G(T.time_out)[env] = (uint8_t)s.time_out; G(T.ep_len)[env] = s.ep_len;
     if (so.rewards) {                                 // the same arithmetic as rollout_store_kernel (csrc/wbc_gae_kernel.hip)
       const float to = s.time_out ? 1.f : 0.f;
       float r0 = s.rew, r1 = s.arm_rew;
-      r0 += so.gamma * (G(so.values)[2 * (size_t)env] * to); r1 += so.gamma * (G(so.values)[2 * (size_t)env + 1] * to);
-      G(so.rewards)[2 * (size_t)env] = r0; G(so.rewards)[2 * (size_t)env + 1] = r1;
+      r0 += so.gamma * (ROW(so.values, env, 2)[0] * to); r1 += so.gamma * (ROW(so.values, env, 2)[1] * to);
+      ROW(so.rewards, env, 2)[0] = r0; ROW(so.rewards, env, 2)[1] = r1;
       G(so.dones)[env] = (uint8_t)(s.reset_flag != 0);
     }
   }
@@ -1489,8 +1492,8 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // action reorder, clip and delay FIFO (WG:1162-1168)
   if (lane < WBC_NACT) {
     const float clipa = C->cfg.clip_actions;
-    const float a = clampf(actions[(size_t)env * WBC_NACT + POLICY_PERM[lane]], -clipa, clipa);
-    auto ah = G(T.act_hist) + (size_t)env * (WBC_ADELAY_LEN * WBC_NACT);
+    const float a = clampf(ROW(actions, env, WBC_NACT)[POLICY_PERM[lane]], -clipa, clipa);
+    auto ah = ROW(T.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT));
     float used = a;
     if (C->cfg.action_delay != -1) {
       float h[WBC_ADELAY_LEN];
@@ -1526,7 +1529,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // observe_and_store at the very end
   float hist_in[12];
   {
-    auto hist = G(T2.obs_hist) + (size_t)env * (WBC_HIST * WBC_NPROP);
+    auto hist = ROW(T2.obs_hist, env, (WBC_HIST * WBC_NPROP));
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
       const int idx = lane + r * LANES;
@@ -1590,8 +1593,8 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const bool do_reset = s.reset_flag != 0;
   if (do_reset) reset_env_call(s, T2, Cq, seed, env, step, s.base_yaw);
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
-    G(T2.act_hist)[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane] = 0.f;
-    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) G(T2.act_hist)[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + lane + LANES] = 0.f;
+    ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane] = 0.f;
+    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane + LANES] = 0.f;
   }
   STAMP(16);
   observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
@@ -1617,17 +1620,17 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors 
   reset_env(s, T, C, seed, env, step, 1, s.base_yaw);
   rigid_body_pass(s, C, cr, chain, k);
   // write back what a reset touches
-  if (lane < 13) { G(T.root)[(size_t)env * 26 + lane] = s.root[lane]; G(T.root)[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
-  if (lane < 40) G(T.dof)[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
-  if (lane < 24) G(T.goal)[(size_t)env * 24 + lane] = s.goal[lane];
-  if (lane < 3) G(T.commands)[(size_t)env * 3 + lane] = s.cmd[lane];
-  if (lane < WBC_NREW) G(T.ep_sums)[(size_t)env * WBC_NREW + lane] = 0.f;
-  if (lane < WBC_NMETRIC) G(T.met_sums)[(size_t)env * WBC_NMETRIC + lane] = 0.f;
-  if (lane < WBC_NACT) G(T.last_actions)[(size_t)env * WBC_NACT + lane] = 0.f;
-  if (lane < WBC_NDOF) G(T.last_dof_vel)[(size_t)env * WBC_NDOF + lane] = 0.f;
-  for (int e = lane; e < WBC_HIST * WBC_NPROP; e += LANES) G(T.obs_hist)[(size_t)env * (WBC_HIST * WBC_NPROP) + e] = 0.f;
-  for (int e = lane; e < WBC_ADELAY_LEN * WBC_NACT; e += LANES) G(T.act_hist)[(size_t)env * (WBC_ADELAY_LEN * WBC_NACT) + e] = 0.f;
-  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) G(T.rb)[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
+  if (lane < 40) ROW(T.dof, env, 40)[lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  if (lane < 24) ROW(T.goal, env, 24)[lane] = s.goal[lane];
+  if (lane < 3) ROW(T.commands, env, 3)[lane] = s.cmd[lane];
+  if (lane < WBC_NREW) ROW(T.ep_sums, env, WBC_NREW)[lane] = 0.f;
+  if (lane < WBC_NMETRIC) ROW(T.met_sums, env, WBC_NMETRIC)[lane] = 0.f;
+  if (lane < WBC_NACT) ROW(T.last_actions, env, WBC_NACT)[lane] = 0.f;
+  if (lane < WBC_NDOF) ROW(T.last_dof_vel, env, WBC_NDOF)[lane] = 0.f;
+  for (int e = lane; e < WBC_HIST * WBC_NPROP; e += LANES) ROW(T.obs_hist, env, (WBC_HIST * WBC_NPROP))[e] = 0.f;
+  for (int e = lane; e < WBC_ADELAY_LEN * WBC_NACT; e += LANES) ROW(T.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[e] = 0.f;
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) ROW(T.rb, env, (WBC_NRB_ENV * 13))[e] = (&s.post.out_rb[0][0])[e];
   if (lane == 0) { G(T.reset_buf)[env] = 1; G(T.ep_len)[env] = 0; }
 }
 
@@ -1642,14 +1645,14 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   ChainRegs cr;
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
-  if (lane < WBC_NDOF) s.tau[lane] = G(T.torques)[(size_t)env * WBC_NDOF + lane];
+  if (lane < WBC_NDOF) s.tau[lane] = ROW(T.torques, env, WBC_NDOF)[lane];
   WSYNC();
   physics_substep(s, C, cr, chain, k, true);
-  if (lane < 13) { G(T.root)[(size_t)env * 26 + lane] = s.root[lane]; G(T.root)[(size_t)env * 26 + 13 + lane] = s.box[lane]; }
+  if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
   if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
-  if (lane < 40) G(T.dof)[(size_t)env * 40 + lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
-  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) G(T.contact)[(size_t)env * (WBC_NRB_ENV * 3) + e] = (&s.out_contact[0][0])[e];
-  if (lane < WBC_NFEET * 6) G(T.sensor)[(size_t)env * (WBC_NFEET * 6) + lane] = (&s.out_sensor[0][0])[lane];
+  if (lane < 40) ROW(T.dof, env, 40)[lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) ROW(T.contact, env, (WBC_NRB_ENV * 3))[e] = (&s.out_contact[0][0])[e];
+  if (lane < WBC_NFEET * 6) ROW(T.sensor, env, (WBC_NFEET * 6))[lane] = (&s.out_sensor[0][0])[lane];
 }
 
 // gym.refresh_rigid_body_state_tensor after a state write: forward kinematics only
@@ -1665,7 +1668,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
   load_env(s, T, C, env);
   WSYNC();
   rigid_body_pass(s, C, cr, chain, k);
-  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) G(T.rb)[(size_t)env * (WBC_NRB_ENV * 13) + e] = (&s.post.out_rb[0][0])[e];
+  for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) ROW(T.rb, env, (WBC_NRB_ENV * 13))[e] = (&s.post.out_rb[0][0])[e];
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
