@@ -95,8 +95,9 @@ __device__ __forceinline__ float rng_u01(uint64_t seed, uint64_t env, uint64_t s
   h = mix64(h + step * 0xD1B54A32D192ED03ULL + slot * 0x8CB92BA72F3D8DD7ULL);
   return (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f);
 }
+__device__ __forceinline__ float urange(float lo, float hi, float u) { return (hi - lo) * u + lo; }
 __device__ __forceinline__ float rng_range(float lo, float hi, uint64_t seed, uint64_t env, uint64_t step, uint64_t slot) {
-  return (hi - lo) * rng_u01(seed, env, step, slot) + lo;
+  return urange(lo, hi, rng_u01(seed, env, step, slot));
 }
 enum {
   SLOT_GOAL_ORN = 0, SLOT_GOAL_SPHERE = 3, SLOT_CMD = 33, SLOT_PUSH = 35, SLOT_RESET_DOF = 37,

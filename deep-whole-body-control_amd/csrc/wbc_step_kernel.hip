@@ -38,6 +38,7 @@ static_assert(LANES == 64, "one wavefront per robot: cross-lane hand-overs rest 
 
 // development aid: phase timestamps of block 0 (tools/time_step.py builds a variant with -DWBC_STEP_TIMING)
 __device__ long long* g_step_dbg = nullptr;
+__device__ long long* g_wave_dbg = nullptr;      // timing builds: per env {start, end, reset | HW_ID << 8} of the step kernel's wave
 #ifdef WBC_STEP_TIMING
 #define STAMP(i) do { if (g_step_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_step_dbg[i] = clock64(); } while (0)
 #else
@@ -1048,47 +1049,74 @@ __device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int ch
   WSYNC();
 }
 
-__device__ __forceinline__ void resample_commands(Smem& s, CP C, uint64_t seed, int env, uint64_t step, int slot) {
-  const float cx = rng_range(C->cur.lin_vel_x_range[0], C->cur.lin_vel_x_range[1], seed, env, step, slot);
-  const float cy = rng_range(C->cur.ang_vel_yaw_range[0], C->cur.ang_vel_yaw_range[1], seed, env, step, slot + 1);
-  const bool keep = (cx > C->cfg.lin_vel_x_clip) || (fabsf(cy) > C->cfg.ang_vel_yaw_clip);
-  s.cmd[0] = keep ? cx : 0.f; s.cmd[1] = 0.f; s.cmd[2] = keep ? cy : 0.f;
-}
-
 enum { G_START = 0, G_GOAL = 3, G_GOAL_CART = 6, G_CURR = 9, G_CURR_CART = 12, G_DORN = 15, G_ORN = 18,
        G_TIMER = 21, G_TRAJ = 22, G_TOTAL = 23 };
 
-__device__ int goal_collision(const Smem& s, CP C) {
+// ---- random events of the task logic, wave-cooperative --------------------------------------------------------------------------
+// The reference's samplers draw a handful of uniforms per event and _resample_ee_goal (WG:1303-1350) retries up to ten times until
+// the straight line from the old goal to the candidate misses the robot's body; every draw is a counter hash of (seed, env, step,
+// slot) -- two 64-bit mixes, ~80 dependent integer instructions. Done on lane 0, one reset was 30-40 dependent hashes plus up to ten
+// 10-sample collision tests, in the wave the launch ends with (the slowest 1 % of the waves of a launch were all resetting ones:
+// tools/wave_spread.py). Here lane j hashes slot j, the (candidate, sample) pairs of all ten candidates are tested at once, and lane
+// 0 only applies the result. Same integers, same float expressions as the oracle's serial loop.
+#define DRAWS(s) (&(s).pA[0][0])    // scratch: the bias-force array is dead once the substeps are done (114 floats)
+enum { DR_PICK = 48, DR_MASK = 51 };  // [0..47] u01 draws of consecutive slots, [48..50] the picked EE goal (l, p, y), [51] (int) candidates that collide
+
+// all lanes: DRAWS[j] = u01(slot0 + j), j < count
+__device__ __forceinline__ void draw_block(Smem& s, uint64_t seed, int env, uint64_t step, int slot0, int count) {
+  const int lane = threadIdx.x;
+  if (lane < count) DRAWS(s)[lane] = rng_u01(seed, env, step, slot0 + lane);
+  if (lane == 0) reinterpret_cast<int*>(DRAWS(s))[DR_MASK] = 0;
+  WSYNC();
+}
+
+// all lanes: the rejection loop of _resample_ee_goal. DRAWS[sph0 + 3 r + j]: draw j of candidate r. Leaves the first candidate whose
+// path from the current goal is free (the tenth if none is) in DRAWS[DR_PICK..].
+__device__ void goal_pick(Smem& s, CP C, int sph0) {
+  const int lane = threadIdx.x;
   const int ns = C->cfg.goal_collision_samples;
-  int hit = 0;
-  for (int kk = 0; kk < ns; ++kk) {
+  const float* u = DRAWS(s) + sph0;
+  int* mask = reinterpret_cast<int*>(DRAWS(s)) + DR_MASK;
+  for (int p = lane; p < 10 * ns; p += LANES) {
+    const int r = p / ns, kk = p - r * ns;
     const float t = (ns > 1) ? (float)kk / (float)(ns - 1) : 0.f;
-    const f3 sp = mk3(lerp_torch(s.goal[G_START], s.goal[G_GOAL], t), lerp_torch(s.goal[G_START + 1], s.goal[G_GOAL + 1], t),
-                      lerp_torch(s.goal[G_START + 2], s.goal[G_GOAL + 2], t));
+    const f3 g = mk3(urange(C->cur.goal_l_range[0], C->cur.goal_l_range[1], u[3 * r]), urange(C->cur.goal_p_range[0], C->cur.goal_p_range[1], u[3 * r + 1]),
+                     urange(C->cur.goal_y_range[0], C->cur.goal_y_range[1], u[3 * r + 2]));
+    const f3 sp = mk3(lerp_torch(s.goal[G_GOAL], g.x, t), lerp_torch(s.goal[G_GOAL + 1], g.y, t), lerp_torch(s.goal[G_GOAL + 2], g.z, t));
     const f3 c = sphere2cart(sp);
     const float cv[3] = {c.x, c.y, c.z};
     int inside = 1;
 #pragma unroll
     for (int j = 0; j < 3; ++j) inside &= (cv[j] < C->cfg.goal_collision_upper[j]) && (cv[j] > C->cfg.goal_collision_lower[j]);
-    hit |= inside;
-    hit |= c.z < C->cfg.goal_underground_limit;
+    if (inside | (c.z < C->cfg.goal_underground_limit)) __hip_atomic_fetch_or(mask, 1 << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
-  return hit;
+  WSYNC();
+  const int m = *mask & 1023;
+  const int rs = (m == 1023) ? 9 : __ffs(~m) - 1;
+  if (lane < 3) {
+    const float lo = lane == 0 ? C->cur.goal_l_range[0] : (lane == 1 ? C->cur.goal_p_range[0] : C->cur.goal_y_range[0]);
+    const float hi = lane == 0 ? C->cur.goal_l_range[1] : (lane == 1 ? C->cur.goal_p_range[1] : C->cur.goal_y_range[1]);
+    DRAWS(s)[DR_PICK + lane] = urange(lo, hi, u[3 * rs + lane]);
+  }
+  WSYNC();
 }
 
-__device__ void resample_ee_goal(Smem& s, CP C, uint64_t seed, int env, uint64_t step, int slot_orn, int slot_sph, float base_yaw) {
+// lane 0: _resample_commands (WG:917-935) from its two draws
+__device__ __forceinline__ void resample_commands(Smem& s, CP C, float u0, float u1) {
+  const float cx = urange(C->cur.lin_vel_x_range[0], C->cur.lin_vel_x_range[1], u0);
+  const float cy = urange(C->cur.ang_vel_yaw_range[0], C->cur.ang_vel_yaw_range[1], u1);
+  const bool keep = (cx > C->cfg.lin_vel_x_clip) || (fabsf(cy) > C->cfg.ang_vel_yaw_clip);
+  s.cmd[0] = keep ? cx : 0.f; s.cmd[1] = 0.f; s.cmd[2] = keep ? cy : 0.f;
+}
+
+// lane 0: _resample_ee_goal's bookkeeping once goal_pick has chosen; DRAWS[orn0 + j]: the orientation draws
+__device__ void goal_apply(Smem& s, CP C, int orn0, float base_yaw) {
   for (int j = 0; j < 3; ++j) {
-    const float d = rng_range(C->cfg.goal_delta_orn_range[j][0], C->cfg.goal_delta_orn_range[j][1], seed, env, step, slot_orn + j);
+    const float d = urange(C->cfg.goal_delta_orn_range[j][0], C->cfg.goal_delta_orn_range[j][1], DRAWS(s)[orn0 + j]);
     s.goal[G_DORN + j] = d;
     s.goal[G_ORN + j] = wrap_to_pi(d + (j == 2 ? base_yaw : 0.f));
   }
-  for (int j = 0; j < 3; ++j) s.goal[G_START + j] = s.goal[G_GOAL + j];
-  for (int r = 0; r < 10; ++r) {
-    s.goal[G_GOAL + 0] = rng_range(C->cur.goal_l_range[0], C->cur.goal_l_range[1], seed, env, step, slot_sph + 3 * r);
-    s.goal[G_GOAL + 1] = rng_range(C->cur.goal_p_range[0], C->cur.goal_p_range[1], seed, env, step, slot_sph + 3 * r + 1);
-    s.goal[G_GOAL + 2] = rng_range(C->cur.goal_y_range[0], C->cur.goal_y_range[1], seed, env, step, slot_sph + 3 * r + 2);
-    if (!goal_collision(s, C)) break;
-  }
+  for (int j = 0; j < 3; ++j) { s.goal[G_START + j] = s.goal[G_GOAL + j]; s.goal[G_GOAL + j] = DRAWS(s)[DR_PICK + j]; }
   st3(&s.goal[G_GOAL_CART], sphere2cart(ld3(&s.goal[G_GOAL])));
   s.goal[G_TIMER] = 0.f;
 }
@@ -1356,7 +1384,11 @@ template <class TT> __device__ __forceinline__ void reset_env(Smem& s, const TT&
   WSYNC();
   if (lane < WBC_NREW) s.ep_sums[lane] = 0.f;
   if (lane < WBC_NMETRIC) s.met_sums[lane] = 0.f;
+  // the reset's draws (slots SLOT_RESET_XY ...: xy 0-1, velocity 2-7, commands 8-9, goal orientation 10-12, goal candidates 13-42) and the goal
+  draw_block(s, seed, env, step, SLOT_RESET_XY, SLOT_RESET_GOAL_SPHERE + 30 - SLOT_RESET_XY);
+  goal_pick(s, C, SLOT_RESET_GOAL_SPHERE - SLOT_RESET_XY);
   if (lane == 0) {
+    const float* dr = DRAWS(s);
     {   // what _update_terrain_curriculum reads of the finished episode (LR:431-435), before root and commands are overwritten
       const float dx = s.root[0] - ROW(T.origins, env, 3)[0], dy = s.root[1] - ROW(T.origins, env, 3)[1];
       ROW(T.reset_travel, env, 2)[0] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
@@ -1364,14 +1396,14 @@ template <class TT> __device__ __forceinline__ void reset_env(Smem& s, const TT&
     }
     for (int j = 0; j < 13; ++j) s.root[j] = C->cfg.base_init_state[j];
     for (int j = 0; j < 3; ++j) s.root[j] += ROW(T.origins, env, 3)[j];
-    for (int j = 0; j < 2; ++j) s.root[j] += rng_range(-C->cfg.origin_perturb_range, C->cfg.origin_perturb_range, seed, env, step, SLOT_RESET_XY + j);
+    for (int j = 0; j < 2; ++j) s.root[j] += urange(-C->cfg.origin_perturb_range, C->cfg.origin_perturb_range, dr[j]);
     s.box[0] = C->cfg.box_origin_x;
     s.box[1] = s.root[1] + G(T.box_dy)[env];
     s.box[2] = C->cfg.box_origin_z;
-    for (int j = 0; j < 6; ++j) s.root[7 + j] = rng_range(-C->cfg.init_vel_perturb_range, C->cfg.init_vel_perturb_range, seed, env, step, SLOT_RESET_VEL + j);
+    for (int j = 0; j < 6; ++j) s.root[7 + j] = urange(-C->cfg.init_vel_perturb_range, C->cfg.init_vel_perturb_range, dr[SLOT_RESET_VEL - SLOT_RESET_XY + j]);
     { const f3 e = euler_from_quat(&s.root[3]); s.rp[0] = e.x; s.rp[1] = e.y; }      // the observation of a reset env shows the new pose
-    if (start || s.time_out) resample_commands(s, C, seed, env, step, SLOT_RESET_CMD);
-    resample_ee_goal(s, C, seed, env, step, SLOT_RESET_GOAL_ORN, SLOT_RESET_GOAL_SPHERE, base_yaw);
+    if (start || s.time_out) resample_commands(s, C, dr[SLOT_RESET_CMD - SLOT_RESET_XY], dr[SLOT_RESET_CMD - SLOT_RESET_XY + 1]);
+    goal_apply(s, C, SLOT_RESET_GOAL_ORN - SLOT_RESET_XY, base_yaw);
     s.ep_len = 0;
     s.reset_flag = 1;
     s.goal[G_TIMER] = 0.f;
@@ -1486,6 +1518,9 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
+#ifdef WBC_STEP_TIMING
+  const long long wave_t0 = clock64();
+#endif
   STAMP(11);
   make_chain_regs(s, cr, C, chain);
   load_env(s, T, C, env);
@@ -1518,6 +1553,9 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   }
   if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
   STAMP(13);
+#ifdef WBC_STEP_TIMING
+  const long long wave_t13 = clock64();
+#endif
   // Everything after the substeps reads its tensor / constant pointers through laundered copies of the two kernel arguments: the
   // compiler otherwise hoists those (invariant) scalar loads above the substep loop, where the ~40 pointers and constants it
   // keeps alive across the loop exhaust the SGPR file and end up spilled to scratch memory through VGPRs.
@@ -1552,6 +1590,18 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const bool base_on = ((Cq->cur.leg_active_mask | Cq->cur.arm_active_mask) >> WBC_NREW_WG) != 0ull;
   BaseSums bsums = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (base_on) bsums = base_reward_sums(s, T2, Cq, env);
+  // this step's random events (wave-uniform conditions, evaluated as lane 0 will find them below): their draws and the new EE goal
+  // are prepared by all lanes, lane 0 applies them
+  {
+    const int pi = Cq->cfg.push_interval;
+    const int need_goal = __builtin_amdgcn_readfirstlane((int)((s.goal[G_TIMER] + 1.f) > s.goal[G_TOTAL]));
+    const int need_cmd = __builtin_amdgcn_readfirstlane((int)(((s.ep_len + 1) % Cq->cfg.resample_interval) == 0));
+    const int need_push = pi > 0 && (step % (uint64_t)pi) == 0;
+    if (need_goal | need_cmd | need_push) {
+      draw_block(s, seed, env, step, SLOT_GOAL_ORN, SLOT_PUSH + 2);
+      if (need_goal) goal_pick(s, Cq, SLOT_GOAL_SPHERE);
+    }
+  }
   float base_yaw = 0.f;
   if (lane == 0) {
     s.ep_len += 1;
@@ -1569,11 +1619,11 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     for (int j = 0; j < 3; ++j) s.goal[G_CURR + j] = lerp_torch(s.goal[G_START + j], s.goal[G_GOAL + j], tt);
     st3(&s.goal[G_CURR_CART], sphere2cart(ld3(&s.goal[G_CURR])));
     s.goal[G_TIMER] += 1.f;
-    if (s.goal[G_TIMER] > s.goal[G_TOTAL]) resample_ee_goal(s, Cq, seed, env, step, SLOT_GOAL_ORN, SLOT_GOAL_SPHERE, base_yaw);
-    if (s.ep_len % Cq->cfg.resample_interval == 0) resample_commands(s, Cq, seed, env, step, SLOT_CMD);
+    if (s.goal[G_TIMER] > s.goal[G_TOTAL]) goal_apply(s, Cq, SLOT_GOAL_ORN, base_yaw);
+    if (s.ep_len % Cq->cfg.resample_interval == 0) resample_commands(s, Cq, DRAWS(s)[SLOT_CMD], DRAWS(s)[SLOT_CMD + 1]);
     if (Cq->cfg.push_interval > 0 && (step % (uint64_t)Cq->cfg.push_interval) == 0) {
-      const float px = rng_range(-Cq->cfg.max_push_vel, Cq->cfg.max_push_vel, seed, env, step, SLOT_PUSH);
-      const float py = rng_range(-Cq->cfg.max_push_vel, Cq->cfg.max_push_vel, seed, env, step, SLOT_PUSH + 1);
+      const float px = urange(-Cq->cfg.max_push_vel, Cq->cfg.max_push_vel, DRAWS(s)[SLOT_PUSH]);
+      const float py = urange(-Cq->cfg.max_push_vel, Cq->cfg.max_push_vel, DRAWS(s)[SLOT_PUSH + 1]);
       const float kk = ((s.cmd[0] + s.cmd[1] + s.cmd[2]) == 0.f) ? 2.5f : 1.f;
       s.root[7] = px * kk; s.root[8] = py * kk;
     }
@@ -1590,6 +1640,9 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   reward_accumulate(s, Cq, rsc_leg, rsc_arm);
   WSYNC();
   STAMP(15);
+#ifdef WBC_STEP_TIMING
+  const long long wave_t15 = clock64();
+#endif
   const bool do_reset = s.reset_flag != 0;
   if (do_reset) reset_env_call(s, T2, Cq, seed, env, step, s.base_yaw);
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
@@ -1597,8 +1650,18 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane + LANES] = 0.f;
   }
   STAMP(16);
+#ifdef WBC_STEP_TIMING
+  const long long wave_t16 = clock64();
+#endif
   observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
   STAMP(17);
+#ifdef WBC_STEP_TIMING
+  if (g_wave_dbg && lane == 0) {
+    g_wave_dbg[6 * (size_t)env] = wave_t0; g_wave_dbg[6 * (size_t)env + 1] = clock64();
+    g_wave_dbg[6 * (size_t)env + 3] = wave_t13; g_wave_dbg[6 * (size_t)env + 4] = wave_t15; g_wave_dbg[6 * (size_t)env + 5] = wave_t16;
+    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | ((long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) << 8);
+  }
+#endif
 }
 
 // reset_idx(all envs, start=True) (BT:129): one wave per env
@@ -1675,6 +1738,11 @@ static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics stag
 static_assert(sizeof(float) * (36 + WBC_NCP * 12) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
 static_assert(sizeof(float) * (WBC_NRB_ENV * 3 + WBC_NFEET * 6) <= sizeof(float) * WBC_NB * 6, "contact outputs alias U");
 static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");
+
+extern "C" void wbc_debug_set_wave_timing(void* dev_buf) {
+  long long* p = (long long*)dev_buf;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_dbg), &p, sizeof(p));
+}
 
 extern "C" void wbc_debug_set_step_timing(void* dev_buf) {
   long long* p = (long long*)dev_buf;

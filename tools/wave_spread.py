@@ -1,0 +1,35 @@
+"""Per-wave durations of ONE wbc_step_kernel launch (timing build: tools/build_variant.py timing -DWBC_STEP_TIMING): how far is the
+launch (= its slowest SIMD) from the mean wave, and what do the slow waves have in common?  usage: python tools/wave_spread.py [N]"""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["WBC_AMD_LIB"] = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_timing.so")
+import numpy as np, torch
+import helpers
+from wbc_amd import abi
+from wbc_amd.config import WidowGo1RoughCfg
+from wbc_amd.native import lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+m = abi.load_default_model(); cfg = WidowGo1RoughCfg(); tc = abi.fill_task_cfg(cfg, m)
+g = helpers.make_gpu(dict(model=m, wmodel=abi.fill_model(m), cfg=cfg, tcfg=tc), n, helpers.random_env_params(n, 0))
+g.reset_all()
+acts = [torch.randn(n, 18, device="cuda") * 0.5 for _ in range(8)]
+for i in range(60): g.step(acts[i % 8])
+L = lib(); L.wbc_debug_set_wave_timing.argtypes = [C.c_void_p]
+buf = torch.zeros(6 * n, dtype=torch.int64, device="cuda")
+L.wbc_debug_set_wave_timing(buf.data_ptr())
+for rep in range(3):
+    g.step(acts[rep]); torch.cuda.synchronize()
+    t = buf.cpu().numpy().reshape(n, 6)
+    t0, t1, fl = t[:, 0], t[:, 1], t[:, 2]
+    dur = (t1 - t0).astype(np.float64); rst = (fl & 1) == 1; hw = fl >> 8
+    simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7; xcc = (hw >> 20) & 15   # HW_ID fields (gfx9 layout; xcc from bits above)
+    span = t1.max() - t0.min()
+    print(f"launch {rep}: span {span} cycles; wave duration mean {dur.mean():.0f} p50 {np.median(dur):.0f} p90 {np.percentile(dur, 90):.0f} p99 {np.percentile(dur, 99):.0f} max {dur.max():.0f}; "
+          f"start spread {t0.max() - t0.min()}; resets {rst.mean():.3f}: mean duration reset {dur[rst].mean():.0f} / no reset {dur[~rst].mean():.0f}")
+    sub, post, rs, obs = (t[:, 3] - t0).astype(float), (t[:, 4] - t[:, 3]).astype(float), (t[:, 5] - t[:, 4]).astype(float), (t1 - t[:, 5]).astype(float)
+    for nm, x in (("load + 4 substeps", sub), ("rigid bodies + task logic + rewards", post), ("reset", rs), ("observe + store", obs)):
+        print(f"   {nm:38s} no reset: mean {x[~rst].mean():8.0f} p90 {np.percentile(x[~rst], 90):8.0f} max {x[~rst].max():8.0f} | reset: mean {x[rst].mean():8.0f} p90 {np.percentile(x[rst], 90):8.0f} max {x[rst].max():8.0f}")
+    late = dur > np.percentile(dur, 99)
+    print(f"   the slowest 1 % of waves: reset share {rst[late].mean():.2f}, mean duration {dur[late].mean():.0f}, mean start offset {(t0[late] - t0.min()).mean():.0f}")
+L.wbc_debug_set_wave_timing(None)
