@@ -98,9 +98,7 @@ struct __align__(16) Smem {
     PostBuf post;
     struct {                     // contact iterations: K of the bodies 1.. is dead once every active contact has built its Delassus
       float K0[36];              // block (the sweeps only apply the root's K), so the per-contact data of the iterations lives there:
-      float cW[WBC_NCP][6];      // the Delassus block (upper triangle 00 01 02 11 12 22) and the sweep response, re-read by the owning
-      float cdv[WBC_NCP][3];     // lane in every iteration, and the impulse, gathered per body by other lanes
-      float clam[WBC_NCP][3];
+      float clam[WBC_NCP][3];    // the impulse, gathered per body by other lanes
     } ctc;
   };
   float E[WBC_NB][9];
@@ -122,6 +120,9 @@ struct __align__(16) Smem {
   // 1/m and 1/Ic, and its response to the contact impulses of the current sweep (centre acceleration, angular acceleration)
   float bxRb[9], bxc[3], bxE[9], bxv[3], bxw[3], bxim, bxiI, bxa[6];
   int bxtimer;                   // substeps the box has been at rest (asleep from box_sleep_time / sim_dt on)
+#ifdef WBC_STEP_TIMING
+  int dbg_ncon;                  // timing builds: active contacts | deepest active level << 8 of the last substep
+#endif
   // contacts (one per lane): only what OTHER lanes read lives here -- the contact point (the impulse: ctc.clam).
   // Normal, free velocity and velocity target stay in the owning lane's registers; the set of active contacts is a wavefront ballot.
   float cxc[WBC_NCP][3];
@@ -737,9 +738,6 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   // the barrier makes the order explicit instead of resting on reconvergence)
   WSYNC();
   if (cact) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) s.ctc.cW[lane][j] = cW[j];
-    s.ctc.cdv[lane][0] = s.ctc.cdv[lane][1] = s.ctc.cdv[lane][2] = 0.f;
     s.ctc.clam[lane][0] = s.ctc.clam[lane][1] = s.ctc.clam[lane][2] = 0.f;
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
@@ -755,6 +753,9 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   int dmax = 1;
 #pragma unroll
   for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
+#ifdef WBC_STEP_TIMING
+  if (lane == 0) s.dbg_ncon = __popcll(abits) | (dmax << 8) | (__popcll(abits & 0x3F800000ull) << 16);
+#endif
   // damped block-Jacobi: relaxation 1 / (number of active contacts acting on the busier of the contact's two bodies)
   float com = 1.f;
   if (cact) {
@@ -771,17 +772,15 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     const int cnt = max(c1, c2);
     com = 1.f / (float)cnt;
   }
+  f3 cdvr = mk3(0.f, 0.f, 0.f);       // this contact's sweep response and its Delassus block (cW) stay in the owning lane's registers
   if (any) {
     const int iters = C->cfg.contact_iters;
     for (int it = 0; it < iters; ++it) {
       if (cact) {
-        float W6[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) W6[j] = s.ctc.cW[lane][j];
-        const f3 own = sym_mul(W6, clamr);
-        const f3 vref = cvfree + ld3(s.ctc.cdv[lane]) - own;
+        const f3 own = sym_mul(cW, clamr);
+        const f3 vref = cvfree + cdvr - own;
         float lam[3];
-        contact_solve(W6, cn, cvtgt, cmu, vref, lam);
+        contact_solve(cW, cn, cvtgt, cmu, vref, lam);
         // damped block-Jacobi: the active contacts acting on one body share the correction
         clamr = clamr + (mk3(lam[0], lam[1], lam[2]) - clamr) * com;
         st3(s.ctc.clam[lane], clamr);
@@ -843,16 +842,18 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
           WSYNC();
         }
         if (it == 0) STAMP(22);
-        if (lane < 6) {       // root: sum of the depth-1 contributions (fixed order), then a0 = -K0 pD0
-          float pd0[6];
+        {   // root: a0 = -K0 pD0, pD0 = its own wrench + the depth-1 contributions (fixed order). Lane (r, c) of a 6 x 8 grid forms
+            // K0[r][c] pD0[c], an 8-lane DPP sum finishes row r: one LDS round trip instead of 42 dependent reads on six lanes
+          const int r = lane >> 3, c = lane & 7;
+          float t = 0.f;
+          if (r < 6 && c < 6) {
+            float acc = PD(s)[0][c];
   #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            float acc = PD(s)[0][j];
-  #pragma unroll
-            for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][j];
-            pd0[j] = acc;
+            for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][c];
+            t = s.ctc.K0[r * 6 + c] * acc;
           }
-          AD(s)[0][lane] = -dot6(&s.ctc.K0[lane * 6], pd0);
+          const float a0r = -sum8(t);
+          if (r < 6 && c == 0) AD(s)[0][r] = a0r;
         }
         WSYNC();
         if (it == 0) STAMP(23);
@@ -891,7 +892,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
           const f3 lv2 = p2box ? xc - ld3(s.bxc) : xc;
           dvv = dvv - (ld3(ad2 + 3) + cross(ld3(ad2), lv2)) * dt;
         }
-        st3(s.ctc.cdv[lane], dvv);
+        cdvr = dvv;
       }
       WSYNC();
     }
@@ -1659,7 +1660,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   if (g_wave_dbg && lane == 0) {
     g_wave_dbg[6 * (size_t)env] = wave_t0; g_wave_dbg[6 * (size_t)env + 1] = clock64();
     g_wave_dbg[6 * (size_t)env + 3] = wave_t13; g_wave_dbg[6 * (size_t)env + 4] = wave_t15; g_wave_dbg[6 * (size_t)env + 5] = wave_t16;
-    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | ((long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) << 8);
+    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | ((long long)s.dbg_ncon << 8);
   }
 #endif
 }
@@ -1735,7 +1736,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
-static_assert(sizeof(float) * (36 + WBC_NCP * 12) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
+static_assert(sizeof(float) * (36 + WBC_NCP * 3) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
 static_assert(sizeof(float) * (WBC_NRB_ENV * 3 + WBC_NFEET * 6) <= sizeof(float) * WBC_NB * 6, "contact outputs alias U");
 static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");
 

@@ -22,14 +22,17 @@ for rep in range(3):
     g.step(acts[rep]); torch.cuda.synchronize()
     t = buf.cpu().numpy().reshape(n, 6)
     t0, t1, fl = t[:, 0], t[:, 1], t[:, 2]
-    dur = (t1 - t0).astype(np.float64); rst = (fl & 1) == 1; hw = fl >> 8
-    simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7; xcc = (hw >> 20) & 15   # HW_ID fields (gfx9 layout; xcc from bits above)
+    dur = (t1 - t0).astype(np.float64); rst = (fl & 1) == 1
+    ncon = (fl >> 8) & 255; dmax = (fl >> 16) & 255; nself = (fl >> 24) & 255      # of the last substep
     span = t1.max() - t0.min()
     print(f"launch {rep}: span {span} cycles; wave duration mean {dur.mean():.0f} p50 {np.median(dur):.0f} p90 {np.percentile(dur, 90):.0f} p99 {np.percentile(dur, 99):.0f} max {dur.max():.0f}; "
           f"start spread {t0.max() - t0.min()}; resets {rst.mean():.3f}: mean duration reset {dur[rst].mean():.0f} / no reset {dur[~rst].mean():.0f}")
     sub, post, rs, obs = (t[:, 3] - t0).astype(float), (t[:, 4] - t[:, 3]).astype(float), (t[:, 5] - t[:, 4]).astype(float), (t1 - t[:, 5]).astype(float)
     for nm, x in (("load + 4 substeps", sub), ("rigid bodies + task logic + rewards", post), ("reset", rs), ("observe + store", obs)):
         print(f"   {nm:38s} no reset: mean {x[~rst].mean():8.0f} p90 {np.percentile(x[~rst], 90):8.0f} max {x[~rst].max():8.0f} | reset: mean {x[rst].mean():8.0f} p90 {np.percentile(x[rst], 90):8.0f} max {x[rst].max():8.0f}")
+    for k in sorted(set(ncon.tolist())):
+        sel = ncon == k
+        if sel.sum() >= 20: print(f"   active contacts {k:2d}: {sel.sum():5d} waves, substeps mean {sub[sel].mean():8.0f} (deepest level mean {dmax[sel].mean():.1f}, self-collision pairs {nself[sel].mean():.2f})")
     late = dur > np.percentile(dur, 99)
     print(f"   the slowest 1 % of waves: reset share {rst[late].mean():.2f}, mean duration {dur[late].mean():.0f}, mean start offset {(t0[late] - t0.min()).mean():.0f}")
 L.wbc_debug_set_wave_timing(None)
