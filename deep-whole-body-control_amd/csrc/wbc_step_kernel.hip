@@ -747,6 +747,10 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   // dmax: deepest chain level that carries an active contact. Deeper levels see no contact wrench, so the inward
   // sweep skips them exactly; the outward sweep needs them only in the last iteration (joint accelerations).
   const int any = abits != 0ull;
+  // A launch ends with its slowest wave, and a wave in contact has the longer way to go (the solver's sweeps: +17 k cycles per
+  // substep over an airborne robot's): it takes the SIMD's issue slots first from here on (s_setprio; nothing changes while all
+  // four waves of a SIMD are in contact).
+  if (any) __builtin_amdgcn_s_setprio(1);
   // contacts that act on the tree (everything but the box's own corners): without one -- the robot in the air while the box lies
   // on the ground -- the tree's response is zero and its sweeps are skipped
   const bool any_tree = (abits & ~Cc->box_corner_mask) != 0ull;
@@ -1645,7 +1649,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const long long wave_t15 = clock64();
 #endif
   const bool do_reset = s.reset_flag != 0;
-  if (do_reset) reset_env_call(s, T2, Cq, seed, env, step, s.base_yaw);
+  if (do_reset) { __builtin_amdgcn_s_setprio(2); reset_env_call(s, T2, Cq, seed, env, step, s.base_yaw); }
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
     ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane] = 0.f;
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane + LANES] = 0.f;
