@@ -34,5 +34,6 @@ for rep in range(3):
         sel = ncon == k
         if sel.sum() >= 20: print(f"   active contacts {k:2d}: {sel.sum():5d} waves, substeps mean {sub[sel].mean():8.0f} (deepest level mean {dmax[sel].mean():.1f}, self-collision pairs {nself[sel].mean():.2f})")
     late = dur > np.percentile(dur, 99)
+    print(f"   the slowest 1 % of waves, phase means: substeps {sub[late].mean():.0f} post {post[late].mean():.0f} reset {rs[late].mean():.0f} observe {obs[late].mean():.0f}; active contacts {ncon[late].mean():.1f}")
     print(f"   the slowest 1 % of waves: reset share {rst[late].mean():.2f}, mean duration {dur[late].mean():.0f}, mean start offset {(t0[late] - t0.min()).mean():.0f}")
 L.wbc_debug_set_wave_timing(None)
