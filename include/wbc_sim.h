@@ -264,7 +264,8 @@ size_t wbc_sim_arena_bytes(int num_envs);
 /* gymapi.acquire_gym + create_sim + load_asset + the create_env/create_actor loop +
  * prepare_sim (BT:42,86-87; WG:234,285,355-392). `arena` is caller-provided device memory
  * of >= wbc_sim_arena_bytes(num_envs) bytes (e.g. a torch allocation, so that the tensors
- * below are zero-copy views of it); NULL lets the library hipMalloc its own. */
+ * below are zero-copy views of it); NULL lets the library hipMalloc its own. 1 <= num_envs <= 2^22 (the kernels index a tensor's
+ * rows with 32-bit element offsets); anything else is -1 with a message in wbc_last_error(). */
 int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, int num_envs, int hip_device,
                    uint64_t seed, void* arena, size_t arena_bytes, wbc_sim** out);
 int wbc_sim_destroy(wbc_sim* sim);

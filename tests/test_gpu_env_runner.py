@@ -340,3 +340,21 @@ def test_episode_statistics_carried_by_the_policy_launch_equal_the_stand_alone_l
         assert s0[k] == pytest.approx(s1[k], rel=1e-6), k
     for t in trackers:
         t.close()
+
+
+def test_create_rejects_what_the_row_addressing_cannot_hold():
+    """wbc_sim_create bounds num_envs (include/wbc_sim.h): the kernels address a tensor's rows with 32-bit element offsets. The
+    check comes before any allocation; the message names the bound."""
+    import ctypes as C
+    from wbc_amd import abi
+    from wbc_amd.native import lib
+    L = lib()
+    m = abi.load_default_model()
+    cfg = _cfg()
+    model, tcfg = abi.fill_model(m), abi.fill_task_cfg(cfg, m)
+    h = C.c_void_p()
+    for n in (0, (1 << 22) + 1):
+        rc = L.wbc_sim_create(C.byref(model), C.byref(tcfg), n, 0, 1, None, 0, C.byref(h))
+        assert rc == -1 and not h.value
+    L.wbc_last_error.restype = C.c_char_p
+    assert b"2^22" in L.wbc_last_error()
