@@ -1664,7 +1664,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   if (g_wave_dbg && lane == 0) {
     g_wave_dbg[6 * (size_t)env] = wave_t0; g_wave_dbg[6 * (size_t)env + 1] = clock64();
     g_wave_dbg[6 * (size_t)env + 3] = wave_t13; g_wave_dbg[6 * (size_t)env + 4] = wave_t15; g_wave_dbg[6 * (size_t)env + 5] = wave_t16;
-    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | ((long long)s.dbg_ncon << 8);
+    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | ((long long)(s.dbg_ncon & 0xFFFF) << 8) | ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15) << 24) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) << 32);
   }
 #endif
 }

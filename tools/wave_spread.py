@@ -23,7 +23,7 @@ for rep in range(3):
     t = buf.cpu().numpy().reshape(n, 6)
     t0, t1, fl = t[:, 0], t[:, 1], t[:, 2]
     dur = (t1 - t0).astype(np.float64); rst = (fl & 1) == 1
-    ncon = (fl >> 8) & 255; dmax = (fl >> 16) & 255; nself = (fl >> 24) & 255      # of the last substep
+    ncon = (fl >> 8) & 255; dmax = (fl >> 16) & 255; nself = np.zeros_like(ncon)      # of the last substep
     span = t1.max() - t0.min()
     print(f"launch {rep}: span {span} cycles; wave duration mean {dur.mean():.0f} p50 {np.median(dur):.0f} p90 {np.percentile(dur, 90):.0f} p99 {np.percentile(dur, 99):.0f} max {dur.max():.0f}; "
           f"start spread {t0.max() - t0.min()}; resets {rst.mean():.3f}: mean duration reset {dur[rst].mean():.0f} / no reset {dur[~rst].mean():.0f}")
@@ -33,6 +33,19 @@ for rep in range(3):
     for k in sorted(set(ncon.tolist())):
         sel = ncon == k
         if sel.sum() >= 20: print(f"   active contacts {k:2d}: {sel.sum():5d} waves, substeps mean {sub[sel].mean():8.0f} (deepest level mean {dmax[sel].mean():.1f}, self-collision pairs {nself[sel].mean():.2f})")
+    hw = (fl >> 32) & 0xFFFFFFFF; xcc = (fl >> 24) & 15
+    simd = ((hw >> 4) & 3) | (((hw >> 8) & 15) << 2) | (((hw >> 12) & 1) << 6) | (((hw >> 13) & 7) << 7) | (xcc << 10)     # simd, cu, sh, se, xcc
+    heavy = (ncon > 0) | rst
+    ids, inv = np.unique(simd, return_inverse=True)
+    nh = np.bincount(inv, weights=heavy.astype(float)); nw = np.bincount(inv)
+    # a SIMD's busy time: from its first wave's start to its last wave's end (stamps of one XCD share a clock)
+    first = np.full(len(ids), np.iinfo(np.int64).max); last = np.zeros(len(ids), dtype=np.int64)
+    np.minimum.at(first, inv, t0); np.maximum.at(last, inv, t1)
+    busy = (last - first).astype(float)
+    print(f"   {len(ids)} SIMDs seen, waves per SIMD min {nw.min()} max {nw.max()}; heavy waves (in contact or resetting) {heavy.mean():.3f}")
+    for k in range(0, int(nh.max()) + 1):
+        sel = nh == k
+        if sel.sum(): print(f"   SIMDs with {k} heavy waves: {sel.sum():4d}, busy cycles mean {busy[sel].mean():8.0f} max {busy[sel].max():8.0f}")
     late = dur > np.percentile(dur, 99)
     print(f"   the slowest 1 % of waves, phase means: substeps {sub[late].mean():.0f} post {post[late].mean():.0f} reset {rs[late].mean():.0f} observe {obs[late].mean():.0f}; active contacts {ncon[late].mean():.1f}")
     print(f"   the slowest 1 % of waves: reset share {rst[late].mean():.2f}, mean duration {dur[late].mean():.0f}, mean start offset {(t0[late] - t0.min()).mean():.0f}")
