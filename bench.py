@@ -421,12 +421,16 @@ def main():
             "roofline": {"kernel": "wbc_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": len(events),
-                         # what actually bounds this kernel (one wavefront per env, 4 per SIMD at 4096 envs): vector-instruction issue.
-                         # active_lanes = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU; valu_issue_frac = the share of the launch the SIMDs
-                         # spend issuing vector instructions = insts per wave x waves per SIMD x 4 cycles / (launch time x 2.4 GHz)
+                         # what actually bounds this kernel (one wavefront per env, 4 per SIMD at 4096 envs): vector-instruction issue
+                         # and the dependent chain of the slowest wave. active_lanes = SQ_THREAD_CYCLES_VALU /
+                         # SQ_INSTS_VALU; valu_issue_frac = the share of the launch the SIMDs spend issuing vector instructions =
+                         # insts per wave x waves per SIMD x 4 cycles / (launch time x 2.4 GHz) -- 4 cycles is what SQ_ACTIVE_INST_VALU
+                         # reports (1.01 quad-cycles per instruction); a plain fp32 v_fma issues in 2 (MI355X_MICROARCH.md): _2cyc
                          "active_lanes": active_lanes,
                          "valu_issue_frac": (valu_per_wave * (args.envs_per_gpu / 1024.0) * 4.0 / (kern_ms * 1e-3 * 2.4e9)
                                              if valu_per_wave and kern_ms > 0 else None),
+                         "valu_issue_frac_2cyc": (valu_per_wave * (args.envs_per_gpu / 1024.0) * 2.0 / (kern_ms * 1e-3 * 2.4e9)
+                                                  if valu_per_wave and kern_ms > 0 else None),
                          "counters_source": counters_source},
         }
         if upd_events:
