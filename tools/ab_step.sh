@@ -1,4 +1,6 @@
-# A/B: the step kernel of this tree against the round-3 snapshot (scratch_r03/, not committed), same scenarios
+# A/B: the step kernel of this tree against a snapshot of an earlier commit in scratch_r03/ (not committed; make it with
+#   mkdir scratch_r03 && git archive <commit> | tar -x -C scratch_r03 && (cd scratch_r03 && python -c 'import __graft_entry__ as g; g.build()')
+# ), same scenarios. For variants of THIS tree use tools/build_variant.py + tools/ab_flags.sh.
 cd $GRAFT_REPO_ROOT
 for sc in "0.5 20" "0.0 120"; do set -- $sc
   for d in scratch_r03 .; do
