@@ -285,26 +285,29 @@ def main():
             raw_step(*a, **kw)
     env.sim.step = timed_step
 
-    # The fused PPO minibatch step (weight pack + ppo_chain + ppo_wgrad + reducers: one C-ABI call) is timed INSIDE the
+    # The fused PPO minibatch step (ppo_chain + ppo_wgrad + reducers: one C-ABI call) is timed INSIDE the
     # timed region on every 10th call (2 of an update's 20 minibatches: an event pair around every call cost 4.5 ms per
     # iteration, around 1 in 10 it is below the run-to-run noise).
     from wbc_amd.native import lib as _lib
     _L = _lib()
-    raw_grad = _L.wbc_ppo_minibatch_grad
     last_grad_args = {}
 
-    def timed_grad(*a):
-        last_grad_args["a"] = a
-        nstep["g"] += 1
-        if timing_on["v"] and nstep["g"] % 10 == 0:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = raw_grad(*a)
-            e1.record()
-            upd_events.append((e0, e1))
-            return r
-        return raw_grad(*a)
-    _L.wbc_ppo_minibatch_grad = timed_grad
+    def timed(raw_grad):
+        def timed_grad(*a):
+            last_grad_args["a"] = a
+            nstep["g"] += 1
+            if timing_on["v"] and nstep["g"] % 10 == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = raw_grad(*a)
+                e1.record()
+                upd_events.append((e0, e1))
+                return r
+            return raw_grad(*a)
+        return timed_grad
+    # (the first minibatch call of an update packs the weight streams, the other 19 find them kept current by the fused Adam)
+    _L.wbc_ppo_minibatch_grad = timed(_L.wbc_ppo_minibatch_grad)
+    _L.wbc_ppo_minibatch_grad_packed = timed(_L.wbc_ppo_minibatch_grad_packed)
 
     def barrier():
         if use_dist:
@@ -438,7 +441,7 @@ def main():
             rows = int(last_grad_args["a"][9])
             flops = UPDATE_FLOPS_PER_ROW * rows
             tf = flops / (upd_ms * 1e-3) / 1e12
-            out["roofline_update"] = {"kernel": "wbc_ppo_minibatch_grad = chain_pack + ppo_chain + ppo_wgrad + reducers", "bound": "mfma",
+            out["roofline_update"] = {"kernel": "wbc_ppo_minibatch_grad(_packed) = ppo_chain + ppo_wgrad + reducers (+ chain_pack on the first call of an update)", "bound": "mfma",
                                       "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                       "traffic": counter_file("ppo_update_traffic.json") if rows == 40960 else None,
                                       "launch_ms": upd_ms, "algorithmic_flops_per_launch": flops, "rows_per_launch": rows,

@@ -84,51 +84,74 @@ static __device__ __forceinline__ int chain_fwd_kcol(int layer, int kq, int g, i
   return t < layer_in(layer) ? t : -1;
 }
 
-// grid = (blocks, 2 parts), one thread per (element, lane): a float4 of the stream.
-static __global__ void __launch_bounds__(256) chain_pack_kernel(PolicyParams P, ChainStreams S, float* __restrict__ pack) {
-  const int p = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// Source of float i of stream float4 (part p, index t = 64 el + lane): parameter 2 l (weight) / 2 l + 1 (bias) of layer l and the
+// element inside it, or layer -1 for a zero of the padding. kind: SEG_FWD / SEG_BWD of its segment.
+struct ChainSrc { int layer, bias, idx, kind; };
+static __device__ __forceinline__ ChainSrc chain_slot_source(const ChainStreams& S, int p, int t, int i) {
   const int lane = t & 63, el = t >> 6;
-  if (el >= S.nelem[p]) return;
   const int g = lane >> 4, m = lane & 15;
   int si = 0;
   while (si + 1 < S.nseg[p] && S.s[p][si + 1].start <= el) ++si;
   const ChainSeg sg = S.s[p][si];
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (sg.kind != SEG_PAD) {
-    const float* W = reinterpret_cast<const float* const*>(&P)[2 * sg.layer];
-    const float* bsrc = reinterpret_cast<const float* const*>(&P)[2 * sg.layer + 1];
-    const int N = layer_out(sg.layer), K = layer_in(sg.layer);
-    const int rel = el - sg.start;
-    // blocks come in pairs (2 p, 2 p + 1) whose elements alternate: two independent accumulators per wave (a dependent
-    // v_mfma_f32_16x16x4_f32 issues every 40 cycles, an independent one every 32); single-block layers (heads) keep k order
-    if (sg.kind == SEG_FWD) {
-      int blk, kq;
-      if (sg.nblk == 1) { blk = 0; kq = rel; }
-      else { const int pe = 2 * (sg.ngrp + 1), pr = rel / pe, r2 = rel - pr * pe; blk = 2 * pr + (r2 & 1); kq = r2 >> 1; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (kq == sg.ngrp) {                                   // bias quadruple of lane group g: features 16 blk + 4 g + i
-          const int o = 16 * blk + 4 * g + i;
-          v[i] = o < N ? bsrc[o] : 0.f;
-        } else {
-          const int o = 16 * blk + m, c = chain_fwd_kcol(sg.layer, kq, g, i);
-          v[i] = (o < N && c >= 0) ? W[(size_t)o * K + c] : 0.f;
-        }
-      }
-    } else {                                                   // dIn^T = W^T dZ^T: rows = the layer's inputs, k over its outputs
-      const int pe = 2 * sg.ngrp, pr = rel / pe, r2 = rel - pr * pe;
-      const int blk = 2 * pr + (r2 & 1), kq = r2 >> 1;
-      int c = 16 * blk + m;
-      if (sg.layer == L_BB) c = c < 20 ? PT_NPROP + c : K;    // only the latent columns of the backbone's input need a gradient
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int o = 16 * kq + 4 * g + i;
-        v[i] = (o < N && c < K) ? W[(size_t)o * K + c] : 0.f;
-      }
+  ChainSrc r{-1, 0, 0, sg.kind};
+  if (sg.kind == SEG_PAD) return r;
+  const int N = layer_out(sg.layer), K = layer_in(sg.layer);
+  const int rel = el - sg.start;
+  // blocks come in pairs (2 p, 2 p + 1) whose elements alternate: two independent accumulators per wave (a dependent
+  // v_mfma_f32_16x16x4_f32 issues every 40 cycles, an independent one every 32); single-block layers (heads) keep k order
+  if (sg.kind == SEG_FWD) {
+    int blk, kq;
+    if (sg.nblk == 1) { blk = 0; kq = rel; }
+    else { const int pe = 2 * (sg.ngrp + 1), pr = rel / pe, r2 = rel - pr * pe; blk = 2 * pr + (r2 & 1); kq = r2 >> 1; }
+    if (kq == sg.ngrp) {                                   // bias quadruple of lane group g: features 16 blk + 4 g + i
+      const int o = 16 * blk + 4 * g + i;
+      if (o < N) { r.layer = sg.layer; r.bias = 1; r.idx = o; }
+    } else {
+      const int o = 16 * blk + m, c = chain_fwd_kcol(sg.layer, kq, g, i);
+      if (o < N && c >= 0) { r.layer = sg.layer; r.idx = o * K + c; }
     }
+  } else {                                                   // dIn^T = W^T dZ^T: rows = the layer's inputs, k over its outputs
+    const int pe = 2 * sg.ngrp, pr = rel / pe, r2 = rel - pr * pe;
+    const int blk = 2 * pr + (r2 & 1), kq = r2 >> 1;
+    int c = 16 * blk + m;
+    if (sg.layer == L_BB) c = c < 20 ? PT_NPROP + c : K;    // only the latent columns of the backbone's input need a gradient
+    const int o = 16 * kq + 4 * g + i;
+    if (o < N && c < K) { r.layer = sg.layer; r.idx = o * K + c; }
+  }
+  return r;
+}
+
+// grid = (blocks, 2 parts), one thread per (element, lane): a float4 of the stream.
+static __global__ void __launch_bounds__(256) chain_pack_kernel(PolicyParams P, ChainStreams S, float* __restrict__ pack) {
+  const int p = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((t >> 6) >= S.nelem[p]) return;
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const ChainSrc r = chain_slot_source(S, p, t, i);
+    v[i] = r.layer < 0 ? 0.f : reinterpret_cast<const float* const*>(&P)[2 * r.layer + r.bias][r.idx];
   }
   reinterpret_cast<float4*>(pack + S.base[p])[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// The inverse of chain_pack_kernel, once per process: tab[kind][flat parameter index] = float offset of its copy in the pack (-1:
+// none), kind 0 = the forward streams, 1 = the backward streams; poff[j] = flat offset of parameter j (the flat gradient's layout).
+// A weight sits at most once in each kind, a bias 16 times in the forward streams (4 floats apart: the first copy is recorded);
+// *clash counts violations.
+struct ChainParamOffsets { int off[2 * NLAYERS]; };
+static __global__ void __launch_bounds__(256) chain_scatter_table_kernel(ChainStreams S, ChainParamOffsets PO, int nparam, int* __restrict__ tab, int* clash) {
+  const int p = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((t >> 6) >= S.nelem[p]) return;
+  for (int i = 0; i < 4; ++i) {
+    const ChainSrc r = chain_slot_source(S, p, t, i);
+    if (r.layer < 0) continue;
+    if (r.bias && (t & 15) != 0) continue;             // a bias sits in all 16 row lanes of its lane group: 16 copies 4 floats apart, the first is recorded
+    const int src = PO.off[2 * r.layer + r.bias] + r.idx;
+    const int kind = r.kind == SEG_BWD ? 1 : 0;
+    if (atomicExch(&tab[kind * nparam + src], S.base[p] + 4 * t + i) != -1) atomicAdd(clash, 1);
+  }
 }
 
 // ---- the ring ---------------------------------------------------------------------------------------------------------

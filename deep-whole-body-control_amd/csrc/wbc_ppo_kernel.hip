@@ -342,9 +342,12 @@ struct AdamTable {
 // g <- s g (s = grad_scale, 1 / world_size after a SUM all-reduce), then g <- g * min(1, max_norm / (||g|| + 1e-6));
 // m, v, p as torch.optim.Adam (no weight decay, no amsgrad):
 // m += (g-m)(1-b1); v = v b2 + (1-b2) g g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+// pack != nullptr: the new value also goes to its copies in the chain kernel's weight streams (tab: chain_scatter_table_kernel), so
+// the next minibatch needs no pack launch.
 extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                                  const float* __restrict__ part, int nparts, float max_norm, float beta1,
-                                                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
+                                                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
+                                                                 float* __restrict__ pack, const int* __restrict__ tab) {
   __shared__ float sh[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float coef = grad_scale;
@@ -368,7 +371,19 @@ extern "C" __global__ void __launch_bounds__(256) ppo_adam_kernel(AdamTable T, f
   const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
   m[i] = mi; v[i] = vi;
   float* pp = T.p[lo] + (i - T.off[lo]);
-  *pp = *pp - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  const float pn = *pp - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  *pp = pn;
+  if (pack) {
+    const int d0 = tab[i], d1 = tab[T.off[33] + i];
+    if (d0 >= 0) {
+      pack[d0] = pn;
+      if ((lo & 1) && lo < 2 * NLAYERS) {               // a bias: one copy per row lane of its lane group
+#pragma unroll
+        for (int mm = 1; mm < 16; ++mm) pack[d0 + 4 * mm] = pn;
+      }
+    }
+    if (d1 >= 0) pack[d1] = pn;
+  }
 }
 
 // ---- C-ABI ----------------------------------------------------------------------------------------
@@ -442,10 +457,17 @@ static int fill_params(const void* const* params, PolicyParams* P) {
 
 // One minibatch: gradients of loss = surrogate + value_coef*value_loss + roa_coef*priv_reg (PPO:218-221, entropy term
 // handled by the caller) w.r.t. the 16 layers' weights/biases and std, into `grad` (wbc_ppo_grad_floats() floats).
-extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions, const float* old_values,
-                                      const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
-                                      const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
-                                      int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream) {
+static float* ppo_wpack_of(float* workspace, int B) {
+  const int ng = wbc_ppo_grad_floats();
+  const size_t tiles16w = (size_t)(B + R16 - 1) / R16;
+  float* wpart = workspace + (size_t)ppo_slab_rows(B) * (A_LD + D_LD) + tiles16w * (18 + 3);
+  return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
+}
+
+static int ppo_minibatch_grad_impl(const void* const* params, const float* obs, const float* actions, const float* old_values,
+                                   const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
+                                   const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
+                                   int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream, bool weights_packed) {
   StreamDeviceGuard sdg(stream);
   PolicyParams P;
   if (!params || !obs || !actions || !old_values || !advantages || !returns || !old_logp || !hist_latent || !idx || !workspace || !grad ||
@@ -461,11 +483,12 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   const size_t tiles16w = (size_t)(B + R16 - 1) / R16;                // the workspace holds one partial per 16-row tile
   float* loss_partial = dstd_partial + tiles16w * 18;
   float* wpart = loss_partial + tiles16w * 3;
-  float* wpack = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
+  float* wpack = ppo_wpack_of(workspace, B);
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, Bs, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   const ChainStreams& S = chain_streams();
   const int tiles16 = (B + 15) / 16;
-  hipLaunchKernelGGL(chain_pack_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, st, P, S, wpack);
+  if (!weights_packed)
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, st, P, S, wpack);
   hipLaunchKernelGGL(ppo_chain_kernel, dim3((2 * tiles16 + CH_WG / 64 - 1) / (CH_WG / 64)), dim3(CH_WG), 0, st, wpack, S.base[1], S.nelem[0] * 1024, S.nelem[1] * 1024, Bt,
                      P.std, act_stash, dz_stash, dstd_partial, loss_partial, tiles16);
   WgradPlan plan;
@@ -478,14 +501,81 @@ extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* ob
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+extern "C" int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const float* actions, const float* old_values,
+                                      const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
+                                      const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
+                                      int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream) {
+  return ppo_minibatch_grad_impl(params, obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef,
+                                 use_clipped_value_loss, workspace, grad, loss_accum, stream, false);
+}
+// The same call without the weight-pack launch: `workspace` still holds the weight streams a wbc_ppo_minibatch_grad call for the same
+// B packed into it, and every change of the parameters since then was a wbc_ppo_clip_adam_packed(..., workspace, B) step.
+extern "C" int wbc_ppo_minibatch_grad_packed(const void* const* params, const float* obs, const float* actions, const float* old_values,
+                                             const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
+                                             const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
+                                             int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream) {
+  return ppo_minibatch_grad_impl(params, obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, clip, value_coef, mixing, roa_coef,
+                                 use_clipped_value_loss, workspace, grad, loss_accum, stream, true);
+}
+
 // clip_grad_norm_(params, max_norm) followed by Adam.step() for the 33 parameters of `params`, whose gradients are
 // grad[0 : wbc_ppo_grad_floats()-3] in the layout above; exp_avg / exp_avg_sq: flat state in the same layout.
 // step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) (computed by the caller in double, as torch does).
 // max_norm <= 0: no clipping. workspace: >= wbc_ppo_clip_adam_workspace_floats() floats.
 extern "C" int wbc_ppo_clip_adam_workspace_floats(void) { return PPO_SQ_PARTS; }
-extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
-                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, const float* sq_partials, float* workspace,
-                                 void* stream) {
+// The process's scatter table (device memory of the current device; built on first use): where each parameter's copies sit in the
+// chain kernel's weight streams.
+static const int* ppo_scatter_table(hipStream_t st, int nparam) {
+  static int* tab = nullptr;
+  static int tab_dev = -1;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (tab && tab_dev == dev) return tab;
+  int* t = nullptr;
+  int* clash = nullptr;
+  if (hipMalloc(&t, sizeof(int) * 2 * (size_t)nparam) != hipSuccess || hipMalloc(&clash, sizeof(int)) != hipSuccess) return nullptr;
+  (void)hipMemsetAsync(t, 0xFF, sizeof(int) * 2 * (size_t)nparam, st);
+  (void)hipMemsetAsync(clash, 0, sizeof(int), st);
+  ChainParamOffsets PO;
+  int off = 0;
+  for (int l = 0; l < NLAYERS; ++l) { PO.off[2 * l] = off; off += layer_out(l) * layer_in(l); PO.off[2 * l + 1] = off; off += layer_out(l); }
+  const ChainStreams& S = chain_streams();
+  hipLaunchKernelGGL(chain_scatter_table_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, st, S, PO, nparam, t, clash);
+  int h = -1;
+  const hipError_t e1 = hipMemcpyAsync(&h, clash, sizeof(int), hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  if (e1 != hipSuccess || e2 != hipSuccess || h != 0) {
+    fprintf(stderr, "wbc_ppo: scatter table not built (copy %d, sync %d, parameters with two copies in one stream kind: %d)\n", (int)e1, (int)e2, h);
+    (void)hipFree(t); (void)hipFree(clash);
+    return nullptr;
+  }
+  (void)hipFree(clash);
+  tab = t; tab_dev = dev;
+  return tab;
+}
+
+// Development aid: for every float of the pack, 2 * (flat parameter index) + kind, or -1 for a padding zero.
+static __global__ void __launch_bounds__(256) chain_sources_kernel(ChainStreams S, ChainParamOffsets PO, int* __restrict__ out) {
+  const int p = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((t >> 6) >= S.nelem[p]) return;
+  for (int i = 0; i < 4; ++i) {
+    const ChainSrc r = chain_slot_source(S, p, t, i);
+    out[S.base[p] + 4 * t + i] = r.layer < 0 ? -1 : 2 * (PO.off[2 * r.layer + r.bias] + r.idx) + (r.kind == SEG_BWD ? 1 : 0);
+  }
+}
+extern "C" int wbc_debug_chain_sources(int* out_dev, void* stream) {
+  ChainParamOffsets PO;
+  int off = 0;
+  for (int l = 0; l < NLAYERS; ++l) { PO.off[2 * l] = off; off += layer_out(l) * layer_in(l); PO.off[2 * l + 1] = off; off += layer_out(l); }
+  const ChainStreams& S = chain_streams();
+  hipLaunchKernelGGL(chain_sources_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, S, PO, out_dev);
+  return (int)PPO_WPACK_FLOATS;
+}
+
+static int ppo_clip_adam_impl(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
+                              float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, const float* sq_partials, float* workspace,
+                              void* stream, float* mb_workspace, int B) {
   StreamDeviceGuard sdg(stream);
   if (!params || !grad || !exp_avg || !exp_avg_sq || !workspace || !(grad_scale > 0.f)) return -1;
   AdamTable T;
@@ -508,7 +598,29 @@ extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* 
     red.nsplit = 0;
     hipLaunchKernelGGL(ppo_sqnorm_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, grad, o, workspace);
   }
+  float* pack = nullptr;
+  const int* tab = nullptr;
+  if (mb_workspace) {
+    if (B <= 0) return -1;
+    tab = ppo_scatter_table(st, off);
+    if (!tab) return -4;
+    pack = ppo_wpack_of(mb_workspace, B);
+  }
   hipLaunchKernelGGL(ppo_adam_kernel, dim3((off + 255) / 256), dim3(256), 0, st, T, grad, exp_avg, exp_avg_sq, have ? sq_partials : workspace,
-                     PPO_SQ_PARTS, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+                     PPO_SQ_PARTS, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, pack, tab);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
+                                 float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, const float* sq_partials, float* workspace,
+                                 void* stream) {
+  return ppo_clip_adam_impl(params, grad, exp_avg, exp_avg_sq, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, sq_partials, workspace, stream, nullptr, 0);
+}
+// The same step, and the new weights also written to their places in the weight streams inside `mb_workspace` (the workspace of
+// wbc_ppo_minibatch_grad for B rows): the next wbc_ppo_minibatch_grad_packed on that workspace needs no pack launch.
+extern "C" int wbc_ppo_clip_adam_packed(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
+                                        float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, const float* sq_partials, float* workspace,
+                                        float* mb_workspace, int B, void* stream) {
+  if (!mb_workspace) return -1;
+  return ppo_clip_adam_impl(params, grad, exp_avg, exp_avg_sq, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, sq_partials, workspace, stream, mb_workspace, B);
 }

@@ -286,10 +286,11 @@ class PPO:
         stream = torch.cuda.current_stream(dev).cuda_stream
         vcoef = self.value_loss_coef
         steps = self._bind_adam_state(params, F)   # once per update: nothing re-binds the optimiser's state inside it
+        packed = False     # the workspace's weight streams are current: packed by the update's first minibatch call, kept by the fused Adam
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = indices[i * mb:(i + 1) * mb]
-                check(L.wbc_ppo_minibatch_grad(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(),
+                check((L.wbc_ppo_minibatch_grad_packed if packed else L.wbc_ppo_minibatch_grad)(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(),
                                                returns.data_ptr(), logp.data_ptr(), F["hist"].data_ptr(), idx.data_ptr(), mb,
                                                float(self.clip_param), float(vcoef), float(value_mixing_ratio), float(priv_reg_coef),
                                                int(self.use_clipped_value_loss), F["ws"].data_ptr(), F["grad"].data_ptr(), sums.data_ptr(), stream),
@@ -306,15 +307,17 @@ class PPO:
                         F["grad"][:F["nparam"]].div_(self.world_size)
                     nn.utils.clip_grad_norm_(params, self.max_grad_norm)
                     self.optimizer.step()
+                    packed = False
                 else:                              # clip_grad_norm_ + Adam.step in two launches on the flat buffers
                     g0 = self.optimizer.param_groups[0]
                     t = float(steps[0]) + 1.0
                     b1, b2 = g0["betas"]
-                    check(L.wbc_ppo_clip_adam(table, F["grad"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(),
-                                              float(self.max_grad_norm), b1, b2, g0["eps"], g0["lr"] / (1.0 - b1 ** t),
-                                              (1.0 - b2 ** t) ** 0.5, 1.0 / self.world_size,
-                                              F["ws"].data_ptr() + 4 * F["sq_off"] if grad_is_fresh else None,
-                                              F["adam_ws"].data_ptr(), stream), "wbc_ppo_clip_adam")
+                    check(L.wbc_ppo_clip_adam_packed(table, F["grad"].data_ptr(), F["m"].data_ptr(), F["v"].data_ptr(),
+                                                     float(self.max_grad_norm), b1, b2, g0["eps"], g0["lr"] / (1.0 - b1 ** t),
+                                                     (1.0 - b2 ** t) ** 0.5, 1.0 / self.world_size,
+                                                     F["ws"].data_ptr() + 4 * F["sq_off"] if grad_is_fresh else None,
+                                                     F["adam_ws"].data_ptr(), F["ws"].data_ptr(), mb, stream), "wbc_ppo_clip_adam_packed")
+                    packed = True
                     torch._foreach_add_(steps, 1.0)
         num_updates = self.num_learning_epochs * self.num_mini_batches
         surr, vls, preg = (sums / num_updates).tolist()

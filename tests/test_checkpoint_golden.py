@@ -131,16 +131,16 @@ def test_reference_checkpoint_on_the_gpu_and_fused_path_after_resume(tmp_path):
     calls = {"n": 0}
     from wbc_amd.native import lib
     L = lib()
-    raw = L.wbc_ppo_clip_adam
+    raw = L.wbc_ppo_clip_adam_packed
 
     def counted(*a):
         calls["n"] += 1
         return raw(*a)
-    L.wbc_ppo_clip_adam = counted
+    L.wbc_ppo_clip_adam_packed = counted
     try:
         r.learn(1)
     finally:
-        L.wbc_ppo_clip_adam = raw
+        L.wbc_ppo_clip_adam_packed = raw
     assert calls["n"] == 20                                                # 5 epochs x 4 minibatches on the fused path
     steps = [float(v["step"]) for v in r.alg.optimizer.state_dict()["state"].values()]
     assert steps and all(s == 40.0 for s in steps)                         # 20 (checkpoint) + 20

@@ -171,3 +171,54 @@ def test_fused_minibatch_is_bitwise_reproducible(B):
         grads.append(grad.clone())
     assert torch.isfinite(grads[0]).all()
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("B", [4096, 1000])
+def test_adam_keeps_the_weight_streams_current(B):
+    """wbc_ppo_clip_adam_packed writes every updated parameter to its copies in the chain kernel's weight streams, so
+    wbc_ppo_minibatch_grad_packed (no pack launch) must see exactly what a fresh pack would: three optimiser steps along both routes
+    from the same start give the same gradients and the same parameters, bit for bit. The entry weight of every layer moves in every
+    step (Adam's first steps are +-lr), so a stale or misplaced copy cannot hide."""
+    import copy
+    import ctypes as C
+    from wbc_amd.native import check, lib
+    L = lib()
+    torch.manual_seed(0)
+    ac0 = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
+    TN, dev = 3 * B, "cuda"
+    obs = torch.randn(TN, 860, device=dev); actions = torch.randn(TN, 18, device=dev); values = torch.randn(TN, 2, device=dev)
+    adv = torch.randn(TN, 2, device=dev); ret = torch.randn(TN, 2, device=dev); logp = -torch.rand(TN, 2, device=dev) * 20
+    hist = torch.randn(TN, 20, device=dev)
+    idx = torch.randperm(TN, device=dev).contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    ng = L.wbc_ppo_grad_floats()
+    results = []
+    for route in ("fresh pack every minibatch", "streams kept by Adam"):
+        ac = copy.deepcopy(ac0)
+        table = ac.fused_param_table()
+        nparam = sum(p.numel() for p in ac.fused_params())
+        ws = torch.full((L.wbc_ppo_workspace_floats(B),), float("nan"), device=dev)
+        grad = torch.zeros(ng, device=dev); m = torch.zeros(nparam, device=dev); v = torch.zeros(nparam, device=dev)
+        aws = torch.empty(int(L.wbc_ppo_clip_adam_workspace_floats()), device=dev)
+        sq = ws.data_ptr() + 4 * int(L.wbc_ppo_sq_partials_offset(B))
+        grads = []
+        for k in range(3):
+            f = L.wbc_ppo_minibatch_grad if (route.startswith("fresh") or k == 0) else L.wbc_ppo_minibatch_grad_packed
+            check(f(table, obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp.data_ptr(), hist.data_ptr(),
+                    idx[k * B:(k + 1) * B].data_ptr(), B, 0.2, 1.0, 0.5, 0.1, 1, ws.data_ptr(), grad.data_ptr(), None, stream), "grad")
+            grads.append(grad.clone())
+            t = k + 1.0
+            args = (table, grad.data_ptr(), m.data_ptr(), v.data_ptr(), 1.0, 0.9, 0.999, 1e-8, 1e-3 / (1.0 - 0.9 ** t), (1.0 - 0.999 ** t) ** 0.5, 1.0, sq, aws.data_ptr())
+            if route.startswith("fresh"):
+                check(L.wbc_ppo_clip_adam(*args, stream), "adam")
+            else:
+                check(L.wbc_ppo_clip_adam_packed(*args, ws.data_ptr(), B, stream), "adam_packed")
+        torch.cuda.synchronize()
+        results.append((grads, [p.detach().clone() for p in ac.fused_params()]))
+    (g0, p0), (g1, p1) = results
+    assert all(torch.isfinite(g).all() for g in g0)
+    assert not torch.equal(g0[0], g0[1])                     # the parameters did move between the minibatches
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
