@@ -531,6 +531,7 @@ static const int* ppo_scatter_table(hipStream_t st, int nparam) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   if (tab && tab_dev == dev) return tab;
+  if (tab) { (void)hipFree(tab); tab = nullptr; }           // (the process moved to another device)
   int* t = nullptr;
   int* clash = nullptr;
   if (hipMalloc(&t, sizeof(int) * 2 * (size_t)nparam) != hipSuccess || hipMalloc(&clash, sizeof(int)) != hipSuccess) return nullptr;
@@ -552,25 +553,6 @@ static const int* ppo_scatter_table(hipStream_t st, int nparam) {
   (void)hipFree(clash);
   tab = t; tab_dev = dev;
   return tab;
-}
-
-// Development aid: for every float of the pack, 2 * (flat parameter index) + kind, or -1 for a padding zero.
-static __global__ void __launch_bounds__(256) chain_sources_kernel(ChainStreams S, ChainParamOffsets PO, int* __restrict__ out) {
-  const int p = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if ((t >> 6) >= S.nelem[p]) return;
-  for (int i = 0; i < 4; ++i) {
-    const ChainSrc r = chain_slot_source(S, p, t, i);
-    out[S.base[p] + 4 * t + i] = r.layer < 0 ? -1 : 2 * (PO.off[2 * r.layer + r.bias] + r.idx) + (r.kind == SEG_BWD ? 1 : 0);
-  }
-}
-extern "C" int wbc_debug_chain_sources(int* out_dev, void* stream) {
-  ChainParamOffsets PO;
-  int off = 0;
-  for (int l = 0; l < NLAYERS; ++l) { PO.off[2 * l] = off; off += layer_out(l) * layer_in(l); PO.off[2 * l + 1] = off; off += layer_out(l); }
-  const ChainStreams& S = chain_streams();
-  hipLaunchKernelGGL(chain_sources_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, S, PO, out_dev);
-  return (int)PPO_WPACK_FLOATS;
 }
 
 static int ppo_clip_adam_impl(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
