@@ -1066,6 +1066,7 @@ enum { G_START = 0, G_GOAL = 3, G_GOAL_CART = 6, G_CURR = 9, G_CURR_CART = 12, G
 // 0 only applies the result. Same integers, same float expressions as the oracle's serial loop.
 #define DRAWS(s) (&(s).pA[0][0])    // scratch: the bias-force array is dead once the substeps are done (114 floats)
 enum { DR_PICK = 48, DR_MASK = 51 };  // [0..47] u01 draws of consecutive slots, [48..50] the picked EE goal (l, p, y), [51] (int) candidates that collide
+static_assert(SLOT_PUSH + 2 <= DR_PICK && SLOT_RESET_GOAL_SPHERE + 30 - SLOT_RESET_XY <= DR_PICK && DR_MASK < WBC_NB * 6, "draw scratch layout");
 
 // all lanes: DRAWS[j] = u01(slot0 + j), j < count
 __device__ __forceinline__ void draw_block(Smem& s, uint64_t seed, int env, uint64_t step, int slot0, int count) {
