@@ -97,22 +97,30 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
     }
     return;
   }
-  if (tid < R16 && row0 + tid < num_rows) {
-    const int r = tid;
-    const size_t g = (size_t)(row0 + r);
+  // Sampling and log-probabilities: thread (r, c) of a 16 x 16 grid takes actions c and (c < 2) 16 + c of row r; the leg / arm
+  // log-probability sums run along the 16 lanes of the row (xor butterfly) -- 18 x (division, log, 2 stores) on one lane per row
+  // before, in the workgroups the launch ends with.
+  {
+    const int r = tid >> 4, c = tid & 15;
+    const bool live = row0 + r < num_rows;
+    const size_t g = (size_t)(row0 + (live ? r : 0));
     float lp_leg = 0.f, lp_arm = 0.f;
 #pragma unroll
-    for (int j = 0; j < 18; ++j) {
-      const float mu = outv[r * 21 + j], sd = P.std[j];
-      const float e = eps ? eps[g * 18 + j] : 0.f;
-      const float a = mu + sd * e;
-      const float dd = a - mu;
-      const float lp = -(dd * dd) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
-      if (j < PT_NLEG) lp_leg += lp; else lp_arm += lp;
-      actions[g * 18 + j] = a;
-      mean_out[g * 18 + j] = mu;
+    for (int h = 0; h < 2; ++h) {
+      const int j = c + 16 * h;
+      if (j < 18) {
+        const float mu = outv[r * 21 + j], sd = P.std[j];
+        const float e = (eps && live) ? eps[g * 18 + j] : 0.f;
+        const float a = mu + sd * e;
+        const float dd = a - mu;
+        const float lp = -(dd * dd) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;
+        if (j < PT_NLEG) lp_leg += lp; else lp_arm += lp;
+        if (live) { actions[g * 18 + j] = a; mean_out[g * 18 + j] = mu; }
+      }
     }
-    logp_out[g * 2] = lp_leg; logp_out[g * 2 + 1] = lp_arm;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { lp_leg += __shfl_xor(lp_leg, off); lp_arm += __shfl_xor(lp_arm, off); }
+    if (live && c == 0) { logp_out[g * 2] = lp_leg; logp_out[g * 2 + 1] = lp_arm; }
   }
 }
 
