@@ -21,3 +21,20 @@ for n in (256, 1024, 2048, 4096, 8192, 16384):
     for _ in range(200): ac.fused_act(obs, eps, out)
     e1.record(); torch.cuda.synchronize()
     print(f"rows {n:6d}: {e0.elapsed_time(e1) / 200 * 1000:.1f} us per launch (no side job)")
+
+# the same launch behind 64 MB of unrelated traffic (as behind the step kernel in a rollout): cold obs + cold weights; then with the weight
+# pack touched again after the traffic (what an L2 prefetch at the end of the step kernel could give)
+n = 4096
+obs = torch.randn(n, 860, device="cuda"); eps = torch.randn(n, 18, device="cuda")
+out = tuple(torch.empty(n, w, device="cuda") for w in (18, 18, 2, 2))
+junk = torch.empty(16 * 1024 * 1024, device="cuda")
+for mode in ("warm", "after 64 MB of traffic", "after the traffic + weight pack re-read"):
+    ts = []
+    for _ in range(30):
+        if mode != "warm": junk.add_(1.0)
+        if mode.endswith("re-read"): ac._wpack.sum()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ac.fused_act(obs, eps, out); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1000)
+    ts.sort()
+    print(f"4096 rows, {mode}: median {ts[len(ts) // 2]:.1f} us (single launches between events)")
