@@ -1,0 +1,53 @@
+"""Code-generation invariants of wbc_step_kernel that the design rests on (DESIGN.md sections 2.1, 7.1b), checked on the assembly hipcc
+emits for gfx950 (cross-compiles without a GPU; ~40 s):
+  * 128 VGPRs and 10 KB of LDS per wavefront-workgroup -> 16 robots per CU, all 4096 envs of the bench resident at once;
+  * no scratch memory (a register spill in this kernel cost 5-10 % twice: rounds 2 and 4);
+  * no flat memory instructions: the constant block and the tensor table are read through the constant address space (scalar loads
+    whatever wavefront fences surround them) and tensor bases are typed global -- through generic pointers every constant read after
+    the first fence was a vector load on the dependent path (148 -> 137 us when that was fixed)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "deep-whole-body-control_amd", "csrc", "wbc_step_kernel.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def step_kernel_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("asm") / "step.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]          # the build's flags (__graft_entry__.build)
+    subprocess.check_call([HIPCC] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), "-o", out, SRC],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    a = text.index("\nwbc_step_kernel:")
+    body = text[a:text.index("s_endpgm", a)]
+    meta = text[text.index(".name:           wbc_step_kernel") - 1500:text.index(".name:           wbc_step_kernel") + 1500]
+    return body, meta, text
+
+
+def _meta(meta, key):
+    return int(re.search(r"\.%s:\s+(\d+)" % key, meta).group(1))
+
+
+def test_step_kernel_keeps_sixteen_robots_per_cu(step_kernel_asm):
+    body, meta, text = step_kernel_asm
+    assert _meta(meta, "vgpr_count") <= 128                       # 4 waves per SIMD
+    assert _meta(meta, "group_segment_fixed_size") <= 10240       # 16 workgroups in 160 KB of LDS
+    assert _meta(meta, "private_segment_fixed_size") == 0         # no scratch
+    assert "scratch_" not in body
+
+
+def test_step_kernel_reads_constants_through_the_scalar_path(step_kernel_asm):
+    body, meta, text = step_kernel_asm
+    assert not re.search(r"\bflat_(load|store|atomic)", body)
+    assert len(re.findall(r"\bs_load_dword", body)) > 60          # constants and tensor pointers arrive by scalar loads
+    # the per-env rows are (scalar base) + (32-bit lane offset): most stores use the SGPR-base form
+    stores = re.findall(r"\bglobal_store_\w+\s+([^\n]*)", body)
+    sgpr_base = [s for s in stores if re.search(r",\s*s\[\d+:\d+\]", s)]
+    assert len(stores) > 40 and len(sgpr_base) >= 0.8 * len(stores)
