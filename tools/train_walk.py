@@ -1,7 +1,8 @@
 """Train the widowGo1 task from scratch (non-RESUME schedules of widowGo1_config.py:359,366) and record what the task is about:
 command tracking (metric tracking_lin_vel_x_l1, WG:1427-1430), EE-goal tracking (metric tracking_ee_sphere, WG:1352-1358),
 episode length, both reward channels; then evaluate teacher (privileged latent) and student (history latent after DAgger).
-usage: python tools/train_walk.py ITERS [key=value ...]  (keys: survive, z, envs, lin_l1, out)"""
+usage: python tools/train_walk.py ITERS [key=value ...] > curve.jsonl  (keys: survive, z, envs, lin_l1, contacts_z, energy, sched, ckpt;
+the curve and the summary are JSON lines on stdout; ckpt=PATH also saves the trained model, a torch checkpoint)"""
 import json
 import os
 import sys
@@ -117,5 +118,5 @@ summary = {"iterations": iters, "envs": n, "wall_s": round(wall, 1), "env_steps"
                       "tracking_lin_vel_x_exp": cfg.rewards.scales.tracking_lin_vel_x_exp, "energy_square": cfg.rewards.scales.energy_square},
            "teacher_eval": evaluate(False), "student_eval": evaluate(True)}
 print(json.dumps(summary), flush=True)
-if "out" in kv:
-    runner.save(kv["out"])
+if "ckpt" in kv:
+    runner.save(kv["ckpt"])
