@@ -27,8 +27,14 @@ def step_kernel_asm(tmp_path_factory):
     text = open(out).read()
     a = text.index("\nwbc_step_kernel:")
     body = text[a:text.index("s_endpgm", a)]
-    meta = text[text.index(".name:           wbc_step_kernel") - 1500:text.index(".name:           wbc_step_kernel") + 1500]
+    meta = _entry(text, "wbc_step_kernel")
     return body, meta, text
+
+
+def _entry(text, kernel):
+    """The amdhsa.kernels metadata entry of `kernel` (entries start at '- .agpr_count', keys in alphabetical order)."""
+    entries = text[text.index("amdhsa.kernels:"):].split("\n  - .agpr_count")
+    return next(e for e in entries if re.search(r"\.name:\s+%s\n" % re.escape(kernel), e))
 
 
 def _meta(meta, key):
@@ -51,3 +57,25 @@ def test_step_kernel_reads_constants_through_the_scalar_path(step_kernel_asm):
     stores = re.findall(r"\bglobal_store_\w+\s+([^\n]*)", body)
     sgpr_base = [s for s in stores if re.search(r",\s*s\[\d+:\d+\]", s)]
     assert len(stores) > 40 and len(sgpr_base) >= 0.8 * len(stores)
+
+
+@pytest.mark.parametrize("src, kernel, max_vgpr", [
+    ("wbc_ppo_kernel.hip", "ppo_chain_kernel", 256),            # two units per SIMD (section 2.3)
+    ("wbc_ppo_kernel.hip", "ppo_wgrad_kernel", 168),            # three workgroups per CU
+    ("wbc_policy_kernel.hip", "wbc_policy_act16_kernel", 256),  # an actor and a critic tile per CU
+    ("wbc_hist_train_kernel.hip", "hist_train_kernel", 256),
+])
+def test_mfma_kernels_keep_their_occupancy_and_do_not_spill(tmp_path, src, kernel, max_vgpr):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path / "k.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                           "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(ROOT, "deep-whole-body-control_amd", "csrc", src)],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = _entry(text, kernel)
+    assert _meta(meta, "private_segment_fixed_size") == 0
+    assert _meta(meta, "vgpr_count") <= max_vgpr
+    body = text[text.index("\n%s:" % kernel):]
+    body = body[:body.index("s_endpgm")]
+    assert not re.search(r"\bflat_(load|store)", body) and "scratch_" not in body
