@@ -1,6 +1,6 @@
 // wbc_step_kernel.hip -- the fused widowGo1 rollout step for gfx950 (MI355X).
 //
-// One 64-lane wavefront per robot (blockDim = 64, gridDim = num_envs). All per-robot link
+// One 64-lane wavefront per robot (blockDim = 64, gridDim = num_envs rounded up to 8: the XCD-aware env mapping). All per-robot link
 // state (frames, joint screws, articulated inertias, inverse inertias, contact rows) lives in
 // LDS for the whole policy step; HBM is touched once on entry (state in) and once on exit
 // (state, observations, rewards out). Lanes are organised as 5 kinematic chains x 12 lanes
@@ -11,7 +11,8 @@
 // including the 4x {_compute_torques WG:1262-1295, gym.simulate WG:1184} decimation loop and
 // post_physics_step WG:865-915. The arithmetic mirrors oracle/wbc_oracle.c statement by
 // statement (that file is the spec and cites the reference line for every step); comments here
-// only describe the lane mapping.
+// only describe the lane mapping. All waves of a launch are resident at once (16 robots per CU), so a launch ends with its
+// slowest wave: what runs on one lane (the task logic, a reset) sits on the launch's critical path.
 #include "wbc_device.h"
 
 // The per-sim constant block is never written while a kernel runs: read through the CONSTANT address space, a wave-uniform load of
