@@ -102,6 +102,33 @@ def test_step_matches_oracle_from_synced_state(robot, precision, atol):
     g.close()
 
 
+@pytest.mark.parametrize("n", [1, 13])
+def test_ragged_env_counts_match_oracle(robot, n):
+    """The step launch rounds its grid up to a multiple of 8 and deals the envs to the XCDs in contiguous ranges: env counts that
+    are not multiples of 8 (and a single env) run through the same kernel, every env is stepped exactly once (the episode length of
+    every env advances) and the results are the oracle's."""
+    import torch
+    params = helpers.random_env_params(n, seed=9)
+    g = helpers.make_gpu(robot, n, params)
+    o = helpers.make_oracle(robot, n, params, "f64")
+    g.reset_all(); o.reset_all()
+    rng = np.random.default_rng(23)
+    for step in range(12):
+        helpers.sync_oracle_from_gpu(o, g)
+        a = (0.6 * rng.normal(size=(n, 18))).astype(np.float32)
+        before = _t(g, "EPISODE_LENGTH").copy()
+        g.step(torch.from_numpy(a).cuda())
+        o.step(a)
+        np.testing.assert_array_equal(_t(g, "RESET_BUF"), o.get("RESET_BUF"))
+        np.testing.assert_array_equal(_t(g, "EPISODE_LENGTH"), o.get("EPISODE_LENGTH"))
+        after = _t(g, "EPISODE_LENGTH")
+        assert np.all((after == before + 1) | (after == 0))            # every env took exactly one step
+        for name in ("DOF_STATE", "ROOT_STATES", "TORQUES", "GOAL_STATE", "COMMANDS"):
+            np.testing.assert_allclose(_t(g, name), o.get(name), atol=3e-4, rtol=5e-4, err_msg=f"{name}, step {step}")
+        np.testing.assert_allclose(_t(g, "OBS_BUF"), o.get("OBS_BUF"), atol=1.5e-3, rtol=1e-4)
+    g.close()
+
+
 def test_free_running_rollout_stays_close(robot):
     """No state syncing: 8 policy steps (32 substeps) of the HIP path vs the fp64 oracle."""
     import torch
