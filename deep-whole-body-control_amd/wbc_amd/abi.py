@@ -225,8 +225,11 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
 
 
 def fill_model(m: RobotModel, foot_name: str = "foot",
-               gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True, box_size: float = 0.1) -> WbcModel:
-    """RobotModel -> wbc_model, with the collision set of this framework's physics spec (collision_set)."""
+               gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True, box_size: float = 0.1,
+               rest_offset: float = 0.0) -> WbcModel:
+    """RobotModel -> wbc_model, with the collision set of this framework's physics spec (collision_set). `rest_offset`
+    (sim.physx.rest_offset, LRC:194): the separation at which two shapes rest -- every contact of the set has a sphere on one side,
+    so holding the surfaces `rest_offset` apart is that sphere grown by it (fill_task_cfg shrinks the contact margin by the same)."""
     assert m.nb == NB and m.num_dofs == NDOF and m.num_rigid_bodies == NRB
     out = WbcModel()
     _seti(out.parent, m.parent)
@@ -258,7 +261,7 @@ def fill_model(m: RobotModel, foot_name: str = "foot",
         k = c["slot"]
         out.cp_body[k], out.cp_rb[k], out.cp_kind[k] = c["body"], c["rb"], c["kind"]
         out.cp_body2[k], out.cp_rb2[k] = c["body2"], c["rb2"]
-        out.cp_radius[k], out.cp_radius2[k] = c["radius"], c["radius2"]
+        out.cp_radius[k], out.cp_radius2[k] = c["radius"] + float(rest_offset), c["radius2"]
         for j in range(3):
             out.cp_pos[k][j], out.cp_a[k][j], out.cp_b[k][j] = float(c["pos"][j]), float(c["a"][j]), float(c["b"][j])
     bp, gp = m.base_piece, m.gripper_piece
@@ -307,7 +310,18 @@ UNSUPPORTED_SWITCHES = [
     ("terrain.restitution", (0.0,), "contacts are inelastic (restitution 0, tests/test_oracle_contact_physics.py)"),
     ("sim.substeps", (1,), "one solver step per gym.simulate (LRC:184)"),
     ("sim.up_axis", (1,), "z is up (LRC:186)"),
+    ("terrain.selected", (False,), "a single generator chosen by name: broken in the reference too (utils/terrain.py:160-173 reads attributes the class never sets)"),
+    ("sim.physx.solver_type", (1,), "the contact solver is this framework's own damped block-Jacobi (DESIGN.md section 3): the shipped value (1 = TGS, "
+     "LRC:190) selects it, PhysX's PGS (0) is not offered"),
+    ("sim.physx.num_velocity_iterations", (0,), "the solver has one kind of sweep (sim.physx.num_position_iterations of them); extra velocity-only iterations "
+     "are not modelled (the reference ships 0, LRC:192)"),
+    ("env.num_privileged_obs", (None,), "the reference hands the critic an all-zero privileged_obs_buf then (BT:77-80: allocated, never written by WG); "
+     "the fused rollout has no such buffer"),
 ]
+# Fields that are compiled into the kernels (observation layout of WG:966-1001, the 18-action / 3-command interface): a config that
+# says otherwise would make the policy built from it (OPR:59-70) and the fused step disagree -- ValueError, not a silent mismatch.
+KERNEL_CONSTANTS = {"env.num_proprio": NPROP, "env.num_priv": NPRIV, "env.history_len": HIST, "env.num_observations": NOBS,
+                    "env.num_actions": NACT, "env.num_torques": NACT, "commands.num_commands": 3}
 # Switches the reference reads but that have NO effect in its widowGo1 task either (the code that would use them is commented out or
 # overridden): ignoring them is the faithful behaviour. (path, where the reference drops it)
 REFERENCE_NO_OPS = [
@@ -328,7 +342,30 @@ REFERENCE_NO_OPS = [
     ("asset.density", "the URDF gives every link its mass"),
     ("asset.replace_cylinder_with_capsule", "the collision set uses sphere-swept primitives throughout"),
     ("env.env_spacing", "custom origins (WG:207-224)"),
-    ("viewer.pos", "headless"), ("viewer.lookat", "headless"),
+    ("viewer.pos", "headless"), ("viewer.lookat", "headless"), ("viewer.ref_env", "headless"),
+    ("noise.noise_level", "WG:65-75 folds it into noise_scale_vec, which compute_observations (WG:966-1001) never applies"),
+    ("noise.noise_scales.dof_pos", "as noise.noise_level"), ("noise.noise_scales.dof_vel", "as noise.noise_level"),
+    ("noise.noise_scales.lin_vel", "as noise.noise_level"), ("noise.noise_scales.ang_vel", "as noise.noise_level"),
+    ("noise.noise_scales.gravity", "as noise.noise_level"), ("noise.noise_scales.height_measurements", "as noise.noise_level"),
+    ("normalization.obs_scales.height_measurements", "only the noise vector (WG:75, never applied) and the base class's overridden compute_observations read it"),
+    ("commands.max_curriculum", "the base class's update_command_curriculum (LR:443-452) is overridden (WG:678-692)"),
+    ("commands.ranges.lin_vel_x", "the base class's ranges: WG:85-90 reads only the init_* / final_* keys of commands.ranges"),
+    ("commands.ranges.lin_vel_y", "as commands.ranges.lin_vel_x (cmd_y is always 0, WG:838)"),
+    ("commands.ranges.ang_vel_yaw", "as commands.ranges.lin_vel_x"), ("commands.ranges.heading", "as commands.ranges.lin_vel_x"),
+    ("goal_ee.num_commands", "never read (WG:630 commented out)"),
+    ("goal_ee.init_ranges.pos_l", "WG:1322 commented out"), ("goal_ee.init_ranges.pos_p", "WG:1322 commented out"), ("goal_ee.init_ranges.pos_y", "WG:1322 commented out"),
+    ("domain_rand.cube_y_range", "never read (the box's y offset comes from box.box_env_origins_y_range, WG:226-227)"),
+    ("terrain.terrain_kwargs", "only read under terrain.selected (utils/terrain.py:158-169), which is refused"),
+    ("terrain.slope_treshold", "only moves vertices of the TRIMESH (utils/terrain.py:60,136: cells steeper than the threshold become vertical walls); contact here is "
+     "against the height grid itself, where such a cell stays a one-cell ramp -- a stated deviation (INTEGRATION.md section 4); the shipped widowGo1 value "
+     "(1e8, WGC:310) never triggers it"),
+    ("terrain.add_slopes", "never read (utils/terrain.py:40-99)"), ("terrain.slope_incline", "never read (utils/terrain.py:40-99)"),
+    # settings that size PhysX's buffers / pick its threads / its contact reporting: no counterpart, no numerical effect
+    ("sim.physx.num_threads", "PhysX CPU worker threads (LRC:189)"), ("sim.physx.max_gpu_contact_pairs", "PhysX buffer size (LRC:197)"),
+    ("sim.physx.default_buffer_size_multiplier", "PhysX buffer size (LRC:198)"),
+    ("sim.physx.contact_collection", "when PhysX refreshes its contact report (LRC:199: 2 = every substep); net_contact_force here is the last substep's, as with 2"),
+    ("sim.physx.bounce_threshold_velocity", "the speed above which PhysX applies restitution: every material here has restitution 0 (terrain.restitution "
+     "other than 0 is refused), so nothing ever bounces at any threshold"),
 ]
 
 
@@ -337,6 +374,10 @@ def unsupported_switches(cfg):
     bad = []
     for path, ok, why in UNSUPPORTED_SWITCHES:
         v = _get(cfg, path, ok[0])
+        if ok[0] is None:
+            if v is not None:
+                bad.append((path, v, why))
+            continue
         if isinstance(v, bool) or isinstance(ok[0], bool):
             v = bool(v)
         if v not in ok:
@@ -345,6 +386,11 @@ def unsupported_switches(cfg):
     if t is not None and float(getattr(t, "dynamic_friction", getattr(t, "static_friction", 1.0))) != float(getattr(t, "static_friction", 1.0)):
         bad.append(("terrain.dynamic_friction", t.dynamic_friction, "one Coulomb coefficient per contact (static = dynamic), DESIGN.md section 3"))
     return bad
+
+
+def constant_mismatches(cfg):
+    """[(path, value, compiled-in value)] for every field of KERNEL_CONSTANTS that `cfg` sets to something else."""
+    return [(p, _get(cfg, p, want), want) for p, want in KERNEL_CONSTANTS.items() if _get(cfg, p, want) != want]
 
 
 def set_soft_limits(out: "WbcTaskCfg", m: RobotModel, soft_pos: float, soft_vel: float, soft_torque: float, max_contact_force: float,
@@ -369,18 +415,30 @@ def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None, check: boo
     if bad:
         raise NotImplementedError("config switches this framework does not implement: " +
                                   "; ".join(f"{p} = {v!r} ({why})" for p, v, why in bad))
+    wrong = constant_mismatches(cfg) if check else []
+    if wrong:
+        raise ValueError("config fields that are compiled into the fused step and the policy kernels (observation layout WG:966-1001, 18 actions, "
+                         "3 commands): " + "; ".join(f"{p} = {v!r}, must be {want}" for p, v, want in wrong))
     out = WbcTaskCfg()
     dt = float(cfg.sim.dt if sim_dt is None else sim_dt)
     out.sim_dt = dt
     out.decimation = int(cfg.control.decimation)
     _set(out.gravity, cfg.sim.gravity)
     px = cfg.sim.physx
-    out.contact_margin = float(px.contact_offset)
+    # sim.physx.rest_offset (LRC:194): shapes rest that far apart -- fill_model grows every contact sphere by it, the margin within
+    # which a contact is generated (contact_offset, measured between the shapes) shrinks by the same
+    rest = float(_get(px, "rest_offset", 0.0))
+    if not float(px.contact_offset) > rest:
+        raise ValueError(f"sim.physx.contact_offset ({px.contact_offset}) must exceed sim.physx.rest_offset ({rest}), as PhysX requires")
+    out.contact_margin = float(px.contact_offset) - rest
     out.contact_erp = 0.2
     out.max_depenetration_vel = float(px.max_depenetration_velocity)
     out.terrain_friction = float(cfg.terrain.static_friction)
     out.limit_kappa, out.limit_delta = 0.25, 0.5
-    out.contact_iters = 2
+    # sim.physx.num_position_iterations (LRC:191, the reference ships 4): sweeps of the contact solver per substep
+    out.contact_iters = int(_get(px, "num_position_iterations", 4))
+    if out.contact_iters < 1:
+        raise ValueError("sim.physx.num_position_iterations must be >= 1")
     out.clip_actions = float(cfg.normalization.clip_actions)
     _set(out.action_scale, cfg.control.action_scale)
     names = m.dof_names

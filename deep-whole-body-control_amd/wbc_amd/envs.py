@@ -67,6 +67,56 @@ class EpisodeInfo(dict):
     vector_index = None
 
 
+def draw_env_params(cfg, n, seed, dt, strip_origins=True, levels=False, gen=None):
+    """The per-env constants the reference draws on the host at construction, as numpy arrays keyed by WbcSim.set_env_params'
+    arguments (+ 'env_origins' as a torch tensor and 'levels_gen', the generator positioned where the terrain-level draw takes
+    it): env origins on the strip in front of the field (WG:207-224), the box's lateral offset (WG:226-227), per-env friction from
+    1000 buckets (WG:480-490), base mass / centre of mass / gripper mass (WG:431-456), the box's added mass (WG:458-466), motor
+    strengths (WG:402-408), EE-trajectory timing (WG:574-575). Pure: nothing but `cfg` decides the result for a given seed."""
+    if gen is None:
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(int(seed))
+    nprng = np.random.default_rng(int(seed))
+    rand = lambda lo, hi, *shape: (hi - lo) * torch.rand(*shape, generator=gen) + lo   # noqa: E731
+    t, dr = cfg.terrain, cfg.domain_rand
+    origins = torch.zeros(n, 3)
+    if strip_origins:                           # WG:207-224: a strip in front of the (Perlin) field
+        half_col = t.tot_cols * t.horizontal_scale / 2
+        half_row = t.tot_rows * t.horizontal_scale / 2
+        origins[:, 0] = rand(-2.5 * half_col / 5, -2 * half_col / 5, n)
+        origins[:, 1] = rand(-half_row + 10, half_row - 10, n)
+    levels_gen = torch.Generator(device="cpu")
+    levels_gen.set_state(gen.get_state())       # (the terrain-level draw of LR:717-731 comes next in the stream)
+    if levels:                                  # advance past it exactly as _get_env_origins_levels will
+        max_init_level = t.max_init_terrain_level if t.curriculum else t.num_rows - 1
+        torch.randint(0, max_init_level + 1, (n,), generator=gen)
+    sign = torch.randint(0, 2, (n,), generator=gen) * 2 - 1
+    box_dy = sign * rand(cfg.box.box_env_origins_y_range[0], cfg.box.box_env_origins_y_range[1], n)
+    if dr.randomize_friction:
+        buckets = rand(dr.friction_range[0], dr.friction_range[1], 1000)
+        friction = buckets[torch.randint(0, 1000, (n,), generator=gen)]
+    else:
+        friction = torch.ones(n)
+    dmass = nprng.uniform(*dr.added_mass_range, size=n) if dr.randomize_base_mass else np.zeros(n)
+    gmass = nprng.uniform(*dr.gripper_added_mass_range, size=n) if dr.randomize_gripper_mass else np.zeros(n)
+    if dr.randomize_base_com:
+        lo = [dr.added_com_range_x[0], dr.added_com_range_y[0], dr.added_com_range_z[0]]
+        hi = [dr.added_com_range_x[1], dr.added_com_range_y[1], dr.added_com_range_z[1]]
+        dcom = nprng.uniform(lo, hi, size=(n, 3))
+    else:
+        dcom = np.zeros((n, 3))
+    if dr.randomize_motor:
+        motor = torch.cat([rand(*dr.leg_motor_strength_range, n, 12), rand(*dr.arm_motor_strength_range, n, 6)], dim=1)
+    else:
+        motor = torch.ones(n, cfg.env.num_torques)
+    box_dmass = nprng.uniform(*cfg.box.added_mass_range, size=n) if cfg.box.randomize_base_mass else np.zeros(n)   # WG:458-466
+    traj = rand(cfg.goal_ee.traj_time[0], cfg.goal_ee.traj_time[1], n) / dt
+    total = traj + rand(cfg.goal_ee.hold_time[0], cfg.goal_ee.hold_time[1], n) / dt
+    return dict(friction=friction.numpy(), base_dmass=dmass, base_dcom=dcom, gripper_dmass=gmass, motor_strength=motor.numpy(),
+                env_origins=origins, box_delta_y=box_dy.numpy(), traj_timesteps=traj.numpy(), traj_total_timesteps=total.numpy(),
+                box_dmass=box_dmass, levels_gen=levels_gen)
+
+
 class BaseTask(VecEnv):
     """Buffer/attribute contract of legged_gym/envs/base/base_task.py:41-131 (viewer omitted: headless)."""
 
@@ -107,8 +157,32 @@ class BaseTask(VecEnv):
         return None
 
 
+# Methods of the reference's WidowGo1 / LeggedRobot whose work happens INSIDE the fused step (csrc/wbc_step_kernel.hip): a Python
+# override in a subclass would never be called, so defining one is an error at class-creation time, not a silent no-op.
+FUSED_METHODS = ("compute_observations", "_compute_torques", "check_termination", "compute_reward", "post_physics_step",
+                 "_post_physics_step_callback", "_push_robots", "_reset_dofs", "_reset_root_states", "update_curr_ee_goal",
+                 "collision_check", "get_body_orientation", "_prepare_reward_function", "_process_rigid_body_props",
+                 "_process_rigid_shape_props", "_process_dof_props", "_get_noise_scale_vec")
+FUSED_PREFIXES = ("_reward_", "_resample_")
+
+
+def _fused_overrides(namespace):
+    return sorted(n for n in namespace if n in FUSED_METHODS or n.startswith(FUSED_PREFIXES))
+
+
 class LeggedRobot(BaseTask):
     """Shared pieces of LR:52-77,279-305: config parsing, DoF limits from the URDF, views."""
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        bad = _fused_overrides(vars(cls))
+        if bad:
+            raise TypeError(
+                f"{cls.__name__} overrides {', '.join(bad)}: the fused step computes this on the device (csrc/wbc_step_kernel.hip, spec "
+                "oracle/wbc_oracle.c) and never calls the Python method. Change a reward through cfg.rewards.scales / arm_scales (every "
+                "_reward_* of the reference is a table entry of wbc_curriculum), thresholds and gains through the config (wbc_task_cfg); for "
+                "new arithmetic either add it to the kernel and the oracle, or step your own torch code on the C-ABI tensors "
+                "(wbc_sim_get_tensor: ROOT_STATES, DOF_STATE, TORQUES, ... are live views) after WidowGo1.step returns.")
 
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
                  robot_model: Optional[RobotModel] = None, seed: Optional[int] = None):
@@ -169,7 +243,7 @@ class WidowGo1(LeggedRobot):
         cfg, m, n = self.cfg, self.robot_model, self.num_envs
         # asset.self_collisions is Isaac Gym's collision FILTER: 0 = self-collision enabled (widowGo1_config.py:180)
         self.wmodel = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(getattr(cfg.asset, "self_collisions", 0)) == 0,
-                                     box_size=float(cfg.box.box_size))
+                                     box_size=float(cfg.box.box_size), rest_offset=float(abi._get(cfg, "sim.physx.rest_offset", 0.0)))
         self.tcfg = abi.fill_task_cfg(cfg, m, sim_dt=self._sim_dt)
         self.sim = WbcSim(self.wmodel, self.tcfg, n, self.device, seed=self._seed)
         self.num_dofs, self.num_bodies = m.num_dofs, m.num_rigid_bodies
@@ -219,52 +293,23 @@ class WidowGo1(LeggedRobot):
 
     def _randomise(self):
         """Host-side draws of _get_env_origins WG:207-228, _process_rigid_shape_props WG:468-496,
-        _process_rigid_body_props WG:431-456, motor strengths WG:402-408, trajectory timing WG:574-575."""
+        _process_rigid_body_props WG:431-456, motor strengths WG:402-408, trajectory timing WG:574-575 (draw_env_params)."""
         cfg, n = self.cfg, self.num_envs
+        t = cfg.terrain
         gen = torch.Generator(device="cpu")
         gen.manual_seed(self._seed)
-        nprng = np.random.default_rng(self._seed)
-        rand = lambda lo, hi, *shape: (hi - lo) * torch.rand(*shape, generator=gen) + lo   # noqa: E731
-        t, dr = cfg.terrain, cfg.domain_rand
         grid = self.terrain is not None and hasattr(self.terrain, "proportions")          # the base class's Terrain
-        origins = torch.zeros(n, 3)
-        if not grid:                                # WG:207-224: a strip in front of the (Perlin) field
-            half_col = t.tot_cols * t.horizontal_scale / 2
-            half_row = t.tot_rows * t.horizontal_scale / 2
-            origins[:, 0] = rand(-2.5 * half_col / 5, -2 * half_col / 5, n)
-            origins[:, 1] = rand(-half_row + 10, half_row - 10, n)
+        self._terrain_levels_on = bool(self.terrain is not None and (grid or t.curriculum))
+        p = draw_env_params(cfg, n, self._seed, self.dt, strip_origins=not grid, levels=self._terrain_levels_on, gen=gen)
+        origins = p.pop("env_origins")
         self.env_origins = origins.to(self.device)
         self.custom_origins = True
-        self._terrain_levels_on = bool(self.terrain is not None and (grid or t.curriculum))
         if self._terrain_levels_on:                 # base-class placement on the terrain's (level, type) platforms, LR:717-731
             if not grid:
                 self.terrain.level_grid(int(t.num_rows), int(t.num_cols))
-            origins = self._get_env_origins_levels(gen).cpu()
-        sign = torch.randint(0, 2, (n,), generator=gen) * 2 - 1
-        box_dy = sign * rand(cfg.box.box_env_origins_y_range[0], cfg.box.box_env_origins_y_range[1], n)
-        if dr.randomize_friction:
-            buckets = rand(dr.friction_range[0], dr.friction_range[1], 1000)
-            friction = buckets[torch.randint(0, 1000, (n,), generator=gen)]
-        else:
-            friction = torch.ones(n)
-        dmass = nprng.uniform(*dr.added_mass_range, size=n) if dr.randomize_base_mass else np.zeros(n)
-        gmass = nprng.uniform(*dr.gripper_added_mass_range, size=n) if dr.randomize_gripper_mass else np.zeros(n)
-        if dr.randomize_base_com:
-            lo = [dr.added_com_range_x[0], dr.added_com_range_y[0], dr.added_com_range_z[0]]
-            hi = [dr.added_com_range_x[1], dr.added_com_range_y[1], dr.added_com_range_z[1]]
-            dcom = nprng.uniform(lo, hi, size=(n, 3))
-        else:
-            dcom = np.zeros((n, 3))
-        if dr.randomize_motor:
-            motor = torch.cat([rand(*dr.leg_motor_strength_range, n, 12), rand(*dr.arm_motor_strength_range, n, 6)], dim=1)
-        else:
-            motor = torch.ones(n, self.num_torques)
-        box_dmass = nprng.uniform(*cfg.box.added_mass_range, size=n) if cfg.box.randomize_base_mass else np.zeros(n)   # WG:458-466
-        traj = rand(cfg.goal_ee.traj_time[0], cfg.goal_ee.traj_time[1], n) / self.dt
-        total = traj + rand(cfg.goal_ee.hold_time[0], cfg.goal_ee.hold_time[1], n) / self.dt
-        self.sim.set_env_params(friction=friction.numpy(), base_dmass=dmass, base_dcom=dcom, gripper_dmass=gmass,
-                                motor_strength=motor.numpy(), env_origins=origins.numpy(), box_delta_y=box_dy.numpy(),
-                                traj_timesteps=traj.numpy(), traj_total_timesteps=total.numpy(), box_dmass=box_dmass)
+            origins = self._get_env_origins_levels(p.pop("levels_gen")).cpu()
+        p.pop("levels_gen", None)
+        self.sim.set_env_params(env_origins=origins.numpy(), **p)
         self.sim.set_curriculum(make_curriculum(cfg, max(self.update_counter, 0)))
 
     def _init_buffers(self):

@@ -292,70 +292,175 @@ def _set_path(cfg, path, value):
     setattr(o, parts[-1], value)
 
 
-def test_no_config_switch_is_silently_ignored():
-    """Every switch of WidowGo1RoughCfg that the reference's widowGo1 path reads is one of: implemented (flipping it changes the
-    task constants / the model handed to the kernels), refused (abi.UNSUPPORTED_SWITCHES: NotImplementedError naming the switch
-    and the reference line), or a no-op in the reference itself (abi.REFERENCE_NO_OPS: the code that would read it is commented
-    out or overridden there; what the reference does with the doubtful ones is recorded by tools/check_reference_dead_switches.py
-    in profiles/r04_reference_switches.txt)."""
-    import ctypes
-    m = abi.load_default_model()
+# a different, valid value for a config leaf: by type, with the exceptions spelled out
+_FLIP = {
+    "control.control_type": "V", "goal_ee.command_mode": "cart", "terrain.mesh_type": "heightfield", "asset.foot_name": "calf",
+    "asset.file": "/nonexistent/other.urdf", "asset.terminate_after_contacts_on": ["thigh"], "asset.penalize_contacts_on": ["calf"],
+    "asset.self_collisions": 1, "asset.default_dof_drive_mode": 1, "sim.up_axis": 0, "sim.substeps": 2, "sim.physx.solver_type": 0,
+    "sim.physx.num_velocity_iterations": 1, "sim.physx.num_position_iterations": 2, "sim.physx.rest_offset": 0.002,
+    "env.num_privileged_obs": 100, "terrain.terrain_kwargs": {"type": "x"}, "control.stiffness": {"joint": 40, "widow": 4},
+    "control.damping": {"joint": 2, "widow": 1}, "terrain.tot_cols": 800, "terrain.tot_rows": 400, "terrain.horizontal_scale": 0.05,
+    "terrain.terrain_proportions": [0.2, 0.2, 0.2, 0.2, 0.2], "terrain.num_rows": 3, "terrain.num_cols": 5,
+    "goal_ee.ranges.final_delta_orn": [[-0.1, 0.1], [-0.1, 0.1], [-0.1, 0.1]], "init_state.rot": [0.0, 0.0, 0.38268343, 0.92387953],
+    "terrain.measured_points_x": [0.0, 0.1], "terrain.measured_points_y": [0.0, 0.1], "commands.lin_vel_x_schedule": [0, 2],
+    "commands.ang_vel_yaw_schedule": [0, 2], "commands.tracking_ang_vel_yaw_schedule": [0, 2], "goal_ee.l_schedule": [0, 2],
+    "goal_ee.p_schedule": [0, 2], "goal_ee.y_schedule": [0, 2], "goal_ee.tracking_ee_reward_schedule": [0, 2],
+    "rewards.scales.orientation": 0.0, "rewards.arm_scales.arm_orientation": 0.0, "rewards.scales.feet_stumble": 0.0,
+}
 
-    def snapshot(cfg):
+
+def _flipped(path, v):
+    if path in _FLIP:
+        return _FLIP[path]
+    if isinstance(v, bool):
+        return not v
+    if isinstance(v, int):
+        return v + 1
+    if isinstance(v, float):
+        return v * 1.5 + 0.125
+    if isinstance(v, list):      # (numbers of a list move together: a [lo, hi] range stays one)
+        return [[float(y) * 1.5 + 0.125 for y in x] if isinstance(x, list) else float(x) * 1.5 + 0.125 for x in v]
+    if isinstance(v, dict):
+        return {k: _flipped(path, x) for k, x in v.items()}
+    raise AssertionError(f"no flip rule for {path} = {v!r}")
+
+
+def _small(cfg):
+    """The same config on a small Perlin field (40 x 20 m instead of 15 x 250: the generators run in milliseconds)."""
+    cfg.terrain.tot_cols, cfg.terrain.tot_rows = 1600, 800
+    return cfg
+
+
+def test_every_config_leaf_is_classified_and_behaves_as_classified():
+    """Nothing the reference reads is silently ignored -- GENERATED over every leaf of WidowGo1RoughCfg (and every key of the golden
+    flattening of the REFERENCE's own class, tests/golden/widowgo1_config.json): each is in exactly one class of
+    wbc_amd/config_audit.py and flipping it does what the class says. kernel: the bytes of wbc_task_cfg / wbc_model / wbc_curriculum
+    change; host: the named file reads it and (for the draws and the terrain generators) the host-side result changes; constant:
+    ValueError; refused: NotImplementedError naming the field; no_effect: nothing handed to the kernels or drawn on the host changes."""
+    import ctypes
+    import re
+    import torch
+    from wbc_amd import config_audit as ca
+    from wbc_amd.envs import draw_env_params
+    from wbc_amd.terrain import TerrainPerlin
+    m = abi.load_default_model()
+    pkg = os.path.join(HERE, "..", "deep-whole-body-control_amd", "wbc_amd")
+
+    def blob(x):
+        return bytes(ctypes.string_at(ctypes.addressof(x), ctypes.sizeof(x)))
+
+    def kernel_view(cfg):
         tc = abi.fill_task_cfg(cfg, m)
-        wm = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0, box_size=float(cfg.box.box_size))
-        return bytes(ctypes.string_at(ctypes.addressof(tc), ctypes.sizeof(tc))) + bytes(ctypes.string_at(ctypes.addressof(wm), ctypes.sizeof(wm)))
-    base = snapshot(WidowGo1RoughCfg())
-    # refused
-    flips = {"control.adaptive_arm_gains": True, "env.reorder_dofs": False, "domain_rand.observe_priv": False, "goal_ee.command_mode": "cart",
-             "asset.fix_base_link": True, "asset.disable_gravity": True, "asset.collapse_fixed_joints": False, "asset.default_dof_drive_mode": 1,
-             "asset.linear_damping": 0.1, "asset.angular_damping": 0.1, "terrain.restitution": 0.5, "sim.substeps": 2, "sim.up_axis": 0}
-    assert set(flips) == {p for p, _, _ in abi.UNSUPPORTED_SWITCHES}
-    for path, value in flips.items():
-        cfg = WidowGo1RoughCfg()
-        _set_path(cfg, path, value)
-        with pytest.raises(NotImplementedError, match=path.replace(".", r"\.")):
-            abi.fill_task_cfg(cfg, m)
-    cfg = WidowGo1RoughCfg()
-    cfg.terrain.dynamic_friction = 0.5
-    with pytest.raises(NotImplementedError, match="dynamic_friction"):
-        abi.fill_task_cfg(cfg, m)
-    # no-ops of the reference: nothing handed to the kernels changes
-    noop_values = {"noise.add_noise": True, "commands.heading_command": False, "commands.curriculum": False, "domain_rand.randomize_arm_ema": True,
-                   "control.control_type": "V", "box.box_pos_obs_range": 2.0, "arm.grasp_offset": 0.2, "arm.init_target_ee_base": [0.3, 0.1, 0.1],
-                   "termination.r_threshold": 0.3, "termination.p_threshold": 0.3, "asset.flip_visual_attachments": True,
-                   "asset.max_linear_velocity": 500.0, "asset.max_angular_velocity": 500.0, "asset.thickness": 0.02, "asset.density": 0.01,
-                   "asset.replace_cylinder_with_capsule": False, "env.env_spacing": 5.0, "viewer.pos": [0, 0, 1], "viewer.lookat": [1, 0, 0]}
-    assert set(noop_values) == {p for p, _ in abi.REFERENCE_NO_OPS}
-    for path, value in noop_values.items():
-        cfg = WidowGo1RoughCfg()
-        try:
-            _set_path(cfg, path, value)
-        except AttributeError:
-            continue                                           # (a field the shipped config does not even define)
-        assert snapshot(cfg) == base, path
-    # implemented: each of these changes what the kernels receive
-    effective = {"control.decimation": 2, "control.action_scale": [0.3] * 18, "control.stiffness": {"joint": 40, "widow": 4},
-                 "control.damping": {"joint": 2, "widow": 1}, "env.action_delay": 1, "env.episode_length_s": 5, "normalization.clip_actions": 50.0,
-                 "normalization.clip_observations": 50.0, "termination.z_threshold": 0.2, "asset.terminate_after_contacts_on": ["thigh"],
-                 "asset.penalize_contacts_on": ["calf"], "asset.self_collisions": 1, "asset.armature": 0.01, "asset.foot_name": "foot",
-                 "commands.resampling_time": 2.0, "commands.lin_vel_x_clip": 0.2, "commands.ang_vel_yaw_clip": 0.4, "domain_rand.push_robots": False,
-                 "domain_rand.push_interval_s": 5, "domain_rand.max_push_vel_xy": 1.0, "goal_ee.underground_limit": -0.4,
-                 "goal_ee.num_collision_check_samples": 5, "goal_ee.collision_upper_limits": [0.3, 0.15, 0.0], "goal_ee.sphere_error_scale": [1, 1, 1],
-                 "goal_ee.orn_error_scale": [1, 1, 1], "rewards.tracking_sigma": 0.5, "rewards.tracking_ee_sigma": 0.5, "rewards.only_positive_rewards": True,
-                 "init_state.pos": [0, 0, 0.5], "terrain.origin_perturb_range": 0.1, "terrain.init_vel_perturb_range": 0.3, "terrain.static_friction": 0.5,
-                 "box.box_env_origins_x": 1.0, "box.box_env_origins_z": 0.3, "box.box_size": 0.2, "sim.dt": 0.0025, "sim.gravity": [0, 0, -5.0]}
-    for path, value in effective.items():
-        cfg = WidowGo1RoughCfg()
-        _set_path(cfg, path, value)
+        wm = abi.fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(cfg.asset.self_collisions) == 0, box_size=float(cfg.box.box_size),
+                            rest_offset=float(cfg.sim.physx.rest_offset))
+        return blob(tc) + blob(wm) + blob(make_curriculum(cfg, 0)) + blob(make_curriculum(cfg, 1))
+
+    def host_view(cfg):
+        d = draw_env_params(cfg, 16, 1, cfg.control.decimation * cfg.sim.dt, strip_origins=True, levels=bool(cfg.terrain.curriculum))
+        d.pop("levels_gen")
+        t = TerrainPerlin(cfg.terrain, seed=1)
+        parts = [np.ascontiguousarray(np.asarray(v, dtype=np.float64)).tobytes() for _, v in sorted(d.items())]
+        return b"".join(parts) + t.heightsamples.tobytes() + np.asarray(t.transform + (t.horizontal_scale, t.vertical_scale)).tobytes()
+
+    base_cfg = _small(WidowGo1RoughCfg())
+    base_k, base_h = kernel_view(base_cfg), host_view(base_cfg)
+    leaves = ca.flatten(WidowGo1RoughCfg())
+    gold = json.load(open(os.path.join(HERE, "golden", "widowgo1_config.json")))["WidowGo1RoughCfg"]
+    gold_leaves = {k for k in gold if not any(k.startswith(p + ".") for p in ("init_state.default_joint_angles", "control.stiffness", "control.damping"))}
+    assert gold_leaves <= set(leaves) | {"init_state.default_joint_angles", "control.stiffness", "control.damping"}, sorted(gold_leaves - set(leaves))
+    assert ca.unclassified(WidowGo1RoughCfg()) == []
+    assert len(leaves) >= 226
+    sources = {fn: open(os.path.join(pkg, fn)).read() for fn in ("envs.py", "terrain.py")}
+    dynamic_host = 0
+    counts = {}
+    for path, value in leaves.items():
+        cls, detail = ca.field_class(path)
+        counts[cls] = counts.get(cls, 0) + 1
+        cfg = _small(WidowGo1RoughCfg())
+        new = _flipped(path, value)
+        assert new != value or path in ("rewards.scales.orientation", "rewards.arm_scales.arm_orientation", "rewards.scales.feet_stumble"), path
+        _set_path(cfg, path, new)
         if path == "terrain.static_friction":
-            cfg.terrain.dynamic_friction = value               # (one Coulomb coefficient: the two must agree)
-        if path == "asset.foot_name":
-            continue                                           # (renaming the feet away is an assertion in fill_model: covered below)
-        assert snapshot(cfg) != base, f"{path} = {value!r} changed nothing"
+            cfg.terrain.dynamic_friction = new                  # (one Coulomb coefficient: the two must agree)
+        if cls == ca.KERNEL:
+            if path == "terrain.dynamic_friction":              # alone it is refused (static = dynamic is the model)
+                with pytest.raises(NotImplementedError, match="dynamic_friction"):
+                    kernel_view(cfg)
+                continue
+            if path == "asset.foot_name":                       # renaming the feet away: fill_model finds no four feet
+                with pytest.raises(AssertionError):
+                    kernel_view(cfg)
+                continue
+            if path.startswith("rewards.") and path.split(".")[-1] in ("orientation", "arm_orientation", "feet_stumble"):
+                _set_path(cfg, path, -1.0)                      # the terms the reference cannot run either: refused by name
+                with pytest.raises(NotImplementedError, match=path.split(".")[-1]):
+                    kernel_view(cfg)
+                continue
+            assert kernel_view(cfg) != base_k, f"{path} = {new!r} changed nothing the kernels receive"
+        elif cls == ca.HOST:
+            leaf = path.split(".")[-1]
+            assert re.search(r"\b" + re.escape(leaf) + r"\b", sources[detail]), f"{path}: {detail} never mentions it"
+            if path in ("terrain.mesh_type", "asset.file", "env.num_envs", "env.send_timeouts", "env.reference_stale_time_outs", "control.torque_supervision",
+                        "arm.osc_kp", "arm.osc_kd", "terrain.measure_heights", "terrain.measured_points_x", "terrain.measured_points_y",
+                        "terrain.num_rows", "terrain.num_cols", "terrain.max_init_terrain_level", "terrain.border_size", "terrain.terrain_length",
+                        "terrain.terrain_width", "terrain.terrain_proportions"):
+                continue                                        # WidowGo1's own switches / the base class's grid terrain: covered by their tests
+            if path == "terrain.curriculum":
+                cfg.terrain.num_rows, cfg.terrain.num_cols = 4, 4
+            assert host_view(cfg) != base_h, f"{path} = {new!r} changed nothing drawn or generated on the host"
+            dynamic_host += 1
+        elif cls == ca.CONSTANT:
+            with pytest.raises(ValueError, match=path.replace(".", r"\.")):
+                abi.fill_task_cfg(cfg, m)
+        elif cls == ca.REFUSED:
+            with pytest.raises(NotImplementedError, match=path.replace(".", r"\.")):
+                abi.fill_task_cfg(cfg, m)
+        else:
+            assert cls == ca.NO_EFFECT
+            assert kernel_view(cfg) == base_k and host_view(cfg) == base_h, path
+    assert counts[ca.KERNEL] >= 100 and counts[ca.REFUSED] >= 17 and counts[ca.CONSTANT] == 7 and dynamic_host >= 25, (counts, dynamic_host)
+    # the base class's grid terrain reads its own block (utils/terrain.py:101-227): each field moves the generated grid
+    from wbc_amd.config import use_grid_terrain
+    from wbc_amd.terrain import Terrain
+
+    def grid_view(**kw):
+        cfg = use_grid_terrain(WidowGo1RoughCfg(), num_rows=2, num_cols=5)
+        for k, v in kw.items():
+            setattr(cfg.terrain, k, v)
+        st = np.random.get_state()
+        np.random.seed(3)
+        try:
+            t = Terrain(cfg.terrain, 16)
+        finally:
+            np.random.set_state(st)
+        return t.heightsamples.tobytes() + np.asarray(t.env_origins).tobytes()
+    g0 = grid_view()
+    assert grid_view(terrain_length=6.0, terrain_width=6.0) != g0       # (square tiles: the reference builds every tile width x width, utils/terrain.py:176-177)
+    for k, v in dict(border_size=5, terrain_proportions=[0.2, 0.2, 0.2, 0.2, 0.2], num_rows=3, num_cols=4,
+                     horizontal_scale=0.2, vertical_scale=0.01, curriculum=False).items():
+        assert grid_view(**{k: v}) != g0, k
+    # rest_offset holds resting shapes that far apart: every contact sphere grows by it, the contact margin shrinks by it
     cfg = WidowGo1RoughCfg()
-    cfg.sim.physx.contact_offset = 0.02
-    assert snapshot(cfg) != base
-    cfg = WidowGo1RoughCfg()
-    cfg.sim.physx.max_depenetration_velocity = 2.0
-    assert snapshot(cfg) != base
+    cfg.sim.physx.rest_offset = 0.002
+    tc = abi.fill_task_cfg(cfg, m)
+    wm0, wm1 = abi.fill_model(m), abi.fill_model(m, rest_offset=0.002)
+    assert tc.contact_margin == pytest.approx(0.008) and tc.contact_iters == 4
+    assert all(wm1.cp_radius[k] == pytest.approx(wm0.cp_radius[k] + 0.002) for k in range(abi.NCP) if wm0.cp_kind[k] >= 0)
+    cfg.sim.physx.rest_offset = 0.02
+    with pytest.raises(ValueError, match="rest_offset"):
+        abi.fill_task_cfg(cfg, m)
+
+
+def test_subclass_overrides_the_fused_step_cannot_honour_are_errors():
+    """A user subclass that overrides a method whose work happens inside the fused step (any _reward_*, compute_observations,
+    _compute_torques, check_termination, _resample_*, ...: widowGo1.py:170-205,937-1001,1262-1295) fails at class creation with the
+    alternatives named; overriding what stays on the host (step, update_command_curriculum, _parse_cfg) is fine."""
+    from wbc_amd import envs
+    for name in ("_reward_survive", "_reward_my_new_term", "compute_observations", "_compute_torques", "check_termination", "_resample_commands",
+                 "_resample_ee_goal", "compute_reward", "_push_robots"):
+        with pytest.raises(TypeError, match=name):
+            type("UserTask", (envs.WidowGo1,), {name: lambda self, *a: None})
+    ok = type("UserTask", (envs.WidowGo1,), {"step": lambda self, a: None, "update_command_curriculum": lambda self: None, "my_helper": lambda self: 1})
+    assert issubclass(ok, envs.WidowGo1)
+    with pytest.raises(TypeError, match="_reward_x"):
+        type("Deeper", (ok,), {"_reward_x": lambda self: None})

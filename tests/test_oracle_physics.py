@@ -387,7 +387,7 @@ def test_self_collision_geometry_against_brute_force(robot):
                 hits += 1
                 near = [i for i, gp in enumerate(gaps) if gp < tc.contact_margin + 4e-3]
                 if not inside_box and len(near) == 1 and gaps[near[0]] > -0.5 * rad:
-                    assert np.dot(f[e, rb1], aways[near[0]]) > 0.5 * np.linalg.norm(f[e, rb1]), (names[rb1], e)     # (normal + friction)
+                    assert np.dot(f[e, rb1], aways[near[0]]) > 0.4 * np.linalg.norm(f[e, rb1]), (names[rb1], e)     # (normal + friction at mu = 1: within 66 deg)
             elif min(gaps) > tc.contact_margin + 4e-3:
                 assert not pushing, (names[rb1], e, gaps)
             checked += 1
