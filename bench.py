@@ -191,6 +191,12 @@ def main():
     ap.add_argument("--terrain", choices=["plane", "trimesh", "grid"], default="plane",
                     help="plane = BASELINE.json configs[1] (the bench line); trimesh = the shipped fractal-Perlin terrain; "
                          "grid = the base class's sub-terrain grid with the terrain-level curriculum (configs[2])")
+    ap.add_argument("--contact-iters", type=int, default=0,
+                    help="override sim.physx.num_position_iterations (the contact solver's sweeps per substep; the reference ships 4 = the default)")
+    ap.add_argument("--regime", choices=["default", "standing"], default="default",
+                    help="default = random-init policy under the shipped thresholds (13 %% of the envs reset per step, most robots airborne); "
+                         "standing = what a trained run looks like to the step kernel: every robot on its feet, 500-step episodes "
+                         "(z_threshold 0.25 as tools/train_walk.py, near-zero mean actions, exploration std at its floor)")
     ap.add_argument("--terrain-curriculum", action="store_true",
                     help="with --terrain trimesh: terrain.curriculum=True on the Perlin field (grid always has it)")
     args = ap.parse_args()
@@ -253,6 +259,10 @@ def main():
     else:
         cfg.terrain.curriculum = bool(args.terrain_curriculum)
         terrain_name, cfg_idx = "fractal-Perlin trimesh" + (", terrain-level curriculum on" if args.terrain_curriculum else ""), 2
+    if args.contact_iters:
+        cfg.sim.physx.num_position_iterations = args.contact_iters
+    if args.regime == "standing":
+        cfg.termination.z_threshold = 0.25            # (the shipped 0.325 ends every episode at touchdown)
     train_cfg = WidowGo1RoughCfgPPO()
     torch.manual_seed(train_cfg.seed)                 # identical replicas; env RNG differs per rank
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)
@@ -263,6 +273,16 @@ def main():
         log_dir = tempfile.mkdtemp(prefix=f"wbc_bench_log_r{rank}_")
     runner = OnPolicyRunner(env, train, log_dir=log_dir, device=device, dist_group=group)
     env.collect_episode_stats = True                  # extras['episode'] is filled on every step as the reference does (WG:743-750)
+    if args.regime == "standing":                     # a policy that keeps the robots up: zero mean action (the PD law holds the default stance), std at its floor
+        ac = runner.alg.actor_critic
+        with torch.no_grad():
+            for name, p in ac.named_parameters():
+                if name.endswith("std"):
+                    p.copy_(torch.as_tensor(train["algorithm"]["min_policy_std"], device=p.device).view_as(p))
+            for head in (ac.actor.actor_leg_control_head, ac.actor.actor_arm_control_head):
+                last = [m for m in head if hasattr(m, "weight")][-1]
+                last.weight.mul_(0.02)
+                last.bias.zero_()
     torch.manual_seed(train_cfg.seed + 1000 * rank)   # replicas are identical (broadcast at construction); exploration noise is per rank
     T = runner.num_steps_per_env
 
@@ -410,7 +430,11 @@ def main():
             "dtype": "f32", "data": f"synthetic (random-init policy, seeded domain randomisation, {terrain_name} terrain)",
             "config": {"workload": f"widowGo1 {terrain_name} terrain, {args.envs_per_gpu} envs per GPU, PPO fp32 "
                                    f"(BASELINE.json configs[{cfg_idx}]); T={T} steps/iteration, 5 epochs x 4 minibatches, "
-                                   f"DAgger every 20th iteration", "envs_per_gpu": args.envs_per_gpu,
+                                   f"DAgger every 20th iteration; contact solver {int(env.tcfg.contact_iters)} sweeps per substep "
+                                   f"(sim.physx.num_position_iterations, reference: 4); regime: "
+                                   + ("random-init policy, shipped thresholds" if args.regime == "default" else
+                                      "STANDING (z_threshold 0.25, zero-mean policy at the std floor: every robot on its feet, 500-step episodes)"),
+                       "envs_per_gpu": args.envs_per_gpu, "contact_iters": int(env.tcfg.contact_iters), "regime": args.regime,
                        "global_envs": args.envs_per_gpu * world, "steps_per_env": T,
                        "parallelism": (f"env-shard x{world}, 1 {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} grad all-reduce/minibatch"
                                        f" + 1 three-scalar all-reduce/iteration" + (", ALL RANKS ON ONE DEVICE (functional run, not a scaling figure)" if args.same_device else "")

@@ -19,7 +19,7 @@ def gpu(wmodel, tcfg, n, seed=1):
 @pytest.mark.parametrize("terrain_friction,tan_theta", [(1.0, 0.5), (0.2, 0.5), (-0.6, 0.1)])
 def test_box_sticks_below_the_friction_angle_on_the_kernel(robot, terrain_friction, tan_theta):
     r = pc.box_on_incline(robot, tan_theta, terrain_friction, make_sim=gpu)
-    assert r["sticks_expected"] and abs(r["acc"]) < 0.01 and abs(r["v_end"]) < 0.05, r
+    assert r["sticks_expected"] and abs(r["acc"]) < 0.02 and abs(r["v_end"]) < 0.05, r
 
 
 @pytest.mark.parametrize("terrain_friction,tan_theta", [(0.2, 0.7), (0.2, 0.9), (-0.6, 0.3), (-0.6, 0.6), (-1.0, 0.2), (-1.0, 0.7)])
