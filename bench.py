@@ -61,16 +61,56 @@ def _usable_cores(cap=16):
 CPU_BASELINE_THREADS = _usable_cores()
 
 
-def _cpu_learner_classes():
-    """(kind, PPO, ActorCritic) of the CPU baseline: always this package's eager torch path -- the same op sequence as the
-    reference's rsl_rl, pinned to it seed for seed by tests/test_ppo_parity.py -- so that the reported baseline does not depend
-    on which box runs the bench and no code outside this repository executes inside it."""
+REFERENCE_RSL_RL = "/root/reference/rsl_rl"     # exists in the build container only (never on the GPU box)
+
+
+def _cpu_learner_classes(kind="port"):
+    """(kind, PPO, ActorCritic) of the CPU baseline. "port" (what every bench line on a GPU box reports: /root/reference does not
+    exist there): this package's eager torch path -- the same op sequence as the reference's rsl_rl, pinned to it seed for seed by
+    tests/test_ppo_parity.py. "reference": the reference's own rsl_rl classes, importable in the build container only -- used by
+    `bench.py --cpu-baseline-only`, which times BOTH on one box so that the port's cost is shown next to the reference's
+    (profiles/r05_cpu_baseline_reference_vs_port.json)."""
+    if kind == "reference":
+        import contextlib
+        import io
+        sys.dont_write_bytecode = True              # the reference tree is read-only
+        if REFERENCE_RSL_RL not in sys.path:
+            sys.path.insert(0, REFERENCE_RSL_RL)
+        with contextlib.redirect_stdout(io.StringIO()):
+            from rsl_rl.algorithms import PPO
+            from rsl_rl.modules import ActorCritic
+        return "reference", PPO, ActorCritic
     from wbc_amd.rsl_rl.algorithms import PPO
     from wbc_amd.rsl_rl.modules import ActorCritic
     return "port", PPO, ActorCritic
 
 
-def cpu_baseline(runner, sim_sample_envs=512):
+def _synthetic_runner(n=ENVS_PER_GPU, t=T_STEPS):
+    """A stand-in for the GPU runner on a box without a GPU: a randomly initialised policy and a synthetic rollout storage of the
+    bench shape (SURVEY.md section 8d config 1's recipe at 4096 x 40: N(0,1) observations, 0.01 N(0,1) rewards, 5 % dones)."""
+    import contextlib
+    import io
+    import types
+    import torch
+    from wbc_amd.config import WidowGo1RoughCfgPPO, class_to_dict
+    from wbc_amd.rsl_rl.algorithms import PPO
+    from wbc_amd.rsl_rl.modules import ActorCritic
+    train = class_to_dict(WidowGo1RoughCfgPPO())
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ac = ActorCritic(76, 76, 18, **train["policy"], num_priv=24, num_hist=10, num_prop=76)
+        alg = PPO(ac, device="cpu", **train["algorithm"])
+        alg.init_storage(n, t, [860], [None], [18])
+    st = alg.storage
+    for x in (st.observations, st.actions, st.values, st.actions_log_prob, st.mu):
+        x.normal_()
+    st.rewards.normal_().mul_(0.01)
+    st.dones.copy_((torch.rand(st.dones.shape) < 0.05).to(st.dones.dtype))
+    st.sigma.fill_(1.0)
+    return types.SimpleNamespace(alg=alg)
+
+
+def cpu_baseline(runner, sim_sample_envs=512, learner="port"):
     """The north star's CPU baseline: the rsl_rl PPO-update path on this box's host cores, on the SAME rollout the GPU
     learner has just consumed (its storage copied to the host): compute_returns + update() (median of 3) and
     update_dagger() (once), torch CPU with all cores. `value` = N*T / (returns + update): the learner-only ceiling of a
@@ -82,7 +122,7 @@ def cpu_baseline(runner, sim_sample_envs=512):
     import numpy as np
     import torch
     from wbc_amd.config import WidowGo1RoughCfgPPO, class_to_dict
-    kind, PPO, ActorCritic = _cpu_learner_classes()
+    kind, PPO, ActorCritic = _cpu_learner_classes(learner)
     nthreads = CPU_BASELINE_THREADS
     torch.set_num_threads(nthreads)
     gst = runner.alg.storage
@@ -128,7 +168,7 @@ def cpu_baseline(runner, sim_sample_envs=512):
     out = {"value": N * T / (ret_s + upd_s), "unit": "env-steps/s", "cores": nthreads, "kind": kind,
            "scope": "learner only: compute_returns + PPO.update on the host; a ceiling for a CPU run, not an end-to-end rate "
                     "(the reference has no CPU simulator; sim_port below is this framework's scalar C oracle)",
-           "sample": f"rsl_rl PPO-update path on the host (this package's eager torch CPU path, pinned to the reference by tests/test_ppo_parity.py): "
+           "sample": f"rsl_rl PPO-update path on the host ({'the REFERENCE rsl_rl classes imported from ' + REFERENCE_RSL_RL if kind == 'reference' else 'this package eager torch CPU path, pinned to the reference by tests/test_ppo_parity.py'}): "
                      f"compute_returns {ret_s * 1e3:.1f} ms + update() {upd_s:.2f} s (median of {len(t_upd)}; 5 epochs x 4 minibatches over the "
                      f"{N}x{T} rollout the GPU learner consumed), update_dagger() {t_dag:.2f} s (once); learner only, no CPU sim exists",
            "compute_returns_s": ret_s, "update_s": upd_s, "update_dagger_s": t_dag,
@@ -199,7 +239,25 @@ def main():
                          "(z_threshold 0.25 as tools/train_walk.py, near-zero mean actions, exploration std at its floor)")
     ap.add_argument("--terrain-curriculum", action="store_true",
                     help="with --terrain trimesh: terrain.curriculum=True on the Perlin field (grid always has it)")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="no GPU needed: time the rsl_rl PPO-update path on this box's host cores over a synthetic 4096 x 40 rollout -- the "
+                         "REFERENCE's own classes where /root/reference/rsl_rl exists (kind 'reference') and this package's eager port "
+                         "(kind 'port'), both on the same storage contents")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        r = _synthetic_runner(args.envs_per_gpu, T_STEPS)
+        out = {"metric": "env-steps/sec, rsl_rl PPO-update path on the host (learner only)", "unit": "env-steps/s", "n_gpus": 0,
+               "config": {"workload": f"synthetic {args.envs_per_gpu} x {T_STEPS} rollout storage, widowGo1 hyper-parameters"}}
+        if os.path.isdir(REFERENCE_RSL_RL):
+            out["cpu_baseline"] = cpu_baseline(r, sim_sample_envs=64, learner="reference")
+        out["cpu_baseline_port"] = cpu_baseline(r, sim_sample_envs=64, learner="port")
+        if "cpu_baseline" in out:
+            out["port_over_reference_update_time"] = out["cpu_baseline_port"]["update_s"] / out["cpu_baseline"]["update_s"]
+        else:
+            out["cpu_baseline"] = out["cpu_baseline_port"]
+        print(json.dumps(out))
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _self_launch(args)

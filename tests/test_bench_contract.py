@@ -3,6 +3,8 @@ path, which tests/test_ppo_parity.py pins to the reference: the same classes on 
 executed inside the bench), the usable-core count, and the launcher's argument handling."""
 import os
 import subprocess
+
+import pytest
 import sys
 import types
 
@@ -43,6 +45,21 @@ def test_cpu_baseline_never_imports_the_reference_tree():
     bench.cpu_baseline(_stand_in_runner(16, 4), sim_sample_envs=8)
     new = [m for m in set(sys.modules) - before if getattr(sys.modules[m], "__file__", None) and "/root/reference" in (sys.modules[m].__file__ or "")]
     assert not new and not any("/root/reference" in p for p in sys.path)
+
+
+@pytest.mark.skipif(not os.path.isdir(bench.REFERENCE_RSL_RL), reason="the reference tree exists in the build container only")
+def test_cpu_baseline_can_time_the_reference_classes_in_the_build_container():
+    """`bench.py --cpu-baseline-only`: kind 'reference' = the reference's own rsl_rl PPO / ActorCritic on the same storage contents
+    (profiles/r05_cpu_baseline_reference_vs_port.json holds both lines from one box)."""
+    r = bench._synthetic_runner(32, 4)
+    try:
+        out = bench.cpu_baseline(r, sim_sample_envs=8, learner="reference")
+    finally:
+        while bench.REFERENCE_RSL_RL in sys.path:
+            sys.path.remove(bench.REFERENCE_RSL_RL)
+    assert out["kind"] == "reference" and bench.REFERENCE_RSL_RL in out["sample"] and out["value"] > 0
+    port = bench.cpu_baseline(r, sim_sample_envs=8, learner="port")
+    assert port["kind"] == "port" and port["value"] > 0
 
 
 def test_world_size_mismatch_is_an_error_message_not_an_assert():
