@@ -67,6 +67,40 @@ def run_procedure(ActorCritic, PPO, device="cpu", counter0=3500, **extra_alg_kw)
     return out
 
 
+STORAGE_FIELDS = ("actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma", "returns", "advantages")
+
+
+def flat_params(module):
+    return np.concatenate([v.detach().cpu().double().numpy().ravel() for v in module.state_dict().values()]).astype(np.float32)
+
+
+def synthetic_storage(storage, seed):
+    """Fill a RolloutStorage with a synthetic but self-consistent rollout WITHOUT any network: N(0,1) observations, a stored policy
+    mean 0.05 N(0,1) (a randomly initialised actor's tanh outputs are that small), sigma = the config's init std, actions = mu +
+    sigma eps, the old log-probabilities in closed form (two channels: 12 leg / 6 arm dimensions, actor_critic.py:341-345), values
+    0.1 N(0,1), rewards 0.01 N(0,1), 3 % dones; returns / advantages by the storage's own compute_returns (RS:136-150). Only the CPU
+    generator and elementwise torch math: the build container (through the reference's RolloutStorage) and the GPU box (through
+    this package's) produce the same inputs; what the reference COMPUTES from them is what the fixture records."""
+    g = torch.Generator().manual_seed(seed)
+    T, N = storage.num_transitions_per_env, storage.num_envs
+    dev = storage.observations.device
+    obs = torch.randn(T, N, 860, generator=g)
+    mu = 0.05 * torch.randn(T, N, 18, generator=g)
+    sigma = torch.tensor(POLICY_KW["init_std"][0]).expand(T, N, 18).contiguous()
+    act = mu + sigma * torch.randn(T, N, 18, generator=g)
+    lp = -0.5 * ((act - mu) / sigma) ** 2 - torch.log(sigma) - 0.5 * np.log(2 * np.pi)
+    logp = torch.stack([lp[..., :12].sum(-1), lp[..., 12:].sum(-1)], dim=-1)
+    val = 0.1 * torch.randn(T, N, 2, generator=g)
+    rew = 0.01 * torch.randn(T, N, 2, generator=g)
+    dones = (torch.rand(T, N, 1, generator=g) < 0.03).to(storage.dones.dtype)
+    last = 0.1 * torch.randn(N, 2, generator=g)
+    for name, x in (("observations", obs), ("mu", mu), ("sigma", sigma), ("actions", act), ("actions_log_prob", logp), ("values", val),
+                    ("rewards", rew), ("dones", dones)):
+        getattr(storage, name).copy_(x.to(dev))
+    storage.step = T
+    return last
+
+
 def gae_known_answer_inputs():
     rew = torch.tensor([[[1, .5], [0, -1]], [[.5, .25], [1, 0]], [[-1, 2], [.5, .5]], [[.25, 0], [2, 1]]], dtype=torch.float32)
     val = torch.tensor([[[.1, .2], [.3, .4]], [[.5, .6], [.7, .8]], [[.9, 1.0], [1.1, 1.2]], [[1.3, 1.4], [1.5, 1.6]]], dtype=torch.float32)

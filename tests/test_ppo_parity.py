@@ -2,8 +2,10 @@
 outputs of the REFERENCE (rsl_rl PPO / RolloutStorage / ActorCritic, imported from /root/reference by
 tools/make_golden_ppo.py) on the seeded procedure of tests/golden_procedure.py; here the same
 procedure runs through wbc_amd.rsl_rl. On the CPU the two share every torch op and RNG draw, so the
-comparison is to float round-off; on the GPU (HIP GAE kernel, rocBLAS GEMMs) GAE returns must stay
-within 1e-3 (BASELINE.json north_star) and in practice stay within 2e-5."""
+comparison is to float round-off; on the GPU the fused learner (HIP GAE kernels, ppo_chain / ppo_wgrad / clip + Adam kernels: no
+rocBLAS on the path) is fed the reference's recorded storage and permutation and compared with the reference's outputs directly
+(test_fused_update_matches_the_reference_one_hop); GAE returns must stay within 1e-3 (BASELINE.json north_star) and in practice
+stay within 2e-5."""
 import os
 
 import numpy as np
@@ -66,20 +68,108 @@ def test_update_and_dagger_match_reference_cpu():
     assert abs(out["it0_stats"][3] - 1.0) < 1e-9 and abs(out["it0_stats"][6] - 0.1 * 500 / 7000) < 1e-9
 
 
+def _load_params(ac, flat):
+    off = 0
+    sd = ac.state_dict()
+    for k, v in sd.items():
+        n = v.numel()
+        v.copy_(torch.from_numpy(np.asarray(flat[off:off + n])).view_as(v))
+        off += n
+    assert off == len(flat)
+
+
+def _assert_params(ac, gold_flat, before_flat, tol_of_step):
+    """Every parameter against the reference's post-update value; the tolerance is a fraction of what the update MOVED (so that a
+    learner that did nothing cannot pass)."""
+    mine = gp.flat_params(ac)
+    moved = np.abs(gold_flat - before_flat)
+    assert moved.max() > 1e-4
+    err = np.abs(mine - gold_flat)
+    assert err.max() < tol_of_step * moved.max(), (err.max(), moved.max())
+    assert np.median(err[moved > 1e-6] / moved[moved > 1e-6]) < 0.02
+
+
 @pytest.mark.gpu
-def test_update_and_dagger_match_reference_gpu():
-    """Same procedure on the MI355X: HIP GAE kernel + rocBLAS. The sampled actions come from the device
-    generator, so the rollout differs from the CPU golden run; what is compared is therefore (a) GAE on
-    the golden rollout's own stored tensors and (b) a full update() from identical storage contents."""
+def test_fused_update_matches_the_reference_one_hop():
+    """ONE hop: the fused GPU learner (csrc/wbc_ppo_chain.h, wbc_ppo_kernel.hip: forward, Advantage-Mixing surrogate, clipped value
+    loss, ROA regulariser, backward, clip + Adam in HIP) is fed the REFERENCE's storage contents and minibatch permutation
+    (tests/golden/ppo_reference.npz, written by tools/make_golden_ppo.py from the reference's own PPO / RolloutStorage /
+    ActorCritic) and compared with the REFERENCE's update() outputs -- the seven returned statistics and every one of the 168 698
+    post-update parameters -- with no CPU port of this package in between. (a) BASELINE.json configs[0]: the 64 x 24 rollout the
+    reference collected itself, 5 epochs x 4 minibatches; (b) the bench's minibatch shape, B = 40 960 rows (1024 x 40, one minibatch
+    per epoch), on the synthetic storage of golden_procedure.synthetic_storage."""
+    import unittest.mock as mock
     dev = "cuda:0"
-    # (a) GAE: feed the golden run's rewards and the values implied by returns/advantages
-    rew, val, dones, last = gp.gae_known_answer_inputs()
-    st = RolloutStorage(2, 4, [3], [None], [1], device=dev)
-    st.rewards.copy_(rew); st.values.copy_(val); st.dones.copy_(dones)
-    st.compute_returns(last.to(dev), 0.99, 0.95)
-    np.testing.assert_allclose(st.returns.cpu().numpy(), GOLD["gae_returns"], atol=2e-6)
-    np.testing.assert_allclose(st.advantages.cpu().numpy(), GOLD["gae_advantages"], atol=2e-5)
-    # (b) update() from identical storage: CPU wbc_amd run (already pinned to the reference above) vs GPU
+    # (a) configs[0]
+    torch.manual_seed(1)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
+    np.testing.assert_allclose(gp.param_digest(ac), GOLD["init_digest"], rtol=1e-6, atol=1e-7)      # the reference's initial weights
+    before = gp.flat_params(ac)
+    np.testing.assert_array_equal(before, GOLD["it0_storage_params_before"])
+    alg = PPO(ac, device=dev, **gp.ALG_KW)
+    alg.counter = 3500
+    alg.init_storage(gp.N, gp.T, [860], [None], [18])
+    st = alg.storage
+    obs = gp.synthetic_rollout(100)[0]
+    st.observations.copy_(obs[:gp.T])
+    for name in gp.STORAGE_FIELDS:
+        getattr(st, name).copy_(torch.from_numpy(GOLD["it0_storage_" + name]).to(getattr(st, name).dtype))
+    st.step = gp.T
+    assert alg._fused_update_supported()
+    perm = torch.from_numpy(GOLD["it0_perm"])
+    with mock.patch("torch.randperm", lambda n, **kw: perm.to(kw.get("device", "cpu"))):
+        stats = alg.update()
+    np.testing.assert_allclose(np.array([float(x) for x in stats]), GOLD["it0_stats"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(ac.std.detach().cpu().numpy(), GOLD["it0_std"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gp.param_digest(ac)[:, :2], GOLD["it0_digest"][:, :2], rtol=2e-4, atol=2e-4)
+    # (b) B = 40960
+    torch.manual_seed(1)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
+    alg = PPO(ac, device=dev, **dict(gp.ALG_KW, num_mini_batches=1, num_learning_epochs=2))
+    alg.counter = 3500
+    alg.init_storage(1024, 40, [860], [None], [18])
+    last = gp.synthetic_storage(alg.storage, 777)
+    alg.storage.compute_returns(last.to(dev), gp.ALG_KW["gamma"], gp.ALG_KW["lam"])
+    np.testing.assert_allclose(alg.storage.returns.cpu().numpy(), GOLD["bench_returns"], atol=2e-5)          # HIP GAE vs the reference's (north star: 1e-3)
+    np.testing.assert_allclose(alg.storage.advantages.cpu().numpy(), GOLD["bench_advantages"], atol=2e-4)
+    alg.storage.returns.copy_(torch.from_numpy(GOLD["bench_returns"]))                                      # then exactly the reference's inputs
+    alg.storage.advantages.copy_(torch.from_numpy(GOLD["bench_advantages"]))
+    assert alg._fused_update_supported()
+    perm = torch.from_numpy(GOLD["bench_perm"])
+    with mock.patch("torch.randperm", lambda n, **kw: perm.to(kw.get("device", "cpu"))):
+        stats = alg.update()
+    np.testing.assert_allclose(np.array([float(x) for x in stats]), GOLD["bench_stats"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(ac.std.detach().cpu().numpy(), GOLD["bench_std"], rtol=1e-4, atol=1e-5)
+    _assert_params(ac, GOLD["bench_params"], before, tol_of_step=0.05)
+
+
+def test_reference_storage_fixture_replays_on_the_cpu_port():
+    """The same one-hop fixture through this package's eager CPU path (no GPU needed): it must land on the reference's
+    post-update parameters to round-off -- which also checks that the fixture's recorded inputs are complete."""
+    import unittest.mock as mock
+    torch.manual_seed(1)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
+    before = gp.flat_params(ac)
+    alg = PPO(ac, device="cpu", **dict(gp.ALG_KW, num_mini_batches=1, num_learning_epochs=2))
+    alg.counter = 3500
+    alg.init_storage(1024, 40, [860], [None], [18])
+    last = gp.synthetic_storage(alg.storage, 777)
+    alg.storage.compute_returns(last, gp.ALG_KW["gamma"], gp.ALG_KW["lam"])
+    np.testing.assert_allclose(alg.storage.returns.numpy(), GOLD["bench_returns"], atol=1e-6)
+    np.testing.assert_allclose(alg.storage.advantages.numpy(), GOLD["bench_advantages"], atol=2e-5)
+    perm = torch.from_numpy(GOLD["bench_perm"])
+    with mock.patch("torch.randperm", lambda n, **kw: perm):
+        stats = alg.update()
+    np.testing.assert_allclose(np.array([float(x) for x in stats]), GOLD["bench_stats"], rtol=1e-4, atol=1e-7)
+    _assert_params(ac, GOLD["bench_params"], before, tol_of_step=0.01)
+
+
+@pytest.mark.gpu
+def test_dagger_update_on_the_gpu_matches_the_cpu_port():
+    """update_dagger on the device (csrc/wbc_hist_train_kernel.hip) against this package's CPU path from identical storage and
+    permutation (the CPU path itself is pinned to the reference's update_dagger by test_update_and_dagger_match_reference_cpu)."""
+    dev = "cuda:0"
+
     def run(device):
         torch.manual_seed(1)
         ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
@@ -89,31 +179,20 @@ def test_update_and_dagger_match_reference_gpu():
         return ac, alg
     ac_c, alg_c = run("cpu")
     ac_g, alg_g = run(dev)
-    obs, rew, arm, dones, touts = gp.synthetic_rollout(100)
-    torch.manual_seed(1000)
-    with torch.inference_mode():
-        for t in range(gp.T):
-            alg_c.act(obs[t], obs[t], False)
-            alg_c.process_env_step(rew[t], arm[t], dones[t], {"time_outs": touts[t]})
-        alg_c.compute_returns(obs[gp.T])
-    sc, sg = alg_c.storage, alg_g.storage
-    for name in ("observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma"):
-        getattr(sg, name).copy_(getattr(sc, name))
-    sg.step = sc.step
-    with torch.inference_mode():
-        last_v = ac_g.evaluate(obs[gp.T].to(dev))
-    sg.compute_returns(last_v, 0.99, 0.95)
-    assert (sg.returns.cpu() - sc.returns).abs().max().item() < 1e-3      # north-star bound
-    np.testing.assert_allclose(sg.returns.cpu().numpy(), sc.returns.numpy(), atol=2e-5)
-    np.testing.assert_allclose(sg.advantages.cpu().numpy(), sc.advantages.numpy(), atol=2e-4)
+    obs = gp.synthetic_rollout(100)[0]
+    for alg in (alg_c, alg_g):
+        st = alg.storage
+        st.observations.copy_(obs[:gp.T])
+        for name in gp.STORAGE_FIELDS:
+            getattr(st, name).copy_(torch.from_numpy(GOLD["it0_storage_" + name]).to(getattr(st, name).dtype))
+        st.step = gp.T
     perm = torch.randperm(gp.N * gp.T)
     import unittest.mock as mock
     with mock.patch("torch.randperm", lambda n, **kw: perm.to(kw.get("device", "cpu"))):
-        out_c = alg_c.update()
-        out_g = alg_g.update()
-    np.testing.assert_allclose(out_g, out_c, rtol=2e-3, atol=1e-5)
-    dc, dg = gp.param_digest(ac_c), gp.param_digest(ac_g)
-    np.testing.assert_allclose(dg[:, :2], dc[:, :2], rtol=2e-4, atol=2e-4)
+        lc = alg_c.update_dagger()
+        lg = alg_g.update_dagger()
+    np.testing.assert_allclose(lg, lc, rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(gp.param_digest(ac_g)[:, :2], gp.param_digest(ac_c)[:, :2], rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.gpu

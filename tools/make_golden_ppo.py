@@ -29,10 +29,67 @@ with contextlib.redirect_stdout(io.StringIO()):
     from rsl_rl.storage import RolloutStorage
 
 out = {}
+# the permutation mini_batch_generator draws (RS:163) and the storage contents at the first update() are recorded next to what
+# the reference computes from them, so that a different implementation (the fused GPU learner) can be fed EXACTLY the reference's
+# inputs and compared with the reference's outputs directly (tests/test_ppo_parity.py, one hop)
+import golden_procedure as gp   # noqa: E402
+
+_real_randperm = torch.randperm
+perms = []
+
+
+def _recording_randperm(n, *a, **kw):
+    p = _real_randperm(n, *a, **kw)
+    perms.append(p.clone())
+    return p
+
+
+captured = {}
+_real_update = PPO.update
+
+
+def _capturing_update(self):
+    if not captured:
+        st = self.storage
+        for name in gp.STORAGE_FIELDS:
+            captured[name] = getattr(st, name).detach().cpu().numpy().copy()
+        captured["params_before"] = gp.flat_params(self.actor_critic)
+    return _real_update(self)
+
+
+torch.randperm = _recording_randperm
+PPO.update = _capturing_update
 with contextlib.redirect_stdout(io.StringIO()):
     res = run_procedure(ActorCritic, PPO, device="cpu")
+PPO.update = _real_update
 for k, v in res.items():
     out[k] = v
+for k, v in captured.items():
+    out["it0_storage_" + k] = v
+out["it0_perm"] = perms[0].numpy()
+
+# bench-shaped minibatch: N = 1024, T = 40 with ONE minibatch per epoch -> 40 960 rows per minibatch call, the shape of the bench's
+# update (4096 envs x 40 steps / 4 minibatches); synthetic storage (golden_procedure.synthetic_storage), 2 epochs
+BN, BT = 1024, 40
+torch.manual_seed(1)
+with contextlib.redirect_stdout(io.StringIO()):
+    ac = ActorCritic(76, 76, 18, **POLICY_KW)
+    kw = dict(ALG_KW, num_mini_batches=1, num_learning_epochs=2)
+    alg = PPO(ac, device="cpu", **kw)
+alg.counter = 3500
+alg.init_storage(BN, BT, [860], [None], [18])
+last = gp.synthetic_storage(alg.storage, 777)
+alg.storage.compute_returns(last, ALG_KW["gamma"], ALG_KW["lam"])
+out["bench_returns"] = alg.storage.returns.numpy().copy()
+out["bench_advantages"] = alg.storage.advantages.numpy().copy()
+perms.clear()
+with contextlib.redirect_stdout(io.StringIO()):
+    stats = alg.update()
+torch.randperm = _real_randperm
+out["bench_perm"] = perms[0].numpy()
+out["bench_stats"] = np.array([float(x) for x in stats])
+out["bench_params"] = gp.flat_params(ac)
+out["bench_std"] = ac.std.detach().numpy().copy()
 # GAE known answer
 rew, val, dones, last = gae_known_answer_inputs()
 st = RolloutStorage(2, 4, [3], [None], [1])
