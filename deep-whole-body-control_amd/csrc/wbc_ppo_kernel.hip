@@ -464,6 +464,32 @@ static float* ppo_wpack_of(float* workspace, int B) {
   return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(wpart + (size_t)PPO_NSPLIT * ng) + 15) & ~(uintptr_t)15);   // float4 loads
 }
 
+// Which workspaces hold CURRENT weight streams: workspace -> (B, the parameter table's first pointer) as left by the last
+// wbc_ppo_minibatch_grad (which packs) / wbc_ppo_clip_adam_packed (which keeps them current). wbc_ppo_minibatch_grad_packed trusts the
+// streams only when its own (workspace, B, params[0]) matches the record; a different B, a reallocated workspace or another parameter
+// set falls back to packing afresh instead of computing gradients against stale weights. (Writes to the parameters by anything but
+// wbc_ppo_clip_adam_packed -- load_state_dict, a broadcast -- must be followed by a plain wbc_ppo_minibatch_grad or wbc_ppo_pack_invalidate.)
+#include <mutex>
+#include <unordered_map>
+struct PackRecord { int B; const void* p0; };
+static std::mutex g_pack_mu;
+static std::unordered_map<const void*, PackRecord> g_pack_records;
+static void pack_record_set(const void* ws, int B, const void* p0) { std::lock_guard<std::mutex> g(g_pack_mu); g_pack_records[ws] = PackRecord{B, p0}; }
+static bool pack_record_ok(const void* ws, int B, const void* p0) {
+  std::lock_guard<std::mutex> g(g_pack_mu);
+  auto it = g_pack_records.find(ws);
+  return it != g_pack_records.end() && it->second.B == B && it->second.p0 == p0;
+}
+static void pack_record_drop_params(const void* p0) {       // a step that moved these parameters without touching the streams
+  std::lock_guard<std::mutex> g(g_pack_mu);
+  for (auto it = g_pack_records.begin(); it != g_pack_records.end();) it = (it->second.p0 == p0) ? g_pack_records.erase(it) : std::next(it);
+}
+extern "C" int wbc_ppo_pack_invalidate(const float* workspace) {
+  std::lock_guard<std::mutex> g(g_pack_mu);
+  if (workspace) g_pack_records.erase(workspace); else g_pack_records.clear();
+  return 0;
+}
+
 static int ppo_minibatch_grad_impl(const void* const* params, const float* obs, const float* actions, const float* old_values,
                                    const float* advantages, const float* returns, const float* old_logp, const float* hist_latent,
                                    const int64_t* idx, int B, float clip, float value_coef, float mixing, float roa_coef,
@@ -487,6 +513,8 @@ static int ppo_minibatch_grad_impl(const void* const* params, const float* obs, 
   PpoBatch Bt{obs, actions, old_values, advantages, returns, old_logp, hist_latent, idx, B, Bs, clip, value_coef, mixing, roa_coef, use_clipped_value_loss};
   const ChainStreams& S = chain_streams();
   const int tiles16 = (B + 15) / 16;
+  if (weights_packed && !pack_record_ok(workspace, B, params[0])) weights_packed = false;     // stale or unknown streams: pack afresh
+  pack_record_set(workspace, B, params[0]);
   if (!weights_packed)
     hipLaunchKernelGGL(chain_pack_kernel, dim3(((S.nelem[0] > S.nelem[1] ? S.nelem[0] : S.nelem[1]) * 64 + 255) / 256, 2), dim3(256), 0, st, P, S, wpack);
   hipLaunchKernelGGL(ppo_chain_kernel, dim3((2 * tiles16 + CH_WG / 64 - 1) / (CH_WG / 64)), dim3(CH_WG), 0, st, wpack, S.base[1], S.nelem[0] * 1024, S.nelem[1] * 1024, Bt,
@@ -526,12 +554,14 @@ extern "C" int wbc_ppo_clip_adam_workspace_floats(void) { return PPO_SQ_PARTS; }
 // The process's scatter table (device memory of the current device; built on first use): where each parameter's copies sit in the
 // chain kernel's weight streams.
 static const int* ppo_scatter_table(hipStream_t st, int nparam) {
-  static int* tab = nullptr;
-  static int tab_dev = -1;
+  // one table per device, built once under a lock and never freed while the process lives (a kernel in flight on another device
+  // may still be reading its table)
+  static std::mutex mu;
+  static int* tabs[64] = {nullptr};
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (tab && tab_dev == dev) return tab;
-  if (tab) { (void)hipFree(tab); tab = nullptr; }           // (the process moved to another device)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> g(mu);
+  if (tabs[dev]) return tabs[dev];
   int* t = nullptr;
   int* clash = nullptr;
   if (hipMalloc(&t, sizeof(int) * 2 * (size_t)nparam) != hipSuccess || hipMalloc(&clash, sizeof(int)) != hipSuccess) return nullptr;
@@ -551,8 +581,8 @@ static const int* ppo_scatter_table(hipStream_t st, int nparam) {
     return nullptr;
   }
   (void)hipFree(clash);
-  tab = t; tab_dev = dev;
-  return tab;
+  tabs[dev] = t;
+  return t;
 }
 
 static int ppo_clip_adam_impl(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm, float beta1,
@@ -582,11 +612,13 @@ static int ppo_clip_adam_impl(const void* const* params, float* grad, float* exp
   }
   float* pack = nullptr;
   const int* tab = nullptr;
-  if (mb_workspace) {
+  if (mb_workspace && pack_record_ok(mb_workspace, B, params[0])) {      // (streams nobody packed for these parameters are not written into)
     if (B <= 0) return -1;
     tab = ppo_scatter_table(st, off);
     if (!tab) return -4;
     pack = ppo_wpack_of(mb_workspace, B);
+  } else {
+    pack_record_drop_params(params[0]);                                  // this step moves the parameters past every stream packed from them
   }
   hipLaunchKernelGGL(ppo_adam_kernel, dim3((off + 255) / 256), dim3(256), 0, st, T, grad, exp_avg, exp_avg_sq, have ? sq_partials : workspace,
                      PPO_SQ_PARTS, max_norm, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, pack, tab);

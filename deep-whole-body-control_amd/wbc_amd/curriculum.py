@@ -48,6 +48,10 @@ def make_curriculum(cfg, update_counter: int) -> abi.WbcCurriculum:
             if val != 0 and name == "base_height" and bool(cfg.terrain.measure_heights):
                 raise NotImplementedError("reward term 'base_height' with terrain.measure_heights = True needs the measured heights inside the fused "
                                           "step (legged_robot.py:845-848); with measure_heights = False (measured_heights = 0, WG:639) it is implemented")
+    if leg.get("feet_air_time", 0) != 0 and arm.get("feet_air_time", 0) != 0:
+        raise NotImplementedError("reward term 'feet_air_time' has a non-zero scale in BOTH rewards.scales and rewards.arm_scales: the reference's "
+                                  "_reward_feet_air_time mutates feet_air_time / last_contacts on every call (legged_robot.py:898-909), so listing it twice "
+                                  "advances that state twice per step; the fused step advances it once -- keep it in one list")
     # the reward-function lists are fixed at construction from the config's non-zero scales (WG:128-157)
     leg_active = {name for name, val in leg.items() if val != 0}
     arm_active = {name for name, val in arm.items() if val != 0}

@@ -75,6 +75,7 @@ def lib():
         L.wbc_policy_pack.argtypes = [c_void, c_void, c_void]
         L.wbc_ppo_minibatch_grad.argtypes = [c_void] * 9 + [c_int] + [C.c_float] * 4 + [c_int, c_void, c_void, c_void, c_void]
         L.wbc_ppo_minibatch_grad_packed.argtypes = L.wbc_ppo_minibatch_grad.argtypes
+        L.wbc_ppo_pack_invalidate.argtypes = [c_void]
         L.wbc_ppo_sq_partials_offset.argtypes = [c_int]
         L.wbc_ppo_sq_partials_offset.restype = C.c_size_t
         L.wbc_ppo_clip_adam.argtypes = [c_void] * 4 + [C.c_float] * 7 + [c_void, c_void, c_void]
@@ -96,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "wbc_sim_set_root_state_indexed", "wbc_sim_set_dof_state_indexed", "wbc_sim_refresh_dof_state",
     "wbc_sim_refresh_root_state", "wbc_sim_refresh_net_contact_force", "wbc_sim_refresh_force_sensor",
     "wbc_sim_refresh_rigid_body_state", "wbc_sim_get_step_counter", "wbc_sim_set_step_counter", "wbc_gae_compute",
-    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_sim_episode_stats", "wbc_rollout_store", "wbc_hist_latent", "wbc_sim_arm_dynamics", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_minibatch_grad_packed", "wbc_ppo_clip_adam", "wbc_ppo_clip_adam_packed", "wbc_ppo_clip_adam_workspace_floats", "wbc_ppo_grad_floats",
+    "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_sim_episode_stats", "wbc_rollout_store", "wbc_hist_latent", "wbc_sim_arm_dynamics", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_minibatch_grad_packed", "wbc_ppo_pack_invalidate", "wbc_ppo_clip_adam", "wbc_ppo_clip_adam_packed", "wbc_ppo_clip_adam_workspace_floats", "wbc_ppo_grad_floats",
     "wbc_ppo_num_splits", "wbc_ppo_workspace_floats", "wbc_ppo_sq_partials_offset", "wbc_hist_train_grad", "wbc_hist_train_grad_floats",
     "wbc_hist_train_workspace_floats", "wbc_hist_clip_adam", "wbc_priv_latent", "wbc_runner_track_episodes", "wbc_sim_episode_stats_track", "wbc_tensor_spec", "wbc_policy_act_job", "wbc_sim_episode_stats_job", "wbc_side_job_run",
     "wbc_runner_track_state_floats"]

@@ -94,6 +94,24 @@ class _EpisodeTracker:
         return dict(mean_reward=float(m[0]), mean_arm_reward=float(m[1]), mean_episode_length=float(m[2]), dones=float(d))
 
 
+def _plain(x, where):
+    """`x` as something torch.load(weights_only=True) reads back: tensors, None, bool / int / float / str, and lists / tuples / dicts
+    of those; numpy scalars and arrays are converted (to Python numbers / tensors); anything else is an error naming its place."""
+    import numpy as _np
+    if x is None or isinstance(x, (bool, int, float, str)) or torch.is_tensor(x):
+        return x
+    if isinstance(x, _np.generic):
+        return x.item()
+    if isinstance(x, _np.ndarray):
+        return torch.from_numpy(_np.ascontiguousarray(x))
+    if isinstance(x, dict):
+        return {str(k): _plain(v, f"{where}[{k!r}]") for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v, f"{where}[{i}]") for i, v in enumerate(x)]
+    raise TypeError(f"OnPolicyRunner.save: {where} is a {type(x).__name__}; a checkpoint holds tensors, numbers, strings and lists / dicts of them "
+                    "(OnPolicyRunner.load reads it with weights_only=True)")
+
+
 class OnPolicyRunner:
     def __init__(self, env: VecEnv, train_cfg, log_dir=None, device="cpu", dist_group=None):
         self.cfg, self.alg_cfg, self.policy_cfg = train_cfg["runner"], train_cfg["algorithm"], train_cfg["policy"]
@@ -299,10 +317,11 @@ class OnPolicyRunner:
         states, and -- with save_env_state -- every device tensor of the sim (64 MB at 4096 envs), so that a resumed run
         continues the same trajectories."""
         env = self.env
+        infos = _plain(infos, "infos")          # load() reads with weights_only=True: what it could not read back is refused here, not at resume time
         extra = {"hist_encoder_optimizer_state_dict": self.alg.hist_encoder_optimizer.state_dict(),
-                 "ppo_counter": self.alg.counter,
-                 "env_update_counter": getattr(env, "update_counter", 0),
-                 "env_common_step_counter": getattr(env, "common_step_counter", 0),
+                 "ppo_counter": int(self.alg.counter),
+                 "env_update_counter": int(getattr(env, "update_counter", 0)),
+                 "env_common_step_counter": int(getattr(env, "common_step_counter", 0)),
                  "torch_rng_state": torch.get_rng_state()}
         sim = getattr(env, "sim", None)
         if sim is not None and hasattr(sim, "step_counter"):
@@ -316,7 +335,7 @@ class OnPolicyRunner:
         torch.save({
             "model_state_dict": self.alg.actor_critic.state_dict(),
             "optimizer_state_dict": self.alg.optimizer.state_dict(),
-            "iter": self.current_learning_iteration,
+            "iter": int(self.current_learning_iteration),
             "infos": infos,
             "wbc_extra": extra,
         }, path)

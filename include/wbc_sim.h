@@ -408,13 +408,17 @@ int wbc_ppo_minibatch_grad(const void* const* params, const float* obs, const fl
                            int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream);
 /* The same call without its weight-pack launch (5.9 us + a launch gap of every minibatch): valid while `workspace` still holds the
  * weight streams that a wbc_ppo_minibatch_grad call for the same B packed into it and every change of the parameters since then
- * was a wbc_ppo_clip_adam_packed(..., workspace, B) step (which keeps the streams current). Anything else that writes the
- * parameters (another optimiser, a checkpoint load, a broadcast) -> call wbc_ppo_minibatch_grad once again. */
+ * was a wbc_ppo_clip_adam_packed(..., workspace, B) step (which keeps the streams current). The library keeps a record per workspace
+ * (B, params[0]) of which streams are current: a call whose (workspace, B, params[0]) does not match it -- a different B, a
+ * reallocated workspace, another parameter set, a plain wbc_ppo_clip_adam step in between -- packs afresh instead of computing
+ * gradients against stale weights. What the library cannot see is a write to the parameters by other code (a checkpoint load, a
+ * broadcast): follow it with wbc_ppo_minibatch_grad (or wbc_ppo_pack_invalidate(workspace); NULL drops every record). */
 int wbc_ppo_minibatch_grad_packed(const void* const* params, const float* obs, const float* actions,
                                   const float* old_values, const float* advantages, const float* returns,
                                   const float* old_logp, const float* hist_latent, const int64_t* idx, int B,
                                   float clip, float value_coef, float mixing, float roa_coef,
                                   int use_clipped_value_loss, float* workspace, float* grad, float* loss_accum, void* stream);
+int wbc_ppo_pack_invalidate(const float* workspace);
 size_t wbc_ppo_sq_partials_offset(int B);
 /* nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (ppo.py:243-246) for the 33 parameters of
  * `params`, reading their gradients from grad[0 : wbc_ppo_grad_floats()-3] (scaled in place by the clip factor);
@@ -430,7 +434,8 @@ int wbc_ppo_clip_adam(const void* const* params, float* grad, float* exp_avg, fl
                       float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
                       const float* sq_partials, float* workspace, void* stream);
 /* wbc_ppo_clip_adam, and every updated parameter is also written to its copies in the weight streams inside `mb_workspace` (the
- * wbc_ppo_minibatch_grad workspace for B rows): see wbc_ppo_minibatch_grad_packed. -4: the scatter table could not be built. */
+ * wbc_ppo_minibatch_grad workspace for B rows): see wbc_ppo_minibatch_grad_packed. A workspace whose streams were not packed from
+ * these parameters for this B is left alone (the step is then a plain wbc_ppo_clip_adam). -4: the scatter table could not be built. */
 int wbc_ppo_clip_adam_packed(const void* const* params, float* grad, float* exp_avg, float* exp_avg_sq, float max_norm,
                              float beta1, float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
                              const float* sq_partials, float* workspace, float* mb_workspace, int B, void* stream);

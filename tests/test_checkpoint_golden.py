@@ -109,6 +109,16 @@ def test_save_load_roundtrip_restores_what_the_reference_forgets(tmp_path):
     assert len(h1) == len(h2) == 8
     for k in h1:
         assert torch.equal(h1[k]["exp_avg"], h2[k]["exp_avg"])
+    # a non-None infos round-trips through the weights_only load: numpy scalars / arrays are converted on save, anything that
+    # could not be read back is refused at save time, not discovered at resume time
+    r1.env.update_counter = np.int64(3)
+    r1.save(path, infos={"note": "x", "best": np.float32(1.5), "curve": np.arange(3.0), "nested": {"k": [1, np.int64(2)]}})
+    r3 = _runner("cpu")
+    r3.load(path)
+    inf = torch.load(path, map_location="cpu", weights_only=True)["infos"]
+    assert inf["note"] == "x" and inf["best"] == 1.5 and inf["nested"]["k"] == [1, 2] and torch.equal(inf["curve"], torch.arange(3.0, dtype=torch.float64))
+    with pytest.raises(TypeError, match="infos"):
+        r1.save(path, infos={"env": r1.env})
 
 
 @pytest.mark.gpu

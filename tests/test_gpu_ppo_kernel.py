@@ -222,3 +222,44 @@ def test_adam_keeps_the_weight_streams_current(B):
         assert torch.equal(a, b)
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+def test_packed_call_with_stale_streams_packs_afresh():
+    """wbc_ppo_minibatch_grad_packed trusts the weight streams of a workspace only while the library's record (workspace, B,
+    params[0]) says they are current: after a plain wbc_ppo_clip_adam step (which moves the parameters without touching the
+    streams), on a workspace nobody packed, or for another parameter set, it packs afresh -- the gradients equal those of
+    wbc_ppo_minibatch_grad bit for bit instead of being computed against stale weights."""
+    import copy
+    from wbc_amd.native import check, lib
+    L = lib()
+    B, dev = 1024, "cuda"
+    torch.manual_seed(0)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
+    TN = 2 * B
+    obs = torch.randn(TN, 860, device=dev); actions = torch.randn(TN, 18, device=dev); values = torch.randn(TN, 2, device=dev)
+    adv = torch.randn(TN, 2, device=dev); ret = torch.randn(TN, 2, device=dev); logp = -torch.rand(TN, 2, device=dev) * 20
+    hist = torch.randn(TN, 20, device=dev)
+    idx = torch.randperm(TN, device=dev).contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    ng = L.wbc_ppo_grad_floats()
+    nparam = sum(p.numel() for p in ac.fused_params())
+
+    def grad_of(f, model, ws, k):
+        g = torch.zeros(ng, device=dev)
+        check(f(model.fused_param_table(), obs.data_ptr(), actions.data_ptr(), values.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp.data_ptr(), hist.data_ptr(),
+                idx[k * B:(k + 1) * B].data_ptr(), B, 0.2, 1.0, 0.5, 0.1, 1, ws.data_ptr(), g.data_ptr(), None, stream), "grad")
+        torch.cuda.synchronize()
+        return g
+    ws = torch.zeros(L.wbc_ppo_workspace_floats(B), device=dev)
+    grad_of(L.wbc_ppo_minibatch_grad, ac, ws, 0)                               # packs; the record says current
+    g = torch.randn(ng, device=dev) * 1e-2
+    m = torch.zeros(nparam, device=dev); v = torch.zeros(nparam, device=dev)
+    aws = torch.empty(int(L.wbc_ppo_clip_adam_workspace_floats()), device=dev)
+    check(L.wbc_ppo_clip_adam(ac.fused_param_table(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1.0, 0.9, 0.999, 1e-8, 1e-2, 0.03, 1.0, None, aws.data_ptr(), stream), "adam")
+    want = grad_of(L.wbc_ppo_minibatch_grad, copy.deepcopy(ac), torch.zeros_like(ws), 1)
+    got = grad_of(L.wbc_ppo_minibatch_grad_packed, ac, ws, 1)                   # streams are one Adam step behind: must not be used
+    assert torch.equal(got, want)
+    got = grad_of(L.wbc_ppo_minibatch_grad_packed, ac, torch.zeros_like(ws), 1)  # a workspace nobody packed
+    assert torch.equal(got, want)
+    check(L.wbc_ppo_pack_invalidate(ws.data_ptr()), "invalidate")
+    assert torch.equal(grad_of(L.wbc_ppo_minibatch_grad_packed, ac, ws, 1), want)
