@@ -6,6 +6,7 @@
 #include "../../include/wbc_sim.h"
 
 #define WBC_NCHAIN 5
+#define WBC_REACH_STEP 0.04f
 
 // Everything the kernels read that is constant over a launch, resident in HBM and read through
 // the scalar/constant path (uniform indices) or L1 (lane-dependent indices).
@@ -28,7 +29,16 @@ struct DevConst {
   uint64_t out_cp2_mask[32];                       // ... and those it receives with the opposite sign (partner of a pair)
   uint64_t body_cp_mask[WBC_NB + 1];               // the same two sets per moving body (the sweeps' wrench gather); entry
   uint64_t body_cp2_mask[WBC_NB + 1];              // WBC_BOX_BODY is the free box actor
-  uint64_t box_corner_mask, box_pair_mask;         // the box's corner contacts; the robot spheres against the box
+  uint64_t box_corner_mask, box_pair_mask;         // the box's corner contacts; the robot spheres against the box (static pairs + its dynamic slots)
+  // self-collision broad phase (wbc_model pr_*): lanes whose descriptor is a candidate limb pair / a candidate robot sphere against
+  // the free box; the dynamic slots their hits are promoted into (outside / inside the box row)
+  uint64_t cand_self_mask, cand_box_mask, dyn_self_mask, dyn_box_mask;
+  // per lane: kind (2 bits) | this lane's own sphere, 31 = none (5) | sphere indices a0, a1, b0, b1 of the descriptor's two bounding
+  // centres (4 x 5) | where the second centre comes from: 0 the spheres b0, b1; 1 the static pair's box centre cp_a (a box on the root
+  // body: frame F); 2 the free box's centre (2 bits) | bounding reach in units of WBC_REACH_STEP, minus one (3 bits)
+  uint32_t pr_pack[WBC_NCP];
+  float trunk_c[3], trunk_h[3];                    // the static pairs' box on the root body (the trunk): centre and half extents, frame F
+  int32_t sph_slot[WBC_NSPH];                      // the terrain slot of each robot sphere
   uint32_t body_pack[WBC_NB];                      // axis | dof << 2
   // heightfield (optional)
   const int16_t* hf;

@@ -118,17 +118,28 @@ static int build_chains(DevConst& hc) {
   for (int i = 0; i <= WBC_NB; ++i) hc.body_cp_mask[i] = hc.body_cp2_mask[i] = 0;
   for (int f = 0; f < WBC_NFEET; ++f) hc.foot_cp[f] = hc.foot_cp2[f] = -1;
   hc.box_corner_mask = hc.box_pair_mask = 0;
+  hc.cand_self_mask = hc.cand_box_mask = hc.dyn_self_mask = hc.dyn_box_mask = 0;
+  for (int i = 0; i < WBC_NSPH; ++i) hc.sph_slot[i] = -1;
   for (int k = 0; k < m.ncp; ++k) {
     const int b = m.cp_body[k], kind = m.cp_kind[k];
     const uint64_t bit = 1ull << k;
     if (kind == WBC_CP_NONE) continue;                          // unused slot
+    if (kind == WBC_CP_DYNAMIC) {                               // a free slot of the dynamic pool: the box row's belong to the free box
+      if (k >= 32 && k <= 47) { hc.dyn_box_mask |= bit; hc.box_pair_mask |= bit; } else hc.dyn_self_mask |= bit;
+      continue;
+    }
     if (b == WBC_BOX_BODY) hc.box_corner_mask |= bit;
     if (kind != WBC_CP_TERRAIN && m.cp_body2[k] == WBC_BOX_BODY) hc.box_pair_mask |= bit;
     // layout rule of the step kernel: the contacts that involve the free box fill the 16-lane row 32..47, and only they do
     if (((hc.box_corner_mask | hc.box_pair_mask) & bit) != 0 ? (k < 32 || k > 47) : (k >= 32 && k <= 47)) return -2;
     if (b < 0 || b > WBC_NB || m.cp_rb[k] < 0 || m.cp_rb[k] >= WBC_NRB_ENV) return -1;
     if ((b == WBC_BOX_BODY) != (m.cp_rb[k] == WBC_BOX_RB)) return -1;
-    if (kind != WBC_CP_TERRAIN && kind != WBC_CP_BOX && kind != WBC_CP_CAPSULE) return -1;
+    if (kind != WBC_CP_TERRAIN && kind != WBC_CP_BOX) return -1;
+    if (kind == WBC_CP_TERRAIN && b != WBC_BOX_BODY) {          // a robot sphere: its centre is cached under its compact index
+      const int si = m.cp_sph[k];
+      if (si < 0 || si >= WBC_NSPH || hc.sph_slot[si] >= 0) return -1;
+      hc.sph_slot[si] = k;
+    }
     int depth = b == WBC_BOX_BODY ? 0 : hc.body_depth[b];       // the box is not part of the tree: its contacts need no sweep level
     hc.body_cp_mask[b] |= bit;
     hc.out_cp_mask[m.cp_rb[k]] |= bit;
@@ -136,7 +147,7 @@ static int build_chains(DevConst& hc) {
       const int b2 = m.cp_body2[k];
       if (b2 < 0 || b2 > WBC_NB || b2 == b || m.cp_rb2[k] < 0 || m.cp_rb2[k] >= WBC_NRB_ENV) return -1;
       if ((b2 == WBC_BOX_BODY) != (m.cp_rb2[k] == WBC_BOX_RB)) return -1;
-      if (b2 == WBC_BOX_BODY && kind != WBC_CP_BOX) return -1;
+      if (b2 != WBC_BOX_BODY && b2 != 0) return -1;             // a static box rides on the root body (its centre cp_a is in frame F) or is the free box
       if (b2 != WBC_BOX_BODY) depth = hc.body_depth[b2] > depth ? hc.body_depth[b2] : depth;
       hc.body_cp2_mask[b2] |= bit;
       hc.out_cp2_mask[m.cp_rb2[k]] |= bit;
@@ -153,6 +164,53 @@ static int build_chains(DevConst& hc) {
     hc.depth_cp_mask[depth] |= bit;
   }
   for (int f = 0; f < WBC_NFEET; ++f) if (hc.foot_cp[f] < 0) return -1;
+  // pair descriptors: every lane tests one in the broad phase
+  if (m.nlimb < 0 || m.nlimb > WBC_NLIMB) return -1;
+  for (int l = 0; l < m.nlimb; ++l) {
+    const int s0 = m.limb_s0[l], s1 = m.limb_s1[l];
+    if (s0 < 0 || s0 >= WBC_NSPH || s1 < 0 || s1 >= WBC_NSPH || hc.sph_slot[s0] < 0 || hc.sph_slot[s1] < 0) return -1;
+    if (m.limb_body[l] < 1 || m.limb_body[l] >= WBC_NB) return -1;
+    const int rbs[3] = {m.limb_rb[l], m.limb_rb0[l], m.limb_rb1[l]};
+    for (int r = 0; r < 3; ++r) if (rbs[r] < 0 || rbs[r] >= WBC_NRB) return -1;
+  }
+  bool have_trunk = false;
+  for (int j = 0; j < 3; ++j) hc.trunk_c[j] = hc.trunk_h[j] = 0.f;
+  for (int k = 0; k < WBC_NCP; ++k) {
+    const int pk = m.pr_kind[k], own = (k < m.ncp && m.cp_kind[k] == WBC_CP_TERRAIN && m.cp_body[k] != WBC_BOX_BODY) ? m.cp_sph[k] : 31;
+    uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, bsel = 0;
+    const uint64_t bit = 1ull << k;
+    if (pk == WBC_PR_LIMBS) {
+      const int la = m.pr_a[k], lb = m.pr_b[k];
+      if (la < 0 || la >= m.nlimb || lb < 0 || lb >= m.nlimb || m.limb_body[la] == m.limb_body[lb]) return -1;
+      a0 = m.limb_s0[la]; a1 = m.limb_s1[la]; b0 = m.limb_s0[lb]; b1 = m.limb_s1[lb];
+      hc.cand_self_mask |= bit;
+    } else if (pk == WBC_PR_SPHERE_BOX) {
+      if (m.pr_a[k] < 0 || m.pr_a[k] >= WBC_NSPH || hc.sph_slot[m.pr_a[k]] < 0) return -1;
+      a0 = a1 = m.pr_a[k]; bsel = 2;
+      hc.cand_box_mask |= bit;
+    } else if (pk == WBC_PR_STATIC) {
+      if (k >= m.ncp || m.cp_kind[k] != WBC_CP_BOX || m.pr_a[k] < 0 || m.pr_a[k] >= WBC_NSPH || hc.sph_slot[m.pr_a[k]] < 0) return -1;
+      const int ss = hc.sph_slot[m.pr_a[k]];                   // the pair's sphere must be that robot sphere
+      if (m.cp_body[ss] != m.cp_body[k] || m.cp_rb[ss] != m.cp_rb[k]) return -1;
+      a0 = a1 = m.pr_a[k]; bsel = m.cp_body2[k] == WBC_BOX_BODY ? 2 : 1;
+      if (bsel == 1) {                                         // the box on the root body: one box for all such pairs (the trunk)
+        for (int j = 0; j < 3; ++j) {
+          if (have_trunk && (hc.trunk_c[j] != m.cp_a[k][j] || hc.trunk_h[j] != m.cp_b[k][j])) return -1;
+          hc.trunk_c[j] = m.cp_a[k][j]; hc.trunk_h[j] = m.cp_b[k][j];
+        }
+        have_trunk = true;
+      } else for (int j = 0; j < 3; ++j) if (m.cp_a[k][j] != 0.f || m.cp_b[k][j] != m.box_half) return -1;
+    } else if (pk != WBC_PR_NONE) return -1;
+    if (k < m.ncp && m.cp_kind[k] == WBC_CP_BOX && pk != WBC_PR_STATIC) return -1;
+    uint32_t rcode = 0;
+    if (pk != WBC_PR_NONE) {
+      const float q = m.pr_reach[k] / WBC_REACH_STEP;
+      const int code = (int)(q + 0.5f);
+      if (code < 1 || code > 8 || fabsf(q - (float)code) > 1e-3f) return -1;       // pr_reach is a multiple of WBC_REACH_STEP (abi.quantise_reach)
+      rcode = (uint32_t)(code - 1);
+    }
+    hc.pr_pack[k] = (uint32_t)pk | (uint32_t)own << 2 | a0 << 7 | a1 << 12 | b0 << 17 | b1 << 22 | bsel << 27 | rcode << 29;
+  }
   static_assert(WBC_NB <= 31 && WBC_NDOF <= 32 && WBC_MAX_DEPTH * 5 <= 32, "bit packing of the chain tables");
   for (int c = 0; c <= WBC_NCHAIN; ++c) {
     uint32_t pb = 0, pd = 0, pa = 0;

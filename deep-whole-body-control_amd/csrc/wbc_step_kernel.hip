@@ -100,6 +100,7 @@ struct __align__(16) Smem {
     struct {                     // contact iterations: K of the bodies 1.. is dead once every active contact has built its Delassus
       float K0[36];              // block (the sweeps only apply the root's K), so the per-contact data of the iterations lives there:
       float clam[WBC_NCP][3];    // the impulse, gathered per body by other lanes
+      float cxc[WBC_NCP][3];     // the contact point (frame F)
     } ctc;
   };
   float E[WBC_NB][9];
@@ -124,9 +125,13 @@ struct __align__(16) Smem {
 #ifdef WBC_STEP_TIMING
   int dbg_ncon;                  // timing builds: active contacts | deepest active level << 8 of the last substep
 #endif
-  // contacts (one per lane): only what OTHER lanes read lives here -- the contact point (the impulse: ctc.clam).
-  // Normal, free velocity and velocity target stay in the owning lane's registers; the set of active contacts is a wavefront ballot.
-  float cxc[WBC_NCP][3];
+  // contacts (one per lane): what OTHER lanes read -- the contact point and the impulse -- lives in ctc; normal, free velocity and
+  // velocity target stay in the owning lane's registers; the set of active contacts is a wavefront ballot.
+  // Centres of the robot's contact spheres in frame F, cached once per substep by the terrain lanes: the broad phase of every pair
+  // descriptor (static pairs and the self-collision candidates) and the exact tests of the promoted ones read them.
+  float sph[WBC_NSPH][3];
+  uint32_t k_prk[WBC_NCP];       // DevConst::pr_pack: every lane's pair descriptor
+  int dyn_dirty;                 // the per-body contact masks below carry bits of dynamic slots (restored before they are used again)
   float goal[24], cmd[3], blv[3], bav[3];
   float act_last[WBC_NACT];      // newest (undelayed) action, sim order
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
@@ -284,6 +289,82 @@ __device__ __forceinline__ void joint_pre_pass(Smem& s, CP C) {
     s.viol[j] = viol;
     s.limd[j] = (qdv * viol > 0.f) ? qdv : 0.f;
   }
+}
+
+// Closest points of two segments (oracle: seg_seg_closest; Ericson 5.1.9): a segment shorter than 1e-5 m counts as a point.
+__device__ __forceinline__ void seg_seg_closest(f3 a0, f3 a1, f3 b0, f3 b1, f3* pa, f3* pb) {
+  const f3 d1 = a1 - a0, d2 = b1 - b0, r = a0 - b0;
+  const float EPS = 1e-10f;
+  const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+  float sp = 0.f, tp = 0.f;
+  if (a <= EPS && e <= EPS) { sp = tp = 0.f; }
+  else if (a <= EPS) { tp = clampf(f / e, 0.f, 1.f); }
+  else {
+    const float c = dot(d1, r);
+    if (e <= EPS) { sp = clampf(-c / a, 0.f, 1.f); }
+    else {
+      const float b = dot(d1, d2), den = a * e - b * b;
+      sp = den > 1e-7f * a * e ? clampf((b * f - c * e) / den, 0.f, 1.f) : 0.f;
+      tp = (b * sp + f) / e;
+      if (tp < 0.f) { tp = 0.f; sp = clampf(-c / a, 0.f, 1.f); }
+      else if (tp > 1.f) { tp = 1.f; sp = clampf((b - c) / a, 0.f, 1.f); }
+    }
+  }
+  *pa = a0 + d1 * sp; *pb = b0 + d2 * tp;
+}
+// Limb A against limb B (oracle: limb_pair): unions of a capsule and up to two end spheres; the feature pair with the smallest gap wins,
+// in the oracle's order (shafts; A's end spheres against B's shaft; B's against A's shaft; end sphere against end sphere; a tie keeps
+// the earlier). ck = the candidate's packed descriptor (sphere indices of the four ends), la / lb = its limbs. Runs on the few lanes a
+// candidate was promoted into, but a launch ends with its slowest wave: one general segment-segment test, then point-segment and
+// point-point tests (a fifth of nine general ones); operands are (re)read where they are used -- LDS sphere centres, constant-block
+// radii -- so that nothing of it is live outside (the kernel is compiled for 128 VGPRs).
+struct LimbHit { float gap, ra, rb; f3 n, q; int fa, fb; };
+__device__ __forceinline__ f3 closest_on_segment(f3 p, f3 b0, f3 b1) {
+  const f3 d = b1 - b0;
+  const float e = dot(d, d);
+  const float t = e <= 1e-10f ? 0.f : clampf(dot(p - b0, d) / e, 0.f, 1.f);
+  return b0 + d * t;
+}
+__device__ void limb_pair(const Smem& s, CP Cc, uint32_t ck, int la, int lb, LimbHit& out) {
+  const float rest = Cc->model.pair_rest_offset;
+  const float ra = Cc->model.limb_radius[la], rb = Cc->model.limb_radius[lb];
+  f3 bpa, bpb;
+  seg_seg_closest(ld3(s.sph[(ck >> 7) & 31]), ld3(s.sph[(ck >> 12) & 31]), ld3(s.sph[(ck >> 17) & 31]), ld3(s.sph[(ck >> 22) & 31]), &bpa, &bpb);
+  float best;
+  {
+    const f3 d = bpa - bpb;
+    best = __builtin_amdgcn_sqrtf(dot(d, d)) - ra - rb - rest;
+  }
+  out.fa = out.fb = 0; out.ra = ra; out.rb = rb;
+#pragma unroll 1
+  for (int f = 1; f < 9; ++f) {
+    int ff = f;
+    asm volatile("" : "+v"(ff));                    // (keeps the loop's loads inside the loop)
+    const int ea = ff <= 2 ? ff - 1 : (ff <= 4 ? -1 : (ff - 5) >> 1);
+    const int eb = ff <= 2 ? -1 : (ff <= 4 ? ff - 3 : (ff - 5) & 1);
+    const float fra = ea < 0 ? ra : (ea == 0 ? Cc->model.limb_cap0[la] : Cc->model.limb_cap1[la]);
+    const float frb = eb < 0 ? rb : (eb == 0 ? Cc->model.limb_cap0[lb] : Cc->model.limb_cap1[lb]);
+    if (!(fra > 0.f) || !(frb > 0.f)) continue;     // (no such end sphere)
+    f3 pa, pb;
+    if (ea >= 0) {
+      pa = ld3(s.sph[(ck >> (ea == 0 ? 7 : 12)) & 31]);
+      pb = eb >= 0 ? ld3(s.sph[(ck >> (eb == 0 ? 17 : 22)) & 31]) : closest_on_segment(pa, ld3(s.sph[(ck >> 17) & 31]), ld3(s.sph[(ck >> 22) & 31]));
+    } else {
+      pb = ld3(s.sph[(ck >> (eb == 0 ? 17 : 22)) & 31]);
+      pa = closest_on_segment(pb, ld3(s.sph[(ck >> 7) & 31]), ld3(s.sph[(ck >> 12) & 31]));
+    }
+    const f3 d = pa - pb;
+    const float g = __builtin_amdgcn_sqrtf(dot(d, d)) - fra - frb - rest;
+    if (g < best) {
+      best = g; bpa = pa; bpb = pb;
+      out.fa = ea + 1; out.fb = eb + 1; out.ra = fra; out.rb = frb;
+    }
+  }
+  const f3 d = bpa - bpb;
+  const float dist = __builtin_amdgcn_sqrtf(dot(d, d));
+  out.n = dist > 1e-9f ? d * (1.f / dist) : mk3(1.f, 0.f, 0.f);
+  out.q = bpb + out.n * out.rb;
+  out.gap = best;
 }
 
 // One physics substep on the LDS-resident state (oracle: physics_substep).
@@ -520,23 +601,12 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   // 64-bit addresses once before the substep loop and keeps ~10 of them alive in VGPR pairs across it -- spilled to scratch)
   CP Cc = C;
   asm volatile("" : "+s"(Cc));
-  int cpb = 0, cpkind = -1;
-  float cpp[3] = {0.f, 0.f, 0.f}, cpr = 0.f;
-  if (lane < Cc->model.ncp) {
-    cpb = Cc->model.cp_body[lane];
-    cpkind = Cc->model.cp_kind[lane];
+  int cpb = Cc->model.cp_body[lane], cpkind = Cc->model.cp_kind[lane];        // (WBC_NCP = 64: every lane has a slot)
+  float cpp[3], cpr = Cc->model.cp_radius[lane];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) cpp[j] = Cc->model.cp_pos[lane][j];
-    cpr = Cc->model.cp_radius[lane];
-  }
+  for (int j = 0; j < 3; ++j) cpp[j] = Cc->model.cp_pos[lane][j];
   int cpb2 = -1;                                                         // the partner of a pair; -1 for terrain contacts
-  float cpa[3] = {0.f, 0.f, 0.f}, cpe[3] = {0.f, 0.f, 0.f}, cpr2 = 0.f;
-  if (cpkind > WBC_CP_TERRAIN) {
-    cpb2 = Cc->model.cp_body2[lane];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { cpa[j] = Cc->model.cp_a[lane][j]; cpe[j] = Cc->model.cp_b[lane][j]; }
-    cpr2 = Cc->model.cp_radius2[lane];
-  }
+  if (cpkind == WBC_CP_BOX) cpb2 = Cc->model.cp_body2[lane];
   // pass 3 and inverse articulated inertias, outward: the parent's K entries (K3) and acceleration component (apr)
   // travel down the chain in registers; one LDS hand-over per level (g = K_p U / D and the terms of U.(a_p + c)).
   {
@@ -581,18 +651,21 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   }
   WSYNC();
   STAMP(6);
-  // contacts: one contact per lane (spheres against the terrain -- the robot's, then the free box's corners -- then the pairs: a
-  // sphere against a box or a capsule riding on another body of the robot, or against the free box). Narrow phase first; only
-  // lanes with an ACTIVE contact build a Delassus block.
-  const bool onbox = cpb == WBC_BOX_BODY, p2box = cpb2 == WBC_BOX_BODY;
-  const float* Eb = onbox ? s.bxE : s.E[onbox ? 0 : cpb];
-  const float* pb = onbox ? s.bxc : s.pos[onbox ? 0 : cpb];
-  const float* E2 = p2box ? s.bxE : s.E[cpb2 < 0 || p2box ? 0 : cpb2];
-  const float* p2 = p2box ? s.bxc : s.pos[cpb2 < 0 || p2box ? 0 : cpb2];
+  // contacts: one contact per lane. (1) spheres against the terrain (the robot's, the free box's corners); the robot spheres' centres
+  // are cached. (2) broad phase: EVERY lane tests its pair descriptor against bounding spheres in the same instructions -- a static
+  // pair lane its own pair (arm vs trunk box, robot spheres vs the free box), every other lane a candidate of the self-collision set
+  // (limb vs limb; more robot spheres vs the free box). (3) candidates that pass are promoted into free dynamic slots (rare). (4) exact
+  // tests on the lanes that need them. Only lanes with an ACTIVE contact build a Delassus block.
+  bool onbox = cpb == WBC_BOX_BODY;
   f3 cn = mk3(0.f, 0.f, 1.f), cxcr = mk3(0.f, 0.f, 0.f);
   float cgap = 1e30f;
+  const uint32_t prk = s.k_prk[lane];                                   // this lane's pair descriptor (DevConst::pr_pack)
   if (cpkind == WBC_CP_TERRAIN) {
+    const float* Eb = onbox ? s.bxE : s.E[onbox ? 0 : cpb];
+    const float* pb = onbox ? s.bxc : s.pos[onbox ? 0 : cpb];
     const f3 xk = ld3(pb) + mat_mul(Eb, mk3(cpp[0], cpp[1], cpp[2]));
+    const int own = (prk >> 2) & 31;
+    if (own < WBC_NSPH) st3(s.sph[own], xk);
     const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
     float h; f3 nw;
     terrain_query(C, Xw.x, Xw.y, &h, &nw);
@@ -600,28 +673,89 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     cn = matT_mul(s.R, nw);
     cxcr = xk - cn * cpr;
   }
-  // pairs. Broad phase: the sphere against the partner's bounding sphere, generous by 1 mm -- a pair it rejects has
-  // a gap far above the contact margin, so the exact test below (box / capsule closest point, square roots, divisions) could not
-  // have found it active either; with the arm carried above the trunk and the box out of reach, as they mostly are, no lane gets
-  // past it and the wavefront skips the exact tests altogether.
-  f3 spl = mk3(0.f, 0.f, 0.f);
-  bool snear = false;
-  if (cpkind > WBC_CP_TERRAIN) {
-    const f3 xk = ld3(pb) + mat_mul(Eb, mk3(cpp[0], cpp[1], cpp[2]));
-    spl = matT_mul(E2, xk - ld3(p2));                                    // sphere centre in the partner's frame
-    const f3 A = mk3(cpa[0], cpa[1], cpa[2]), B = mk3(cpe[0], cpe[1], cpe[2]);
-    const bool box = cpkind == WBC_CP_BOX;
-    const f3 ctr = box ? A : (A + B) * 0.5f, ext = box ? B : (B - A) * 0.5f;
-    const float reach = __builtin_amdgcn_sqrtf(dot(ext, ext)) + cpr + cpr2 + C->cfg.contact_margin + 1e-3f;
-    const f3 dc = spl - ctr;
-    snear = dot(dc, dc) < reach * reach;
+  WSYNC();
+  // (2) broad phase: |centre A - centre B|^2 < (reach + margin + 1 mm)^2, centres = midpoints of two cached spheres (a sphere: twice the
+  // same), the static pair's box centre (a box on the root body: frame F) or the free box's centre. A pair it rejects has a gap far above
+  // the contact margin, so the exact test could not have found it active either.
+  bool near = false;
+  {
+    const int pk = prk & 3;
+    const f3 ca = (ld3(s.sph[(prk >> 7) & 31]) + ld3(s.sph[(prk >> 12) & 31])) * 0.5f;
+    const f3 cbl = (ld3(s.sph[(prk >> 17) & 31]) + ld3(s.sph[(prk >> 22) & 31])) * 0.5f;
+    const int bsel = (prk >> 27) & 3;
+    const f3 cb = bsel == 0 ? cbl : (bsel == 1 ? mk3(C->trunk_c[0], C->trunk_c[1], C->trunk_c[2]) : ld3(s.bxc));
+    const float reach = (float)((prk >> 29) + 1u) * WBC_REACH_STEP + C->cfg.contact_margin + 1e-3f;
+    const f3 dc = ca - cb;
+    near = pk != WBC_PR_NONE && dot(dc, dc) < reach * reach;
+    // second stage for the limb pairs that pass (two legs standing side by side always do): the two shafts' segments against a generous
+    // common radius -- one segment-segment distance on those lanes instead of a promotion and nine feature pairs every substep
+    const bool limbs = near && pk == WBC_PR_LIMBS;
+    if (__ballot(limbs) != 0ull && limbs) {
+      f3 pa, pb;
+      seg_seg_closest(ld3(s.sph[(prk >> 7) & 31]), ld3(s.sph[(prk >> 12) & 31]), ld3(s.sph[(prk >> 17) & 31]), ld3(s.sph[(prk >> 22) & 31]), &pa, &pb);
+      const f3 dd = pa - pb;
+      const float r2 = WBC_LIMB_RSUM_MAX + Cc->model.pair_rest_offset + C->cfg.contact_margin + 1e-3f;
+      near = dot(dd, dd) < r2 * r2;
+    }
   }
-  if (__ballot(snear) != 0ull && snear) {
-    const f3 pl = spl;
-    const f3 A = mk3(cpa[0], cpa[1], cpa[2]), B = mk3(cpe[0], cpe[1], cpe[2]);
-    f3 ql, nl;
-    float dist;
-    if (cpkind == WBC_CP_BOX) {                                          // box: centre A, half extents B
+  const uint64_t nearbits = __ballot(near);
+  // (3) promotion: hits of the candidate lanes into the free dynamic slots, ascending lane -> ascending slot (robot-vs-robot hits outside
+  // the box row, robot-vs-box hits inside it); hits beyond the free slots are dropped. Wave-uniform loops over the few set bits.
+  int cand = -1;
+  {
+    uint64_t h = nearbits & Cc->cand_self_mask, pool = Cc->dyn_self_mask;
+    while (h != 0ull && pool != 0ull) {
+      const int c = __ffsll((unsigned long long)h) - 1, d = __ffsll((unsigned long long)pool) - 1;
+      h &= h - 1; pool &= pool - 1;
+      cand = (lane == d) ? c : cand;
+    }
+    h = nearbits & Cc->cand_box_mask; pool = Cc->dyn_box_mask;
+    while (h != 0ull && pool != 0ull) {
+      const int c = __ffsll((unsigned long long)h) - 1, d = __ffsll((unsigned long long)pool) - 1;
+      h &= h - 1; pool &= pool - 1;
+      cand = (lane == d) ? c : cand;
+    }
+  }
+  // (4) exact tests: the static pair lanes that passed, and the promoted candidates (their slot takes the pair's bodies, rigid bodies and
+  // feature radii: drb / drb2 / drad2 are only meaningful on a promoted lane)
+  int dpk = 0;                    // promoted lane: rigid body | partner's rigid body << 8 | partner's feature (0 shaft, 1 / 2 end sphere) << 16 | its limb << 18
+  const bool do_static = cpkind == WBC_CP_BOX && near;
+  if (__ballot(do_static || cand >= 0) != 0ull) {
+    bool sbox = do_static;
+    int si = (prk >> 7) & 31;                                            // the sphere of a sphere-vs-box test
+    if (cand >= 0) {
+      const uint32_t ck = Cc->pr_pack[cand];
+      if ((ck & 3) == WBC_PR_LIMBS) {
+        const int la = Cc->model.pr_a[cand], lb = Cc->model.pr_b[cand];
+        LimbHit hit;
+        limb_pair(s, Cc, ck, la, lb, hit);
+        cgap = hit.gap; cn = hit.n; cxcr = hit.q;
+        cpkind = WBC_CP_LIMBS;
+        cpb = Cc->model.limb_body[la]; cpb2 = Cc->model.limb_body[lb];
+        const int drb = hit.fa == 0 ? Cc->model.limb_rb[la] : (hit.fa == 1 ? Cc->model.limb_rb0[la] : Cc->model.limb_rb1[la]);
+        const int drb2 = hit.fb == 0 ? Cc->model.limb_rb[lb] : (hit.fb == 1 ? Cc->model.limb_rb0[lb] : Cc->model.limb_rb1[lb]);
+        cpr = hit.ra;
+        dpk = drb | drb2 << 8 | hit.fb << 16 | lb << 18;
+      } else {                                                           // a robot sphere against the free box
+        si = (ck >> 7) & 31;
+        const int ss = Cc->sph_slot[si];
+        cpkind = WBC_CP_BOX;
+        cpb = Cc->model.cp_body[ss]; cpr = Cc->model.cp_radius[ss];
+        cpb2 = WBC_BOX_BODY;
+        dpk = Cc->model.cp_rb[ss] | WBC_BOX_RB << 8;
+        sbox = true;
+      }
+    }
+    if (sbox) {                                                          // sphere against a box: centre A, half extents B, the box's frame
+      const bool fb = cpb2 == WBC_BOX_BODY;
+      const float* E2 = fb ? s.bxE : s.E[fb ? 0 : cpb2];
+      const float* p2 = fb ? s.bxc : s.pos[fb ? 0 : cpb2];
+      const f3 pl = matT_mul(E2, ld3(s.sph[si]) - ld3(p2));               // sphere centre in the box's frame
+      const float bh = Cc->model.box_half;                                // (the trunk box, or the free box: centre 0, half edge)
+      const f3 A = fb ? mk3(0.f, 0.f, 0.f) : mk3(C->trunk_c[0], C->trunk_c[1], C->trunk_c[2]);
+      const f3 B = fb ? mk3(bh, bh, bh) : mk3(C->trunk_h[0], C->trunk_h[1], C->trunk_h[2]);
+      f3 ql, nl;
+      float dist;
       const f3 r = pl - A;
       const f3 cl = mk3(clampf(r.x, -B.x, B.x), clampf(r.y, -B.y, B.y), clampf(r.z, -B.z, B.z));
       const bool inside = cl.x == r.x && cl.y == r.y && cl.z == r.z;
@@ -641,19 +775,11 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         dist = -best;
       }
       cgap = dist - cpr;
-    } else {                                                             // capsule: segment A..B, radius cpr2
-      const f3 ab = B - A, ap = pl - A;
-      const float tt = clampf(dot(ap, ab) / dot(ab, ab), 0.f, 1.f);
-      ql = A + ab * tt;
-      nl = pl - ql;
-      dist = __builtin_amdgcn_sqrtf(dot(nl, nl));
-      nl = dist > 1e-9f ? nl * (1.f / dist) : mk3(1.f, 0.f, 0.f);
-      ql = ql + nl * cpr2;
-      cgap = dist - cpr - cpr2;
+      cn = mat_mul(E2, nl);
+      cxcr = ld3(p2) + mat_mul(E2, ql);                                  // on the box's surface
     }
-    cn = mat_mul(E2, nl);
-    cxcr = ld3(p2) + mat_mul(E2, ql);                                    // on the partner's surface
   }
+  const bool p2box = cpb2 == WBC_BOX_BODY;
   STAMP(18);
   bool cact = cgap < C->cfg.contact_margin;
   uint64_t abits = __ballot(cact);                                      // the active set (WBC_NCP <= 64 lanes)
@@ -676,13 +802,37 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     }
   }
   const uint32_t ablo = (uint32_t)abits, abhi = (uint32_t)(abits >> 32);
+  // Dynamic slots in contact (rare): the per-body contact masks of their two bodies (the gather loops, the relaxation counts) take
+  // the slots' bits for this substep -- restored from the constant block first whenever an earlier substep left some behind -- and
+  // the sweeps must reach their bodies' levels.
+  const bool dyn_act = cact && cand >= 0;
+  const uint64_t dynbits = __ballot(dyn_act);
+  int ddmax = 0;
+  if (dynbits != 0ull || __builtin_amdgcn_readfirstlane(s.dyn_dirty) != 0) {
+    if (lane < WBC_NB) {
+      const uint64_t m1 = C->body_cp_mask[lane], m2 = C->body_cp2_mask[lane];
+      s.k_gmlo[lane] = make_uint2((uint32_t)m1, (uint32_t)m2); s.k_gmhi[lane] = make_uint2((uint32_t)(m1 >> 32), (uint32_t)(m2 >> 32));
+    }
+    if (lane == 0) s.dyn_dirty = dynbits != 0ull;
+    WSYNC();
+    int dd = 0;
+    if (dyn_act) {
+      const uint32_t bit = 1u << (lane & 31);
+      uint2* gm = lane < 32 ? s.k_gmlo : s.k_gmhi;
+      atomicOr(&gm[cpb].x, bit);                                          // the sphere-side body
+      dd = Cc->body_depth[cpb];
+      if (!p2box) { atomicOr(&gm[cpb2].y, bit); dd = max(dd, Cc->body_depth[cpb2]); }
+    }
+#pragma unroll
+    for (int d = 2; d <= WBC_MAX_DEPTH; ++d) ddmax = (__ballot(dd >= d) != 0ull) ? d : ddmax;
+    WSYNC();
+  }
   // friction coefficient of this contact: robot-terrain, box-terrain, robot-robot, robot-box
   const float cmu = s.mu[cpkind == WBC_CP_TERRAIN ? (onbox ? 2 : 0) : (p2box ? 3 : 1)];
   f3 cvfree = mk3(0.f, 0.f, 0.f), clamr = mk3(0.f, 0.f, 0.f);
   float cvtgt = 0.f;
   float cW[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (cact) {
-    st3(s.cxc[lane], cxcr);
     cvtgt = (cgap >= 0.f) ? -cgap * idt : fminf(C->cfg.contact_erp * (-cgap) * idt, C->cfg.max_depenetration_vel);
     const f3 xc = cxcr;
     // W = J K J^T with J = [-[xc]x  I] (point velocity = v + omega x xc): for any 6-vector (a; l), J-row products are
@@ -740,6 +890,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   WSYNC();
   if (cact) {
     s.ctc.clam[lane][0] = s.ctc.clam[lane][1] = s.ctc.clam[lane][2] = 0.f;
+    st3(s.ctc.cxc[lane], cxcr);
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
   if (lane < 6) { AD(s)[0][lane] = 0.f; s.bxa[lane] = 0.f; }
@@ -758,6 +909,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   int dmax = 1;
 #pragma unroll
   for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
+  dmax = max(dmax, ddmax);
 #ifdef WBC_STEP_TIMING
   if (lane == 0) s.dbg_ncon = __popcll(abits) | (dmax << 8) | (__popcll(abits & 0x3F800000ull) << 16);
 #endif
@@ -797,7 +949,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       // sums them, the row's last lane turns the sum into the box's response (angular acceleration n / Ic, centre acceleration F / m)
       if ((abhi & 0xFFFFu) != 0u && (lane >> 4) == 2) {
         const f3 f = cact ? clamr * (onbox ? idt : -idt) : mk3(0.f, 0.f, 0.f);
-        const f3 mom = cross((cact ? ld3(s.cxc[lane]) : ld3(s.bxc)) - ld3(s.bxc), f);
+        const f3 mom = cross((cact ? ld3(s.ctc.cxc[lane]) : ld3(s.bxc)) - ld3(s.bxc), f);
         const float nx = row_scan16(mom.x), ny = row_scan16(mom.y), nz = row_scan16(mom.z);
         const float fx = row_scan16(f.x), fy = row_scan16(f.y), fz = row_scan16(f.z);
         if (lane == 47) { st3(&s.bxa[0], mk3(nx, ny, nz) * s.bxiI); st3(&s.bxa[3], mk3(fx, fy, fz) * s.bxim); }
@@ -816,7 +968,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
               mask &= mask - 1;
               const float sg = ((gm.x >> kb) & 1u) ? idt : -idt;
               const f3 f = ld3(s.ctc.clam[kc]) * sg;
-              const f3 mom = cross(ld3(s.cxc[kc]), f);
+              const f3 mom = cross(ld3(s.ctc.cxc[kc]), f);
               acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
             }
           }
@@ -886,7 +1038,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       }
       if (it == 0) STAMP(24);
       if (it < iters - 1 && cact) {      // the last sweep's contact-point response is not used
-        const f3 xc = ld3(s.cxc[lane]);
+        const f3 xc = ld3(s.ctc.cxc[lane]);
         // response of a body at the contact point: (angular; linear) acceleration change, lever from F's origin (tree) / from the
         // box centre (free box)
         const float* ad1 = onbox ? s.bxa : AD(s)[onbox ? 0 : cpb];
@@ -948,6 +1100,37 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         ta = ta + matT_mul(s.E[b], cross(n2 * (-rad), f));
       }
       st3(&s.out_sensor[ftl][0], fa); st3(&s.out_sensor[ftl][3], ta);
+    }
+    // the dynamic slots in contact (rare): one after the other, the owning lane adds its force to the rows of its pair's two rigid
+    // bodies (the free box's row already holds it: the row reduction) and, where a foot is one of them, to that foot's sensor
+    if (dynbits != 0ull) {
+      WSYNC();
+      uint64_t db = dynbits;
+      while (db != 0ull) {
+        const int d = __ffsll((unsigned long long)db) - 1;
+        db &= db - 1;
+        if (lane == d) {
+          const int drb = dpk & 255, drb2 = (dpk >> 8) & 255, dfb = (dpk >> 16) & 3, dlb = (dpk >> 18) & 15;
+          const float drad2 = dfb == 0 ? Cc->model.limb_radius[dlb] : (dfb == 1 ? Cc->model.limb_cap0[dlb] : Cc->model.limb_cap1[dlb]);
+          const f3 f = clamr * idt, fw = mat_mul(s.R, f);
+          st3(s.out_contact[drb], ld3(s.out_contact[drb]) + fw);
+          if (drb2 != WBC_BOX_RB) st3(s.out_contact[drb2], ld3(s.out_contact[drb2]) - fw);
+#pragma unroll
+          for (int ft = 0; ft < WBC_NFEET; ++ft) {
+            const int frb = Cc->model.feet_rb[ft];
+            if (frb == drb) {
+              st3(&s.out_sensor[ft][0], ld3(&s.out_sensor[ft][0]) + matT_mul(s.E[cpb], f));
+              st3(&s.out_sensor[ft][3], ld3(&s.out_sensor[ft][3]) + matT_mul(s.E[cpb], cross(cn * (-cpr), f)));
+            }
+            if (frb == drb2) {
+              const f3 fo = f * -1.f;
+              st3(&s.out_sensor[ft][0], ld3(&s.out_sensor[ft][0]) + matT_mul(s.E[cpb2], fo));
+              st3(&s.out_sensor[ft][3], ld3(&s.out_sensor[ft][3]) + matT_mul(s.E[cpb2], cross(cn * drad2, fo)));
+            }
+          }
+        }
+        WSYNC();
+      }
     }
   }
   STAMP(9);
@@ -1350,6 +1533,8 @@ __device__ void make_chain_regs(Smem& s, ChainRegs& cr, CP C, int chain) {
     const uint64_t m1 = C->body_cp_mask[lane], m2 = C->body_cp2_mask[lane];
     s.k_gmlo[lane] = make_uint2((uint32_t)m1, (uint32_t)m2); s.k_gmhi[lane] = make_uint2((uint32_t)(m1 >> 32), (uint32_t)(m2 >> 32));
   }
+  if (lane == 0) s.dyn_dirty = 0;
+  s.k_prk[lane] = C->pr_pack[lane];
   if (lane < WBC_NDOF) s.k_qdlim[lane] = C->model.qd_limit[lane];
   if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
     const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
@@ -1480,7 +1665,13 @@ template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C
   }
   // state write-back
   if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
-  if (lane < 40) ROW(T.dof, env, 40)[lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  {   // (a laundered lane index: left alone, the compiler keeps lane & 1 and lane >> 1 of load_env's dof rows alive across the whole
+      // kernel for this store -- two VGPRs the substeps cannot spare)
+    int l2 = threadIdx.x;
+    asm volatile("" : "+v"(l2));
+    l2 &= LANES - 1;
+    if (l2 < 40) ROW(T.dof, env, 40)[l2] = (l2 & 1) ? s.qd[l2 >> 1] : s.q[l2 >> 1];
+  }
   if (lane < WBC_NDOF) { ROW(T.torques, env, WBC_NDOF)[lane] = s.tau[lane]; ROW(T.last_dof_vel, env, WBC_NDOF)[lane] = s.qd[lane]; }
   if (lane < WBC_NACT) { ROW(T.actions, env, WBC_NACT)[lane] = s.act[lane]; ROW(T.last_actions, env, WBC_NACT)[lane] = s.act[lane]; }
   if (lane < 6) ROW(T.last_root_vel, env, 6)[lane] = s.root[7 + lane];
@@ -1691,7 +1882,13 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors 
   rigid_body_pass(s, C, cr, chain, k);
   // write back what a reset touches
   if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
-  if (lane < 40) ROW(T.dof, env, 40)[lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  {   // (a laundered lane index: left alone, the compiler keeps lane & 1 and lane >> 1 of load_env's dof rows alive across the whole
+      // kernel for this store -- two VGPRs the substeps cannot spare)
+    int l2 = threadIdx.x;
+    asm volatile("" : "+v"(l2));
+    l2 &= LANES - 1;
+    if (l2 < 40) ROW(T.dof, env, 40)[l2] = (l2 & 1) ? s.qd[l2 >> 1] : s.q[l2 >> 1];
+  }
   if (lane < 24) ROW(T.goal, env, 24)[lane] = s.goal[lane];
   if (lane < 3) ROW(T.commands, env, 3)[lane] = s.cmd[lane];
   if (lane < WBC_NREW) ROW(T.ep_sums, env, WBC_NREW)[lane] = 0.f;
@@ -1720,7 +1917,13 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   physics_substep(s, C, cr, chain, k, true);
   if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
   if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
-  if (lane < 40) ROW(T.dof, env, 40)[lane] = (lane & 1) ? s.qd[lane >> 1] : s.q[lane >> 1];
+  {   // (a laundered lane index: left alone, the compiler keeps lane & 1 and lane >> 1 of load_env's dof rows alive across the whole
+      // kernel for this store -- two VGPRs the substeps cannot spare)
+    int l2 = threadIdx.x;
+    asm volatile("" : "+v"(l2));
+    l2 &= LANES - 1;
+    if (l2 < 40) ROW(T.dof, env, 40)[l2] = (l2 & 1) ? s.qd[l2 >> 1] : s.q[l2 >> 1];
+  }
   for (int e = lane; e < WBC_NRB_ENV * 3; e += LANES) ROW(T.contact, env, (WBC_NRB_ENV * 3))[e] = (&s.out_contact[0][0])[e];
   if (lane < WBC_NFEET * 6) ROW(T.sensor, env, (WBC_NFEET * 6))[lane] = (&s.out_sensor[0][0])[lane];
 }

@@ -12,9 +12,11 @@ import numpy as np
 
 from .urdf_model import RobotModel, merge_piece
 
-NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 52
+NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 64
+NSPH, NLIMB = 27, 11
 BOX_BODY, BOX_RB = NB, NRB                                # the free box actor's pseudo body index / rigid-body row
-CP_NONE, CP_TERRAIN, CP_BOX, CP_CAPSULE = -1, 0, 1, 2
+CP_NONE, CP_TERRAIN, CP_BOX, CP_LIMBS, CP_DYNAMIC = -1, 0, 1, 2, 3
+PR_NONE, PR_STATIC, PR_LIMBS, PR_SPHERE_BOX = 0, 1, 2, 3
 NPROP, NPRIV, HIST, NOBS, ADELAY_LEN, NREW, NMETRIC = 76, 24, 10, 860, 4, 37, 10
 
 f32, i32 = C.c_float, C.c_int32
@@ -42,7 +44,11 @@ class WbcModel(C.Structure):
         ("rb_body", i32 * NRB), ("rb_offset", (f32 * 3) * NRB), ("feet_rb", i32 * NFEET), ("gripper_rb", i32),
         ("ncp", i32), ("cp_body", i32 * NCP), ("cp_pos", (f32 * 3) * NCP), ("cp_radius", f32 * NCP),
         ("cp_rb", i32 * NCP), ("cp_kind", i32 * NCP), ("cp_body2", i32 * NCP), ("cp_rb2", i32 * NCP),
-        ("cp_a", (f32 * 3) * NCP), ("cp_b", (f32 * 3) * NCP), ("cp_radius2", f32 * NCP),
+        ("cp_a", (f32 * 3) * NCP), ("cp_b", (f32 * 3) * NCP), ("cp_radius2", f32 * NCP), ("cp_sph", i32 * NCP),
+        ("pr_kind", i32 * NCP), ("pr_a", i32 * NCP), ("pr_b", i32 * NCP), ("pr_reach", f32 * NCP),
+        ("nlimb", i32), ("limb_s0", i32 * NLIMB), ("limb_s1", i32 * NLIMB), ("limb_radius", f32 * NLIMB), ("limb_cap0", f32 * NLIMB),
+        ("limb_cap1", f32 * NLIMB), ("limb_body", i32 * NLIMB), ("limb_rb", i32 * NLIMB), ("limb_rb0", i32 * NLIMB), ("limb_rb1", i32 * NLIMB),
+        ("pair_rest_offset", f32),
         ("base_piece_mass", f32), ("base_piece_com", f32 * 3), ("base_piece_inertia", f32 * 6),
         ("base_rest_mass", f32), ("base_rest_com", f32 * 3), ("base_rest_inertia", f32 * 6),
         ("gripper_body", i32),
@@ -143,38 +149,52 @@ BOX_DENSITY, BOX_FRICTION = 1000.0, 1.0                  # asset_options.density
 BOX_SLEEP_SPEED, BOX_SLEEP_TIME = 0.01, 0.4                # m/s, s: a box at rest for 0.4 s is frozen, as PhysX puts resting actors to sleep
 
 
+KNEE_RADIUS, FOOT_RADIUS, ELBOW_RADIUS, WRIST_RADIUS, GRIP_RADIUS = 0.02, 0.02, 0.025, 0.025, 0.012
+LIMB_RSUM_MAX = 0.045     # WBC_LIMB_RSUM_MAX (include/wbc_sim.h): bounds the radius sums of all candidate limb pairs
+STATIC_SELF_SLOT0, BOX_ROW, SHANK0 = 23, 32, 48
+# dynamic slots: what the self-collision broad phase promotes its hits into (robot-vs-robot: outside the box row; robot-vs-box: inside)
+DYN_SELF_SLOTS = list(range(26, 32)) + list(range(52, 64))
+DYN_BOX_SLOTS = [45, 46, 47]
+LEGS = ("FL", "FR", "RL", "RR")
+
+
 def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True,
                   box_half: float = 0.05):
-    """The contact list of this framework's physics spec, as dicts with the wbc_model cp_* fields and the
-    contact SLOT (= wavefront lane) each one occupies. Sphere-swept stand-ins for the URDF's collision geometry:
-      terrain contacts -- 4 feet (the URDF's r = 0.02 spheres), 4 knees (calf box upper ends = thigh box lower ends), gripper
-        tip, elbow, wrist (the arm-link meshes), 4 thigh tops (thigh box upper ends), 8 trunk-box corners, 4 mid-shanks (the
-        middle of the calf boxes: what touches a stair edge between knee and foot), the 8 corners of the free box actor;
-      self-collision pairs (asset.self_collisions = 0 means enabled, widowGo1_config.py:180) -- gripper / wrist / elbow spheres
-        against the trunk box, gripper / wrist against the two front thighs (capsules): what bounds the arm's workspace;
-      robot-vs-box pairs (the box actor is created with the same collision filter, WG:384) -- the 4 foot spheres and the
-        gripper tip against the cube.
-    Slots (= wavefront lanes): 0..22 the robot's spheres against the terrain, 23..29 its self-collision pairs (the set a walking
-    robot lives in: the kernel's per-body loops over slots < 32); 32..47 everything that involves the free box (its corners, the
-    feet and the gripper tip against it: one 16-lane row, summed by a row reduction instead of a per-body loop); 48..51 the
-    mid-shanks (second loop half, empty unless a shin touches something)."""
+    """The contact list of this framework's physics spec: (slots, limbs, candidates).
+    `slots`: dicts with the wbc_model cp_* fields and the contact SLOT (= wavefront lane) each one occupies. Sphere-swept stand-ins
+    for the URDF's <collision> blocks (legged_gym/resources/robots/widowGo1/urdf/widowGo1.urdf):
+      terrain contacts -- 4 feet (the URDF's r = 0.02 spheres), 4 knees (calf box upper ends = thigh box lower ends), gripper tip,
+        elbow, wrist (the arm-link meshes), 4 thigh tops (thigh box upper ends), 8 trunk-box corners, 4 mid-shanks (the middle of
+        the calf boxes: what touches a stair edge between knee and foot), the 8 corners of the free box actor;
+      static pairs -- gripper / wrist / elbow spheres against the trunk box (what bounds the arm's workspace: 3-5 % of uniformly drawn
+        joint configurations, tools/self_collision_reach.py), the 4 foot spheres and the gripper tip against the free box (created
+        with the robot's collision filter, WG:384);
+      dynamic slots -- free lanes that the broad phase promotes its hits into.
+    `limbs`: the capsules / spheres of the self-collision broad phase (thighs r 0.017, calves r 0.008 with knee / foot end spheres r
+    0.02, elbow, wrist, gripper tip), ends given as sphere indices. `candidates`: every pair of them on non-adjacent links that can
+    touch inside the joint limits (asset.self_collisions = 0 means enabled for all of them, widowGo1_config.py:180) -- calf-calf x 6,
+    thigh-calf of different legs x 12, left-right thigh pairs x 2, arm spheres against the 8 leg limbs x 24 -- and the robot spheres
+    that can meet the free box besides the static five (knees, shins, the trunk's bottom corners), most frequent first.
+    Slots (= wavefront lanes): 0..22 the robot's spheres against the terrain, 23..25 arm vs trunk, 26..31 dynamic; 32..47 everything
+    that involves the free box (corners 32..39, static pairs 40..44, dynamic 45..47: one 16-lane row, summed by a row reduction);
+    48..51 the mid-shanks; 52..63 dynamic."""
     rbn = m.rb_names
     feet = [i for i, n in enumerate(rbn) if foot_name in n]
     grip_rb = rbn.index(gripper_name)
     cps = []
 
-    def sphere(rb, pos, rad, slot=None):
+    def sphere(rb, pos, rad, slot=None, sph=None):
         cps.append(dict(body=int(m.rb_body[rb]), pos=np.asarray(m.rb_offset[rb], dtype=np.float64) + np.asarray(pos, dtype=np.float64),
                         radius=rad, rb=rb, kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0,
-                        slot=len(cps) if slot is None else slot))
+                        slot=len(cps) if slot is None else slot, sph=len(cps) if sph is None else sph))
         return len(cps) - 1
     for rb in feet:
-        sphere(rb, np.zeros(3), 0.02)
+        sphere(rb, np.zeros(3), FOOT_RADIUS)
     for rb in feet:                                                         # knees = calf origins
-        sphere(rb - 1, np.zeros(3), 0.02)
-    k_grip = sphere(grip_rb, np.zeros(3), 0.012)
-    k_elbow = sphere(rbn.index("wx250s/upper_forearm_link"), np.zeros(3), 0.025)
-    k_wrist = sphere(rbn.index("wx250s/wrist_link"), np.zeros(3), 0.025)
+        sphere(rb - 1, np.zeros(3), KNEE_RADIUS)
+    k_grip = sphere(grip_rb, np.zeros(3), GRIP_RADIUS)
+    k_elbow = sphere(rbn.index("wx250s/upper_forearm_link"), np.zeros(3), ELBOW_RADIUS)
+    k_wrist = sphere(rbn.index("wx250s/wrist_link"), np.zeros(3), WRIST_RADIUS)
     thighs = [rb - 2 for rb in feet]
     for rb in thighs:
         assert "thigh" in rbn[rb]
@@ -185,51 +205,105 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
         for sy in (1, -1):
             for sz in (-1, 1):
                 sphere(trunk_rb, np.array([sx * hx, sy * hy, sz * hz]), CORNER_RADIUS)
-    assert len(cps) == 23
-    BOX_ROW, SHANK0 = 32, 48
+    assert len(cps) == STATIC_SELF_SLOT0
     for i, rb in enumerate(feet):                                           # mid-shank: calf rigid body, half way down the calf box
         assert "calf" in rbn[rb - 1]
-        sphere(rb - 1, np.array([0.0, 0.0, -CALF_LEN / 2]), CALF_RADIUS, slot=SHANK0 + i)
+        sphere(rb - 1, np.array([0.0, 0.0, -CALF_LEN / 2]), CALF_RADIUS, slot=SHANK0 + i, sph=STATIC_SELF_SLOT0 + i)
+    assert len(cps) == NSPH
     hb = box_half - BOX_CORNER_RADIUS                                       # the free box: corner spheres inset so that the surface is the cube's
     hi = BOX_ROW
     for sx in (1, -1):
         for sy in (1, -1):
             for sz in (-1, 1):
                 cps.append(dict(body=BOX_BODY, pos=np.array([sx * hb, sy * hb, sz * hb]), radius=BOX_CORNER_RADIUS, rb=BOX_RB,
-                                kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0, slot=hi))
+                                kind=CP_TERRAIN, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0, slot=hi, sph=-1))
                 hi += 1
+    limbs, cands = [], []
     if self_collisions:
-        lo = 23
+        lo = STATIC_SELF_SLOT0
 
-        def pair(k, kind, body2, rb2, a, b, radius2, slot):
+        def pair(k, body2, rb2, a, b, slot):
             c = dict(cps[k])
-            c.update(kind=kind, body2=body2, rb2=rb2, a=np.asarray(a, dtype=np.float64), b=np.asarray(b, dtype=np.float64), radius2=radius2,
-                     slot=slot)
+            c.update(kind=CP_BOX, body2=body2, rb2=rb2, a=np.asarray(a, dtype=np.float64), b=np.asarray(b, dtype=np.float64), radius2=0.0, slot=slot)
             cps.append(c)
         for k in (k_grip, k_wrist, k_elbow):
-            pair(k, CP_BOX, int(m.rb_body[trunk_rb]), trunk_rb, np.asarray(m.rb_offset[trunk_rb]), np.array(TRUNK_HALF), 0.0, lo)
+            pair(k, int(m.rb_body[trunk_rb]), trunk_rb, np.asarray(m.rb_offset[trunk_rb]), np.array(TRUNK_HALF), lo)
             lo += 1
-        front = [rb for rb in thighs if rbn[rb].startswith("F")]
-        for k in (k_grip, k_wrist):
-            for rb in front:
-                off = np.asarray(m.rb_offset[rb])
-                pair(k, CP_CAPSULE, int(m.rb_body[rb]), rb, off, off + np.array([0.0, 0.0, -THIGH_LEN]), THIGH_RADIUS, lo)
-                lo += 1
-        assert lo <= 32
         for k in list(range(len(feet))) + [k_grip]:                           # the foot spheres and the gripper tip against the free box
-            pair(k, CP_BOX, BOX_BODY, BOX_RB, np.zeros(3), np.full(3, box_half), 0.0, hi)
+            pair(k, BOX_BODY, BOX_RB, np.zeros(3), np.full(3, box_half), hi)
             hi += 1
+        for slot in DYN_SELF_SLOTS + DYN_BOX_SLOTS:
+            cps.append(dict(body=0, pos=np.zeros(3), radius=0.0, rb=0, kind=CP_DYNAMIC, body2=-1, rb2=-1, a=np.zeros(3), b=np.zeros(3), radius2=0.0,
+                            slot=slot, sph=-1))
+        # limbs: ends = compact sphere indices (thigh: thigh top .. knee; calf: knee .. foot)
+        for i, leg in enumerate(LEGS):
+            assert rbn[feet[i]].startswith(leg)
+        for i in range(4):
+            limbs.append(dict(name=LEGS[i] + "_thigh", s0=11 + i, s1=4 + i, radius=THIGH_RADIUS, cap0=0.0, cap1=0.0, length=THIGH_LEN,
+                              body=int(m.rb_body[thighs[i]]), rb=thighs[i], rb0=thighs[i], rb1=thighs[i]))
+        for i in range(4):
+            limbs.append(dict(name=LEGS[i] + "_calf", s0=4 + i, s1=i, radius=CALF_RADIUS, cap0=KNEE_RADIUS, cap1=FOOT_RADIUS, length=CALF_LEN,
+                              body=int(m.rb_body[feet[i] - 1]), rb=feet[i] - 1, rb0=feet[i] - 1, rb1=feet[i]))
+        for name, k in (("elbow", k_elbow), ("wrist", k_wrist), ("gripper", k_grip)):
+            limbs.append(dict(name=name, s0=k, s1=k, radius=cps[k]["radius"], cap0=0.0, cap1=0.0, length=0.0, body=cps[k]["body"], rb=cps[k]["rb"],
+                              rb0=cps[k]["rb"], rb1=cps[k]["rb"]))
+        assert len(limbs) == NLIMB
+        L = {l["name"]: i for i, l in enumerate(limbs)}
+
+        def bound(l):
+            return 0.5 * l["length"] + max(l["radius"], l["cap0"], l["cap1"])
+
+        def limb_pair(a, b):
+            cands.append(dict(kind=PR_LIMBS, a=L[a], b=L[b], reach=bound(limbs[L[a]]) + bound(limbs[L[b]])))
+        side = [("FL", "RL"), ("FR", "RR")]
+        lr = [("FL", "FR"), ("RL", "RR")]
+        diag = [("FL", "RR"), ("FR", "RL")]
+        # most frequent first (tools/self_collision_reach.py): neighbouring calves, a calf against the neighbouring leg's thigh, the
+        # left-right thigh pairs, then the arm against the legs, the diagonal pairs last
+        for a, b in side + lr:
+            limb_pair(a + "_calf", b + "_calf")
+        for a, b in side + lr:
+            limb_pair(a + "_calf", b + "_thigh")
+            limb_pair(b + "_calf", a + "_thigh")
+        for a, b in lr:
+            limb_pair(a + "_thigh", b + "_thigh")
+        for arm in ("wrist", "elbow", "gripper"):
+            for leg in LEGS:
+                for part in ("_thigh", "_calf"):
+                    limb_pair(arm, leg + part)
+        for a, b in diag:
+            limb_pair(a + "_calf", b + "_calf")
+            limb_pair(a + "_calf", b + "_thigh")
+            limb_pair(b + "_calf", a + "_thigh")
+        assert len(cands) == 44
+        assert max(max(limbs[c["a"]][k] for k in ("radius", "cap0", "cap1")) + max(limbs[c["b"]][k] for k in ("radius", "cap0", "cap1")) for c in cands) <= LIMB_RSUM_MAX
+        # robot spheres that can meet the free box besides the five static pairs: knees, shins, the trunk box's bottom corners
+        bottom = [k for k in range(15, 23) if cps[k]["pos"][2] < m.rb_offset[trunk_rb][2]]
+        for k in list(range(4, 8)) + [STATIC_SELF_SLOT0 + i for i in range(4)] + bottom:
+            sp = next(c for c in cps if c["sph"] == k and c["kind"] == CP_TERRAIN)
+            cands.append(dict(kind=PR_SPHERE_BOX, a=k, b=0, reach=box_half * math.sqrt(3.0) + sp["radius"]))
+        assert len(cands) == 56
     assert hi <= BOX_ROW + 16
     assert len({c["slot"] for c in cps}) == len(cps) and max(c["slot"] for c in cps) < NCP
-    return sorted(cps, key=lambda c: c["slot"])
+    return sorted(cps, key=lambda c: c["slot"]), limbs, cands
+
+
+REACH_STEP = 0.04      # pr_reach is a multiple of this (3 bits of the kernel's packed descriptor), rounded up: a bounding radius may only grow
+
+
+def quantise_reach(r: float) -> float:
+    code = int(math.ceil(r / REACH_STEP - 1e-9))
+    assert 1 <= code <= 8, f"bounding reach {r} m does not fit the descriptor's 3 bits"
+    return code * REACH_STEP
 
 
 def fill_model(m: RobotModel, foot_name: str = "foot",
                gripper_name: str = "wx250s/ee_gripper_link", self_collisions: bool = True, box_size: float = 0.1,
                rest_offset: float = 0.0) -> WbcModel:
     """RobotModel -> wbc_model, with the collision set of this framework's physics spec (collision_set). `rest_offset`
-    (sim.physx.rest_offset, LRC:194): the separation at which two shapes rest -- every contact of the set has a sphere on one side,
-    so holding the surfaces `rest_offset` apart is that sphere grown by it (fill_task_cfg shrinks the contact margin by the same)."""
+    (sim.physx.rest_offset, LRC:194): the separation at which two shapes rest -- every static contact has a sphere on one side,
+    so holding the surfaces `rest_offset` apart is that sphere grown by it (fill_task_cfg shrinks the contact margin by the same);
+    limb pairs subtract it from their gap (pair_rest_offset)."""
     assert m.nb == NB and m.num_dofs == NDOF and m.num_rigid_bodies == NRB
     out = WbcModel()
     _seti(out.parent, m.parent)
@@ -250,20 +324,35 @@ def fill_model(m: RobotModel, foot_name: str = "foot",
     assert len(feet) == NFEET
     _seti(out.feet_rb, feet)
     out.gripper_rb = m.rb_names.index(gripper_name)                         # WG:318
-    cps = collision_set(m, foot_name, gripper_name, self_collisions, box_half=0.5 * box_size)
+    cps, limbs, cands = collision_set(m, foot_name, gripper_name, self_collisions, box_half=0.5 * box_size)
     out.box_half, out.box_mass, out.box_friction = 0.5 * box_size, BOX_DENSITY * box_size ** 3, BOX_FRICTION
     out.box_sleep_speed, out.box_sleep_time = BOX_SLEEP_SPEED, BOX_SLEEP_TIME
     out.ncp = max(c["slot"] for c in cps) + 1                              # slots in use: 0 .. ncp-1, unused ones marked kind = -1
     for k in range(NCP):
-        out.cp_body2[k] = out.cp_rb2[k] = -1
+        out.cp_body2[k] = out.cp_rb2[k] = out.cp_sph[k] = -1
         out.cp_kind[k] = CP_NONE
+        out.pr_kind[k] = PR_NONE
     for c in cps:
         k = c["slot"]
         out.cp_body[k], out.cp_rb[k], out.cp_kind[k] = c["body"], c["rb"], c["kind"]
         out.cp_body2[k], out.cp_rb2[k] = c["body2"], c["rb2"]
-        out.cp_radius[k], out.cp_radius2[k] = c["radius"] + float(rest_offset), c["radius2"]
+        out.cp_radius[k], out.cp_radius2[k] = c["radius"] + (float(rest_offset) if c["kind"] != CP_DYNAMIC else 0.0), c["radius2"]
+        out.cp_sph[k] = c["sph"]
         for j in range(3):
             out.cp_pos[k][j], out.cp_a[k][j], out.cp_b[k][j] = float(c["pos"][j]), float(c["a"][j]), float(c["b"][j])
+        if c["kind"] == CP_BOX:                                            # the lane's own pair is what it tests in the broad phase
+            out.pr_kind[k], out.pr_a[k], out.pr_b[k] = PR_STATIC, c["sph"], 0
+            out.pr_reach[k] = quantise_reach(float(np.linalg.norm(c["b"])) + out.cp_radius[k])
+    out.nlimb = len(limbs)
+    for i, l in enumerate(limbs):
+        out.limb_s0[i], out.limb_s1[i], out.limb_radius[i], out.limb_cap0[i], out.limb_cap1[i] = l["s0"], l["s1"], l["radius"], l["cap0"], l["cap1"]
+        out.limb_body[i], out.limb_rb[i], out.limb_rb0[i], out.limb_rb1[i] = l["body"], l["rb"], l["rb0"], l["rb1"]
+    out.pair_rest_offset = float(rest_offset)
+    lanes = [k for k in range(NCP) if out.pr_kind[k] != PR_STATIC]          # every lane without a static pair of its own tests a candidate
+    assert len(cands) <= len(lanes)
+    for k, c in zip(lanes, cands):
+        out.pr_kind[k], out.pr_a[k], out.pr_b[k] = c["kind"], c["a"], c["b"]
+        out.pr_reach[k] = quantise_reach(c["reach"] + float(rest_offset))
     bp, gp = m.base_piece, m.gripper_piece
     out.base_piece_mass = bp["mass"]
     _set(out.base_piece_com, bp["com"])

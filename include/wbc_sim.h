@@ -35,8 +35,13 @@ extern "C" {
 #define WBC_NRB 27       /* robot rigid bodies as the importer lists them */
 #define WBC_NRB_ENV 28   /* + the free box actor (WG:384,542,546) */
 #define WBC_NFEET 4
-#define WBC_NCP 52       /* contact slots per env (one wavefront lane each): robot spheres vs terrain, box corners vs terrain,
-                            the robot's self-collision pairs, robot spheres vs the free box */
+#define WBC_NCP 64       /* contact slots per env (one wavefront lane each): robot spheres vs terrain, box corners vs terrain,
+                            the static pairs (arm spheres vs the trunk box, robot spheres vs the free box) and the DYNAMIC slots
+                            that the self-collision broad phase promotes its hits into */
+#define WBC_NSPH 27      /* the robot's contact spheres (their centres in frame F are cached once per substep) */
+#define WBC_NLIMB 11     /* capsules / spheres of the self-collision broad phase: 4 thighs, 4 calves, elbow, wrist, gripper tip */
+#define WBC_LIMB_RSUM_MAX 0.045f   /* an upper bound of (largest radius of limb a) + (largest radius of limb b) over all candidate pairs (second
+                                      stage of the broad phase: the distance between the two shafts' segments against this + rest + margin) */
 #define WBC_BOX_BODY WBC_NB   /* pseudo body index of the free box actor (WG:321-325,384) in cp_body / cp_body2 */
 #define WBC_BOX_RB WBC_NRB    /* its row in the [N,28,...] rigid-body tensors (WG:544-548: the last one) */
 #define WBC_NPROP 76     /* num_proprio (widowGo1_config.py:122) */
@@ -70,16 +75,30 @@ typedef struct {
    * rigid body cp_rb) and a partner selected by cp_kind:
    *   WBC_CP_TERRAIN  the terrain (plane or height grid);
    *   WBC_CP_BOX      a box fixed to moving body cp_body2 (rigid body cp_rb2): centre cp_a, half extents cp_b, its frame;
-   *   WBC_CP_CAPSULE  a capsule on cp_body2: segment cp_a..cp_b, radius cp_radius2.
-   * The last two are the robot's self-collision pairs (asset.self_collisions = 0 = enabled, widowGo1_config.py:180): the
-   * impulse acts on both bodies with opposite signs. Terrain contacts come first (the force sensors read contacts 0..3).
+   * Pairs are two-body contacts (the robot's self-collision, asset.self_collisions = 0 = enabled, widowGo1_config.py:180; the robot
+   * against the free box): the impulse acts on both bodies with opposite signs. Terrain contacts come first (the force sensors read contacts 0..3).
    * The free box actor (WG:321-325: a cube, density 1000) takes part under the pseudo body index WBC_BOX_BODY / rigid-body row
    * WBC_BOX_RB: its eight corner spheres against the terrain (cp_body = WBC_BOX_BODY, cp_pos in the box frame) and robot spheres
    * against it (kind WBC_CP_BOX with cp_body2 = WBC_BOX_BODY, cp_a = 0, cp_b = box_half).
    * Slots 0 .. ncp-1 are in use except those marked WBC_CP_NONE. The step kernel's layout rules (checked at wbc_sim_create): every
    * contact that involves the free box sits in slots 32..47 (one 16-lane row: their wrenches on the box are summed by a row
    * reduction) and nothing else does; keep what a walking robot normally touches with (feet, knees, trunk, arm) below 32 -- the
-   * per-body loops walk the slots below 32 and those from 48 separately. */
+   * per-body loops walk the slots below 32 and those from 48 separately.
+   *
+   * Self-collision as configured (asset.self_collisions = 0: every pair of non-adjacent links collides): the pairs that can touch
+   * inside the URDF's joint limits (tools/self_collision_reach.py: 47 of 59; the legs never reach the trunk box, the front and
+   * rear thighs never meet) are too many for one lane each, and almost never active. They are CANDIDATES: every lane carries one
+   * pair descriptor (pr_*) -- its own pair for a static pair slot, otherwise a candidate -- and tests it against bounding spheres
+   * in the same instructions (the broad phase; a limb pair that passes -- two legs standing side by side always do -- is then tested
+   * segment against segment with the generous radius WBC_LIMB_RSUM_MAX before it counts as a hit). A candidate that passes is promoted into a free DYNAMIC slot (kind
+   * WBC_CP_DYNAMIC: robot-vs-robot hits into the dynamic slots outside 32..47, in ascending order of candidate and slot;
+   * robot-vs-free-box hits into the dynamic slots of the box row), where the exact test runs and, if the gap is inside the contact
+   * margin, the contact is solved like any other pair. Hits beyond the free slots (14 + 3) are dropped.
+   * Primitives of the candidates, all in frame F from the cached sphere centres (cp_sph: the compact index of a robot sphere):
+   *   limbs -- capsules between two sphere centres (thigh: hip-side end to knee, r 0.017; calf: knee to foot, r 0.008, with its end
+   *   spheres knee r 0.02 / foot r 0.02) or single spheres (elbow, wrist, gripper tip); kind WBC_PR_LIMBS tests limb pr_a against
+   *   limb pr_b as the union of shaft and end spheres (deepest feature pair wins: one contact per limb pair);
+   *   kind WBC_PR_SPHERE_BOX tests robot sphere pr_a against the free box (knees, shins, trunk corners, wrist, elbow). */
   int32_t ncp;
   int32_t cp_body[WBC_NCP];
   float cp_pos[WBC_NCP][3];
@@ -90,6 +109,17 @@ typedef struct {
   int32_t cp_rb2[WBC_NCP];      /* rigid body that receives the opposite force, -1 for terrain contacts */
   float cp_a[WBC_NCP][3], cp_b[WBC_NCP][3];
   float cp_radius2[WBC_NCP];
+  int32_t cp_sph[WBC_NCP];      /* compact index (0 .. WBC_NSPH-1) of the robot sphere of a terrain slot / of a static pair's sphere; -1 otherwise */
+  /* pair descriptor of every lane (broad phase): kind, operands, bounding reach (sum of the two bounding radii + contact margin) */
+  int32_t pr_kind[WBC_NCP];     /* enum wbc_pair_kind */
+  int32_t pr_a[WBC_NCP], pr_b[WBC_NCP];   /* WBC_PR_LIMBS: limb ids; WBC_PR_SPHERE_BOX / WBC_PR_STATIC: pr_a = robot sphere (compact index) */
+  float pr_reach[WBC_NCP];
+  int32_t nlimb;
+  int32_t limb_s0[WBC_NLIMB], limb_s1[WBC_NLIMB];   /* compact sphere indices of the segment's ends (equal: a sphere) */
+  float limb_radius[WBC_NLIMB], limb_cap0[WBC_NLIMB], limb_cap1[WBC_NLIMB];   /* shaft radius; end-sphere radii (0: none) */
+  int32_t limb_body[WBC_NLIMB];                     /* moving body */
+  int32_t limb_rb[WBC_NLIMB], limb_rb0[WBC_NLIMB], limb_rb1[WBC_NLIMB];   /* rigid body reported for a touch on the shaft / end sphere 0 / 1 */
+  float pair_rest_offset;                           /* sim.physx.rest_offset for limb pairs (sphere radii already carry it) */
   /* pieces for per-env mass randomisation (WG:431-456) */
   float base_piece_mass, base_piece_com[3], base_piece_inertia[6];
   float base_rest_mass, base_rest_com[3], base_rest_inertia[6];
@@ -107,7 +137,10 @@ typedef struct {
   float box_sleep_speed, box_sleep_time;
 } wbc_model;
 
-enum wbc_contact_kind { WBC_CP_NONE = -1 /* unused slot */, WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1, WBC_CP_CAPSULE = 2 };
+enum wbc_contact_kind { WBC_CP_NONE = -1 /* unused slot */, WBC_CP_TERRAIN = 0, WBC_CP_BOX = 1,
+                        WBC_CP_LIMBS = 2 /* run time only: a dynamic slot holding a promoted limb pair */,
+                        WBC_CP_DYNAMIC = 3 /* a free slot of the dynamic pool */ };
+enum wbc_pair_kind { WBC_PR_NONE = 0, WBC_PR_STATIC = 1 /* the lane's own static pair (kind WBC_CP_BOX) */, WBC_PR_LIMBS = 2, WBC_PR_SPHERE_BOX = 3 };
 
 enum wbc_reward_term {   /* the _reward_* methods WG defines (WG:1352-1469), then the base class's (LR = envs/base/legged_robot.py:832-922)
                             that work in the widowGo1 task. Not offered: orientation (LR:841-843 reads self.projected_gravity, which

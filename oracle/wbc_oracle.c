@@ -330,6 +330,69 @@ static void contact_solve(const contact_t* c, const REAL* vref, REAL* lam) {
   for (int k = 0; k < 3; ++k) lam[k] = dir[k] * l;
 }
 
+/* What contact slot k stands for in this substep: the model's static tables, or -- a dynamic slot -- the pair the broad phase promoted
+ * into it. rad / rad2: radii of the touching features on the two sides (the force sensors' lever arms). */
+typedef struct { int kind, body, body2, rb, rb2; REAL rad, rad2; } slot_t;
+
+/* Closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9), parameters s on a0..a1 and t on b0..b1; a segment
+ * shorter than 1e-5 m counts as a point. */
+static void seg_seg_closest(const REAL* a0, const REAL* a1, const REAL* b0, const REAL* b1, REAL* pa, REAL* pb) {
+  REAL d1[3], d2[3], r[3];
+  for (int j = 0; j < 3; ++j) { d1[j] = a1[j] - a0[j]; d2[j] = b1[j] - b0[j]; r[j] = a0[j] - b0[j]; }
+  const REAL EPS = (REAL)1e-10;
+  REAL a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), sp = 0, tp = 0;
+  if (a <= EPS && e <= EPS) { sp = tp = 0; }
+  else if (a <= EPS) { sp = 0; tp = clampr(f / e, 0, 1); }
+  else {
+    REAL c = dot3(d1, r);
+    if (e <= EPS) { tp = 0; sp = clampr(-c / a, 0, 1); }
+    else {
+      REAL b = dot3(d1, d2), den = a * e - b * b;
+      sp = den > (REAL)1e-7 * a * e ? clampr((b * f - c * e) / den, 0, 1) : 0;       /* (near-)parallel: any point of a will do */
+      tp = (b * sp + f) / e;
+      if (tp < 0) { tp = 0; sp = clampr(-c / a, 0, 1); }
+      else if (tp > 1) { tp = 1; sp = clampr((b - c) / a, 0, 1); }
+    }
+  }
+  for (int j = 0; j < 3; ++j) { pa[j] = a0[j] + d1[j] * sp; pb[j] = b0[j] + d2[j] * tp; }
+}
+
+/* Limb A against limb B, each the union of a capsule (segment x0..x1, radius r) and up to two end spheres (radii c0, c1 > 0 at x0, x1;
+ * 0: none): the feature pair with the smallest gap wins -- shaft/shaft, A's end spheres against B's shaft, B's end spheres against
+ * A's shaft, end sphere against end sphere, in this order (a tie keeps the earlier). Out: the gap (minus rest), the unit normal from B
+ * to A, the contact point on B's surface, which feature touched on each side (0 shaft, 1 end 0, 2 end 1) and its radius. */
+typedef struct { REAL gap, n[3], q[3], ra, rb; int fa, fb; } limb_hit;
+static void limb_pair(const REAL* a0, const REAL* a1, REAL ra, REAL ca0, REAL ca1, const REAL* b0, const REAL* b1, REAL rb, REAL cb0, REAL cb1,
+                      REAL rest, limb_hit* out) {
+  const REAL* aend[2] = {a0, a1}; const REAL* bend[2] = {b0, b1};
+  const REAL acap[2] = {ca0, ca1}, bcap[2] = {cb0, cb1};
+  REAL best = 0, bpa[3] = {0, 0, 0}, bpb[3] = {0, 0, 0};
+  int first = 1;
+  out->fa = out->fb = 0; out->ra = ra; out->rb = rb;
+  for (int f = 0; f < 9; ++f) {
+    /* f = 0: shafts; 1, 2: A's end ea = f - 1 vs B's shaft; 3, 4: A's shaft vs B's end eb = f - 3; 5..8: ends (ea, eb) = ((f - 5) / 2, (f - 5) % 2) */
+    int ea = f == 0 ? -1 : (f <= 2 ? f - 1 : (f <= 4 ? -1 : (f - 5) / 2));
+    int eb = f <= 2 ? -1 : (f <= 4 ? f - 3 : (f - 5) % 2);
+    if ((ea >= 0 && !(acap[ea] > 0)) || (eb >= 0 && !(bcap[eb] > 0))) continue;
+    REAL pa[3], pb[3];
+    seg_seg_closest(ea >= 0 ? aend[ea] : a0, ea >= 0 ? aend[ea] : a1, eb >= 0 ? bend[eb] : b0, eb >= 0 ? bend[eb] : b1, pa, pb);
+    REAL fra = ea >= 0 ? acap[ea] : ra, frb = eb >= 0 ? bcap[eb] : rb;
+    REAL d[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    REAL g = sqrt(dot3(d, d)) - fra - frb - rest;
+    if (first || g < best) {
+      first = 0; best = g;
+      for (int j = 0; j < 3; ++j) { bpa[j] = pa[j]; bpb[j] = pb[j]; }
+      out->fa = ea + 1; out->fb = eb + 1; out->ra = fra; out->rb = frb;
+    }
+  }
+  REAL d[3] = {bpa[0] - bpb[0], bpa[1] - bpb[1], bpa[2] - bpb[2]};
+  REAL dist = sqrt(dot3(d, d));
+  if (dist > (REAL)1e-9) { for (int j = 0; j < 3; ++j) out->n[j] = d[j] / dist; }
+  else { out->n[0] = 1; out->n[1] = 0; out->n[2] = 0; }
+  for (int j = 0; j < 3; ++j) out->q[j] = bpb[j] + out->rb * out->n[j];
+  out->gap = best;
+}
+
 /* diagnostics (tests only): when set, physics_substep copies its contact list here */
 typedef struct { int active[WBC_NCP]; double lam[WBC_NCP][3], n[WBC_NCP][3], xc[WBC_NCP][3], resid[WBC_NCP]; int nshare[WBC_NCP]; } contact_dump;
 static _Thread_local contact_dump* g_dump = NULL;
@@ -455,9 +518,14 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     bx.m = e->box_mass;
     bx.Ic = bx.m * (REAL)(2.0 / 3.0) * (REAL)md->box_half * (REAL)md->box_half;    /* m (2h)^2 / 6 */
   }
-  /* contacts: spheres against the terrain (the robot's, then the box's corners), then the pairs (a sphere against a box / capsule
-   * riding on another body of the robot, or against the free box) */
+  /* contacts. (1) every sphere against the terrain (the robot's, the box's corners); the robot spheres' centres in F are cached.
+   * (2) broad phase: every lane's pair descriptor (its own static pair, or a candidate of the self-collision set) against bounding
+   * spheres. (3) candidates that pass are promoted into free dynamic slots. (4) exact tests: sphere vs box (the trunk's, the free
+   * box), limb vs limb. Slot k of this substep is described by sl[k] (static slots: the model's tables; dynamic: what was promoted). */
   contact_t ct[WBC_NCP];
+  slot_t sl[WBC_NCP];
+  REAL sph[WBC_NSPH][3];
+  int sph_slot[WBC_NSPH];
   REAL mu = (REAL)0.5 * (e->friction + (REAL)cf->terrain_friction);   /* PhysX default combine: average */
   if (mu < 0) mu = 0;
   REAL mu_self = e->friction < 0 ? 0 : e->friction;                   /* both shapes carry the robot's material */
@@ -466,82 +534,158 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
   if (mu_box_terrain < 0) mu_box_terrain = 0;
   if (mu_box_robot < 0) mu_box_robot = 0;
   int any = 0;
-  for (int k = 0; k < md->ncp; ++k) {
+  for (int k = 0; k < WBC_NSPH; ++k) { sph_slot[k] = -1; sph[k][0] = sph[k][1] = sph[k][2] = 0; }
+  for (int k = 0; k < WBC_NCP; ++k) {
     contact_t* c = &ct[k];
-    int b = md->cp_body[k], kind = md->cp_kind[k], b2 = md->cp_body2[k];
+    c->lam[0] = c->lam[1] = c->lam[2] = 0;
+    c->active = 0; c->gap = 0;
+    slot_t* q = &sl[k];
+    q->kind = k < md->ncp ? md->cp_kind[k] : WBC_CP_NONE;
+    q->body = md->cp_body[k]; q->body2 = md->cp_body2[k]; q->rb = md->cp_rb[k]; q->rb2 = md->cp_rb2[k];
+    q->rad = md->cp_radius[k]; q->rad2 = 0;
+    if (q->kind != WBC_CP_TERRAIN) continue;
+    int b = q->body;
     const REAL* Eb = (b == WBC_BOX_BODY) ? bx.E : w->E[b];
     const REAL* pb = (b == WBC_BOX_BODY) ? bx.c : w->pos[b];
     REAL o[3] = {md->cp_pos[k][0], md->cp_pos[k][1], md->cp_pos[k][2]}, xk[3], t[3];
     mat3_mul_vec(Eb, o, t);
     for (int j = 0; j < 3; ++j) xk[j] = pb[j] + t[j];
-    REAL rad = md->cp_radius[k], gap;
-    c->lam[0] = c->lam[1] = c->lam[2] = 0;
-    c->active = 0;
-    if (kind < 0) continue;                               /* unused slot */
-    if (kind == WBC_CP_TERRAIN) {
-      REAL Xw[3], h, nw[3];
-      mat3_mul_vec(R, xk, t);
-      for (int j = 0; j < 3; ++j) Xw[j] = e->root[0][j] + t[j];
-      terrain_query(s, Xw[0], Xw[1], &h, nw);
-      gap = (Xw[2] - h) * nw[2] - rad;
-      c->active = gap < (REAL)cf->contact_margin;
-      if (!c->active) continue;
-      mat3T_mul_vec(R, nw, c->n);
-      for (int j = 0; j < 3; ++j) c->xc[j] = xk[j] - rad * c->n[j];
-      c->mu = (b == WBC_BOX_BODY) ? mu_box_terrain : mu;
+    if (md->cp_sph[k] >= 0) { sph_slot[md->cp_sph[k]] = k; for (int j = 0; j < 3; ++j) sph[md->cp_sph[k]][j] = xk[j]; }
+    REAL rad = q->rad, Xw[3], h, nw[3];
+    mat3_mul_vec(R, xk, t);
+    for (int j = 0; j < 3; ++j) Xw[j] = e->root[0][j] + t[j];
+    terrain_query(s, Xw[0], Xw[1], &h, nw);
+    REAL gap = (Xw[2] - h) * nw[2] - rad;
+    c->active = gap < (REAL)cf->contact_margin;
+    c->gap = gap;
+    if (!c->active) continue;
+    mat3T_mul_vec(R, nw, c->n);
+    for (int j = 0; j < 3; ++j) c->xc[j] = xk[j] - rad * c->n[j];
+    c->mu = (b == WBC_BOX_BODY) ? mu_box_terrain : mu;
+  }
+  /* (2) broad phase */
+  int near[WBC_NCP];
+  for (int k = 0; k < WBC_NCP; ++k) {
+    near[k] = 0;
+    int pk = md->pr_kind[k];
+    if (pk == WBC_PR_NONE) continue;
+    REAL ca[3], cb[3];
+    if (pk == WBC_PR_LIMBS) {
+      int la = md->pr_a[k], lb = md->pr_b[k];
+      for (int j = 0; j < 3; ++j) {
+        ca[j] = (REAL)0.5 * (sph[md->limb_s0[la]][j] + sph[md->limb_s1[la]][j]);
+        cb[j] = (REAL)0.5 * (sph[md->limb_s0[lb]][j] + sph[md->limb_s1[lb]][j]);
+      }
     } else {
-      /* sphere centre in the partner body's frame */
+      for (int j = 0; j < 3; ++j) ca[j] = sph[md->pr_a[k]][j];
+      int b2 = pk == WBC_PR_STATIC ? md->cp_body2[k] : WBC_BOX_BODY;
+      if (b2 == WBC_BOX_BODY) { for (int j = 0; j < 3; ++j) cb[j] = bx.c[j]; }
+      else {                                   /* a box fixed to a tree body: its centre in F */
+        REAL A[3] = {md->cp_a[k][0], md->cp_a[k][1], md->cp_a[k][2]}, t[3];
+        mat3_mul_vec(w->E[b2], A, t);
+        for (int j = 0; j < 3; ++j) cb[j] = w->pos[b2][j] + t[j];
+      }
+    }
+    REAL reach = (REAL)md->pr_reach[k] + (REAL)cf->contact_margin + (REAL)1e-3, d2 = 0;
+    for (int j = 0; j < 3; ++j) d2 += (ca[j] - cb[j]) * (ca[j] - cb[j]);
+    near[k] = d2 < reach * reach;
+    if (near[k] && pk == WBC_PR_LIMBS) {       /* second stage: the two shafts' segments against a generous common radius */
+      int la = md->pr_a[k], lb = md->pr_b[k];
+      REAL pa[3], pb[3], dd = 0;
+      seg_seg_closest(sph[md->limb_s0[la]], sph[md->limb_s1[la]], sph[md->limb_s0[lb]], sph[md->limb_s1[lb]], pa, pb);
+      for (int j = 0; j < 3; ++j) dd += (pa[j] - pb[j]) * (pa[j] - pb[j]);
+      REAL r2 = (REAL)WBC_LIMB_RSUM_MAX + (REAL)md->pair_rest_offset + (REAL)cf->contact_margin + (REAL)1e-3;
+      near[k] = dd < r2 * r2;
+    }
+  }
+  /* (3) promotion: robot-vs-robot hits into the dynamic slots outside the box row, robot-vs-box hits into those inside it, both in
+   * ascending order of lane and slot; hits beyond the free slots are dropped */
+  int src[WBC_NCP];
+  for (int k = 0; k < WBC_NCP; ++k) src[k] = -1;
+  {
+    int ds = 0, db = 32;
+    for (int k = 0; k < WBC_NCP; ++k) {
+      if (!near[k] || md->pr_kind[k] == WBC_PR_STATIC) continue;
+      if (md->pr_kind[k] == WBC_PR_LIMBS) {
+        while (ds < md->ncp && !(md->cp_kind[ds] == WBC_CP_DYNAMIC && (ds < 32 || ds > 47))) ++ds;
+        if (ds < md->ncp) src[ds++] = k;
+      } else {
+        while (db < 48 && db < md->ncp && md->cp_kind[db] != WBC_CP_DYNAMIC) ++db;
+        if (db < 48 && db < md->ncp) src[db++] = k;
+      }
+    }
+  }
+  /* (4) exact tests */
+  for (int k = 0; k < md->ncp; ++k) {
+    contact_t* c = &ct[k];
+    slot_t* q = &sl[k];
+    int cand = -1;
+    if (q->kind == WBC_CP_BOX) { if (!near[k]) continue; }
+    else if (q->kind == WBC_CP_DYNAMIC) { if (src[k] < 0) continue; cand = src[k]; }
+    else continue;
+    REAL gap, nF[3], xcF[3];
+    if (cand >= 0 && md->pr_kind[cand] == WBC_PR_LIMBS) {
+      int la = md->pr_a[cand], lb = md->pr_b[cand];
+      limb_hit hit;
+      limb_pair(sph[md->limb_s0[la]], sph[md->limb_s1[la]], md->limb_radius[la], md->limb_cap0[la], md->limb_cap1[la],
+                sph[md->limb_s0[lb]], sph[md->limb_s1[lb]], md->limb_radius[lb], md->limb_cap0[lb], md->limb_cap1[lb],
+                (REAL)md->pair_rest_offset, &hit);
+      gap = hit.gap;
+      for (int j = 0; j < 3; ++j) { nF[j] = hit.n[j]; xcF[j] = hit.q[j]; }
+      q->kind = WBC_CP_LIMBS;
+      q->body = md->limb_body[la]; q->body2 = md->limb_body[lb];
+      q->rb = hit.fa == 0 ? md->limb_rb[la] : (hit.fa == 1 ? md->limb_rb0[la] : md->limb_rb1[la]);
+      q->rb2 = hit.fb == 0 ? md->limb_rb[lb] : (hit.fb == 1 ? md->limb_rb0[lb] : md->limb_rb1[lb]);
+      q->rad = hit.ra; q->rad2 = hit.rb;
+    } else {
+      /* sphere against a box: the lane's own static pair, or a promoted robot sphere against the free box */
+      int si = cand >= 0 ? md->pr_a[cand] : md->pr_a[k];
+      int b2 = cand >= 0 ? WBC_BOX_BODY : q->body2;
+      REAL A[3], B[3], rad;
+      if (cand >= 0) {
+        int ss = sph_slot[si];
+        q->kind = WBC_CP_BOX; q->body = md->cp_body[ss]; q->rb = md->cp_rb[ss]; q->body2 = WBC_BOX_BODY; q->rb2 = WBC_BOX_RB;
+        q->rad = md->cp_radius[ss];
+        for (int j = 0; j < 3; ++j) { A[j] = 0; B[j] = (REAL)md->box_half; }
+      } else for (int j = 0; j < 3; ++j) { A[j] = md->cp_a[k][j]; B[j] = md->cp_b[k][j]; }
+      rad = q->rad;
       const REAL* E2 = (b2 == WBC_BOX_BODY) ? bx.E : w->E[b2];
       const REAL* p2 = (b2 == WBC_BOX_BODY) ? bx.c : w->pos[b2];
-      REAL d[3], pl[3], ql[3], nl[3], dist;
-      for (int j = 0; j < 3; ++j) d[j] = xk[j] - p2[j];
-      mat3T_mul_vec(E2, d, pl);
-      const float* A = md->cp_a[k]; const float* B = md->cp_b[k];
-      if (kind == WBC_CP_BOX) {            /* closest point of the box (centre A, half extents B) */
-        int inside = 1;
-        for (int j = 0; j < 3; ++j) {
-          REAL r = pl[j] - (REAL)A[j], hb = (REAL)B[j];
-          REAL cl = r < -hb ? -hb : (r > hb ? hb : r);
-          if (cl != r) inside = 0;
-          ql[j] = (REAL)A[j] + cl;
-        }
-        if (!inside) {
-          for (int j = 0; j < 3; ++j) nl[j] = pl[j] - ql[j];
-          dist = sqrt(dot3(nl, nl));
-          for (int j = 0; j < 3; ++j) nl[j] /= dist;
-        } else {                            /* centre inside the box: leave through the nearest face */
-          int ax = 0; REAL best = 0; 
-          for (int j = 0; j < 3; ++j) {
-            REAL depth = (REAL)B[j] - fabs(pl[j] - (REAL)A[j]);
-            if (j == 0 || depth < best) { best = depth; ax = j; }
-          }
-          for (int j = 0; j < 3; ++j) nl[j] = 0;
-          nl[ax] = (pl[ax] - (REAL)A[ax]) >= 0 ? 1 : -1;
-          ql[ax] = (REAL)A[ax] + nl[ax] * (REAL)B[ax];
-          dist = -best;
-        }
-        gap = dist - rad;
-      } else {                              /* capsule: segment A..B, radius cp_radius2 */
-        REAL ab[3], ap[3];
-        for (int j = 0; j < 3; ++j) { ab[j] = (REAL)B[j] - (REAL)A[j]; ap[j] = pl[j] - (REAL)A[j]; }
-        REAL tt = dot3(ap, ab) / dot3(ab, ab);
-        tt = clampr(tt, 0, 1);
-        for (int j = 0; j < 3; ++j) { ql[j] = (REAL)A[j] + tt * ab[j]; nl[j] = pl[j] - ql[j]; }
-        dist = sqrt(dot3(nl, nl));
-        if (dist > (REAL)1e-9) { for (int j = 0; j < 3; ++j) nl[j] /= dist; }
-        else { nl[0] = 1; nl[1] = 0; nl[2] = 0; }
-        REAL r2 = md->cp_radius2[k];
-        for (int j = 0; j < 3; ++j) ql[j] += r2 * nl[j];
-        gap = dist - rad - r2;
+      REAL d[3], pl[3], ql[3], nl[3], dist, t[3];
+      for (int j = 0; j < 3; ++j) d[j] = sph[si][j] - p2[j];
+      mat3T_mul_vec(E2, d, pl);                /* sphere centre in the box's frame */
+      int inside = 1;
+      for (int j = 0; j < 3; ++j) {
+        REAL r = pl[j] - A[j], hb = B[j];
+        REAL cl = r < -hb ? -hb : (r > hb ? hb : r);
+        if (cl != r) inside = 0;
+        ql[j] = A[j] + cl;
       }
-      c->active = gap < (REAL)cf->contact_margin;
-      if (!c->active) continue;
-      mat3_mul_vec(E2, nl, c->n);
+      if (!inside) {
+        for (int j = 0; j < 3; ++j) nl[j] = pl[j] - ql[j];
+        dist = sqrt(dot3(nl, nl));
+        for (int j = 0; j < 3; ++j) nl[j] /= dist;
+      } else {                            /* centre inside the box: leave through the nearest face */
+        int ax = 0; REAL best = 0;
+        for (int j = 0; j < 3; ++j) {
+          REAL depth = B[j] - fabs(pl[j] - A[j]);
+          if (j == 0 || depth < best) { best = depth; ax = j; }
+        }
+        for (int j = 0; j < 3; ++j) nl[j] = 0;
+        nl[ax] = (pl[ax] - A[ax]) >= 0 ? 1 : -1;
+        ql[ax] = A[ax] + nl[ax] * B[ax];
+        dist = -best;
+      }
+      gap = dist - rad;
+      mat3_mul_vec(E2, nl, nF);
       mat3_mul_vec(E2, ql, t);
-      for (int j = 0; j < 3; ++j) c->xc[j] = p2[j] + t[j];             /* on the partner's surface */
-      c->mu = (b2 == WBC_BOX_BODY) ? mu_box_robot : mu_self;
+      for (int j = 0; j < 3; ++j) xcF[j] = p2[j] + t[j];             /* on the box's surface */
     }
     c->gap = gap;
+    c->active = gap < (REAL)cf->contact_margin;
+    if (!c->active) { if (cand >= 0) q->kind = WBC_CP_DYNAMIC; continue; }
+    for (int j = 0; j < 3; ++j) { c->n[j] = nF[j]; c->xc[j] = xcF[j]; }
+    c->mu = (q->body2 == WBC_BOX_BODY) ? mu_box_robot : mu_self;
   }
   /* sleeping box (as PhysX puts resting actors to sleep): slow, supported by at least three corners, untouched by the robot ->
    * frozen for this substep: its corner contacts are dropped, its velocity is zero, gravity does not act on it */
@@ -550,19 +694,19 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     const REAL vs2 = (REAL)md->box_sleep_speed * (REAL)md->box_sleep_speed, h2 = (REAL)md->box_half * (REAL)md->box_half;
     int ncorner = 0, touched = 0;
     for (int k = 0; k < md->ncp; ++k) if (ct[k].active) {
-      if (md->cp_body[k] == WBC_BOX_BODY) ncorner += 1;
-      if (md->cp_kind[k] > WBC_CP_TERRAIN && md->cp_body2[k] == WBC_BOX_BODY) touched = 1;
+      if (sl[k].body == WBC_BOX_BODY) ncorner += 1;
+      if (sl[k].kind > WBC_CP_TERRAIN && sl[k].body2 == WBC_BOX_BODY) touched = 1;
     }
     const int resting = dot3(e->root[1] + 7, e->root[1] + 7) < vs2 && dot3(e->root[1] + 10, e->root[1] + 10) * h2 < vs2 && ncorner >= 3 && !touched;
     const REAL nsleep = (REAL)(int)(md->box_sleep_time * (1.0f / cf->sim_dt) + 0.5f);   /* the timer counts substeps (exact in fp32) */
     box_asleep = resting && e->box_timer >= nsleep;
     e->box_timer = resting ? fmin(e->box_timer + 1, nsleep) : 0;
-    if (box_asleep) for (int k = 0; k < md->ncp; ++k) if (md->cp_body[k] == WBC_BOX_BODY) ct[k].active = 0;
+    if (box_asleep) for (int k = 0; k < md->ncp; ++k) if (sl[k].body == WBC_BOX_BODY) ct[k].active = 0;
   }
   for (int k = 0; k < md->ncp; ++k) {
     contact_t* c = &ct[k];
     if (!c->active) continue;
-    int b = md->cp_body[k], kind = md->cp_kind[k], b2 = md->cp_body2[k];
+    int b = sl[k].body, kind = sl[k].kind, b2 = sl[k].body2;
     REAL gap = c->gap, t[3];
     any = 1;
     c->vn_tgt = (gap >= 0) ? -gap / dt : fmin((REAL)cf->contact_erp * (-gap) / dt, (REAL)cf->max_depenetration_vel);
@@ -616,14 +760,14 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     /* damped block-Jacobi: how many active contacts act on each body (as the sphere's body or as the partner of a pair) */
     int cnt[WBC_NB + 1] = {0};
     for (int k = 0; k < md->ncp; ++k) if (ct[k].active) {
-      cnt[md->cp_body[k]] += 1;
-      if (md->cp_kind[k] != WBC_CP_TERRAIN) cnt[md->cp_body2[k]] += 1;
+      cnt[sl[k].body] += 1;
+      if (sl[k].kind != WBC_CP_TERRAIN) cnt[sl[k].body2] += 1;
     }
     for (int k = 0; k < md->ncp; ++k) {
       ct[k].nshare = 0;
       if (!ct[k].active) continue;
-      ct[k].nshare = cnt[md->cp_body[k]];
-      if (md->cp_kind[k] != WBC_CP_TERRAIN && cnt[md->cp_body2[k]] > ct[k].nshare) ct[k].nshare = cnt[md->cp_body2[k]];
+      ct[k].nshare = cnt[sl[k].body];
+      if (sl[k].kind != WBC_CP_TERRAIN && cnt[sl[k].body2] > ct[k].nshare) ct[k].nshare = cnt[sl[k].body2];
     }
   }
   if (any) {
@@ -656,10 +800,10 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
         REAL rb3[3] = {c->xc[0] - bx.c[0], c->xc[1] - bx.c[1], c->xc[2] - bx.c[2]};
         cross3(c->xc, f, mom);                            /* about F's origin (tree bodies) */
         cross3(rb3, f, momb);                             /* about the box centre */
-        int b = md->cp_body[k], b2 = md->cp_body2[k];
+        int b = sl[k].body, b2 = sl[k].body2;
         if (b == WBC_BOX_BODY) { for (int j = 0; j < 3; ++j) { bN[j] += momb[j]; bF[j] += f[j]; } }
         else for (int j = 0; j < 3; ++j) { pD[b][j] -= mom[j]; pD[b][3 + j] -= f[j]; }
-        if (md->cp_kind[k] != WBC_CP_TERRAIN) {          /* the partner body receives the opposite wrench */
+        if (sl[k].kind != WBC_CP_TERRAIN) {          /* the partner body receives the opposite wrench */
           if (b2 == WBC_BOX_BODY) { for (int j = 0; j < 3; ++j) { bN[j] -= momb[j]; bF[j] -= f[j]; } }
           else for (int j = 0; j < 3; ++j) { pD[b2][j] += mom[j]; pD[b2][3 + j] += f[j]; }
         }
@@ -684,9 +828,9 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       for (int k = 0; k < md->ncp; ++k) {
         contact_t* c = &ct[k];
         if (!c->active) continue;
-        int b = md->cp_body[k], b2 = md->cp_body2[k];
+        int b = sl[k].body, b2 = sl[k].body2;
         REAL t[3];
-        for (int side = 0; side < (md->cp_kind[k] == WBC_CP_TERRAIN ? 1 : 2); ++side) {
+        for (int side = 0; side < (sl[k].kind == WBC_CP_TERRAIN ? 1 : 2); ++side) {
           int bb = side == 0 ? b : b2;
           REAL sgn = side == 0 ? 1 : -1, resp[3];
           if (bb == WBC_BOX_BODY) {
@@ -720,17 +864,19 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
     if (!c->active) continue;
     REAL f[3] = {c->lam[0] / dt, c->lam[1] / dt, c->lam[2] / dt}, fw[3];
     mat3_mul_vec(R, f, fw);
-    int rb = md->cp_rb[k];
+    int rb = sl[k].rb;
     for (int j = 0; j < 3; ++j) e->contact_force[rb][j] += fw[j];
-    if (md->cp_kind[k] != WBC_CP_TERRAIN)                /* PhysX reports pair forces in net_contact_force too */
-      for (int j = 0; j < 3; ++j) e->contact_force[md->cp_rb2[k]][j] -= fw[j];
-    /* a foot's sensor sees every contact of the foot sphere: the terrain's and the box's */
-    for (int ft = 0; ft < WBC_NFEET; ++ft) if (md->feet_rb[ft] == rb) {
-      int b = md->cp_body[k];
+    if (sl[k].kind != WBC_CP_TERRAIN)                /* PhysX reports pair forces in net_contact_force too */
+      for (int j = 0; j < 3; ++j) e->contact_force[sl[k].rb2][j] -= fw[j];
+    /* a foot's sensor sees every contact of the foot sphere: the terrain's, the box's, another limb's (on either side of the pair) */
+    for (int ft = 0; ft < WBC_NFEET; ++ft) for (int side = 0; side < (sl[k].kind == WBC_CP_TERRAIN ? 1 : 2); ++side) {
+      if (md->feet_rb[ft] != (side == 0 ? rb : sl[k].rb2)) continue;
+      int b = side == 0 ? sl[k].body : sl[k].body2;
+      REAL sg = side == 0 ? 1 : -1, fs[3] = {sg * f[0], sg * f[1], sg * f[2]};
       REAL fl[3], arm[3], tq[3], tl[3];
-      mat3T_mul_vec(w->E[b], f, fl);
-      for (int j = 0; j < 3; ++j) arm[j] = -md->cp_radius[k] * c->n[j];
-      cross3(arm, f, tq);
+      mat3T_mul_vec(w->E[b], fs, fl);
+      for (int j = 0; j < 3; ++j) arm[j] = (side == 0 ? -sl[k].rad : sl[k].rad2) * c->n[j];     /* from the foot's centre to the contact point */
+      cross3(arm, fs, tq);
       mat3T_mul_vec(w->E[b], tq, tl);
       for (int j = 0; j < 3; ++j) { e->force_sensor[ft][j] += fl[j]; e->force_sensor[ft][3 + j] += tl[j]; }
     }

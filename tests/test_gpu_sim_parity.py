@@ -340,6 +340,83 @@ def test_collision_set_matches_oracle(robot):
     g.close()
 
 
+def test_self_collision_candidates_match_oracle(robot):
+    """Self-collision as configured (asset.self_collisions = 0: every pair of non-adjacent links): the broad phase on all 64 lanes,
+    the promotion of its hits into dynamic contact slots and the exact limb-vs-limb / sphere-vs-box tests, HIP vs the fp64 oracle
+    from a synced state. Staged: robots in the air with EVERY joint drawn uniformly inside its limits (legs crossing, the arm in the
+    legs: up to a dozen simultaneous pairs), robots near the stance with one leg swung into its neighbour, and free boxes placed
+    at knees, shins and under the trunk (the candidates beyond the five static box pairs). Same contact forces per rigid body (the
+    set of bodies in contact included), state to tolerance, masks bit-exact."""
+    import torch
+    n = 512
+    params = helpers.random_env_params(n, seed=71)
+    params["env_origins"] = np.zeros((n, 3), dtype=np.float32)
+    tc = type(robot["tcfg"]).from_buffer_copy(robot["tcfg"])
+    tc.term_z_threshold = 0.02
+    g = helpers.make_gpu(robot, n, params, tcfg=tc)
+    o = helpers.make_oracle(robot, n, params, "f64", tcfg=tc)
+    g.reset_all()
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(72)
+    model = robot["model"]
+    names = model.rb_names
+    root = _t(g, "ROOT_STATES").astype(np.float32)
+    dof = _t(g, "DOF_STATE").astype(np.float32)
+    lo, hi = np.array(model.dof_lower, dtype=np.float64), np.array(model.dof_upper, dtype=np.float64)
+    free = ~(lo < hi)
+    lo[free], hi[free] = -np.pi, np.pi
+    lo[18:], hi[18:] = 0.0, 0.0
+    half = n // 2
+    root[:, 0, 2] = 1.2                                                        # in the air for the five steps: no terrain contact
+    root[:, 0, 7:] = 0
+    dof[:, :, 1] = 0
+    dof[:half, :, 0] = rng.uniform(lo, hi, (half, 20))                          # every joint anywhere
+    q = np.array(tc.default_dof_pos, dtype=np.float64)[None] + rng.uniform(-0.3, 0.3, (n - half, 20))
+    leg = rng.integers(0, 4, n - half)
+    for e in range(n - half):                                                  # one hip rolled inward, that leg swung at its neighbour
+        q[e, 3 * leg[e]] = (-1 if leg[e] % 2 == 0 else 1) * rng.uniform(0.6, 1.04)
+        q[e, 3 * leg[e] + 1] = rng.uniform(-0.6, 2.9)
+    dof[half:, :, 0] = np.clip(q, lo, hi)
+    dof[:, 18:, 0] = 0
+    # boxes: at a knee / a shin / under the trunk of every third robot (else far away), at rest
+    g.tensor("ROOT_STATES").copy_(torch.from_numpy(root)); g.tensor("DOF_STATE").copy_(torch.from_numpy(dof))
+    g.refresh_rigid_body_state()
+    torch.cuda.synchronize()
+    rb = _t(g, "RIGID_BODY_STATE")
+    root[:, 1, :3] = root[:, 0, :3] + np.array([3.0, 0.0, -1.15])
+    root[:, 1, 3:7] = [0, 0, 0, 1]; root[:, 1, 7:] = 0
+    targets = [names.index(k) for k in ("FL_calf", "FR_calf", "RL_calf", "RR_calf", "trunk")]
+    for e in range(0, n, 3):
+        t = targets[(e // 3) % 5]
+        off = rng.uniform(-0.03, 0.03, 3) + (np.array([0, 0, -0.11]) if names[t] == "trunk" else np.array([0.05, 0, rng.choice([0.0, -0.1])]))
+        root[e, 1, :3] = rb[e, t, :3] + off
+        root[e, 1, 3:7] = helpers.random_quat(rng) if hasattr(helpers, "random_quat") else [0, 0, 0, 1]
+    g.tensor("ROOT_STATES").copy_(torch.from_numpy(root))
+    seen = np.zeros(28, dtype=np.int64)
+    legleg = boxhits = 0
+    legs_rb = [i for i, nm in enumerate(names) if any(k in nm for k in ("thigh", "calf", "foot"))]
+    for step in range(4):
+        helpers.sync_oracle_from_gpu(o, g)
+        a = (0.3 * rng.normal(size=(n, 18))).astype(np.float32)
+        g.step(torch.from_numpy(a).cuda()); o.step(a)
+        tag = f"self-collision candidates, step {step}"
+        for name in ("RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH"):
+            np.testing.assert_array_equal(_t(g, name), o.get(name), err_msg=f"{tag} {name}")
+        fo, fg = o.get("NET_CONTACT_FORCE"), _t(g, "NET_CONTACT_FORCE")
+        strong = np.abs(fo).sum(-1) > 0.5
+        assert ((np.abs(fg).sum(-1) > 0) == (np.abs(fo).sum(-1) > 0))[strong | (np.abs(fo).sum(-1) == 0)].mean() > 0.998, tag
+        _assert_close_bulk(fg, fo, 0.08, 5e-3, f"{tag} NET_CONTACT_FORCE", frac=4e-3, slack=1e3)
+        _assert_close_bulk(_t(g, "FORCE_SENSOR"), o.get("FORCE_SENSOR"), 0.08, 5e-3, f"{tag} FORCE_SENSOR", frac=4e-3, slack=1e3)
+        for name, atol, rtol in (("DOF_STATE", 6e-4, 1e-3), ("ROOT_STATES", 4e-4, 5e-4), ("TORQUES", 4e-4, 5e-4), ("OBS_BUF", 3e-3, 1e-3)):
+            _close(name, _t(g, name), o.get(name), atol, rtol, f"{tag} {name}", frac=4e-3)
+        hit = np.abs(fo).sum(-1) > 0
+        seen += hit.sum(0)
+        legleg += int((hit[:, legs_rb].sum(1) >= 2).sum())
+        boxhits += int((hit[:, 27] & (hit[:, [names.index(k) for k in ("FL_calf", "FR_calf", "RL_calf", "RR_calf", "trunk")]].any(1))).sum())
+    assert legleg > 60 and boxhits > 100 and seen[[names.index(k) for k in ("wx250s/upper_forearm_link", "wx250s/wrist_link")]].sum() > 30, (legleg, boxhits, seen)
+    g.close()
+
+
 # ---- BASELINE.json configurations ----------------------------------------------------------------------------------
 def _assert_close_bulk(a, b, atol, rtol, msg, frac=2e-5, slack=10.0):
     """allclose for batches of thousands of envs: every element within slack x the tolerance, and all but a fraction `frac`

@@ -224,28 +224,54 @@ def test_rollout_slot_hand_over_is_cuda_only_and_storage_skips_filled_slots():
 def test_collision_set_follows_the_urdf_collision_blocks():
     """abi.collision_set: the URDF's <collision> geometry (urdf/widowGo1.urdf) as the contact list of the physics spec: one sphere
     per foot first (the force sensors read contacts 0..3), trunk-box corners on the box surface, thigh tops / knees / mid-shanks on
-    the thigh and calf rows, arm spheres, the corners of the free box actor (WG:321-325); then the pairs, each naming a partner
-    body different from its own: the robot's self-collision pairs and the robot spheres against the box; fits WBC_NCP."""
+    the thigh and calf rows, arm spheres, the corners of the free box actor (WG:321-325); the static pairs (arm spheres vs the trunk
+    box, feet / gripper tip vs the free box); the dynamic slots; and the candidates of the self-collision broad phase: every pair
+    of primitives on non-adjacent links that can touch inside the joint limits (profiles/r05_self_collision_reach.txt)."""
     m = abi.load_default_model()
-    cps = abi.collision_set(m)
+    cps, limbs, cands = abi.collision_set(m)
     names = m.rb_names
-    assert len(cps) == 47 <= abi.NCP
+    assert len(cps) == 64 == abi.NCP
     feet = [i for i, n in enumerate(names) if "foot" in n]
     assert [c["rb"] for c in cps[:4]] == feet and all(c["kind"] == abi.CP_TERRAIN and c["radius"] == 0.02 for c in cps[:4])
     terrain = [c for c in cps if c["kind"] == abi.CP_TERRAIN]
-    pairs = [c for c in cps if c["kind"] != abi.CP_TERRAIN]
-    assert len(terrain) == 35 and len(pairs) == 12
-    # slots (= wavefront lanes): the robot's terrain spheres and self pairs below 32 (the set a walking robot lives in), everything
-    # that involves the free box in the 16-lane row 32..47 (summed by a row reduction in the kernel), the mid-shanks from 48
+    pairs = [c for c in cps if c["kind"] == abi.CP_BOX]
+    dyn = [c for c in cps if c["kind"] == abi.CP_DYNAMIC]
+    assert len(terrain) == 35 and len(pairs) == 8 and len(dyn) == 21
+    # slots (= wavefront lanes): the robot's terrain spheres and the arm-vs-trunk pairs below 26, everything that involves the free
+    # box in the 16-lane row 32..47 (summed by a row reduction in the kernel), the mid-shanks 48..51, dynamic slots in between
     slots = [c["slot"] for c in cps]
-    assert slots == sorted(slots) and len(set(slots)) == 47 and max(slots) < abi.NCP
-    low = [c for c in cps if c["slot"] < 32]
-    assert [c["slot"] for c in low] == list(range(30)) and all(c["body"] != abi.BOX_BODY and c["body2"] != abi.BOX_BODY for c in low)
+    assert slots == list(range(64))
+    low = [c for c in cps if c["slot"] < 26]
+    assert all(c["body"] != abi.BOX_BODY and c["body2"] != abi.BOX_BODY and c["kind"] != abi.CP_DYNAMIC for c in low)
     row = [c for c in cps if 32 <= c["slot"] < 48]
-    assert len(row) == 13 and all(c["body"] == abi.BOX_BODY or c["body2"] == abi.BOX_BODY for c in row)
+    assert len(row) == 16 and all(c["body"] == abi.BOX_BODY or c["body2"] == abi.BOX_BODY or c["kind"] == abi.CP_DYNAMIC for c in row)
+    assert [c["slot"] for c in dyn] == abi.DYN_SELF_SLOTS[:6] + abi.DYN_BOX_SLOTS + abi.DYN_SELF_SLOTS[6:]
     assert [c["slot"] for c in cps if c["radius"] == abi.CALF_RADIUS] == [48, 49, 50, 51]
     wm = abi.fill_model(m)
-    assert wm.ncp == 52 and wm.cp_kind[31] == abi.CP_NONE and all(wm.cp_kind[c["slot"]] == c["kind"] for c in cps)
+    assert wm.ncp == 64 and all(wm.cp_kind[c["slot"]] == c["kind"] for c in cps)
+    # the robot's 27 spheres carry compact indices (their centres are cached once per substep); a static pair names its sphere
+    sph = sorted(c["sph"] for c in terrain if c["body"] != abi.BOX_BODY)
+    assert sph == list(range(abi.NSPH)) and all(wm.cp_sph[c["slot"]] == c["sph"] for c in cps)
+    for c in pairs:
+        assert wm.pr_kind[c["slot"]] == abi.PR_STATIC and wm.pr_a[c["slot"]] == c["sph"]
+        own = next(t for t in terrain if t["sph"] == c["sph"])
+        assert own["rb"] == c["rb"] and own["radius"] == c["radius"] and np.allclose(own["pos"], c["pos"])
+    # limbs and candidates: 20 leg-leg pairs + 24 arm-leg pairs (the three arm-trunk pairs are static), then 12 more robot spheres
+    # against the free box; every lane without a static pair tests exactly one candidate
+    assert [l["name"] for l in limbs] == [f"{l}_thigh" for l in abi.LEGS] + [f"{l}_calf" for l in abi.LEGS] + ["elbow", "wrist", "gripper"]
+    for l in limbs[:8]:
+        a, b = (next(t for t in terrain if t["sph"] == l[k]) for k in ("s0", "s1"))
+        assert np.isclose(np.linalg.norm(a["pos"] - b["pos"]), 0.213) and a["body"] == b["body"] == l["body"] or "thigh" in l["name"]
+    lp = [(limbs[c["a"]]["name"], limbs[c["b"]]["name"]) for c in cands if c["kind"] == abi.PR_LIMBS]
+    assert len(lp) == 44 and len({frozenset(p) for p in lp}) == 44
+    assert all(a[:2] != b[:2] for a, b in lp)                              # never the thigh and calf of one leg (adjacent links)
+    assert not any("thigh" in a and "thigh" in b and a[0] != b[0] for a, b in lp)      # front and rear thighs never meet
+    assert sum(1 for a, b in lp if a in ("elbow", "wrist", "gripper")) == 24
+    bx = [c for c in cands if c["kind"] == abi.PR_SPHERE_BOX]
+    assert len(bx) == 12 and sorted(c["a"] for c in bx) == [4, 5, 6, 7, 15, 17, 19, 21, 23, 24, 25, 26]
+    lanes = [k for k in range(64) if wm.pr_kind[k] != abi.PR_STATIC]
+    assert len(lanes) == 56 and all(wm.pr_kind[k] in (abi.PR_LIMBS, abi.PR_SPHERE_BOX) for k in lanes)
+    assert all(abs(wm.pr_reach[k] / abi.REACH_STEP - round(wm.pr_reach[k] / abi.REACH_STEP)) < 1e-5 for k in range(64))
     robot_terrain = [c for c in terrain if c["body"] != abi.BOX_BODY]
     box_corners = [c for c in terrain if c["body"] == abi.BOX_BODY]
     assert len(robot_terrain) == 27 and len(box_corners) == 8 and all(c["rb"] == abi.BOX_RB for c in box_corners)
@@ -266,16 +292,15 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     assert arm == {"wx250s/ee_gripper_link", "wx250s/upper_forearm_link", "wx250s/wrist_link"}
     self_pairs = [c for c in pairs if c["body2"] != abi.BOX_BODY]
     box_pairs = [c for c in pairs if c["body2"] == abi.BOX_BODY]
-    assert len(self_pairs) == 7 and len(box_pairs) == 5
+    assert len(self_pairs) == 3 and len(box_pairs) == 5
     for c in self_pairs:
-        assert c["body2"] >= 0 and c["body2"] != c["body"] and "wx250s" in names[c["rb"]]
-        assert names[c["rb2"]] in ("trunk", "FL_thigh", "FR_thigh")
-        assert (c["kind"] == abi.CP_BOX) == (names[c["rb2"]] == "trunk")
+        assert c["body2"] == 0 and c["body2"] != c["body"] and "wx250s" in names[c["rb"]] and names[c["rb2"]] == "trunk"
     for c in box_pairs:
         assert c["kind"] == abi.CP_BOX and c["rb2"] == abi.BOX_RB and np.allclose(c["b"], 0.05) and np.allclose(c["a"], 0)
     assert sorted(names[c["rb"]] for c in box_pairs) == sorted([names[i] for i in feet] + ["wx250s/ee_gripper_link"])
     wm0 = abi.fill_model(m, self_collisions=False)                      # no pairs at all: the box actor shares the filter (WG:384)
     assert sum(wm0.cp_kind[k] != abi.CP_NONE for k in range(wm0.ncp)) == 35 and all(wm0.cp_kind[k] <= abi.CP_TERRAIN for k in range(wm0.ncp))
+    assert all(wm0.pr_kind[k] == abi.PR_NONE for k in range(abi.NCP))
     # rigid-body masks of the task config (WG:299-306: substring match)
     cfg = WidowGo1RoughCfg()
     cfg.asset.terminate_after_contacts_on = ["wx250", "base"]        # the list the reference keeps commented out (widowGo1_config.py:179)
@@ -445,7 +470,8 @@ def test_every_config_leaf_is_classified_and_behaves_as_classified():
     tc = abi.fill_task_cfg(cfg, m)
     wm0, wm1 = abi.fill_model(m), abi.fill_model(m, rest_offset=0.002)
     assert tc.contact_margin == pytest.approx(0.008) and tc.contact_iters == 4
-    assert all(wm1.cp_radius[k] == pytest.approx(wm0.cp_radius[k] + 0.002) for k in range(abi.NCP) if wm0.cp_kind[k] >= 0)
+    assert all(wm1.cp_radius[k] == pytest.approx(wm0.cp_radius[k] + 0.002) for k in range(abi.NCP) if wm0.cp_kind[k] in (abi.CP_TERRAIN, abi.CP_BOX))
+    assert wm1.pair_rest_offset == pytest.approx(0.002) and wm0.pair_rest_offset == 0
     cfg.sim.physx.rest_offset = 0.02
     with pytest.raises(ValueError, match="rest_offset"):
         abi.fill_task_cfg(cfg, m)

@@ -322,73 +322,78 @@ def test_trunk_and_thighs_rest_on_the_ground(robot):
 
 
 def test_self_collision_geometry_against_brute_force(robot):
-    """The narrow phase of the self-collision pairs (closest point of the trunk box / of a thigh capsule to an arm sphere) against
-    a brute-force search: for random arm poses of a robot at rest in free fall, a pair reports a contact force when the sphere
-    penetrates a dense point sampling of the partner's surface (a separating velocity is demanded), none when it is clear of the
-    contact margin (in between the contact is speculative: active, but bodies at relative rest need no impulse), and the force on
-    the sphere's body points away from the partner (along the line from the nearest sampled surface point to the sphere centre)."""
+    """Self-collision as configured (asset.self_collisions = 0: every pair of non-adjacent links, widowGo1_config.py:180): the oracle's
+    broad phase, promotion into dynamic slots and exact tests (sphere vs trunk box, limb vs limb as unions of capsule and end spheres)
+    against brute-force geometry that shares no code with it (tests/self_collision_geometry.py). Robots at rest in free fall, every
+    joint drawn uniformly inside its limits: a rigid body reports a contact force when one of its primitives penetrates another
+    link's by more than 4 mm (bodies at relative rest: only a penetration demands an impulse), none when all of its pairs are clear
+    of the contact margin by 4 mm; pair forces are internal (they cancel over the robot); with one penetrating pair on a body the
+    force on it points away from the partner."""
+    import self_collision_geometry as G
     model, tc = robot["model"], copy.copy(robot["tcfg"])
     wm = robot["wmodel"]
-    n = 600
+    n = 8000
     rng = np.random.default_rng(23)
     o = OracleSim(wm, tc, n)
     root = np.zeros((n, 2, 13)); root[:, :, 6] = 1; root[:, 0, 2] = 40.0
-    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = np.array(tc.default_dof_pos)[None]
-    lo, hi = np.array(model.dof_lower[12:18]), np.array(model.dof_upper[12:18])
-    lo[0], hi[0] = -1.5, 1.5
-    dof[:, 12:18, 0] = rng.uniform(lo, hi, (n, 6))
-    dof[:, [1, 4], 0] = rng.uniform(0.3, 1.4, (n, 2))                 # front thighs swung as well
+    lo, hi = np.array(model.dof_lower, dtype=np.float64), np.array(model.dof_upper, dtype=np.float64)
+    free = ~(lo < hi)
+    lo[free], hi[free] = -np.pi, np.pi
+    lo[18:], hi[18:] = 0.0, 0.0
+    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = rng.uniform(lo, hi, (n, 20))
+    dof[: n // 2, :12, 0] = np.array(tc.default_dof_pos)[None, :12] + rng.uniform(-0.5, 0.5, (n // 2, 12))     # half of them: legs near the stance
+    dof[:, :12, 0] = np.clip(dof[:, :12, 0], lo[:12], hi[:12])
     o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
     o.refresh_rigid_body_state()
     rb = o.get("RIGID_BODY_STATE")                                     # world poses of the rigid bodies BEFORE the substep
     o.simulate()
     f = o.get("NET_CONTACT_FORCE")
     names = model.rb_names
+    gaps = G.all_pairs(rb, names)
+    prim_rbs = {"trunk": ["trunk"], "elbow": ["wx250s/upper_forearm_link"], "wrist": ["wx250s/wrist_link"], "gripper": ["wx250s/ee_gripper_link"]}
+    for l in G.LEGS:
+        prim_rbs[l + "_thigh"] = [l + "_thigh"]
+        prim_rbs[l + "_calf"] = [l + "_calf", l + "_foot"]               # the calf limb: its shaft and knee report on the calf, its foot sphere on the foot
+    idx = {p: [names.index(r) for r in rbs] for p, rbs in prim_rbs.items()}
+    margin = float(tc.contact_margin)
+    fnorm = np.linalg.norm(f[:, :27], axis=-1)
+    np.testing.assert_allclose(f[:, :27].sum(1), 0.0, atol=1e-9)           # internal forces
+    hits = clear = 0
+    per_prim_pen = {p: np.zeros(n, dtype=int) for p in prim_rbs}
+    per_prim_near = {p: np.zeros(n, dtype=bool) for p in prim_rbs}
+    for (a, b), g in gaps.items():
+        for p in (a, b):
+            per_prim_pen[p] += g < -4e-3
+            per_prim_near[p] |= g < margin + 4e-3
+    # "must push" is asserted where the penetrating pair is the robot's ONLY pair inside the margin: with several contacts on one chain
+    # another one's impulse may already be separating the pair (the solver then rightly gives it none)
+    n_near = sum((g < margin + 4e-3).astype(int) for g in gaps.values())
+    for p, rbs in idx.items():
+        pushing = fnorm[:, rbs].sum(1) > 0
+        must, mustnot = (per_prim_pen[p] > 0) & (n_near == 1), ~per_prim_near[p]
+        assert pushing[must].all(), (p, np.nonzero(must & ~pushing)[0][:5])
+        assert not pushing[mustnot].any(), (p, np.nonzero(mustnot & pushing)[0][:5])
+        hits += int(must.sum()); clear += int(mustnot.sum())
+    assert hits > 300 and clear > 50000, (hits, clear)
+    # direction: an arm sphere whose ONLY near pair is one limb / the trunk is pushed away from it
+    limbs, arm, trunk = G.primitives(rb, names)
+    checked = 0
+    for sname, (c, r) in arm.items():
+        mine = {k: g for k, g in gaps.items() if sname in k}
+        near_count = sum((g < margin + 4e-3).astype(int) for g in mine.values())
+        for (a, b), g in mine.items():
+            other = b if a == sname else a
+            if other == "trunk":
+                continue
+            a0, a1 = limbs[other][0], limbs[other][1]
+            d = a1 - a0
+            t = np.clip(((c - a0) * d).sum(-1) / (d * d).sum(-1), 0, 1)
+            away = c - (a0 + d * t[:, None])
+            away /= np.linalg.norm(away, axis=-1, keepdims=True)
+            sel = (g < -4e-3) & (g > -0.5 * r) & (near_count == 1) & (n_near == 1)
+            fa = f[:, idx[sname][0]]
+            for e in np.nonzero(sel)[0]:
+                assert np.dot(fa[e], away[e]) > 0.4 * np.linalg.norm(fa[e]) > 0, (sname, other, e)     # (normal + friction at mu = 1: within 66 deg)
+                checked += 1
+    assert checked > 10, checked
 
-    def rot(q):
-        x, y, z, w = q
-        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
-    # surface samplings in the partner's frame
-    hx, hy, hz = 0.3762 / 2, 0.0935 / 2, 0.114 / 2
-    g = np.linspace(-1, 1, 41)
-    u, v = np.meshgrid(g, g, indexing="ij")
-    box = np.concatenate([np.stack([s * hx * np.ones_like(u), hy * u, hz * v], -1).reshape(-1, 3) for s in (-1, 1)] +
-                         [np.stack([hx * u, s * hy * np.ones_like(u), hz * v], -1).reshape(-1, 3) for s in (-1, 1)] +
-                         [np.stack([hx * u, hy * v, s * hz * np.ones_like(u)], -1).reshape(-1, 3) for s in (-1, 1)])
-    ang = np.linspace(0, 2 * np.pi, 48, endpoint=False)
-    zs = np.linspace(-0.213, 0.0, 60)
-    cyl = np.stack([0.017 * np.cos(ang)[None] * np.ones((60, 1)), 0.017 * np.sin(ang)[None] * np.ones((60, 1)), zs[:, None] * np.ones((1, 48))], -1).reshape(-1, 3)
-    th, ph = np.meshgrid(np.linspace(0, np.pi / 2, 12), ang, indexing="ij")
-    cap = np.stack([0.017 * np.sin(th) * np.cos(ph), 0.017 * np.sin(th) * np.sin(ph), 0.017 * np.cos(th)], -1).reshape(-1, 3)
-    caps = np.concatenate([cyl, cap, cap * [1, 1, -1] + [0, 0, -0.213]])
-    checked = hits = 0
-    pair_ids = [k for k in range(wm.ncp) if wm.cp_kind[k] != abi.CP_TERRAIN and wm.cp_body2[k] != abi.BOX_BODY]
-    for rb1 in sorted({wm.cp_rb[k] for k in pair_ids}):               # per arm sphere: its net_contact_force row sums its pairs
-        mine = [k for k in pair_ids if wm.cp_rb[k] == rb1]
-        rad = wm.cp_radius[mine[0]]
-        off1 = np.array(wm.cp_pos[mine[0]]) - np.array(model.rb_offset[rb1])
-        for e in range(n):
-            c = rb[e, rb1, :3] + rot(rb[e, rb1, 3:7]) @ off1
-            gaps, aways, inside_box = [], [], False
-            for k in mine:
-                rb2 = wm.cp_rb2[k]
-                R2 = rot(rb[e, rb2, 3:7])
-                surf = box if names[rb2] == "trunk" else caps
-                pts = rb[e, rb2, :3] + surf @ R2.T
-                d = np.linalg.norm(pts - c, axis=1)
-                gaps.append(d.min() - rad)
-                aways.append((c - pts[d.argmin()]) / d.min())
-                inside_box |= names[rb2] == "trunk" and bool(np.all(np.abs(R2.T @ (c - rb[e, rb2, :3])) < [hx, hy, hz]))
-            pushing = np.abs(f[e, rb1]).sum() > 0
-            if inside_box or min(gaps) < -4e-3:
-                assert pushing, (names[rb1], e, gaps)
-                hits += 1
-                near = [i for i, gp in enumerate(gaps) if gp < tc.contact_margin + 4e-3]
-                if not inside_box and len(near) == 1 and gaps[near[0]] > -0.5 * rad:
-                    assert np.dot(f[e, rb1], aways[near[0]]) > 0.4 * np.linalg.norm(f[e, rb1]), (names[rb1], e)     # (normal + friction at mu = 1: within 66 deg)
-            elif min(gaps) > tc.contact_margin + 4e-3:
-                assert not pushing, (names[rb1], e, gaps)
-            checked += 1
-    assert checked > 1500 and hits > 20, (checked, hits)

@@ -19,7 +19,12 @@ for var in variants:
     if var.startswith("it"): tc.contact_iters = int(var[2:])
     if var == "nocontact": tc.contact_margin = -1e9
     if var == "noreset": tc.term_z_threshold = -10.0; tc.term_rp_threshold = 100.0
-    robot = dict(model=m, wmodel=abi.fill_model(m), cfg=cfg, tcfg=tc)
+    wm = abi.fill_model(m)
+    for k in range(abi.NCP):      # table-driven ablations of the self-collision broad phase: no candidates / no box candidates / no limb pairs
+        if (var == "nocand" and wm.pr_kind[k] in (abi.PR_LIMBS, abi.PR_SPHERE_BOX)) or (var == "noboxcand" and wm.pr_kind[k] == abi.PR_SPHERE_BOX) or \
+           (var == "nolimbcand" and wm.pr_kind[k] == abi.PR_LIMBS):
+            wm.pr_kind[k] = abi.PR_NONE
+    robot = dict(model=m, wmodel=wm, cfg=cfg, tcfg=tc)
     g = helpers.make_gpu(robot, n, helpers.random_env_params(n, 0))
     g.reset_all()
     acts = [torch.randn(n, 18, device="cuda") * float(os.environ.get("WBC_ACT_SCALE", "0.5")) for _ in range(8)]
