@@ -554,5 +554,62 @@ extern "C" int wbc_sim_internal_arm_inputs(wbc_sim* s, const DevConst** hc, cons
 extern "C" int wbc_sim_get_step_counter(wbc_sim* s, int64_t* out) { if (!s || !out) return fail(-1, "null"); *out = s->step_counter; return 0; }
 extern "C" int wbc_sim_set_step_counter(wbc_sim* s, int64_t v) { if (!s) return fail(-1, "null"); s->step_counter = v; return 0; }
 
+// ---- asset file (host only): model + task configuration + curricula + names, see include/wbc_sim.h --------------------------------
+struct wbc_asset {
+  wbc_model model;
+  wbc_task_cfg cfg;
+  wbc_curriculum cur[2];
+  int ndof = 0, nrb = 0;
+  std::vector<std::string> dof_names, rb_names;
+};
+static const char kAssetMagic[10] = "WBCASSET1";
+extern "C" int wbc_asset_load(const char* path, wbc_asset** out) {
+  if (!path || !out) return fail(-1, "wbc_asset_load: bad arguments");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(-2, std::string("wbc_asset_load: cannot open ") + path);
+  char magic[10];
+  uint32_t hdr[5];
+  wbc_asset* a = new wbc_asset();
+  bool ok = fread(magic, 1, 10, f) == 10 && memcmp(magic, kAssetMagic, 10) == 0 && fread(hdr, 4, 5, f) == 5;
+  if (ok && (hdr[0] != sizeof(wbc_model) || hdr[1] != sizeof(wbc_task_cfg) || hdr[2] != sizeof(wbc_curriculum))) {
+    fclose(f); delete a;
+    return fail(-3, "wbc_asset_load: the file was written for another version of the wbc_model / wbc_task_cfg / wbc_curriculum structs");
+  }
+  ok = ok && hdr[3] == WBC_NDOF && hdr[4] == WBC_NRB;
+  ok = ok && fread(&a->model, sizeof(wbc_model), 1, f) == 1 && fread(&a->cfg, sizeof(wbc_task_cfg), 1, f) == 1 &&
+       fread(a->cur, sizeof(wbc_curriculum), 2, f) == 2;
+  if (ok) {
+    a->ndof = (int)hdr[3]; a->nrb = (int)hdr[4];
+    char name[64];
+    for (int i = 0; ok && i < a->ndof + a->nrb; ++i) {
+      ok = fread(name, 1, 64, f) == 64;
+      name[63] = 0;
+      (i < a->ndof ? a->dof_names : a->rb_names).push_back(name);
+    }
+  }
+  fclose(f);
+  if (!ok) { delete a; return fail(-2, std::string("wbc_asset_load: not a wbc asset file: ") + path); }
+  *out = a;
+  return 0;
+}
+extern "C" void wbc_asset_free(wbc_asset* a) { delete a; }
+extern "C" int wbc_asset_dof_count(const wbc_asset* a) { return a ? a->ndof : -1; }
+extern "C" int wbc_asset_rigid_body_count(const wbc_asset* a) { return a ? a->nrb : -1; }
+extern "C" const char* wbc_asset_dof_name(const wbc_asset* a, int i) { return (a && i >= 0 && i < a->ndof) ? a->dof_names[i].c_str() : nullptr; }
+extern "C" const char* wbc_asset_rigid_body_name(const wbc_asset* a, int i) { return (a && i >= 0 && i < a->nrb) ? a->rb_names[i].c_str() : nullptr; }
+extern "C" int wbc_asset_dof_properties(const wbc_asset* a, float* lower, float* upper, float* velocity, float* effort) {
+  if (!a) return fail(-1, "null asset");
+  for (int i = 0; i < a->ndof; ++i) {
+    if (lower) lower[i] = a->model.q_lower[i];
+    if (upper) upper[i] = a->model.q_upper[i];
+    if (velocity) velocity[i] = a->model.qd_limit[i];
+    if (effort) effort[i] = a->model.effort[i];
+  }
+  return 0;
+}
+extern "C" const wbc_model* wbc_asset_model(const wbc_asset* a) { return a ? &a->model : nullptr; }
+extern "C" const wbc_task_cfg* wbc_asset_task_cfg(const wbc_asset* a) { return a ? &a->cfg : nullptr; }
+extern "C" const wbc_curriculum* wbc_asset_curriculum(const wbc_asset* a, int which) { return (a && (which == 0 || which == 1)) ? &a->cur[which] : nullptr; }
+
 // sizes of the ABI structs, checked against the ctypes mirrors by the CPU tests
 extern "C" void wbc_abi_sizes(int* out) { out[0] = (int)sizeof(wbc_model); out[1] = (int)sizeof(wbc_task_cfg); out[2] = (int)sizeof(wbc_curriculum); }

@@ -607,3 +607,25 @@ def body_params_from_randomisation(m: RobotModel, base_dmass, base_dcom, gripper
                              np.broadcast_to(gp["inertia"], (n, 6)))
     out = np.concatenate([M0[:, None], C0, I0, M1[:, None], C1, I1], axis=1)
     return out.astype(np.float32)
+
+
+DEFAULT_ASSET = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "widowgo1_default.wbcasset")
+ASSET_MAGIC = b"WBCASSET1\0"
+
+
+def asset_bytes(m: RobotModel, cfg) -> bytes:
+    """The binary asset wbc_asset_load reads (include/wbc_sim.h): the structs this module builds from a RobotModel and a config --
+    wbc_model, wbc_task_cfg, wbc_curriculum at update counter 0 and 1 -- and the DoF / rigid-body names: everything a binding that
+    is not this package needs to create a sim (tools/make_asset.py writes the packaged widowGo1 one)."""
+    import struct
+    from .curriculum import make_curriculum
+    wm = fill_model(m, foot_name=cfg.asset.foot_name, self_collisions=int(_get(cfg, "asset.self_collisions", 0)) == 0, box_size=float(cfg.box.box_size),
+                    rest_offset=float(_get(cfg, "sim.physx.rest_offset", 0.0)))
+    tc = fill_task_cfg(cfg, m)
+    parts = [ASSET_MAGIC, struct.pack("<5I", C.sizeof(WbcModel), C.sizeof(WbcTaskCfg), C.sizeof(WbcCurriculum), NDOF, NRB),
+             bytes(wm), bytes(tc), bytes(make_curriculum(cfg, 0)), bytes(make_curriculum(cfg, 1))]
+    for name in list(m.dof_names) + list(m.rb_names):
+        b = name.encode()
+        assert len(b) < 64
+        parts.append(b.ljust(64, b"\0"))
+    return b"".join(parts)

@@ -76,6 +76,21 @@ def lib():
         L.wbc_ppo_minibatch_grad.argtypes = [c_void] * 9 + [c_int] + [C.c_float] * 4 + [c_int, c_void, c_void, c_void, c_void]
         L.wbc_ppo_minibatch_grad_packed.argtypes = L.wbc_ppo_minibatch_grad.argtypes
         L.wbc_ppo_pack_invalidate.argtypes = [c_void]
+        L.wbc_asset_load.argtypes = [C.c_char_p, C.POINTER(c_void)]
+        L.wbc_asset_free.argtypes = [c_void]
+        L.wbc_asset_free.restype = None
+        for fn in ("wbc_asset_dof_count", "wbc_asset_rigid_body_count"):
+            getattr(L, fn).argtypes = [c_void]
+        for fn in ("wbc_asset_dof_name", "wbc_asset_rigid_body_name"):
+            getattr(L, fn).argtypes = [c_void, c_int]
+            getattr(L, fn).restype = C.c_char_p
+        L.wbc_asset_dof_properties.argtypes = [c_void] * 5
+        L.wbc_asset_model.argtypes = [c_void]
+        L.wbc_asset_model.restype = C.POINTER(abi.WbcModel)
+        L.wbc_asset_task_cfg.argtypes = [c_void]
+        L.wbc_asset_task_cfg.restype = C.POINTER(abi.WbcTaskCfg)
+        L.wbc_asset_curriculum.argtypes = [c_void, c_int]
+        L.wbc_asset_curriculum.restype = C.POINTER(abi.WbcCurriculum)
         L.wbc_ppo_sq_partials_offset.argtypes = [c_int]
         L.wbc_ppo_sq_partials_offset.restype = C.c_size_t
         L.wbc_ppo_clip_adam.argtypes = [c_void] * 4 + [C.c_float] * 7 + [c_void, c_void, c_void]
@@ -100,7 +115,8 @@ EXPORTED_SYMBOLS = [
     "wbc_gae_normalize", "wbc_gae_workspace_doubles", "wbc_abi_sizes", "wbc_sim_episode_stats", "wbc_rollout_store", "wbc_hist_latent", "wbc_sim_arm_dynamics", "wbc_policy_act", "wbc_policy_pack", "wbc_policy_pack_floats", "wbc_ppo_minibatch_grad", "wbc_ppo_minibatch_grad_packed", "wbc_ppo_pack_invalidate", "wbc_ppo_clip_adam", "wbc_ppo_clip_adam_packed", "wbc_ppo_clip_adam_workspace_floats", "wbc_ppo_grad_floats",
     "wbc_ppo_num_splits", "wbc_ppo_workspace_floats", "wbc_ppo_sq_partials_offset", "wbc_hist_train_grad", "wbc_hist_train_grad_floats",
     "wbc_hist_train_workspace_floats", "wbc_hist_clip_adam", "wbc_priv_latent", "wbc_runner_track_episodes", "wbc_sim_episode_stats_track", "wbc_tensor_spec", "wbc_policy_act_job", "wbc_sim_episode_stats_job", "wbc_side_job_run",
-    "wbc_runner_track_state_floats"]
+    "wbc_runner_track_state_floats", "wbc_asset_load", "wbc_asset_free", "wbc_asset_dof_count", "wbc_asset_rigid_body_count", "wbc_asset_dof_name",
+    "wbc_asset_rigid_body_name", "wbc_asset_dof_properties", "wbc_asset_model", "wbc_asset_task_cfg", "wbc_asset_curriculum"]
 
 
 def check(rc: int, what: str = "") -> None:

@@ -291,6 +291,29 @@ typedef struct wbc_sim wbc_sim;
 
 const char* wbc_last_error(void);
 
+/* ---- asset: what gym.load_asset + the get_asset_* getters (WG:268-294) and the config resolution of WidowGo1._parse_cfg /
+ * _init_buffers (WG:78-121, 498-672) hand to the reference, as ONE binary file -- so that a binding in any language can create a
+ * sim without this repository's Python: wbc_asset_load -> wbc_asset_model / _task_cfg / _curriculum -> (edit the documented fields
+ * of its own copies: gains, thresholds, reward scales ...) -> wbc_sim_create. The packaged widowGo1 asset with the shipped config is
+ * deep-whole-body-control_amd/wbc_amd/assets/widowgo1_default.wbcasset (written by tools/make_asset.py from the URDF tables and
+ * WidowGo1RoughCfg; a test keeps it equal to what the Python host path builds). File layout: magic "WBCASSET1", the three struct
+ * sizes (checked against this library's: -3 on a mismatch = another ABI version), dof / rigid-body counts, the structs (wbc_model,
+ * wbc_task_cfg, wbc_curriculum before and after the first update_command_curriculum call), then the names (64-byte fields). */
+typedef struct wbc_asset wbc_asset;
+int wbc_asset_load(const char* path, wbc_asset** out);
+void wbc_asset_free(wbc_asset* asset);
+int wbc_asset_dof_count(const wbc_asset* asset);                       /* gym.get_asset_dof_count (WG:287) */
+int wbc_asset_rigid_body_count(const wbc_asset* asset);                /* gym.get_asset_rigid_body_count (WG:288) */
+const char* wbc_asset_dof_name(const wbc_asset* asset, int i);         /* gym.get_asset_dof_names (WG:293) */
+const char* wbc_asset_rigid_body_name(const wbc_asset* asset, int i);  /* gym.get_asset_rigid_body_names (WG:292) */
+/* gym.get_asset_dof_properties (WG:289, LR:279-305): lower / upper / velocity / effort, each dof_count floats (NULL: skipped) */
+int wbc_asset_dof_properties(const wbc_asset* asset, float* lower, float* upper, float* velocity, float* effort);
+const wbc_model* wbc_asset_model(const wbc_asset* asset);
+const wbc_task_cfg* wbc_asset_task_cfg(const wbc_asset* asset);
+/* which = 0: as the task object carries them before the first update_command_curriculum call; 1: after it (the shipped schedules
+ * saturate on the first call, WG:678-692) */
+const wbc_curriculum* wbc_asset_curriculum(const wbc_asset* asset, int which);
+
 /* Bytes of device memory a sim of `num_envs` needs. */
 size_t wbc_sim_arena_bytes(int num_envs);
 
