@@ -397,3 +397,64 @@ def test_self_collision_geometry_against_brute_force(robot):
                 checked += 1
     assert checked > 10, checked
 
+
+
+def test_free_box_candidates_against_brute_force(robot):
+    """The robot spheres that can meet the free box besides the five static pairs (knees, shins, the trunk's bottom corners: promoted
+    into the box row's dynamic slots) and the static five (feet, gripper tip), against brute-force sphere-vs-cube geometry: boxes at
+    random poses around robots in free fall, everything at rest. The box reports a contact force when a listed sphere penetrates it
+    by more than 3 mm, none when all of them are clear of the margin by 3 mm; the robot's rows carry the opposite force."""
+    model, tc = robot["model"], copy.copy(robot["tcfg"])
+    wm = robot["wmodel"]
+    n = 4000
+    rng = np.random.default_rng(31)
+    o = OracleSim(wm, tc, n)
+    root = np.zeros((n, 2, 13)); root[:, :, 6] = 1; root[:, 0, 2] = 40.0
+    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = np.array(tc.default_dof_pos)[None] + rng.uniform(-0.3, 0.3, (n, 20))
+    dof[:, 18:, 0] = 0
+    o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
+    o.refresh_rigid_body_state()
+    rb = o.get("RIGID_BODY_STATE")
+    names = model.rb_names
+    cps, _, cands = abi.collision_set(model)
+    sph = {c["sph"]: c for c in cps if c["kind"] == abi.CP_TERRAIN and c["body"] != abi.BOX_BODY}
+    listed = sorted({c["a"] for c in cands if c["kind"] == abi.PR_SPHERE_BOX} | {c["sph"] for c in cps if c["kind"] == abi.CP_BOX and c["body2"] == abi.BOX_BODY})
+    assert len(listed) == 17
+
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    centres = np.zeros((n, len(listed), 3))
+    for e in range(n):
+        for i, si in enumerate(listed):
+            c = sph[si]
+            centres[e, i] = rb[e, c["rb"], :3] + rot(rb[e, c["rb"], 3:7]) @ (np.asarray(c["pos"]) - np.asarray(model.rb_offset[c["rb"]]))
+    # the box: next to one of the listed spheres (a random one per env), random orientation
+    pick = rng.integers(0, len(listed), n)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    root[:, 1, :3] = centres[np.arange(n), pick] + d * rng.uniform(0.03, 0.11, (n, 1))
+    root[:, 1, 3:7] = q
+    o.set("ROOT_STATES", root)
+    o.simulate()
+    f = o.get("NET_CONTACT_FORCE")
+    h = float(wm.box_half)
+    gaps = np.zeros((n, len(listed)))
+    for e in range(n):
+        Rb = rot(q[e])
+        for i, si in enumerate(listed):
+            loc = Rb.T @ (centres[e, i] - root[e, 1, :3])
+            cl = np.clip(loc, -h, h)
+            out = np.linalg.norm(loc - cl)
+            gaps[e, i] = (out if out > 0 else -(h - np.abs(loc)).min()) - sph[si]["radius"]
+    box_push = np.abs(f[:, 27]).sum(-1) > 0
+    pen, clear = (gaps < -3e-3).any(1), (gaps > float(tc.contact_margin) + 3e-3).all(1)
+    few = (gaps < float(tc.contact_margin) + 3e-3).sum(1) <= 3                      # (the box row has three dynamic slots)
+    assert box_push[pen & few].all() and not box_push[clear].any(), (np.nonzero(pen & few & ~box_push)[0][:5], np.nonzero(clear & box_push)[0][:5])
+    assert (pen & few).sum() > 800 and clear.sum() > 300, (pen.sum(), clear.sum())
+    np.testing.assert_allclose(f[:, :28].sum(1), 0.0, atol=1e-9)                    # the pair forces cancel over robot + box
+    # candidates beyond the static five were exercised
+    dyn = [i for i, si in enumerate(listed) if si not in (0, 1, 2, 3, 8)]
+    assert ((gaps[:, dyn] < -3e-3).any(1) & box_push).sum() > 400
