@@ -39,6 +39,11 @@ struct DevConst {
   uint32_t pr_pack[WBC_NCP];
   float trunk_c[3], trunk_h[3];                    // the static pairs' box on the root body (the trunk): centre and half extents, frame F
   int32_t sph_slot[WBC_NSPH];                      // the terrain slot of each robot sphere
+  // what a promoted candidate needs, per candidate lane, so that the promoted lane fetches it in ONE round of independent loads (a launch
+  // ends with its slowest wave): radii (limb a: shaft, end 0, end 1; limb b: the same | a sphere-vs-box candidate: [0] = the sphere's
+  // radius), rigid bodies (6 x 5 bits in the same order | [0] = the sphere's), moving bodies (a | b << 8)
+  float cand_rad[WBC_NCP][8];
+  uint32_t cand_rbs[WBC_NCP], cand_bodies[WBC_NCP];
   uint32_t body_pack[WBC_NB];                      // axis | dof << 2
   // heightfield (optional)
   const int16_t* hf;

@@ -202,6 +202,20 @@ static int build_chains(DevConst& hc) {
       } else for (int j = 0; j < 3; ++j) if (m.cp_a[k][j] != 0.f || m.cp_b[k][j] != m.box_half) return -1;
     } else if (pk != WBC_PR_NONE) return -1;
     if (k < m.ncp && m.cp_kind[k] == WBC_CP_BOX && pk != WBC_PR_STATIC) return -1;
+    for (int j = 0; j < 8; ++j) hc.cand_rad[k][j] = 0.f;
+    hc.cand_rbs[k] = hc.cand_bodies[k] = 0;
+    if (pk == WBC_PR_LIMBS) {
+      const int la = m.pr_a[k], lb = m.pr_b[k];
+      const float r[6] = {m.limb_radius[la], m.limb_cap0[la], m.limb_cap1[la], m.limb_radius[lb], m.limb_cap0[lb], m.limb_cap1[lb]};
+      const int rbs[6] = {m.limb_rb[la], m.limb_rb0[la], m.limb_rb1[la], m.limb_rb[lb], m.limb_rb0[lb], m.limb_rb1[lb]};
+      for (int j = 0; j < 6; ++j) { hc.cand_rad[k][j] = r[j]; hc.cand_rbs[k] |= (uint32_t)rbs[j] << (5 * j); }
+      hc.cand_bodies[k] = (uint32_t)m.limb_body[la] | (uint32_t)m.limb_body[lb] << 8;
+    } else if (pk == WBC_PR_SPHERE_BOX) {
+      const int ss = hc.sph_slot[m.pr_a[k]];
+      hc.cand_rad[k][0] = m.cp_radius[ss];
+      hc.cand_rbs[k] = (uint32_t)m.cp_rb[ss];
+      hc.cand_bodies[k] = (uint32_t)m.cp_body[ss] | (uint32_t)WBC_BOX_BODY << 8;
+    }
     uint32_t rcode = 0;
     if (pk != WBC_PR_NONE) {
       const float q = m.pr_reach[k] / WBC_REACH_STEP;

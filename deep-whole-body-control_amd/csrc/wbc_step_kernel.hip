@@ -296,38 +296,37 @@ __device__ __forceinline__ void seg_seg_closest(f3 a0, f3 a1, f3 b0, f3 b1, f3* 
   const f3 d1 = a1 - a0, d2 = b1 - b0, r = a0 - b0;
   const float EPS = 1e-10f;
   const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+  const float ia = rcpf(fmaxf(a, EPS)), ie = rcpf(fmaxf(e, EPS));            // (v_rcp_f32: the stage runs on every near limb pair, every substep)
   float sp = 0.f, tp = 0.f;
   if (a <= EPS && e <= EPS) { sp = tp = 0.f; }
-  else if (a <= EPS) { tp = clampf(f / e, 0.f, 1.f); }
+  else if (a <= EPS) { tp = clampf(f * ie, 0.f, 1.f); }
   else {
     const float c = dot(d1, r);
-    if (e <= EPS) { sp = clampf(-c / a, 0.f, 1.f); }
+    if (e <= EPS) { sp = clampf(-c * ia, 0.f, 1.f); }
     else {
       const float b = dot(d1, d2), den = a * e - b * b;
-      sp = den > 1e-7f * a * e ? clampf((b * f - c * e) / den, 0.f, 1.f) : 0.f;
-      tp = (b * sp + f) / e;
-      if (tp < 0.f) { tp = 0.f; sp = clampf(-c / a, 0.f, 1.f); }
-      else if (tp > 1.f) { tp = 1.f; sp = clampf((b - c) / a, 0.f, 1.f); }
+      sp = den > 1e-7f * a * e ? clampf((b * f - c * e) * rcpf(den), 0.f, 1.f) : 0.f;
+      tp = (b * sp + f) * ie;
+      if (tp < 0.f) { tp = 0.f; sp = clampf(-c * ia, 0.f, 1.f); }
+      else if (tp > 1.f) { tp = 1.f; sp = clampf((b - c) * ia, 0.f, 1.f); }
     }
   }
   *pa = a0 + d1 * sp; *pb = b0 + d2 * tp;
 }
 // Limb A against limb B (oracle: limb_pair): unions of a capsule and up to two end spheres; the feature pair with the smallest gap wins,
 // in the oracle's order (shafts; A's end spheres against B's shaft; B's against A's shaft; end sphere against end sphere; a tie keeps
-// the earlier). ck = the candidate's packed descriptor (sphere indices of the four ends), la / lb = its limbs. Runs on the few lanes a
-// candidate was promoted into, but a launch ends with its slowest wave: one general segment-segment test, then point-segment and
-// point-point tests (a fifth of nine general ones); operands are (re)read where they are used -- LDS sphere centres, constant-block
-// radii -- so that nothing of it is live outside (the kernel is compiled for 128 VGPRs).
+// the earlier). ck = the candidate's packed descriptor (sphere indices of the four ends), rad = its six radii (DevConst::cand_rad).
+// Runs on the few lanes a candidate was promoted into, but a launch ends with its slowest wave: one general segment-segment test,
+// then point-segment and point-point tests; the sphere centres are (re)read from LDS where they are used.
 struct LimbHit { float gap, ra, rb; f3 n, q; int fa, fb; };
 __device__ __forceinline__ f3 closest_on_segment(f3 p, f3 b0, f3 b1) {
   const f3 d = b1 - b0;
   const float e = dot(d, d);
-  const float t = e <= 1e-10f ? 0.f : clampf(dot(p - b0, d) / e, 0.f, 1.f);
+  const float t = e <= 1e-10f ? 0.f : clampf(dot(p - b0, d) * rcpf(e), 0.f, 1.f);
   return b0 + d * t;
 }
-__device__ void limb_pair(const Smem& s, CP Cc, uint32_t ck, int la, int lb, LimbHit& out) {
-  const float rest = Cc->model.pair_rest_offset;
-  const float ra = Cc->model.limb_radius[la], rb = Cc->model.limb_radius[lb];
+__device__ void limb_pair(const Smem& s, uint32_t ck, const float (&rad)[6], float rest, LimbHit& out) {
+  const float ra = rad[0], rb = rad[3];
   f3 bpa, bpb;
   seg_seg_closest(ld3(s.sph[(ck >> 7) & 31]), ld3(s.sph[(ck >> 12) & 31]), ld3(s.sph[(ck >> 17) & 31]), ld3(s.sph[(ck >> 22) & 31]), &bpa, &bpb);
   float best;
@@ -338,12 +337,10 @@ __device__ void limb_pair(const Smem& s, CP Cc, uint32_t ck, int la, int lb, Lim
   out.fa = out.fb = 0; out.ra = ra; out.rb = rb;
 #pragma unroll 1
   for (int f = 1; f < 9; ++f) {
-    int ff = f;
-    asm volatile("" : "+v"(ff));                    // (keeps the loop's loads inside the loop)
-    const int ea = ff <= 2 ? ff - 1 : (ff <= 4 ? -1 : (ff - 5) >> 1);
-    const int eb = ff <= 2 ? -1 : (ff <= 4 ? ff - 3 : (ff - 5) & 1);
-    const float fra = ea < 0 ? ra : (ea == 0 ? Cc->model.limb_cap0[la] : Cc->model.limb_cap1[la]);
-    const float frb = eb < 0 ? rb : (eb == 0 ? Cc->model.limb_cap0[lb] : Cc->model.limb_cap1[lb]);
+    const int ea = f <= 2 ? f - 1 : (f <= 4 ? -1 : (f - 5) >> 1);
+    const int eb = f <= 2 ? -1 : (f <= 4 ? f - 3 : (f - 5) & 1);
+    const float fra = ea < 0 ? ra : (ea == 0 ? rad[1] : rad[2]);
+    const float frb = eb < 0 ? rb : (eb == 0 ? rad[4] : rad[5]);
     if (!(fra > 0.f) || !(frb > 0.f)) continue;     // (no such end sphere)
     f3 pa, pb;
     if (ea >= 0) {
@@ -362,7 +359,7 @@ __device__ void limb_pair(const Smem& s, CP Cc, uint32_t ck, int la, int lb, Lim
   }
   const f3 d = bpa - bpb;
   const float dist = __builtin_amdgcn_sqrtf(dot(d, d));
-  out.n = dist > 1e-9f ? d * (1.f / dist) : mk3(1.f, 0.f, 0.f);
+  out.n = dist > 1e-9f ? d * rcpf(dist) : mk3(1.f, 0.f, 0.f);
   out.q = bpb + out.n * out.rb;
   out.gap = best;
 }
@@ -716,33 +713,36 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       cand = (lane == d) ? c : cand;
     }
   }
+  // (a wave that promotes has the exact limb tests ahead of it -- the longer way to go: it takes the SIMD's issue slots first, as a
+  // wave in contact does)
+  if ((nearbits & (Cc->cand_self_mask | Cc->cand_box_mask)) != 0ull) __builtin_amdgcn_s_setprio(1);
   // (4) exact tests: the static pair lanes that passed, and the promoted candidates (their slot takes the pair's bodies, rigid bodies and
   // feature radii: drb / drb2 / drad2 are only meaningful on a promoted lane)
-  int dpk = 0;                    // promoted lane: rigid body | partner's rigid body << 8 | partner's feature (0 shaft, 1 / 2 end sphere) << 16 | its limb << 18
+  int dpk = 0;                    // promoted lane: rigid body | partner's rigid body << 8 | partner's feature (0 shaft, 1 / 2 end sphere) << 16 | the candidate << 18
   const bool do_static = cpkind == WBC_CP_BOX && near;
   if (__ballot(do_static || cand >= 0) != 0ull) {
     bool sbox = do_static;
     int si = (prk >> 7) & 31;                                            // the sphere of a sphere-vs-box test
     if (cand >= 0) {
-      const uint32_t ck = Cc->pr_pack[cand];
+      // everything the promoted pair needs in one round of independent loads: its descriptor (LDS), radii, rigid bodies, moving bodies
+      const uint32_t ck = s.k_prk[cand], crb = Cc->cand_rbs[cand], cbd = Cc->cand_bodies[cand];
+      float rad[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) rad[j] = Cc->cand_rad[cand][j];
+      cpb = cbd & 255; cpb2 = (cbd >> 8) & 255;
       if ((ck & 3) == WBC_PR_LIMBS) {
-        const int la = Cc->model.pr_a[cand], lb = Cc->model.pr_b[cand];
         LimbHit hit;
-        limb_pair(s, Cc, ck, la, lb, hit);
+        limb_pair(s, ck, rad, Cc->model.pair_rest_offset, hit);
         cgap = hit.gap; cn = hit.n; cxcr = hit.q;
         cpkind = WBC_CP_LIMBS;
-        cpb = Cc->model.limb_body[la]; cpb2 = Cc->model.limb_body[lb];
-        const int drb = hit.fa == 0 ? Cc->model.limb_rb[la] : (hit.fa == 1 ? Cc->model.limb_rb0[la] : Cc->model.limb_rb1[la]);
-        const int drb2 = hit.fb == 0 ? Cc->model.limb_rb[lb] : (hit.fb == 1 ? Cc->model.limb_rb0[lb] : Cc->model.limb_rb1[lb]);
         cpr = hit.ra;
-        dpk = drb | drb2 << 8 | hit.fb << 16 | lb << 18;
+        const int drb = (crb >> (5 * hit.fa)) & 31, drb2 = (crb >> (15 + 5 * hit.fb)) & 31;
+        dpk = drb | drb2 << 8 | hit.fb << 16 | cand << 18;
       } else {                                                           // a robot sphere against the free box
         si = (ck >> 7) & 31;
-        const int ss = Cc->sph_slot[si];
         cpkind = WBC_CP_BOX;
-        cpb = Cc->model.cp_body[ss]; cpr = Cc->model.cp_radius[ss];
-        cpb2 = WBC_BOX_BODY;
-        dpk = Cc->model.cp_rb[ss] | WBC_BOX_RB << 8;
+        cpr = rad[0];
+        dpk = (crb & 31) | WBC_BOX_RB << 8;
         sbox = true;
       }
     }
@@ -1110,8 +1110,8 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         const int d = __ffsll((unsigned long long)db) - 1;
         db &= db - 1;
         if (lane == d) {
-          const int drb = dpk & 255, drb2 = (dpk >> 8) & 255, dfb = (dpk >> 16) & 3, dlb = (dpk >> 18) & 15;
-          const float drad2 = dfb == 0 ? Cc->model.limb_radius[dlb] : (dfb == 1 ? Cc->model.limb_cap0[dlb] : Cc->model.limb_cap1[dlb]);
+          const int drb = dpk & 255, drb2 = (dpk >> 8) & 255, dfb = (dpk >> 16) & 3, dcand = (dpk >> 18) & 63;
+          const float drad2 = Cc->cand_rad[dcand][3 + dfb];               // the partner limb's touching feature
           const f3 f = clamr * idt, fw = mat_mul(s.R, f);
           st3(s.out_contact[drb], ld3(s.out_contact[drb]) + fw);
           if (drb2 != WBC_BOX_RB) st3(s.out_contact[drb2], ld3(s.out_contact[drb2]) - fw);
