@@ -206,3 +206,36 @@ def test_foot_against_the_box_exchanges_momentum(robot):
     assert r["dP"] < 0.02 * r["robot_dP"] + 1e-3, r                         # ... by what the box received (first-order integrator: 1 %)
     assert r["dL"] < 2e-3 * r["L_scale"], r
     assert r["separated"], r                                                 # depenetration lets go
+
+
+# ------------------------------------------------------------------------------------------------- solver settings of the config
+def test_rest_offset_and_position_iterations_are_honoured(robot):
+    """sim.physx.rest_offset (legged_robot_config.py:194): shapes rest that far apart -- a box dropped on the plane settles with its
+    faces rest_offset above the ground (0 with the shipped value). sim.physx.num_position_iterations (:191) is the number of solver
+    sweeps: one substep from a state with several contacts on one body differs between 2 and 4 sweeps, and 4 equals the default."""
+    import copy
+    from wbc_amd import abi
+    from wbc_amd.config import WidowGo1RoughCfg
+    from oracle import OracleSim
+    m = robot["model"]
+    rest = {}
+    for ro in (0.0, 0.003):
+        cfg = WidowGo1RoughCfg()
+        cfg.sim.physx.rest_offset = ro
+        tc, wm = abi.fill_task_cfg(cfg, m), abi.fill_model(m, rest_offset=ro)
+        o = OracleSim(wm, tc, 1)
+        root = np.zeros((1, 2, 13)); root[:, :, 6] = 1; root[0, 0, :3] = [0, 0, 30.0]; root[0, 1, :3] = [2.0, 0.0, 0.08]
+        o.set("ROOT_STATES", root)
+        dof = np.zeros((1, 20, 2)); dof[0, :, 0] = np.array(tc.default_dof_pos)
+        o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((1, 20)))
+        for _ in range(300):
+            o.simulate()
+        rest[ro] = float(o.get("ROOT_STATES")[0, 1, 2]) - 0.05                      # height of the cube's bottom face
+    assert abs(rest[0.0]) < 5e-4 and abs(rest[0.003] - 0.003) < 5e-4, rest
+    st = pc.contact_states(robot, 16)
+    assert int(abi.fill_task_cfg(WidowGo1RoughCfg(), m).contact_iters) == 4         # the shipped value
+    cfg = WidowGo1RoughCfg()
+    cfg.sim.physx.num_position_iterations = 2
+    assert int(abi.fill_task_cfg(cfg, m).contact_iters) == 2
+    res = pc.solver_convergence(robot, st, (2, 4))
+    assert np.abs(res[2]["f"] - res[4]["f"]).max() > 1.0                          # the sweeps are what the field sets
