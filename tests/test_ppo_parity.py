@@ -164,35 +164,45 @@ def test_reference_storage_fixture_replays_on_the_cpu_port():
     _assert_params(ac, GOLD["bench_params"], before, tol_of_step=0.01)
 
 
-@pytest.mark.gpu
-def test_dagger_update_on_the_gpu_matches_the_cpu_port():
-    """update_dagger on the device (csrc/wbc_hist_train_kernel.hip) against this package's CPU path from identical storage and
-    permutation (the CPU path itself is pinned to the reference's update_dagger by test_update_and_dagger_match_reference_cpu)."""
-    dev = "cuda:0"
-
-    def run(device):
-        torch.manual_seed(1)
-        ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
-        alg = PPO(ac, device=device, **gp.ALG_KW)
-        alg.counter = 3500
-        alg.init_storage(gp.N, gp.T, [860], [None], [18])
-        return ac, alg
-    ac_c, alg_c = run("cpu")
-    ac_g, alg_g = run(dev)
-    obs = gp.synthetic_rollout(100)[0]
-    for alg in (alg_c, alg_g):
-        st = alg.storage
-        st.observations.copy_(obs[:gp.T])
-        for name in gp.STORAGE_FIELDS:
-            getattr(st, name).copy_(torch.from_numpy(GOLD["it0_storage_" + name]).to(getattr(st, name).dtype))
-        st.step = gp.T
-    perm = torch.randperm(gp.N * gp.T)
+def _dagger_from_reference_fixture(device):
+    """The reference's DAgger iteration (it2 of the seeded procedure) replayed: its parameters before the call, its storage and its
+    permutation in, update_dagger() on `device`; returns (loss, actor-critic)."""
     import unittest.mock as mock
+    torch.manual_seed(1)
+    ac = ActorCritic(76, 76, 18, **gp.POLICY_KW)
+    _load_params(ac, GOLD["it2_params_before"])
+    alg = PPO(ac, device=device, **gp.ALG_KW)
+    alg.counter = 3502                                     # two update() calls came before it (SURVEY quirk L7)
+    alg.init_storage(gp.N, gp.T, [860], [None], [18])
+    st = alg.storage
+    st.observations.copy_(gp.synthetic_rollout(102)[0][:gp.T])
+    for name in gp.STORAGE_FIELDS:
+        getattr(st, name).copy_(torch.from_numpy(GOLD["it2_storage_" + name]).to(getattr(st, name).dtype))
+    st.step = gp.T
+    perm = torch.from_numpy(GOLD["it2_perm"])
     with mock.patch("torch.randperm", lambda n, **kw: perm.to(kw.get("device", "cpu"))):
-        lc = alg_c.update_dagger()
-        lg = alg_g.update_dagger()
-    np.testing.assert_allclose(lg, lc, rtol=2e-3, atol=1e-5)
-    np.testing.assert_allclose(gp.param_digest(ac_g)[:, :2], gp.param_digest(ac_c)[:, :2], rtol=2e-4, atol=2e-4)
+        loss = alg.update_dagger()
+    return float(loss), ac
+
+
+def test_dagger_fixture_replays_on_the_cpu_port():
+    loss, ac = _dagger_from_reference_fixture("cpu")
+    np.testing.assert_allclose(loss, GOLD["it2_stats"][0], rtol=1e-4)
+    _assert_params(ac, GOLD["it2_params_after"], GOLD["it2_params_before"], tol_of_step=0.01)
+
+
+@pytest.mark.gpu
+def test_fused_dagger_update_matches_the_reference_one_hop():
+    """update_dagger on the device (csrc/wbc_hist_train_kernel.hip: history-encoder forward, ||priv - hist|| loss, backward, clip + Adam
+    in HIP) fed the REFERENCE's recorded storage, permutation and starting parameters of its DAgger iteration (ppo.py:265-291), against
+    the reference's returned loss and post-update parameters -- no CPU port in between. Only the history encoder moves (quirk L6)."""
+    loss, ac = _dagger_from_reference_fixture("cuda:0")
+    np.testing.assert_allclose(loss, GOLD["it2_stats"][0], rtol=2e-3)
+    before, after = GOLD["it2_params_before"], GOLD["it2_params_after"]
+    _assert_params(ac, after, before, tol_of_step=0.05)
+    mine = gp.flat_params(ac)
+    frozen = before == after                                # everything but the history encoder
+    assert frozen.sum() > 160000 and np.array_equal(mine[frozen], before[frozen])
 
 
 @pytest.mark.gpu

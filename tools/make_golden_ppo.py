@@ -57,16 +57,40 @@ def _capturing_update(self):
     return _real_update(self)
 
 
+captured_dagger = {}
+_real_update_dagger = PPO.update_dagger
+
+
+def _capturing_update_dagger(self):
+    st = self.storage
+    for name in gp.STORAGE_FIELDS:
+        captured_dagger[name] = getattr(st, name).detach().cpu().numpy().copy()
+    captured_dagger["params_before"] = gp.flat_params(self.actor_critic)
+    captured_dagger["perm_index"] = len(perms)              # the permutation this call is about to draw
+    r = _real_update_dagger(self)
+    captured_dagger["params_after"] = gp.flat_params(self.actor_critic)
+    return r
+
+
 torch.randperm = _recording_randperm
 PPO.update = _capturing_update
+PPO.update_dagger = _capturing_update_dagger
 with contextlib.redirect_stdout(io.StringIO()):
     res = run_procedure(ActorCritic, PPO, device="cpu")
 PPO.update = _real_update
+PPO.update_dagger = _real_update_dagger
 for k, v in res.items():
     out[k] = v
 for k, v in captured.items():
     out["it0_storage_" + k] = v
 out["it0_perm"] = perms[0].numpy()
+# the DAgger iteration (it2 of the procedure: student rollouts, then update_dagger, ppo.py:265-291): its storage, permutation, the
+# parameters before and after
+for k in gp.STORAGE_FIELDS:
+    out["it2_storage_" + k] = captured_dagger[k]
+out["it2_params_before"] = captured_dagger["params_before"]
+out["it2_params_after"] = captured_dagger["params_after"]
+out["it2_perm"] = perms[captured_dagger["perm_index"]].numpy()
 
 # bench-shaped minibatch: N = 1024, T = 40 with ONE minibatch per epoch -> 40 960 rows per minibatch call, the shape of the bench's
 # update (4096 envs x 40 steps / 4 minibatches); synthetic storage (golden_procedure.synthetic_storage), 2 epochs
