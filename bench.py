@@ -45,8 +45,8 @@ def step_kernel_sha16():
     """First 16 hex digits of sha256 over the step kernel's sources: ties profiles/step_kernel_counters.json to the build it measured."""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("wbc_step_kernel.hip", "wbc_device.h"):
-        h.update(open(os.path.join(ROOT, "deep-whole-body-control_amd", "csrc", fn), "rb").read())
+    for fn in ("deep-whole-body-control_amd/csrc/wbc_step_kernel.hip", "deep-whole-body-control_amd/csrc/wbc_device.h", "include/wbc_sim.h"):
+        h.update(open(os.path.join(ROOT, fn), "rb").read())
     return h.hexdigest()[:16]
 
 

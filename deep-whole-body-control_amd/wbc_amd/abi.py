@@ -13,7 +13,7 @@ import numpy as np
 from .urdf_model import RobotModel, merge_piece
 
 NB, NJ, NDOF, NACT, NRB, NRB_ENV, NFEET, NCP = 19, 18, 20, 18, 27, 28, 4, 64
-NSPH, NLIMB = 27, 11
+NSPH, NLIMB = 28, 11
 BOX_BODY, BOX_RB = NB, NRB                                # the free box actor's pseudo body index / rigid-body row
 CP_NONE, CP_TERRAIN, CP_BOX, CP_LIMBS, CP_DYNAMIC = -1, 0, 1, 2, 3
 PR_NONE, PR_STATIC, PR_LIMBS, PR_SPHERE_BOX = 0, 1, 2, 3
@@ -150,10 +150,14 @@ BOX_SLEEP_SPEED, BOX_SLEEP_TIME = 0.01, 0.4                # m/s, s: a box at re
 
 
 KNEE_RADIUS, FOOT_RADIUS, ELBOW_RADIUS, WRIST_RADIUS, GRIP_RADIUS = 0.02, 0.02, 0.025, 0.025, 0.012
+HAND_RADIUS = 0.02                                        # gripper body + fingers (a 4 cm bar) as a capsule from the wrist to the tip
+UPPER_ARM_LEN = math.hypot(0.25, 0.04975)                 # shoulder joint .. elbow: the L-shaped upper-arm link (urdf:512-530) as the straight capsule between its joints
+FOREARM_LEN, HAND_LEN = 0.25, 0.1586                       # elbow .. wrist (0.175 + 0.075) and wrist .. gripper tip (0.065 + 0.0936) along the arm (urdf:531-700)
 LIMB_RSUM_MAX = 0.045     # WBC_LIMB_RSUM_MAX (include/wbc_sim.h): bounds the radius sums of all candidate limb pairs
 STATIC_SELF_SLOT0, BOX_ROW, SHANK0 = 23, 32, 48
 # dynamic slots: what the self-collision broad phase promotes its hits into (robot-vs-robot: outside the box row; robot-vs-box: inside)
-DYN_SELF_SLOTS = list(range(26, 32)) + list(range(52, 64))
+SHOULDER_SLOT = 26
+DYN_SELF_SLOTS = list(range(27, 32)) + list(range(52, 64))
 DYN_BOX_SLOTS = [45, 46, 47]
 LEGS = ("FL", "FR", "RL", "RR")
 
@@ -170,12 +174,13 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
         joint configurations, tools/self_collision_reach.py), the 4 foot spheres and the gripper tip against the free box (created
         with the robot's collision filter, WG:384);
       dynamic slots -- free lanes that the broad phase promotes its hits into.
-    `limbs`: the capsules / spheres of the self-collision broad phase (thighs r 0.017, calves r 0.008 with knee / foot end spheres r
-    0.02, elbow, wrist, gripper tip), ends given as sphere indices. `candidates`: every pair of them on non-adjacent links that can
-    touch inside the joint limits (asset.self_collisions = 0 means enabled for all of them, widowGo1_config.py:180) -- calf-calf x 6,
-    thigh-calf of different legs x 12, left-right thigh pairs x 2, arm spheres against the 8 leg limbs x 24 -- and the robot spheres
-    that can meet the free box besides the static five (knees, shins, the trunk's bottom corners), most frequent first.
-    Slots (= wavefront lanes): 0..22 the robot's spheres against the terrain, 23..25 arm vs trunk, 26..31 dynamic; 32..47 everything
+    `limbs`: the capsules of the self-collision broad phase (thighs r 0.017, calves r 0.008 with knee / foot end spheres r 0.02, the
+    upper arm shoulder .. elbow and the forearm elbow .. wrist r 0.025, the hand wrist .. gripper tip r 0.02), ends given as sphere indices. `candidates`: every pair of
+    them on non-adjacent links that can touch inside the joint limits (asset.self_collisions = 0 means enabled for all of them,
+    widowGo1_config.py:180) -- calf-calf x 6, thigh-calf of different legs x 12, left-right thigh pairs x 2, upper arm, forearm and hand against
+    the 8 leg limbs x 24 -- and the robot spheres that can meet the free box besides the static five (knees, shins, the trunk's bottom
+    corners), most frequent first.
+    Slots (= wavefront lanes): 0..22 the robot's spheres against the terrain, 23..25 arm vs trunk, 26 the shoulder sphere, 27..31 dynamic; 32..47 everything
     that involves the free box (corners 32..39, static pairs 40..44, dynamic 45..47: one 16-lane row, summed by a row reduction);
     48..51 the mid-shanks; 52..63 dynamic."""
     rbn = m.rb_names
@@ -209,6 +214,7 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
     for i, rb in enumerate(feet):                                           # mid-shank: calf rigid body, half way down the calf box
         assert "calf" in rbn[rb - 1]
         sphere(rb - 1, np.array([0.0, 0.0, -CALF_LEN / 2]), CALF_RADIUS, slot=SHANK0 + i, sph=STATIC_SELF_SLOT0 + i)
+    k_shoulder = sphere(rbn.index("wx250s/upper_arm_link"), np.zeros(3), ELBOW_RADIUS, slot=SHOULDER_SLOT, sph=NSPH - 1)   # the shoulder joint (wx250s_2_shoulder / 3_upper_arm meshes)
     assert len(cps) == NSPH
     hb = box_half - BOX_CORNER_RADIUS                                       # the free box: corner spheres inset so that the surface is the cube's
     hi = BOX_ROW
@@ -244,10 +250,18 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
         for i in range(4):
             limbs.append(dict(name=LEGS[i] + "_calf", s0=4 + i, s1=i, radius=CALF_RADIUS, cap0=KNEE_RADIUS, cap1=FOOT_RADIUS, length=CALF_LEN,
                               body=int(m.rb_body[feet[i] - 1]), rb=feet[i] - 1, rb0=feet[i] - 1, rb1=feet[i]))
-        for name, k in (("elbow", k_elbow), ("wrist", k_wrist), ("gripper", k_grip)):
-            limbs.append(dict(name=name, s0=k, s1=k, radius=cps[k]["radius"], cap0=0.0, cap1=0.0, length=0.0, body=cps[k]["body"], rb=cps[k]["rb"],
-                              rb0=cps[k]["rb"], rb1=cps[k]["rb"]))
-        assert len(limbs) == NLIMB
+        # the arm against the legs: its links BETWEEN the spheres collide too -- the upper arm (shoulder joint .. elbow), the forearm (elbow ..
+        # wrist: upper + lower forearm link, the roll joint turns about this very axis) and the hand (wrist .. gripper tip: wrist, gripper
+        # and finger links, about the wrist-rotate axis) as capsules. (The arm's own links do not collide with each other: the one pair
+        # that could, hand vs upper arm, is the stated exception.)
+        rbi = {n: i for i, n in enumerate(rbn)}
+        limbs.append(dict(name="upper_arm", s0=NSPH - 1, s1=k_elbow, radius=ELBOW_RADIUS, cap0=0.0, cap1=0.0, length=UPPER_ARM_LEN,
+                          body=cps[k_shoulder]["body"], rb=cps[k_shoulder]["rb"], rb0=cps[k_shoulder]["rb"], rb1=cps[k_shoulder]["rb"]))
+        limbs.append(dict(name="forearm", s0=k_elbow, s1=k_wrist, radius=ELBOW_RADIUS, cap0=0.0, cap1=0.0, length=FOREARM_LEN,
+                          body=cps[k_elbow]["body"], rb=cps[k_elbow]["rb"], rb0=cps[k_elbow]["rb"], rb1=cps[k_wrist]["rb"]))
+        limbs.append(dict(name="hand", s0=k_wrist, s1=k_grip, radius=HAND_RADIUS, cap0=0.0, cap1=0.0, length=HAND_LEN,
+                          body=cps[k_grip]["body"], rb=rbi["wx250s/gripper_link"], rb0=rbi["wx250s/gripper_link"], rb1=rbi["wx250s/gripper_link"]))
+        assert len(limbs) <= NLIMB
         L = {l["name"]: i for i, l in enumerate(limbs)}
 
         def bound(l):
@@ -267,7 +281,7 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
             limb_pair(b + "_calf", a + "_thigh")
         for a, b in lr:
             limb_pair(a + "_thigh", b + "_thigh")
-        for arm in ("wrist", "elbow", "gripper"):
+        for arm in ("upper_arm", "forearm", "hand"):
             for leg in LEGS:
                 for part in ("_thigh", "_calf"):
                     limb_pair(arm, leg + part)

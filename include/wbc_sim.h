@@ -38,8 +38,8 @@ extern "C" {
 #define WBC_NCP 64       /* contact slots per env (one wavefront lane each): robot spheres vs terrain, box corners vs terrain,
                             the static pairs (arm spheres vs the trunk box, robot spheres vs the free box) and the DYNAMIC slots
                             that the self-collision broad phase promotes its hits into */
-#define WBC_NSPH 27      /* the robot's contact spheres (their centres in frame F are cached once per substep) */
-#define WBC_NLIMB 11     /* capsules / spheres of the self-collision broad phase: 4 thighs, 4 calves, elbow, wrist, gripper tip */
+#define WBC_NSPH 28      /* the robot's contact spheres (their centres in frame F are cached once per substep) */
+#define WBC_NLIMB 11     /* capsules of the self-collision broad phase: 4 thighs, 4 calves, upper arm, forearm, hand */
 #define WBC_LIMB_RSUM_MAX 0.045f   /* an upper bound of (largest radius of limb a) + (largest radius of limb b) over all candidate pairs (second
                                       stage of the broad phase: the distance between the two shafts' segments against this + rest + margin) */
 #define WBC_BOX_BODY WBC_NB   /* pseudo body index of the free box actor (WG:321-325,384) in cp_body / cp_body2 */
@@ -96,7 +96,8 @@ typedef struct {
    * margin, the contact is solved like any other pair. Hits beyond the free slots (14 + 3) are dropped.
    * Primitives of the candidates, all in frame F from the cached sphere centres (cp_sph: the compact index of a robot sphere):
    *   limbs -- capsules between two sphere centres (thigh: hip-side end to knee, r 0.017; calf: knee to foot, r 0.008, with its end
-   *   spheres knee r 0.02 / foot r 0.02) or single spheres (elbow, wrist, gripper tip); kind WBC_PR_LIMBS tests limb pr_a against
+   *   spheres knee r 0.02 / foot r 0.02; upper arm: shoulder joint to elbow, forearm: elbow to wrist, r 0.025; hand: wrist to gripper
+   *   tip, r 0.02; equal end indices would make a single sphere); kind WBC_PR_LIMBS tests limb pr_a against
    *   limb pr_b as the union of shaft and end spheres (deepest feature pair wins: one contact per limb pair);
    *   kind WBC_PR_SPHERE_BOX tests robot sphere pr_a against the free box (knees, shins, trunk corners, wrist, elbow). */
   int32_t ncp;

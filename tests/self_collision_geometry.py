@@ -46,6 +46,11 @@ def primitives(rb, names):
         limbs[l + "_calf"] = (P[l + "_calf"], P[l + "_foot"], abi.CALF_RADIUS, abi.KNEE_RADIUS, abi.FOOT_RADIUS)
     arm = {"elbow": (P["wx250s/upper_forearm_link"], abi.ELBOW_RADIUS), "wrist": (P["wx250s/wrist_link"], abi.WRIST_RADIUS),
            "gripper": (P["wx250s/ee_gripper_link"], abi.GRIP_RADIUS)}
+    # the arm's links between those spheres, as the legs meet them: upper arm (shoulder joint .. elbow: the L-shaped link as the straight
+    # capsule between its two joints), forearm and hand capsules
+    limbs["upper_arm"] = (P["wx250s/upper_arm_link"], P["wx250s/upper_forearm_link"], abi.ELBOW_RADIUS, 0.0, 0.0)
+    limbs["forearm"] = (P["wx250s/upper_forearm_link"], P["wx250s/wrist_link"], abi.ELBOW_RADIUS, 0.0, 0.0)
+    limbs["hand"] = (P["wx250s/wrist_link"], P["wx250s/ee_gripper_link"], abi.HAND_RADIUS, 0.0, 0.0)
     ti = names.index("trunk")
     return limbs, arm, (rotm(rb[:, ti, 3:7]), rb[:, ti, :3], np.array(abi.TRUNK_HALF))
 
@@ -85,22 +90,27 @@ def seg_box(a0, a1, r, trunk, k=9):
     return np.min([sphere_box(a0 + (a1 - a0) * t, r, trunk) for t in np.linspace(0, 1, k)], axis=0)
 
 
+ARM_LIMBS = ("upper_arm", "forearm", "hand")
+
+
 def all_pairs(rb, names):
-    """{(prim a, prim b): gaps [n]} for every pair of primitives on non-adjacent links (limb names 'FL_thigh', ..., arm sphere names,
-    'trunk')."""
+    """{(prim a, prim b): gaps [n]} for every pair of primitives on non-adjacent links (limb names 'FL_thigh', ..., 'upper_arm',
+    'forearm', 'hand'; the arm spheres against 'trunk')."""
     limbs, arm, trunk = primitives(rb, names)
     out = {}
     ln = list(limbs)
+    arm_limbs = ARM_LIMBS
+    adjacent = {frozenset(("upper_arm", "forearm")), frozenset(("forearm", "hand"))}
     for i in range(len(ln)):
         for j in range(i + 1, len(ln)):
-            if ln[i][:2] == ln[j][:2]:
-                continue                                                      # thigh and calf of one leg: adjacent links (filtered)
+            if (ln[i][:2] == ln[j][:2] and ln[i] not in arm_limbs) or frozenset((ln[i], ln[j])) in adjacent:
+                continue                                                      # thigh and calf of one leg, neighbouring arm links: adjacent (filtered)
             out[(ln[i], ln[j])] = limb_limb(limbs[ln[i]], limbs[ln[j]])
     for s, (c, r) in arm.items():
         out[(s, "trunk")] = sphere_box(c, r, trunk)
-        for k in ln:
-            out[(s, k)] = sphere_limb(c, r, limbs[k])
     for k in ln:
+        if k in arm_limbs:
+            continue
         a0, a1, rr, c0, c1 = limbs[k]
         g = seg_box(a0, a1, rr, trunk)
         for q, cc in ((a0, c0), (a1, c1)):

@@ -236,7 +236,7 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     terrain = [c for c in cps if c["kind"] == abi.CP_TERRAIN]
     pairs = [c for c in cps if c["kind"] == abi.CP_BOX]
     dyn = [c for c in cps if c["kind"] == abi.CP_DYNAMIC]
-    assert len(terrain) == 35 and len(pairs) == 8 and len(dyn) == 21
+    assert len(terrain) == 36 and len(pairs) == 8 and len(dyn) == 20
     # slots (= wavefront lanes): the robot's terrain spheres and the arm-vs-trunk pairs below 26, everything that involves the free
     # box in the 16-lane row 32..47 (summed by a row reduction in the kernel), the mid-shanks 48..51, dynamic slots in between
     slots = [c["slot"] for c in cps]
@@ -245,20 +245,22 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     assert all(c["body"] != abi.BOX_BODY and c["body2"] != abi.BOX_BODY and c["kind"] != abi.CP_DYNAMIC for c in low)
     row = [c for c in cps if 32 <= c["slot"] < 48]
     assert len(row) == 16 and all(c["body"] == abi.BOX_BODY or c["body2"] == abi.BOX_BODY or c["kind"] == abi.CP_DYNAMIC for c in row)
-    assert [c["slot"] for c in dyn] == abi.DYN_SELF_SLOTS[:6] + abi.DYN_BOX_SLOTS + abi.DYN_SELF_SLOTS[6:]
+    assert [c["slot"] for c in dyn] == abi.DYN_SELF_SLOTS[:5] + abi.DYN_BOX_SLOTS + abi.DYN_SELF_SLOTS[5:]
     assert [c["slot"] for c in cps if c["radius"] == abi.CALF_RADIUS] == [48, 49, 50, 51]
     wm = abi.fill_model(m)
     assert wm.ncp == 64 and all(wm.cp_kind[c["slot"]] == c["kind"] for c in cps)
-    # the robot's 27 spheres carry compact indices (their centres are cached once per substep); a static pair names its sphere
+    # the robot's 28 spheres carry compact indices (their centres are cached once per substep); a static pair names its sphere
     sph = sorted(c["sph"] for c in terrain if c["body"] != abi.BOX_BODY)
     assert sph == list(range(abi.NSPH)) and all(wm.cp_sph[c["slot"]] == c["sph"] for c in cps)
     for c in pairs:
         assert wm.pr_kind[c["slot"]] == abi.PR_STATIC and wm.pr_a[c["slot"]] == c["sph"]
         own = next(t for t in terrain if t["sph"] == c["sph"])
         assert own["rb"] == c["rb"] and own["radius"] == c["radius"] and np.allclose(own["pos"], c["pos"])
-    # limbs and candidates: 20 leg-leg pairs + 24 arm-leg pairs (the three arm-trunk pairs are static), then 12 more robot spheres
-    # against the free box; every lane without a static pair tests exactly one candidate
-    assert [l["name"] for l in limbs] == [f"{l}_thigh" for l in abi.LEGS] + [f"{l}_calf" for l in abi.LEGS] + ["elbow", "wrist", "gripper"]
+    # limbs and candidates: 20 leg-leg pairs + 24 arm-leg pairs (upper arm, forearm, hand as capsules; the three arm-sphere-vs-trunk
+    # pairs are static), then 12 more robot spheres against the free box; every lane without a static pair tests exactly one candidate
+    assert [l["name"] for l in limbs] == [f"{l}_thigh" for l in abi.LEGS] + [f"{l}_calf" for l in abi.LEGS] + ["upper_arm", "forearm", "hand"]
+    zero = {c["sph"]: np.asarray(c["pos"]) for c in terrain if c["body"] != abi.BOX_BODY}
+    assert abs(abi.UPPER_ARM_LEN - 0.2549) < 1e-3 and limbs[8]["s0"] == 27 and limbs[8]["s1"] == limbs[9]["s0"] and limbs[9]["s1"] == limbs[10]["s0"]
     for l in limbs[:8]:
         a, b = (next(t for t in terrain if t["sph"] == l[k]) for k in ("s0", "s1"))
         assert np.isclose(np.linalg.norm(a["pos"] - b["pos"]), 0.213) and a["body"] == b["body"] == l["body"] or "thigh" in l["name"]
@@ -266,7 +268,7 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     assert len(lp) == 44 and len({frozenset(p) for p in lp}) == 44
     assert all(a[:2] != b[:2] for a, b in lp)                              # never the thigh and calf of one leg (adjacent links)
     assert not any("thigh" in a and "thigh" in b and a[0] != b[0] for a, b in lp)      # front and rear thighs never meet
-    assert sum(1 for a, b in lp if a in ("elbow", "wrist", "gripper")) == 24
+    assert sum(1 for a, b in lp if a in ("upper_arm", "forearm", "hand")) == 24
     bx = [c for c in cands if c["kind"] == abi.PR_SPHERE_BOX]
     assert len(bx) == 12 and sorted(c["a"] for c in bx) == [4, 5, 6, 7, 15, 17, 19, 21, 23, 24, 25, 26]
     lanes = [k for k in range(64) if wm.pr_kind[k] != abi.PR_STATIC]
@@ -274,7 +276,7 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     assert all(abs(wm.pr_reach[k] / abi.REACH_STEP - round(wm.pr_reach[k] / abi.REACH_STEP)) < 1e-5 for k in range(64))
     robot_terrain = [c for c in terrain if c["body"] != abi.BOX_BODY]
     box_corners = [c for c in terrain if c["body"] == abi.BOX_BODY]
-    assert len(robot_terrain) == 27 and len(box_corners) == 8 and all(c["rb"] == abi.BOX_RB for c in box_corners)
+    assert len(robot_terrain) == 28 and len(box_corners) == 8 and all(c["rb"] == abi.BOX_RB for c in box_corners)
     for c in box_corners:                                # sphere surface = the 0.1 m cube (box.box_size, widowGo1_config.py:186)
         np.testing.assert_allclose(np.abs(c["pos"]) + c["radius"], 0.05, atol=1e-9)
     corners = [c for c in robot_terrain if names[c["rb"]] == "trunk"]
@@ -289,7 +291,7 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     for c in shank:
         np.testing.assert_allclose(c["pos"] - np.asarray(m.rb_offset[c["rb"]]), [0, 0, -0.1065], atol=1e-9)
     arm = {names[c["rb"]] for c in robot_terrain if "wx250s" in names[c["rb"]]}
-    assert arm == {"wx250s/ee_gripper_link", "wx250s/upper_forearm_link", "wx250s/wrist_link"}
+    assert arm == {"wx250s/ee_gripper_link", "wx250s/upper_forearm_link", "wx250s/wrist_link", "wx250s/upper_arm_link"}
     self_pairs = [c for c in pairs if c["body2"] != abi.BOX_BODY]
     box_pairs = [c for c in pairs if c["body2"] == abi.BOX_BODY]
     assert len(self_pairs) == 3 and len(box_pairs) == 5
@@ -299,7 +301,7 @@ def test_collision_set_follows_the_urdf_collision_blocks():
         assert c["kind"] == abi.CP_BOX and c["rb2"] == abi.BOX_RB and np.allclose(c["b"], 0.05) and np.allclose(c["a"], 0)
     assert sorted(names[c["rb"]] for c in box_pairs) == sorted([names[i] for i in feet] + ["wx250s/ee_gripper_link"])
     wm0 = abi.fill_model(m, self_collisions=False)                      # no pairs at all: the box actor shares the filter (WG:384)
-    assert sum(wm0.cp_kind[k] != abi.CP_NONE for k in range(wm0.ncp)) == 35 and all(wm0.cp_kind[k] <= abi.CP_TERRAIN for k in range(wm0.ncp))
+    assert sum(wm0.cp_kind[k] != abi.CP_NONE for k in range(wm0.ncp)) == 36 and all(wm0.cp_kind[k] <= abi.CP_TERRAIN for k in range(wm0.ncp))
     assert all(wm0.pr_kind[k] == abi.PR_NONE for k in range(abi.NCP))
     # rigid-body masks of the task config (WG:299-306: substring match)
     cfg = WidowGo1RoughCfg()

@@ -328,7 +328,7 @@ def test_self_collision_geometry_against_brute_force(robot):
     joint drawn uniformly inside its limits: a rigid body reports a contact force when one of its primitives penetrates another
     link's by more than 4 mm (bodies at relative rest: only a penetration demands an impulse), none when all of its pairs are clear
     of the contact margin by 4 mm; pair forces are internal (they cancel over the robot); with one penetrating pair on a body the
-    force on it points away from the partner."""
+    force on an arm sphere points away from the trunk box."""
     import self_collision_geometry as G
     model, tc = robot["model"], copy.copy(robot["tcfg"])
     wm = robot["wmodel"]
@@ -349,12 +349,14 @@ def test_self_collision_geometry_against_brute_force(robot):
     o.simulate()
     f = o.get("NET_CONTACT_FORCE")
     names = model.rb_names
-    gaps = G.all_pairs(rb, names)
-    prim_rbs = {"trunk": ["trunk"], "elbow": ["wx250s/upper_forearm_link"], "wrist": ["wx250s/wrist_link"], "gripper": ["wx250s/ee_gripper_link"]}
+    gaps = {k: g for k, g in G.all_pairs(rb, names).items() if not (k[0] in G.ARM_LIMBS and k[1] in G.ARM_LIMBS)}     # (the arm's own links do not collide with each other: the stated exception)
+    # which rigid bodies report a primitive's contacts: the calf limb's shaft and knee on the calf, its foot sphere on the foot; the arm
+    # capsules on their links (the elbow sphere shares its row with the forearm capsule, the wrist / gripper-tip spheres have their own)
+    prim_rbs = {"trunk": ["trunk"], "elbow": ["wx250s/upper_forearm_link"], "wrist": ["wx250s/wrist_link"], "gripper": ["wx250s/ee_gripper_link"],
+                "upper_arm": ["wx250s/upper_arm_link"], "forearm": ["wx250s/upper_forearm_link"], "hand": ["wx250s/gripper_link"]}
     for l in G.LEGS:
         prim_rbs[l + "_thigh"] = [l + "_thigh"]
-        prim_rbs[l + "_calf"] = [l + "_calf", l + "_foot"]               # the calf limb: its shaft and knee report on the calf, its foot sphere on the foot
-    idx = {p: [names.index(r) for r in rbs] for p, rbs in prim_rbs.items()}
+        prim_rbs[l + "_calf"] = [l + "_calf", l + "_foot"]
     margin = float(tc.contact_margin)
     fnorm = np.linalg.norm(f[:, :27], axis=-1)
     np.testing.assert_allclose(f[:, :27].sum(1), 0.0, atol=1e-9)           # internal forces
@@ -368,35 +370,35 @@ def test_self_collision_geometry_against_brute_force(robot):
     # "must push" is asserted where the penetrating pair is the robot's ONLY pair inside the margin: with several contacts on one chain
     # another one's impulse may already be separating the pair (the solver then rightly gives it none)
     n_near = sum((g < margin + 4e-3).astype(int) for g in gaps.values())
-    for p, rbs in idx.items():
-        pushing = fnorm[:, rbs].sum(1) > 0
-        must, mustnot = (per_prim_pen[p] > 0) & (n_near == 1), ~per_prim_near[p]
-        assert pushing[must].all(), (p, np.nonzero(must & ~pushing)[0][:5])
-        assert not pushing[mustnot].any(), (p, np.nonzero(mustnot & pushing)[0][:5])
+    groups = {}                                                            # primitives by the rigid-body rows they report on
+    for p, rbs in prim_rbs.items():
+        groups.setdefault(tuple(rbs), []).append(p)
+    for rbs, prims in groups.items():
+        pushing = fnorm[:, [names.index(r) for r in rbs]].sum(1) > 0
+        must = (sum(per_prim_pen[p] for p in prims) > 0) & (n_near == 1)
+        mustnot = ~np.any([per_prim_near[p] for p in prims], axis=0)
+        assert pushing[must].all(), (prims, np.nonzero(must & ~pushing)[0][:5])
+        assert not pushing[mustnot].any(), (prims, np.nonzero(mustnot & pushing)[0][:5])
         hits += int(must.sum()); clear += int(mustnot.sum())
     assert hits > 300 and clear > 50000, (hits, clear)
-    # direction: an arm sphere whose ONLY near pair is one limb / the trunk is pushed away from it
+    idx = {p: [names.index(r) for r in rbs] for p, rbs in prim_rbs.items()}
+    # direction: an arm sphere whose ONLY near pair is the trunk is pushed away from the box (out through the nearest face when inside)
     limbs, arm, trunk = G.primitives(rb, names)
+    Rt, pt, half = trunk
     checked = 0
     for sname, (c, r) in arm.items():
-        mine = {k: g for k, g in gaps.items() if sname in k}
-        near_count = sum((g < margin + 4e-3).astype(int) for g in mine.values())
-        for (a, b), g in mine.items():
-            other = b if a == sname else a
-            if other == "trunk":
-                continue
-            a0, a1 = limbs[other][0], limbs[other][1]
-            d = a1 - a0
-            t = np.clip(((c - a0) * d).sum(-1) / (d * d).sum(-1), 0, 1)
-            away = c - (a0 + d * t[:, None])
-            away /= np.linalg.norm(away, axis=-1, keepdims=True)
-            sel = (g < -4e-3) & (g > -0.5 * r) & (near_count == 1) & (n_near == 1)
-            fa = f[:, idx[sname][0]]
-            for e in np.nonzero(sel)[0]:
-                assert np.dot(fa[e], away[e]) > 0.4 * np.linalg.norm(fa[e]) > 0, (sname, other, e)     # (normal + friction at mu = 1: within 66 deg)
-                checked += 1
+        g = gaps[(sname, "trunk")]
+        loc = np.einsum("nji,nj->ni", Rt, c - pt)
+        outside = np.any(np.abs(loc) > half, axis=1)
+        cl = np.clip(loc, -half, half)
+        away = np.einsum("nij,nj->ni", Rt, loc - cl)
+        nrm = np.linalg.norm(away, axis=1)
+        sel = (g < -4e-3) & outside & (nrm > 1e-6) & (n_near == 1)
+        fa = f[:, idx[sname][0]]
+        for e in np.nonzero(sel)[0]:
+            assert np.dot(fa[e], away[e] / nrm[e]) > 0.4 * np.linalg.norm(fa[e]) > 0, (sname, e)     # (normal + friction at mu = 1: within 66 deg)
+            checked += 1
     assert checked > 10, checked
-
 
 
 def test_free_box_candidates_against_brute_force(robot):

@@ -25,8 +25,8 @@ def med(name, c):
     v = acc.get((name, c)); return statistics.median(v) if v else None
 import hashlib
 _h = hashlib.sha256()
-for fn in ("wbc_step_kernel.hip", "wbc_device.h"):
-    _h.update(open(R + "/deep-whole-body-control_amd/csrc/" + fn, "rb").read())
+for fn in ("deep-whole-body-control_amd/csrc/wbc_step_kernel.hip", "deep-whole-body-control_amd/csrc/wbc_device.h", "include/wbc_sim.h"):
+    _h.update(open(R + "/" + fn, "rb").read())
 out = {"kernel_sha16": _h.hexdigest()[:16], "contact_iters": 4, "collected_with": "tools/r05_profile.sh: rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --no-cpu-baseline --steps 10 --warmup 2",
        "date": datetime.datetime.utcnow().strftime("%Y-%m-%d"), "num_envs": 4096, "kernels": {}}
 for name in ('wbc_step_kernel', 'ppo_chain_kernel', 'ppo_wgrad_kernel', 'wbc_policy_act16_kernel'):

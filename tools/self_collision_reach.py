@@ -49,6 +49,9 @@ print(f"{'pair':32s} {'penetrating':>12s} {'within margin':>14s} {'closest [m]':
 for pair, (pen, near, mn) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     print(f"{pair[0] + ' ~ ' + pair[1]:32s} {pen / N:12.5f} {near / N:14.5f} {mn:12.4f}   {'yes' if frozenset(pair) in in_set else ''}")
 never = [p for p, r in rows.items() if r[1] == 0]
-missing = [p for p, r in rows.items() if r[1] > 0 and frozenset(p) not in in_set]
+ARM = set(G.ARM_LIMBS)
+missing = [p for p, r in rows.items() if r[1] > 0 and frozenset(p) not in in_set and not (p[0] in ARM and p[1] in ARM)]
+arm_internal = [p for p, r in rows.items() if r[1] > 0 and p[0] in ARM and p[1] in ARM]
 print(f"\npairs that never come within the margin ({len(never)} of {len(rows)}): " + ", ".join(a + ' ~ ' + b for a, b in never))
 print("pairs that can touch and are NOT in the collision set: " + (", ".join(a + ' ~ ' + b for a, b in missing) or "none"))
+print("the arm's own links (not collided with each other, the stated exception): " + ", ".join(a + ' ~ ' + b for a, b in arm_internal))
