@@ -458,6 +458,59 @@ def free_flight_energy(robot, T=2.0, seed=0, gravity=True):
                 qd_max=float(np.abs(o.get("DOF_STATE")[0, :, 1]).max()))
 
 
+def self_collision_momentum(robot, n=400, seed=0):
+    """Self-collision is internal to the robot. Robots at rest in free flight (no gravity), every joint drawn uniformly inside its
+    limits, so that limb pairs start out penetrating: ONE substep with the collision set on and one with self-collision off, from the
+    same state. The contact impulses set joints and base in motion (momentum of the parts: `impulse`), but the robot's total linear
+    momentum and its angular momentum about the centre of mass must end where the contact-free run ends (zero: nothing else acts).
+    Returns, per env with a contact, the impulse scale and the two momentum differences."""
+    from test_oracle_physics import body_twists, make_params
+    model = robot["model"]
+    tc = clone_struct(robot["tcfg"])
+    for k in range(3):
+        tc.gravity[k] = 0.0
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(model.dof_lower, dtype=np.float64), np.array(model.dof_upper, dtype=np.float64)
+    free = ~(lo < hi)
+    lo[free], hi[free] = -np.pi, np.pi
+    lo[18:], hi[18:] = 0.0, 0.0
+    root = np.zeros((n, 2, 13)); root[:, :, 6] = 1; root[:, 0, 2] = 50.0; root[:, 1, :3] = [9.0, 9.0, 0.05]
+    dof = np.zeros((n, 20, 2)); dof[:, :, 0] = rng.uniform(lo, hi, (n, 20))
+    out = []
+    sims = []
+    for wm in (clone_struct(robot["wmodel"]), abi.fill_model(model, self_collisions=False)):
+        for j in range(20):
+            wm.qd_limit[j] = 0.0           # (the URDF's joint-velocity clamp is not a force: it would eat momentum after a deep penetration's kick)
+        o = OracleSim(wm, tc, n)
+        o.set("ROOT_STATES", root); o.set("DOF_STATE", dof); o.set("TORQUES", np.zeros((n, 20)))
+        o.simulate()
+        sims.append(o)
+    on, off = sims
+    f = on.get("NET_CONTACT_FORCE")
+    bp = make_params(model, on.get("BODY_PARAMS")[0])
+    mtot = sum(b[0] for b in bp)
+
+    def momenta(o, e):
+        # (the velocities the substep produced, at the configuration it started from: the contact impulses act there, and the two
+        # runs then differ in velocities only)
+        r = o.get("ROOT_STATES")[e, 0]
+        d = o.get("DOF_STATE")[e]
+        tw = body_twists(model, bp, root[e, 0, :3], root[e, 0, 3:7], dof[e, :, 0], r[7:10], r[10:13], d[:, 1])
+        cm = sum(m * c for m, I, c, vc, om in tw) / mtot
+        vcm = sum(m * vc for m, I, c, vc, om in tw) / mtot
+        L = sum(I @ om + m * np.cross(c - cm, vc - vcm) for m, I, c, vc, om in tw)
+        parts = sum(m * np.linalg.norm(vc) for m, I, c, vc, om in tw)
+        return mtot * vcm, L, parts
+    for e in range(n):
+        if np.abs(f[e, :27]).sum() == 0:
+            continue
+        P1, L1, parts = momenta(on, e)
+        P0, L0, _ = momenta(off, e)
+        out.append(dict(impulse=float(np.abs(f[e, :27]).sum() * 0.5 * tc.sim_dt), parts=float(parts), dP=float(np.linalg.norm(P1 - P0)),
+                        dL=float(np.linalg.norm(L1 - L0)), pair_sum=float(np.abs(f[e, :27].sum(0)).max())))
+    return out
+
+
 def robot_kicks_box(robot, seed=0, make_sim=_oracle_factory):
     """A foot sphere started inside the box actor, both in free fall far above the ground (no terrain contact, no gravity): the pair
     impulse is internal to the robot + box system, so its total linear momentum and its angular momentum about the common centre

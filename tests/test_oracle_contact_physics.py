@@ -239,3 +239,17 @@ def test_rest_offset_and_position_iterations_are_honoured(robot):
     assert int(abi.fill_task_cfg(cfg, m).contact_iters) == 2
     res = pc.solver_convergence(robot, st, (2, 4))
     assert np.abs(res[2]["f"] - res[4]["f"]).max() > 1.0                          # the sweeps are what the field sets
+
+
+# ------------------------------------------------------------------------------------------------- self-collision is internal
+def test_self_collision_conserves_the_robots_momentum(robot):
+    """Limb pairs in contact exchange impulses that are internal to the robot: one substep from rest with limb pairs penetrating (every
+    joint anywhere inside its limits, no gravity) sets the robot's parts in motion, but its total linear momentum and its angular
+    momentum about the centre of mass end where the run WITHOUT self-collision ends -- to 1e-9 of the momentum the parts picked up (the
+    two bodies of a pair receive +f / -f at the same point)."""
+    rows = pc.self_collision_momentum(robot, n=600)
+    assert len(rows) > 120
+    assert max(r["pair_sum"] for r in rows) < 1e-9
+    assert min(r["parts"] for r in rows) > 1e-4                                  # the contacts did move the parts
+    assert max(r["dP"] / r["parts"] for r in rows) < 1e-6, max(rows, key=lambda r: r["dP"] / r["parts"])
+    assert max(r["dL"] / r["parts"] for r in rows) < 1e-6, max(rows, key=lambda r: r["dL"] / r["parts"])
