@@ -12,6 +12,12 @@ STATE_TENSORS = ["ROOT_STATES", "DOF_STATE", "TORQUES", "OBS_HISTORY", "ACTION_H
                  "RESET_BUF", "BOX_SLEEP_TIMER", "FEET_AIR_TIME", "LAST_CONTACTS"]
 
 
+def random_quat(rng):
+    """A uniformly random unit quaternion (xyzw)."""
+    q = rng.normal(size=4)
+    return q / np.linalg.norm(q)
+
+
 def random_env_params(n, seed=0):
     rng = np.random.default_rng(seed)
     tt = rng.uniform(1, 3, n) / 0.02

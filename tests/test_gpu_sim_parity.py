@@ -390,7 +390,7 @@ def test_self_collision_candidates_match_oracle(robot):
         t = targets[(e // 3) % 5]
         off = rng.uniform(-0.03, 0.03, 3) + (np.array([0, 0, -0.11]) if names[t] == "trunk" else np.array([0.05, 0, rng.choice([0.0, -0.1])]))
         root[e, 1, :3] = rb[e, t, :3] + off
-        root[e, 1, 3:7] = helpers.random_quat(rng) if hasattr(helpers, "random_quat") else [0, 0, 0, 1]
+        root[e, 1, 3:7] = helpers.random_quat(rng)
     g.tensor("ROOT_STATES").copy_(torch.from_numpy(root))
     seen = np.zeros(28, dtype=np.int64)
     legleg = boxhits = 0

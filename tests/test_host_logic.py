@@ -259,7 +259,6 @@ def test_collision_set_follows_the_urdf_collision_blocks():
     # limbs and candidates: 20 leg-leg pairs + 24 arm-leg pairs (upper arm, forearm, hand as capsules; the three arm-sphere-vs-trunk
     # pairs are static), then 12 more robot spheres against the free box; every lane without a static pair tests exactly one candidate
     assert [l["name"] for l in limbs] == [f"{l}_thigh" for l in abi.LEGS] + [f"{l}_calf" for l in abi.LEGS] + ["upper_arm", "forearm", "hand"]
-    zero = {c["sph"]: np.asarray(c["pos"]) for c in terrain if c["body"] != abi.BOX_BODY}
     assert abs(abi.UPPER_ARM_LEN - 0.2549) < 1e-3 and limbs[8]["s0"] == 27 and limbs[8]["s1"] == limbs[9]["s0"] and limbs[9]["s1"] == limbs[10]["s0"]
     for l in limbs[:8]:
         a, b = (next(t for t in terrain if t["sph"] == l[k]) for k in ("s0", "s1"))

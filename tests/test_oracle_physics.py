@@ -383,7 +383,7 @@ def test_self_collision_geometry_against_brute_force(robot):
     assert hits > 300 and clear > 50000, (hits, clear)
     idx = {p: [names.index(r) for r in rbs] for p, rbs in prim_rbs.items()}
     # direction: an arm sphere whose ONLY near pair is the trunk is pushed away from the box (out through the nearest face when inside)
-    limbs, arm, trunk = G.primitives(rb, names)
+    _, arm, trunk = G.primitives(rb, names)
     Rt, pt, half = trunk
     checked = 0
     for sname, (c, r) in arm.items():
