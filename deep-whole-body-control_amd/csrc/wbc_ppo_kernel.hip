@@ -70,7 +70,7 @@ extern "C" void wbc_debug_set_ppo_timing(void* dev_buf) {
 // gradient falls out of one extra MFMA block whose B operand is the constant 1. No LDS, no atomics.
 struct WgradLayer { int out, in, dcol, dw, acol, aw, aoff, goff, nsplit, rows, ldw, boff, bias; };   // ldw: row stride of dW (the layer's full input width), goff: first element of this column range, boff: the bias gradient (written iff bias)   // nsplit row ranges of `rows` rows: proportional to the layer's MFMAs per row pair, so every wave has the same work   // dZ slab (start, width), A slab (start, width, first column in it); goff: offset of this layer's weight gradient in the flat buffer
 #ifndef WG_U
-#define WG_U 4               // row pairs per batch of operand loads (two batches in flight per wave)
+#define WG_U 4               // row pairs per batch of operand loads (WG_STAGES - 1 batches in flight per wave behind the one being computed)
 #endif
 
 // NIB = 32-column blocks of the layer's input. IL (NIB == 4 only): block b holds the input columns 4 j + b (j = lane & 31)
@@ -134,12 +134,12 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   int r = r_begin;
   const int nfull = (r_end - r_begin) / (2 * U);                   // full batches
 #ifndef WG_STAGES
-#define WG_STAGES 2        // 3 (two batches in flight behind the one being computed) measured the same: 168.8 vs 168.2 us
+#define WG_STAGES 3        // with three waves per SIMD, 2 and 3 measured the same (168.8 vs 168.2 us); with two (round 5) 3 is better: 155 vs 165
 #endif
   if (nfull > 0) {
 #if WG_STAGES == 3
     // Three operand sets: while a batch's MFMAs run, the loads of the next TWO batches are in flight (2 x 1024 cycles of
-    // latency hiding per wave instead of one; 60 operand registers, still three waves per SIMD).
+    // latency hiding per wave instead of one; 60 operand registers).
     Ops A, Bq, Cq;
     issue(A);
     issue(Bq);                                  // (past the last batch these read the following rows, inside the workspace, unused)
@@ -208,9 +208,9 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   if (lane < 32 && o_ok && L.bias) dst[L.boff + o] = bsum;
 }
 
-// Grid = (row ranges, layers), 4 waves per workgroup = the layer's four 32-row output blocks. About three workgroups per
-// CU: co-resident waves do not overlap each other's vector-ALU work with MFMAs, but they do hide each other's memory latency
-// (one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
+// Grid = (row ranges, layers), 4 waves per workgroup = the layer's four 32-row output blocks. Two workgroups per CU (three
+// until round 5): co-resident waves do not overlap each other's vector-ALU work with MFMAs, but they do hide each other's memory
+// latency (round 2: one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
 // Work decomposition. A 32-row output block x 32-column input block of a layer costs one MFMA per row pair; the layers
 // have 2, 2, 12, 4 or 16 such blocks. With one workgroup per (layer, row range) all workgroups are resident at once (three
 // per CU) and the CUs that happen to hold three 16-block workgroups set the kernel's duration (169 us at 54 % matrix-pipe
@@ -219,14 +219,25 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
 // priv0 (2) + priv2 (2, its two input blocks on different waves); the four heads (4 each) -- and every wave of every
 // workgroup gets tasks worth 4 MFMAs per row pair: all workgroups are equal, whatever the placement. 168.6 -> 150.4 us.
 #ifndef PPO_NSPLIT
-#define PPO_NSPLIT 69       // x 11 virtual layers = 759 workgroups: one resident wave of three per CU
+#define PPO_NSPLIT 46       // x 11 virtual layers = 506 workgroups: one resident wave of TWO per CU (the workspace is sized for this many partials)
 #endif
+// Row ranges per layer for a minibatch of B rows. Round 5, same box, wgrad / reducer us per launch at B = 40960 | 20480 | 10240:
+// 69 splits (three waves per SIMD, 2 stages) 163 / 12.3 | 92 / 11.7 | 50 / 10.4; 46 (two per SIMD, 3 stages x 4 row pairs) 155 / 10.0 |
+// 84 / 9.2 | 46 / 8.4; 23 (one per SIMD) 174 / 8.5 | 88 / 6.8 | 46 / 6.3 -- a third wave buys nothing the deeper operand ring does not,
+// and every split is another 0.67 MB of partials written, read back by the reducer and pushed through L2 under the next chain launch.
+// With every operand load removed the kernel takes 127 us, without its stores 150 (of 157, the same box): the matrix pipe at the
+// clock the chip sustains under it, not the memory system, is most of what is left.
+// Small minibatches (a strong-scaled shard) take the 23: the same weight-gradient time and the cheaper reduction.
+static int ppo_nsplit(int B) { return B <= 12288 ? PPO_NSPLIT / 2 : PPO_NSPLIT; }
 struct WgradTask { int sub, ob; };                      // sub-layer (a layer or a column range of one), 32-row output block
 #define WG_NVL 11
 #define WG_NSUB (NLAYERS + 1)
 struct WgradPlan { WgradLayer sub[WG_NSUB]; WgradTask task[WG_NVL][4][2]; int ntask[WG_NVL][4]; int nsplit, rows; };
 
-extern "C" __global__ void __launch_bounds__(PT_THREADS, 3) ppo_wgrad_kernel(WgradPlan plan, const float* __restrict__ act_stash,
+#ifndef WG_OCC
+#define WG_OCC 2            // resident workgroups per CU the register budget is set for
+#endif
+extern "C" __global__ void __launch_bounds__(PT_THREADS, WG_OCC) ppo_wgrad_kernel(WgradPlan plan, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
                                                                          int B, int Bs, int nparams) {
   const int vl = blockIdx.x / plan.nsplit, split = blockIdx.x - vl * plan.nsplit;
@@ -251,6 +262,9 @@ struct RedLayer { int goff, count; };
 struct RedTable { RedLayer l[NLAYERS]; int nsplit; };
 #define RED_BX ((128 * 128 + 128 + 255) / 256)            // blocks per grid row (the largest layer: 65)
 #define PPO_SQ_PARTS ((NLAYERS + 1) * RED_BX)             // one partial sum of squares per block of ppo_grad_reduce_kernel
+// (Round 5, tried and not kept: this reduction, the clip and the Adam step as ONE launch whose 1105 workgroups meet at a counter --
+// bit-identical, but the meeting costs more than the launch it saves: with agent-scope release fences (a whole-L2 write-back per
+// workgroup) +170 us per minibatch, with the partial sums stored write-through and relaxed polling +20 us at 4096 envs, +50 at 1024.)
 // ONE reduction launch per minibatch. Grid rows 0 .. NLAYERS-1: grad[goff + i] = sum_{s < nsplit} part[s][goff + i] in a fixed
 // order (the split-K weight-gradient partials). Grid row NLAYERS: block j < 18 + 3 sums the per-tile partials of column j of
 // the std gradient (18) / the loss sums (3) -- fixed-order tree -- into out_cols[j]; the loss sums are also ADDED to
@@ -422,8 +436,8 @@ static int make_wgrad_plan(WgradPlan& plan, RedTable& red, int B) {
       }
       if (units != 4) return -1;
     }
-  plan.nsplit = red.nsplit = PPO_NSPLIT;
-  plan.rows = ((B + PPO_NSPLIT - 1) / PPO_NSPLIT + 7) / 8 * 8;
+  plan.nsplit = red.nsplit = ppo_nsplit(B);
+  plan.rows = ((B + plan.nsplit - 1) / plan.nsplit + 7) / 8 * 8;
   return off;
 }
 
@@ -523,7 +537,7 @@ static int ppo_minibatch_grad_impl(const void* const* params, const float* obs, 
   RedTable red;
   const int off = make_wgrad_plan(plan, red, B);
   if (off < 0) return -2;
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WG_NVL * PPO_NSPLIT), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WG_NVL * plan.nsplit), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
   hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, wpart, ng, grad, dstd_partial, tiles16, loss_partial,
                      grad + off, loss_accum, workspace + ppo_sq_offset(B));
   return hipGetLastError() == hipSuccess ? 0 : -2;
