@@ -517,7 +517,7 @@ int wbc_hist_clip_adam(const void* const* params, float* grad, float* exp_avg, f
  * [20,64], [20]); obs f32 [rows, 860]; out f32 [rows, 20]. */
 int wbc_priv_latent(const void* const* params, const float* obs, float* out, int rows, void* stream);
 int wbc_ppo_grad_floats(void);
-int wbc_ppo_num_splits(void);       /* row ranges per layer of the weight-gradient kernel the workspace is sized for (small minibatches use half) */
+int wbc_ppo_num_splits(void);
 size_t wbc_ppo_workspace_floats(int B);
 
 /* What Isaac Gym's mass-matrix / Jacobian tensors give the torque-supervision path (widowGo1.py:550-558, 1201-1242):
