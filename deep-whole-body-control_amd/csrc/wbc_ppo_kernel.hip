@@ -208,6 +208,101 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
   if (lane < 32 && o_ok && L.bias) dst[L.boff + o] = bsum;
 }
 
+// The four output heads (12, 6, 1 and 1 rows of dW, 128 columns each) on v_mfma_f32_16x16x4_f32: a 16-row output block wastes a
+// quarter to 15/16 of the matrix pipe where a 32-row one wastes 5/8 to 31/32, and costs half the cycles per minibatch row (8 MFMAs
+// of 32 cycles per FOUR rows against 4 of 64 per TWO) -- the heads' workgroups therefore take row ranges twice as long (plan).
+// Lane (g, n) = (lane >> 4, lane & 15): A operand = dZ[row 4 q + g][output n] (one dword), B operands of the eight 16-column
+// blocks = act[row 4 q + g][8 n + b], b = 0..7 (two 16-byte loads: a lane group reads the whole 512-byte row); D of block b leaves
+// dW[4 g + i][8 n + b], i = 0..3, in the lane. The bias gradient is the running sum of the A operands, summed over g at the end.
+static __device__ __forceinline__ void wgrad_heads_body(const WgradLayer& L, const float* __restrict__ act_stash, const float* __restrict__ dz_stash,
+                                                        float* __restrict__ dst, int r_begin, int r_end, int B) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  f32x4 acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool o_ok = n < L.out;
+  const char* dbase = reinterpret_cast<const char*>(dz_stash + (size_t)L.dcol * B);
+  const char* abase = reinterpret_cast<const char*>(act_stash + (size_t)L.acol * B + L.aoff);
+  uint32_t doff = (uint32_t)(((r_begin + g) * L.dw + (o_ok ? n : 0)) * 4);      // (outputs past the layer's width: a duplicate of output 0, never stored)
+  uint32_t aoff = (uint32_t)(((r_begin + g) * L.aw + 8 * n) * 4);
+  const uint32_t dstep = 4u * (uint32_t)L.dw * 4u, astep = 4u * (uint32_t)L.aw * 4u;           // bytes per group of four rows
+  constexpr int U = WG_U;
+  struct Ops { float av[U]; float4 b0[U], b1[U]; };
+  auto issue = [&](Ops& q) {
+#pragma unroll
+    for (int t = 0; t < U; ++t) {
+      q.av[t] = *reinterpret_cast<const float*>(dbase + (doff + t * dstep));
+      q.b0[t] = *reinterpret_cast<const float4*>(abase + (aoff + t * astep));
+      q.b1[t] = *reinterpret_cast<const float4*>(abase + (aoff + t * astep) + 16);
+    }
+    doff += U * dstep; aoff += U * astep;
+  };
+  auto mfmas = [&](float a, const float4& b0, const float4& b1) {
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.y, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.z, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0.w, acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.x, acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.y, acc[5], 0, 0, 0);
+    acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.z, acc[6], 0, 0, 0);
+    acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1.w, acc[7], 0, 0, 0);
+    bsum += a;
+  };
+  auto compute = [&](const Ops& q) {
+#pragma unroll
+    for (int t = 0; t < U; ++t) mfmas(q.av[t], q.b0[t], q.b1[t]);
+  };
+  int r = r_begin;
+  const int nfull = (r_end - r_begin) / (4 * U);                   // full batches of 4 U rows
+  if (nfull > 0) {
+    Ops A, Bq, Cq;
+    issue(A);
+    issue(Bq);                                  // (past the last batch these read the following rows, inside the workspace, unused)
+    int i = 0;
+#pragma unroll 1
+    for (; i + 3 <= nfull; i += 3) {
+      issue(Cq);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(A);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(A);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(Bq);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(Bq);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(Cq);
+      __builtin_amdgcn_sched_barrier(0);
+      r += 12 * U;
+    }
+    if (i < nfull) { compute(A); r += 4 * U; ++i; }
+    if (i < nfull) { compute(Bq); r += 4 * U; }
+  }
+  for (; r < r_end; r += 4) {                                      // ragged tail: groups of four rows, rows past the range contribute zeros
+    const int row = r + g;
+    const bool r_ok = row < r_end;
+    const size_t rc = (size_t)(r_ok ? row : r);
+    const float* dp = dz_stash + (size_t)L.dcol * B + rc * (size_t)L.dw + (o_ok ? n : 0);
+    const float* bp = act_stash + (size_t)L.acol * B + L.aoff + rc * (size_t)L.aw + 8 * n;
+    const float a = r_ok ? *dp : 0.f;
+    float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+    if (!r_ok) { b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = b0; }
+    mfmas(a, b0, b1);
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oo = 4 * g + i;
+      if (oo < L.out) dst[L.goff + (size_t)oo * L.ldw + 8 * n + b] = acc[b][i];
+    }
+  }
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 16 && o_ok && L.bias) dst[L.boff + n] = bsum;
+}
+
 // Grid = (row ranges, layers), 4 waves per workgroup = the layer's four 32-row output blocks. Two workgroups per CU (three
 // until round 5): co-resident waves do not overlap each other's vector-ALU work with MFMAs, but they do hide each other's memory
 // latency (round 2: one workgroup per CU, 8 row pairs in flight per wave: 340 us; three: 180 us).
@@ -218,8 +313,10 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
 // bundled into WG_NVL = 11 "virtual layers" of exactly 16 blocks each -- the nine 128 x 128-class layers; backbone (12) +
 // priv0 (2) + priv2 (2, its two input blocks on different waves); the four heads (4 each) -- and every wave of every
 // workgroup gets tasks worth 4 MFMAs per row pair: all workgroups are equal, whatever the placement. 168.6 -> 150.4 us.
+// (Round 5: the heads' virtual layer runs wgrad_heads_body on 16-row blocks, half the cycles per row, over half as many ranges of
+// twice the rows: still the same work per workgroup, 1/22 less of it in total.)
 #ifndef PPO_NSPLIT
-#define PPO_NSPLIT 46       // x 11 virtual layers = 506 workgroups: one resident wave of TWO per CU (the workspace is sized for this many partials)
+#define PPO_NSPLIT 48       // x 10 virtual layers + 24 double-length ranges of the heads' = 504 workgroups: one resident wave of TWO per CU (the workspace is sized for this many partials)
 #endif
 // Row ranges per layer for a minibatch of B rows. Round 5, same box, wgrad / reducer us per launch at B = 40960 | 20480 | 10240:
 // 69 splits (three waves per SIMD, 2 stages) 163 / 12.3 | 92 / 11.7 | 50 / 10.4; 46 (two per SIMD, 3 stages x 4 row pairs) 155 / 10.0 |
@@ -227,12 +324,13 @@ static __device__ __forceinline__ void wgrad_body(const WgradLayer& L, const flo
 // and every split is another 0.67 MB of partials written, read back by the reducer and pushed through L2 under the next chain launch.
 // With every operand load removed the kernel takes 127 us, without its stores 150 (of 157, the same box): the matrix pipe at the
 // clock the chip sustains under it, not the memory system, is most of what is left.
-// Small minibatches (a strong-scaled shard) take the 23: the same weight-gradient time and the cheaper reduction.
+// Small minibatches (a strong-scaled shard) take half as many: the same weight-gradient time and the cheaper reduction.
+// (48 since the heads' virtual layer needs half as many workgroups: 10 x 48 + 24 = 504 <= 512 resident, each 1/22 shorter than with 46.)
 static int ppo_nsplit(int B) { return B <= 12288 ? PPO_NSPLIT / 2 : PPO_NSPLIT; }
 struct WgradTask { int sub, ob; };                      // sub-layer (a layer or a column range of one), 32-row output block
 #define WG_NVL 11
 #define WG_NSUB (NLAYERS + 1)
-struct WgradPlan { WgradLayer sub[WG_NSUB]; WgradTask task[WG_NVL][4][2]; int ntask[WG_NVL][4]; int nsplit, rows; };
+struct WgradPlan { WgradLayer sub[WG_NSUB]; WgradTask task[WG_NVL][4][2]; int ntask[WG_NVL][4]; int nsplit, rows, nsplit_heads; };   // the heads' virtual layer (the last): nsplit_heads ranges of 2 x rows rows
 
 #ifndef WG_OCC
 #define WG_OCC 2            // resident workgroups per CU the register budget is set for
@@ -240,10 +338,15 @@ struct WgradPlan { WgradLayer sub[WG_NSUB]; WgradTask task[WG_NVL][4][2]; int nt
 extern "C" __global__ void __launch_bounds__(PT_THREADS, WG_OCC) ppo_wgrad_kernel(WgradPlan plan, const float* __restrict__ act_stash,
                                                                          const float* __restrict__ dz_stash, float* __restrict__ wpart,
                                                                          int B, int Bs, int nparams) {
-  const int vl = blockIdx.x / plan.nsplit, split = blockIdx.x - vl * plan.nsplit;
+  const int vl = min((int)blockIdx.x / plan.nsplit, WG_NVL - 1), split = blockIdx.x - vl * plan.nsplit;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // uniform: the task and its layer live in SGPRs
-  const int r_begin = min(B, split * plan.rows), r_end = min(B, r_begin + plan.rows);     // (an empty range still writes its zeros)
+  const int rows = vl == WG_NVL - 1 ? 2 * plan.rows : plan.rows;
+  const int r_begin = min(B, split * rows), r_end = min(B, r_begin + rows);     // (an empty range still writes its zeros)
   float* dst = wpart + (size_t)split * nparams;
+  if (vl == WG_NVL - 1) {                                                      // the four heads, one per wave
+    wgrad_heads_body(plan.sub[plan.task[vl][wave][0].sub], act_stash, dz_stash, dst, r_begin, r_end, Bs);
+    return;
+  }
   const int nt = plan.ntask[vl][wave];
 #pragma unroll 1
   for (int t = 0; t < nt; ++t) {
@@ -258,7 +361,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, WG_OCC) ppo_wgrad_kerne
   }
 }
 
-struct RedLayer { int goff, count; };
+struct RedLayer { int goff, count, nsplit; };           // nsplit: the row ranges this layer's partials come in
 struct RedTable { RedLayer l[NLAYERS]; int nsplit; };
 #define RED_BX ((128 * 128 + 128 + 255) / 256)            // blocks per grid row (the largest layer: 65)
 #define PPO_SQ_PARTS ((NLAYERS + 1) * RED_BX)             // one partial sum of squares per block of ppo_grad_reduce_kernel
@@ -283,14 +386,14 @@ extern "C" __global__ void __launch_bounds__(256) ppo_grad_reduce_kernel(RedTabl
     if (i < L.count) {
       const int p = L.goff + i;
       int s2 = 0;
-      for (; s2 + 8 <= tab.nsplit; s2 += 8) {
+      for (; s2 + 8 <= L.nsplit; s2 += 8) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(s2 + j) * stride + p];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += v[j];
       }
-      for (; s2 < tab.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
+      for (; s2 < L.nsplit; ++s2) acc += part[(size_t)s2 * stride + p];
       grad[p] = acc;
       counts = true;
     }
@@ -410,7 +513,11 @@ static const int kAcol[NLAYERS] = {A_X + PT_NPROP, A_H1, A_Z, A_BB, A_L1, A_L2, 
 // The equal-work plan of ppo_wgrad_kernel for this network (checked: every wave of every virtual layer gets 4 blocks).
 static int make_wgrad_plan(WgradPlan& plan, RedTable& red, int B) {
   int goff[NLAYERS], off = 0;
-  for (int l = 0; l < NLAYERS; ++l) { goff[l] = off; red.l[l] = RedLayer{off, layer_out(l) * layer_in(l) + layer_out(l)}; off += layer_out(l) * layer_in(l) + layer_out(l); }
+  const int nsplit = ppo_nsplit(B), nsplit_heads = (nsplit + 1) / 2;
+  for (int l = 0; l < NLAYERS; ++l) {
+    const bool head = l == L_LEG4 || l == L_ARM4 || l == L_CLEG4 || l == L_CARM4;
+    goff[l] = off; red.l[l] = RedLayer{off, layer_out(l) * layer_in(l) + layer_out(l), head ? nsplit_heads : nsplit}; off += layer_out(l) * layer_in(l) + layer_out(l);
+  }
   auto sub = [&](int l, int col0, int ncol, int bias) {
     const int aslab = (l == L_PRIV0) ? A_X : kAcol[l];                    // priv0 reads columns 76.. of the x slab
     return WgradLayer{layer_out(l), ncol, kDcol[l], d_slab_w(kDcol[l]), aslab, a_slab_w(aslab), kAcol[l] - aslab + col0, goff[l] + col0, 0, 0,
@@ -436,7 +543,8 @@ static int make_wgrad_plan(WgradPlan& plan, RedTable& red, int B) {
       }
       if (units != 4) return -1;
     }
-  plan.nsplit = red.nsplit = ppo_nsplit(B);
+  plan.nsplit = red.nsplit = nsplit;
+  plan.nsplit_heads = nsplit_heads;
   plan.rows = ((B + plan.nsplit - 1) / plan.nsplit + 7) / 8 * 8;
   return off;
 }
@@ -537,7 +645,7 @@ static int ppo_minibatch_grad_impl(const void* const* params, const float* obs, 
   RedTable red;
   const int off = make_wgrad_plan(plan, red, B);
   if (off < 0) return -2;
-  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(WG_NVL * plan.nsplit), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
+  hipLaunchKernelGGL(ppo_wgrad_kernel, dim3((WG_NVL - 1) * plan.nsplit + plan.nsplit_heads), dim3(PT_THREADS), 0, st, plan, act_stash, dz_stash, wpart, B, Bs, ng);
   hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, wpart, ng, grad, dstd_partial, tiles16, loss_partial,
                      grad + off, loss_accum, workspace + ppo_sq_offset(B));
   return hipGetLastError() == hipSuccess ? 0 : -2;
