@@ -323,7 +323,9 @@ static __device__ __forceinline__ void wgrad_heads_body(const WgradLayer& L, con
 // 84 / 9.2 | 46 / 8.4; 23 (one per SIMD) 174 / 8.5 | 88 / 6.8 | 46 / 6.3 -- a third wave buys nothing the deeper operand ring does not,
 // and every split is another 0.67 MB of partials written, read back by the reducer and pushed through L2 under the next chain launch.
 // With every operand load removed the kernel takes 127 us, without its stores 150 (of 157, the same box): the matrix pipe at the
-// clock the chip sustains under it, not the memory system, is most of what is left.
+// clock the chip sustains under it, not the memory system, is most of what is left. What the loads cost is not the CU's address
+// unit either: two output blocks per wave with the row range halved between two wave pairs (24 bytes per lane and row pair for 8
+// MFMAs instead of 20 for 4; sums handed over through LDS) measured 148.8 us against 149.5 -- not kept.
 // Small minibatches (a strong-scaled shard) take half as many: the same weight-gradient time and the cheaper reduction.
 // (48 since the heads' virtual layer needs half as many workgroups: 10 x 48 + 24 = 504 <= 512 resident, each 1/22 shorter than with 46.)
 static int ppo_nsplit(int B) { return B <= 12288 ? PPO_NSPLIT / 2 : PPO_NSPLIT; }
