@@ -730,7 +730,7 @@ static int ppo_clip_adam_impl(const void* const* params, float* grad, float* exp
   if (max_norm > 0.f && !have) {
     RedTable red;
     int o = 0;
-    for (int l = 0; l < NLAYERS; ++l) { red.l[l] = RedLayer{o, layer_out(l) * layer_in(l) + layer_out(l)}; o += layer_out(l) * layer_in(l) + layer_out(l); }
+    for (int l = 0; l < NLAYERS; ++l) { red.l[l] = RedLayer{o, layer_out(l) * layer_in(l) + layer_out(l), 0}; o += layer_out(l) * layer_in(l) + layer_out(l); }
     red.nsplit = 0;
     hipLaunchKernelGGL(ppo_sqnorm_kernel, dim3(RED_BX, NLAYERS + 1), dim3(256), 0, st, red, grad, o, workspace);
   }
