@@ -25,6 +25,11 @@ struct DevConst {
   uint32_t chain_pack_body[WBC_NCHAIN + 1];        // 6 x 5 bits: body at depth d (31 = none); row WBC_NCHAIN = idle lanes
   uint32_t chain_pack_dof[WBC_NCHAIN + 1];         // 6 x 5 bits: dof of that body
   uint32_t chain_pack_ax[WBC_NCHAIN + 1];          // 6 x 2 bits: joint axis
+  // The solver sweeps' layout: eight groups of 8 lanes, each walks a segment of up to three levels of one chain with its operands in
+  // registers. A chain deeper than three levels takes two groups of one 16-lane DPP row (even group: levels 1..3, odd group: 4..6;
+  // the hand-over between them is one DPP row shift). 3 x 5 bits: the segment's bodies (31 = none) | chain << 15 (7 = unused group)
+  // | 1 << 18: the deep half of its chain | 1 << 19: its chain has a deep half (in the next group)
+  uint32_t sweep_pack[8];
   uint64_t out_cp_mask[32];                        // [rb]: contacts whose force net_contact_force row rb receives ...
   uint64_t out_cp2_mask[32];                       // ... and those it receives with the opposite sign (partner of a pair)
   uint64_t body_cp_mask[WBC_NB + 1];               // the same two sets per moving body (the sweeps' wrench gather); entry

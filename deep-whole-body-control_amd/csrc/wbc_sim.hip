@@ -110,6 +110,25 @@ static int build_chains(DevConst& hc) {
     hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
   }
   if (nchain != WBC_NCHAIN) return -1;
+  {   // sweep groups (DevConst::sweep_pack): chains deeper than three levels first, on the group pairs (0,1), (2,3), ...
+    for (int g = 0; g < 8; ++g) hc.sweep_pack[g] = 0x7FFFu | 7u << 15;
+    int g = 0;
+    auto seg = [&](int c, int d0) {
+      uint32_t b = 0;
+      for (int l = 0; l < 3; ++l) b |= (uint32_t)((d0 + l < WBC_MAX_DEPTH && hc.chain_body[c][d0 + l] >= 0) ? hc.chain_body[c][d0 + l] : 31) << (5 * l);
+      return b;
+    };
+    for (int c = 0; c < WBC_NCHAIN; ++c) if (hc.chain_len[c] > 3) {
+      if (g + 2 > 8) return -1;
+      hc.sweep_pack[g] = seg(c, 0) | (uint32_t)c << 15 | 1u << 19;
+      hc.sweep_pack[g + 1] = seg(c, 3) | (uint32_t)c << 15 | 1u << 18;
+      g += 2;
+    }
+    for (int c = 0; c < WBC_NCHAIN; ++c) if (hc.chain_len[c] <= 3) {
+      if (g + 1 > 8) return -1;
+      hc.sweep_pack[g++] = seg(c, 0) | (uint32_t)c << 15;
+    }
+  }
   // collision set: every contact has a sphere on a moving body (or on the free box actor); a pair also a partner body
   static_assert(WBC_NCP <= 64 && WBC_NRB_ENV <= 32, "contact sets are 64-bit masks (one lane per contact, ballot of the active ones)");
   if (m.ncp < WBC_NFEET || m.ncp > WBC_NCP) return -1;

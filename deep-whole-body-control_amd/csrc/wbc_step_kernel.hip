@@ -77,15 +77,6 @@ __device__ __forceinline__ float row_scan16(float x) {
   return x;
 }
 
-// Packed bodies (DevConst::chain_pack_body) of chain `sch` of the 8-lane sweep layout: five scalar loads and a select chain
-// (LDS has no room for another table: 16 robots per CU need <= 10240 B each).
-__device__ __forceinline__ uint32_t sweep_chain_bodies(CP C, int sch) {
-  uint32_t b = C->chain_pack_body[WBC_NCHAIN];
-#pragma unroll
-  for (int c = 0; c < WBC_NCHAIN; ++c) b = (sch == c) ? C->chain_pack_body[c] : b;
-  return b;
-}
-
 struct PostBuf {                  // post-physics staging; shares LDS with IA (dead once the substeps are done)
   float out_rb[WBC_NRB_ENV][13];
   float quatB[WBC_NB][4], omB[WBC_NB][3], voB[WBC_NB][3];
@@ -271,7 +262,9 @@ __device__ __forceinline__ void terrain_query(CP C, float x, float y, float* h, 
 // HALF (post-physics): the limit slots receive sin/cos of the half angles instead (joint quaternions).
 template <bool HALF>
 __device__ __forceinline__ void joint_pre_pass(Smem& s, CP C) {
-  const int j = (int)threadIdx.x - 32;
+  int j = (int)threadIdx.x;
+  asm volatile("" : "+v"(j));      // (laundered: lane - 32 is otherwise one more value held across the substep loop)
+  j -= 32;
   if (j >= 0 && j < WBC_NDOF) {
     const float qq = s.q[j], qdv = s.qd[j];
     float sq, cq;
@@ -365,13 +358,17 @@ __device__ void limb_pair(const Smem& s, uint32_t ck, const float (&rad)[6], flo
 }
 
 // One physics substep on the LDS-resident state (oracle: physics_substep).
-__device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int chain, const int k,
+__device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int chain_, const int k_,
                                 const bool want_outputs) {
   // the lane index as a value the optimiser cannot see through: everything derived from it (LDS / constant-table addresses of the
   // one-body / one-DoF / one-contact-per-lane phases) is then recomputed inside each substep (a few integer operations) instead
   // of being computed once before the substep loop and held in ~20 VGPRs across it (the kernel is compiled for 128)
   int lane = threadIdx.x;
   asm volatile("" : "+v"(lane));
+  // (the chain coordinates likewise: re-derived from the laundered lane, so that what depends on them -- the matrix entries a lane
+  // owns in the passes, their LDS addresses -- is not held in registers across the substep loop either)
+  const int chain = (int)((uint32_t)lane / CH_LANES), k = lane - chain * CH_LANES;
+  (void)chain_; (void)k_;
   const float dt = C->cfg.sim_dt;
   const float idt = 1.f / dt;
   // constants of the one-body-per-lane phases: issued here, consumed after the kinematics (latency hidden)
@@ -932,6 +929,38 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   f3 cdvr = mk3(0.f, 0.f, 0.f);       // this contact's sweep response and its Delassus block (cW) stay in the owning lane's registers
   if (any) {
     const int iters = C->cfg.contact_iters;
+    // The tree sweeps' operands stay in registers across the iterations. Sweep layout (DevConst::sweep_pack): eight groups of 8 lanes
+    // (sg = lane >> 3, component sk = lane & 7 < 6), a group walks a SEGMENT of up to three levels of one chain: lane (sg, sk) holds
+    // component sk of S and U and 1/D of the segment's bodies (zeros where there is none and on the two spare lanes of a group: the
+    // sweeps then need no lane masks) and the S.p products of the inward sweep (uD) for the outward one. A chain deeper than three
+    // levels (the arm) takes the two groups of one 16-lane row: its deep half hands its wrench to the shallow half -- and receives the
+    // acceleration from it -- by one DPP row shift. A level of a sweep is a handful of dependent vector instructions (the 6-term
+    // products are DPP sums) instead of two LDS round trips: the solver's sweeps are the dependent chain of the waves a launch ends
+    // with (a robot in contact: 4 substeps x contact_iters of them).
+    const int sk = lane & 7;
+    uint32_t sbody;
+    {
+      const int sg = lane >> 3;
+      sbody = (uint32_t)__builtin_amdgcn_readfirstlane(C->sweep_pack[7]);     // (scalar loads and a select chain)
+#pragma unroll
+      for (int g = 0; g < 7; ++g) sbody = (sg == g) ? (uint32_t)__builtin_amdgcn_readfirstlane(C->sweep_pack[g]) : sbody;
+    }
+    const bool sdeep = ((sbody >> 18) & 1u) != 0u, shasdeep = ((sbody >> 19) & 1u) != 0u;
+    float sS[3] = {0.f, 0.f, 0.f}, sU[3] = {0.f, 0.f, 0.f}, siD[3] = {0.f, 0.f, 0.f}, suD[3] = {0.f, 0.f, 0.f};
+    float k0e = 0.f;                                  // the root's 6 x 8 grid: K0[lane >> 3][sk]
+    if (any_tree) {
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        const int i = (sbody >> (5 * l)) & 31;
+        const bool act = i != CH_NONE && sk < 6;
+        const int ii = act ? i : 0, kk = act ? sk : 0;
+        const float vs = s.S[ii][kk], vu = s.U[ii][kk], vd = s.iD[ii];
+        sS[l] = act ? vs : 0.f; sU[l] = act ? vu : 0.f; siD[l] = act ? vd : 0.f;
+      }
+      if (lane < 48 && sk < 6) k0e = s.ctc.K0[(lane >> 3) * 6 + sk];
+    }
+    // levels a sweep has to reach: the shallow segments' (nlA) and, for a contact below level 3, the deep segments' (nlB)
+    const int nlA = min(dmax, 3), nlB = max(dmax - 3, 0);
     for (int it = 0; it < iters; ++it) {
       if (cact) {
         const f3 own = sym_mul(cW, clamr);
@@ -974,61 +1003,99 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
           }
 #pragma unroll
           for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
-          s.uD[lane] = 0.f;                          // levels the inward sweep skips
         }
         WSYNC();
         if (it == 0) STAMP(21);
-        {   // inward. Sweep layout: 8 lanes per chain (sch = lane >> 3, component sk = lane & 7 < 6): lane (sch, sk) carries
-            // component sk of the accumulated wrench in a register, the 6-term products S.p are DPP sums (no LDS hand-over)
-          const int sch = lane >> 3, sk = lane & 7;
-          const uint32_t sbody = sweep_chain_bodies(C, sch);
-          float carry = 0.f;
-  #pragma unroll 1
-          for (int d = dmax - 1; d >= 0; --d) {
-            const int i = (sbody >> (5 * d)) & 31;
-            const bool act = i != CH_NONE && sk < 6;
-            float pk = 0.f, t = 0.f;
-            if (act) { pk = PD(s)[i][sk] + carry; t = s.S[i][sk] * pk; }
-            const float uD = -sum8(t);
-            if (act) {
-              if (sk == 0) s.uD[i] = uD;
-              carry = pk + s.U[i][sk] * (uD * s.iD[i]);
-              if (d == 0) s.pa1[sch][sk] = carry;
+        {   // inward: lane (sg, sk) carries component sk of the accumulated wrench in a register. The segments' own wrenches are
+            // requested at once; levels that carry no contact are skipped by scalar tests (their uD stays 0).
+          float pd[3];
+#pragma unroll
+          for (int l = 0; l < 3; ++l) {
+            pd[l] = 0.f;
+            if (l < nlA) {
+              const int i = (sbody >> (5 * l)) & 31;
+              const bool act = i != CH_NONE && sk < 6;
+              const float v = PD(s)[act ? i : 0][act ? sk : 0];
+              pd[l] = act ? v : 0.f;
             }
           }
+          float carry = 0.f;
+#pragma unroll
+          for (int l = 2; l >= 0; --l) {
+            if (l < nlA) {
+              const float pk = pd[l] + carry;
+              const float uD = -sum8(sS[l] * pk);
+              suD[l] = uD;
+              carry = pk + sU[l] * (uD * siD[l]);
+            }
+          }
+          if (nlB > 0) {
+            // a contact below level 3: every group has walked its segment (nlA = 3); the deep halves' results stand, the shallow
+            // halves walk theirs again from the wrench their deep half hands over (the other groups arrive at what they had)
+            const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(carry), 0x108, 0xF, 0xF, true));   // row_shl:8
+            carry = shasdeep ? up : 0.f;
+#pragma unroll
+            for (int l = 2; l >= 0; --l) {
+              const float pk = pd[l] + carry;
+              const float uD = -sum8(sS[l] * pk);
+              suD[l] = uD;
+              carry = pk + sU[l] * (uD * siD[l]);
+            }
+          }
+          const int sc = (sbody >> 15) & 7;
+          if (sc < WBC_NCHAIN && !sdeep && sk < 6) s.pa1[sc][sk] = carry;
           WSYNC();
         }
         if (it == 0) STAMP(22);
         {   // root: a0 = -K0 pD0, pD0 = its own wrench + the depth-1 contributions (fixed order). Lane (r, c) of a 6 x 8 grid forms
             // K0[r][c] pD0[c], an 8-lane DPP sum finishes row r: one LDS round trip instead of 42 dependent reads on six lanes
-          const int r = lane >> 3, c = lane & 7;
           float t = 0.f;
-          if (r < 6 && c < 6) {
-            float acc = PD(s)[0][c];
+          if (lane < 48 && sk < 6) {
+            float acc = PD(s)[0][sk];
   #pragma unroll
-            for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][c];
-            t = s.ctc.K0[r * 6 + c] * acc;
+            for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][sk];
+            t = k0e * acc;
           }
           const float a0r = -sum8(t);
-          if (r < 6 && c == 0) AD(s)[0][r] = a0r;
+          if (lane < 48 && sk == 0) AD(s)[0][lane >> 3] = a0r;
         }
         WSYNC();
         if (it == 0) STAMP(23);
-        const int dout = (it == iters - 1) ? WBC_MAX_DEPTH : dmax;
-        {   // outward: component sk of the parent's acceleration change travels in a register
-          const int sch = lane >> 3, sk = lane & 7;
-          const uint32_t sbody = sweep_chain_bodies(C, sch);
+        {   // outward: component sk of the parent's acceleration change travels in a register. The sweeps before the last one stop at
+            // the deepest level that carries a contact (only the contact points' responses are read); the last one yields every joint's
+            // acceleration change.
+          const bool last = it == iters - 1;
+          const int nA = last ? 3 : nlA, nB = last ? 3 : nlB;
           float adk = (sk < 6) ? AD(s)[0][sk] : 0.f;
-  #pragma unroll 1
-          for (int d = 0; d < dout; ++d) {
-            const int i = (sbody >> (5 * d)) & 31;
-            const bool act = i != CH_NONE && sk < 6;
-            const float ut = sum8(act ? s.U[i][sk] * adk : 0.f);
-            if (act) {
-              const float qdd = (s.uD[i] - ut) * s.iD[i];
-              adk += s.S[i][sk] * qdd;
-              AD(s)[i][sk] = adk;
-              if (sk == 0) s.qddD[i] = qdd;
+#pragma unroll
+          for (int l = 0; l < 3; ++l) {
+            if (l < nA) {
+              const int i = (sbody >> (5 * l)) & 31;
+              const bool act = i != CH_NONE && sk < 6 && !sdeep;
+              const float ut = sum8(sU[l] * adk);
+              const float qdd = (suD[l] - ut) * siD[l];
+              adk += sS[l] * qdd;
+              if (act) {
+                AD(s)[i][sk] = adk;
+                if (last && sk == 0) s.qddD[i] = qdd;
+              }
+            }
+          }
+          if (nB > 0) {
+            adk = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(adk), 0x118, 0xF, 0xF, true));               // row_shr:8
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+              if (l < nB) {
+                const int i = (sbody >> (5 * l)) & 31;
+                const bool act = i != CH_NONE && sk < 6 && sdeep;
+                const float ut = sum8(sU[l] * adk);
+                const float qdd = (suD[l] - ut) * siD[l];
+                adk += sS[l] * qdd;
+                if (act) {
+                  AD(s)[i][sk] = adk;
+                  if (last && sk == 0) s.qddD[i] = qdd;
+                }
+              }
             }
           }
           WSYNC();
