@@ -30,6 +30,7 @@ struct DevConst {
   // the hand-over between them is one DPP row shift). 3 x 5 bits: the segment's bodies (31 = none) | chain << 15 (7 = unused group)
   // | 1 << 18: the deep half of its chain | 1 << 19: its chain has a deep half (in the next group)
   uint32_t sweep_pack[8];
+  float chain_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];  // cfg.joint_armature of the joint at (chain, depth-1); 0 where there is none (row WBC_NCHAIN: idle)
   uint64_t out_cp_mask[32];                        // [rb]: contacts whose force net_contact_force row rb receives ...
   uint64_t out_cp2_mask[32];                       // ... and those it receives with the opposite sign (partner of a pair)
   uint64_t body_cp_mask[WBC_NB + 1];               // the same two sets per moving body (the sweeps' wrench gather); entry

@@ -110,6 +110,11 @@ static int build_chains(DevConst& hc) {
     hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
   }
   if (nchain != WBC_NCHAIN) return -1;
+  for (int c = 0; c <= WBC_NCHAIN; ++c) for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+    const int b = c < WBC_NCHAIN ? hc.chain_body[c][d] : -1;
+    const int dj = b >= 0 ? m.dof[b] : -1;
+    hc.chain_arm[c][d] = (dj >= 0 && dj < WBC_NACT) ? hc.cfg.joint_armature[dj] : 0.f;
+  }
   {   // sweep groups (DevConst::sweep_pack): chains deeper than three levels first, on the group pairs (0,1), (2,3), ...
     for (int g = 0; g < 8; ++g) hc.sweep_pack[g] = 0x7FFFu | 7u << 15;
     int g = 0;

@@ -45,6 +45,11 @@ __device__ long long* g_wave_dbg = nullptr;      // timing builds: per env {star
 #else
 #define STAMP(i) do { } while (0)
 #endif
+#ifdef WBC_XSTAMPS
+#define XSTAMP(i) STAMP(i)
+#else
+#define XSTAMP(i) do { } while (0)
+#endif
 #define CH_LANES 12
 
 // A workgroup is ONE wavefront: its LDS operations execute in program order, so cross-lane hand-over through LDS
@@ -56,6 +61,11 @@ __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x)
 // value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], VALU speed, no LDS
 __device__ __forceinline__ float pair_swap(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
+
+// LDS float add without a return value (ds_add_f32). One wavefront per workgroup: lanes that hit one address are served in lane order.
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // Sum over an aligned group of 8 lanes, every lane gets the total: three DPP adds at VALU speed, no LDS round trip.
@@ -104,7 +114,7 @@ struct __align__(16) Smem {
       float out_sensor[WBC_NFEET][6];
     };
   };
-  float iD[WBC_NB], u[WBC_NB], uD[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];   // iD = 1/D
+  float iD[WBC_NB], u[WBC_NB], qdd[WBC_NB], qddD[WBC_NB];   // iD = 1/D
   float pa1[WBC_NCHAIN][6];      // depth-1 contributions to the root, summed in fixed order
   float q[WBC_NDOF], qd[WBC_NDOF], tau[WBC_NDOF], act[WBC_NACT];
   float root[13], box[13], R[9], wb[3], vb[3], gF[3];
@@ -138,6 +148,7 @@ struct __align__(16) Smem {
   uint32_t k_body[WBC_NB];               // DevConst::body_pack
   float k_qdlim[WBC_NDOF];
   float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];   // joint armature at (chain, depth); row WBC_NCHAIN is the idle row
+  uint32_t k_qpack[3][8];                        // DevConst::chain_pack_body / _dof / _ax by quad of the kinematics walk (rows >= WBC_NCHAIN: idle)
   // DevConst::body_cp_mask / body_cp2_mask of the tree's bodies, contact slots 0..31 and 32..63 apart: the per-body loops walk the
   // two halves separately (32-bit mask arithmetic; the upper half -- mid-shanks, feet / gripper against the box -- is mostly idle).
   // The free box is not in these loops: its contacts fill one 16-lane row and are summed by a row reduction.
@@ -159,43 +170,92 @@ struct ChainRegs {
   const float* arm;             // LDS row of joint armatures
 };
 #define CH_NONE 31
+// (the unrolled passes decode a level's body / dof from an opaque copy of the packed registers, taken where the level starts: the
+// compiler otherwise computes every level's LDS addresses at the top of the pass and holds them in ~30 registers)
+__device__ __forceinline__ ChainRegs ch_here(const ChainRegs& cr) {
+  ChainRegs c = cr;
+  asm volatile("" : "+v"(c.body), "+v"(c.dof));
+  return c;
+}
 __device__ __forceinline__ int ch_body(const ChainRegs& cr, int d) { return (cr.body >> (5 * d)) & 31; }
 __device__ __forceinline__ int ch_par(const ChainRegs& cr, int d) { return d ? ((cr.body >> (5 * d - 5)) & 31) : 0; }
 __device__ __forceinline__ int ch_dof(const ChainRegs& cr, int d) { return (cr.dof >> (5 * d)) & 31; }
 __device__ __forceinline__ int ch_ax(const ChainRegs& cr, int d) { return (cr.ax >> (2 * d)) & 3; }
 
-__device__ __forceinline__ void fk_pass(Smem& s, CP C, const ChainRegs& cr, int chain, int k) {
-  const int lane = threadIdx.x;
-  if (lane < 9) s.E[0][lane] = (lane % 4 == 0) ? 1.f : 0.f;
-  if (lane < 3) s.pos[0][lane] = 0.f;
-  WSYNC();
-  // every lane: out = base + sum_j E_p[row][j] w_j. Lanes k<9 (entry (row, col) of E_i = E_p Rot(ax, q)): w = column
-  // col of the joint rotation, base 0; lanes 9..11 (component row of the origin): w = joint offset, base = pos_p[row].
-  const bool isE = k < 9;
-  const int row = isE ? k / 3 : k - 9, col = k % 3;
-#pragma unroll 1
-  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-    const int i = ch_body(cr, d);
-    if (i != CH_NONE) {
-      const int p = ch_par(cr, d), ax = ch_ax(cr, d), dj = ch_dof(cr, d);
-      const float e0 = s.E[p][row * 3], e1 = s.E[p][row * 3 + 1], e2 = s.E[p][row * 3 + 2];
-      const float base = s.pos[p][row], sq = s.sq[dj], cq = s.cq[dj];
-      const float r0 = s.k_jxyz[i][0], r1 = s.k_jxyz[i][1], r2 = s.k_jxyz[i][2];
-      // Rot(ax,q)[j][col]: 1 on (ax,ax); c on the other two diagonal entries; (a1,a2) = -s, (a2,a1) = +s; else 0
-      const int a1 = (ax == 2) ? 0 : ax + 1;
-      const bool col_ax = col == ax;
-      float w[3];
+// value of lane (row + 1) % 3 / (row + 2) % 3 of this lane's quad (lane 3 of a quad reads itself): DPP quad_perm [1,2,0,3] / [2,0,1,3]
+// (bound_ctrl set: the compiler folds the permutation into the consuming multiply instead of a v_mov pair)
+__device__ __forceinline__ float quad_rot1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xC9, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_rot2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xD2, 0xF, 0xF, true)); }
+
+// Kinematics of the tree in frame F: ONE walk down every chain with the running frame in registers. A chain is a quad of lanes
+// (q = lane >> 2 < 5), lane `row` = lane & 3 < 3 of it holds ROW `row` of the current body's rotation E (3 registers), component
+// `row` of its origin and of its spatial velocity. E_i = E_p Rot(axis, q) touches only the lane's own row (a rotation about a
+// coordinate axis mixes two columns), the origin needs the parent's row times the joint offset: a level of forward kinematics has no
+// cross-lane step at all. The joint screw S = (axis; origin x axis), the velocity v_i = v_p + S qd and the velocity-product term
+// c = v x (S qd) need the other two rows' components: DPP rotations within the quad. Every operand of every level (sin / cos, joint
+// offset, joint velocity) is requested before the walk starts; everything later phases read goes to LDS as it is produced (E, pos,
+// S, v, c: the layouts they had); nothing is read back. (Rounds 1-5 ran this as four phases -- a 12-lane-per-chain forward
+// kinematics with an LDS hand-over per level, then S, v and c as 108-entry maps with a hand-over between them: 6.7 k cycles of a
+// wave's dependent chain per substep, 540 vector instructions.)
+// POST: frames only (the rigid-body pass after the last substep). All 64 lanes run the same instructions (the DPP steps must not
+// be masked); lanes without a body store nothing.
+template <bool POST>
+__device__ __forceinline__ void kin_walk(Smem& s, int lane) {
+  const int q = lane >> 2, row = lane & 3;
+  const bool on = q < WBC_NCHAIN && row < 3;
+  const uint32_t pb = s.k_qpack[0][q & 7], pd = s.k_qpack[1][q & 7], pa = s.k_qpack[2][q & 7];   // (rows >= WBC_NCHAIN: no bodies)
+  const int r3 = row < 3 ? row : 0;
+  float e0 = row == 0 ? 1.f : 0.f, e1 = row == 1 ? 1.f : 0.f, e2 = row == 2 ? 1.f : 0.f, pos = 0.f, w = 0.f, vl = 0.f;
+  float sq[WBC_MAX_DEPTH], cq[WBC_MAX_DEPTH], qd[WBC_MAX_DEPTH], jx[WBC_MAX_DEPTH], jy[WBC_MAX_DEPTH], jz[WBC_MAX_DEPTH];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float off = (j == col) ? cq : ((j == a1) ? -sq : sq);
-        w[j] = (j == ax) ? (col_ax ? 1.f : 0.f) : (col_ax ? 0.f : off);
-      }
-      const float w0 = isE ? w[0] : r0, w1 = isE ? w[1] : r1, w2 = isE ? w[2] : r2;
-      const float val = (isE ? 0.f : base) + e0 * w0 + e1 * w1 + e2 * w2;
-      float* dst = isE ? &s.E[i][k] : &s.pos[i][row];
-      *dst = val;
+  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+    const int i = (pb >> (5 * d)) & 31;
+    const int ii = i != CH_NONE ? i : 0, dj = i != CH_NONE ? (int)((pd >> (5 * d)) & 31) : 0;
+    sq[d] = s.sq[dj]; cq[d] = s.cq[dj]; qd[d] = POST ? 0.f : s.qd[dj];
+    jx[d] = s.k_jxyz[ii][0]; jy[d] = s.k_jxyz[ii][1]; jz[d] = s.k_jxyz[ii][2];
+  }
+  if (!POST) XSTAMP(27);
+  if (!POST) {
+    // the root's velocity in F: component row of R^T omega, R^T v
+    const float r0 = s.R[r3], r1 = s.R[3 + r3], r2 = s.R[6 + r3];
+    w = r0 * s.root[10] + r1 * s.root[11] + r2 * s.root[12];
+    vl = r0 * s.root[7] + r1 * s.root[8] + r2 * s.root[9];
+  }
+  if (q == 0 && row < 3) {
+    s.E[0][3 * row] = e0; s.E[0][3 * row + 1] = e1; s.E[0][3 * row + 2] = e2; s.pos[0][row] = 0.f;
+    if (!POST) { s.v[0][row] = w; s.v[0][3 + row] = vl; s.S[0][row] = 0.f; s.S[0][3 + row] = 0.f; s.c[0][row] = 0.f; s.c[0][3 + row] = 0.f; }
+  }
+#pragma unroll
+  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+    const int i = (pb >> (5 * d)) & 31, ax = (pa >> (2 * d)) & 3;
+    const bool act = on && i != CH_NONE;
+    if (!POST && d == 3) XSTAMP(28);
+    // origin: the parent's row times the joint offset
+    pos = pos + e0 * jx[d] + e1 * jy[d] + e2 * jz[d];
+    // E_i = E_p Rot(ax, q): column ax stays, columns a1 = ax + 1, a2 = ax + 2 (mod 3) mix: new a1 = c a1 + s a2, new a2 = c a2 - s a1
+    const bool ax0 = ax == 0, ax1 = ax == 1;
+    const float ea1 = ax0 ? e1 : (ax1 ? e2 : e0), ea2 = ax0 ? e2 : (ax1 ? e0 : e1);
+    const float axw = ax0 ? e0 : (ax1 ? e1 : e2);                 // the joint axis in F, component row
+    const float n1 = cq[d] * ea1 + sq[d] * ea2, n2 = cq[d] * ea2 - sq[d] * ea1;
+    e0 = ax0 ? e0 : (ax1 ? n2 : n1); e1 = ax0 ? n1 : (ax1 ? e1 : n2); e2 = ax0 ? n2 : (ax1 ? n1 : e2);
+    float lin = 0.f, cang = 0.f, clin = 0.f;
+    if (!POST) {
+      const float x1 = quad_rot1(axw), x2 = quad_rot2(axw);
+      lin = quad_rot1(pos) * x2 - quad_rot2(pos) * x1;                        // (origin x axis)[row]
+      const float ja = axw * qd[d], jl = lin * qd[d], ja1 = x1 * qd[d], ja2 = x2 * qd[d];
+      w += ja; vl += jl;
+      const float w1 = quad_rot1(w), w2 = quad_rot2(w);
+      cang = w1 * ja2 - w2 * ja1;                                             // (w x ja)[row]
+      clin = (w1 * quad_rot2(jl) - w2 * quad_rot1(jl)) + (quad_rot1(vl) * ja2 - quad_rot2(vl) * ja1);   // (w x jl + vl x ja)[row]
     }
-    WSYNC();
+    if (act) {
+      s.E[i][3 * row] = e0; s.E[i][3 * row + 1] = e1; s.E[i][3 * row + 2] = e2; s.pos[i][row] = pos;
+      if (!POST) {
+        s.S[i][row] = axw; s.S[i][3 + row] = lin;
+        s.v[i][row] = w; s.v[i][3 + row] = vl;
+        s.c[i][row] = cang; s.c[i][3 + row] = clin;
+      }
+    }
   }
 }
 
@@ -382,15 +442,17 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   }
   // root-frame quantities (lane 1, in the same instructions: the rotation of the free box actor)
   if (lane < 2) quat_to_mat(lane == 0 ? &s.root[3] : &s.box[3], lane == 0 ? s.R : s.bxRb);
-  if (lane == 0) {
-    st3(s.wb, matT_mul(s.R, ld3(&s.root[10])));
-    st3(s.vb, matT_mul(s.R, ld3(&s.root[7])));
-    st3(s.gF, matT_mul(s.R, ld3(C->cfg.gravity)));
-  }
   joint_pre_pass<false>(s, C);
+  WSYNC();
   STAMP(0);
-  fk_pass(s, C, cr, chain, k);   // begins with a barrier after the identity write, ends with one
-  STAMP(1);
+  // angular / linear velocity of the base and gravity in frame F (wb, vb, gF: contiguous), one component per lane
+  if (lane >= 20 && lane < 29) {
+    const int e = lane - 20, which = e / 3, j = e - 3 * which;
+    const int src = which == 0 ? 10 : 7;
+    const float x0 = which == 2 ? C->cfg.gravity[0] : s.root[src], x1 = which == 2 ? C->cfg.gravity[1] : s.root[src + 1], x2 = which == 2 ? C->cfg.gravity[2] : s.root[src + 2];
+    s.wb[e] = s.R[j] * x0 + s.R[3 + j] * x1 + s.R[6 + j] * x2;
+  }
+  XSTAMP(25);
   // the free box in frame F (oracle: box_ws), 18 entries on otherwise idle lanes: out = sum_j R[j][r] x_j with x = a column of the
   // box's rotation (bxE = R^T Rb), its position relative to the base, its velocity, its spin
   if (lane >= 44 && lane < 62) {
@@ -406,42 +468,12 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     float* dst = isE ? &s.bxE[e] : (which == 0 ? &s.bxc[r] : (which == 1 ? &s.bxv[r] : &s.bxw[r]));
     *dst = acc;
   }
-  // joint screws S for all 18 joints: 108 entries
-  for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
-    // component m of the axis (kk < 3) or of pos x axis (kk >= 3): only the operands of that component are read
-    const int i = 1 + t / 6, kk = t % 6;
-    const int m = kk < 3 ? kk : kk - 3, a = (m == 2) ? 0 : m + 1, b = (m == 0) ? 2 : m - 1;
-    const int ax = s.k_body[i] & 3;
-    const float* Ei = s.E[i] + ax;
-    const float sm = Ei[3 * m], sa = Ei[3 * a], sb = Ei[3 * b];
-    const float lin = s.pos[i][a] * sb - s.pos[i][b] * sa;
-    s.S[i][kk] = kk < 3 ? sm : lin;
-  }
-  if (lane < 6) { s.v[0][lane] = (lane < 3) ? s.wb[lane] : s.vb[lane - 3]; s.S[0][lane] = 0.f; s.c[0][lane] = 0.f; }
+  XSTAMP(26);
+  // frames, joint screws, velocities and velocity-product terms: one walk per chain, in registers
+  kin_walk<false>(s, lane);
+  XSTAMP(29);
   WSYNC();
-  // velocities: each (chain, k<6) lane carries component k down its chain in a register
-  if (k < 6) {
-    float vr = s.v[0][k];
-#pragma unroll 1
-    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-      const int i = ch_body(cr, d);
-      if (i != CH_NONE) { vr += s.S[i][k] * s.qd[ch_dof(cr, d)]; s.v[i][k] = vr; }
-    }
-  }
-  WSYNC();
-  // velocity-product accelerations c: 108 entries
-  for (int t = lane; t < (WBC_NB - 1) * 6; t += LANES) {
-    // component m of w x ja (kk < 3) or of w x jl + vl x ja (kk >= 3), ja / jl = angular / linear part of S qd
-    const int i = 1 + t / 6, kk = t % 6;
-    const int m = kk < 3 ? kk : kk - 3, a = (m == 2) ? 0 : m + 1, b = (m == 0) ? 2 : m - 1;
-    const float qd = s.qd[(s.k_body[i] >> 2) & 31];
-    const float* vi = s.v[i];
-    const float* Si = s.S[i];
-    const float wa = vi[a], wb2 = vi[b], jaa = Si[a] * qd, jab = Si[b] * qd;
-    const float ang = wa * jab - wb2 * jaa;
-    const float lin = (wa * (Si[3 + b] * qd) - wb2 * (Si[3 + a] * qd)) + (vi[3 + a] * jab - vi[3 + b] * jaa);
-    s.c[i][kk] = kk < 3 ? ang : lin;
-  }
+  STAMP(1);
   STAMP(2);
   // spatial inertias in frame F and bias forces: one body per lane
   if (lane < WBC_NB) {
@@ -506,39 +538,67 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   const float kap_dt2 = C->cfg.limit_kappa * idt * idt, del_dt = C->cfg.limit_delta * idt;
   const int mr = k >> 1, mc = (k & 1) * 3;
   {
+    // The operands of a level that do not depend on the recursion (the body's own inertia entries, S, its bias force, torque, limit
+    // terms, armature, c) are requested one level AHEAD, right after the previous level's hand-over: the pass never writes them, and
+    // their LDS latency runs under that level's arithmetic instead of heading this one's dependent chain (levels unrolled: the
+    // operand sets are plain registers).
+    struct Lvl { float ia[3], s3[3], smr, pa; };
+    struct LvlB { float tau, viol, limd, arm, c3[3]; };
+    auto fetch = [&](int d, Lvl& o) {
+      const ChainRegs cl = ch_here(cr);
+      const int i = ch_body(cl, d);
+      const int ii = i != CH_NONE ? i : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { o.ia[j] = s.IA[ii][3 * k + j]; o.s3[j] = s.S[ii][mc + j]; }
+      o.smr = s.S[ii][mr]; o.pa = s.pA[ii][mr];
+    };
+    auto fetchB = [&](int d, LvlB& o) {       // what the second half of a level needs: requested at the level's start
+      const ChainRegs cl = ch_here(cr);
+      const int i = ch_body(cl, d);
+      const bool have = i != CH_NONE;
+      const int ii = have ? i : 0, dj = have ? ch_dof(cl, d) : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o.c3[j] = s.c[ii][mc + j];
+      o.tau = s.tau[dj]; o.viol = s.viol[dj]; o.limd = s.limd[dj]; o.arm = cr.arm[d];
+    };
     float acc3[3] = {0.f, 0.f, 0.f}, pacc = 0.f;
-#pragma unroll 1
+    Lvl cur, nxt;
+    fetch(WBC_MAX_DEPTH - 1, cur);
+#pragma unroll
     for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
-      const int i = ch_body(cr, d);
+      const int i = ch_body(ch_here(cr), d);
       const bool act = i != CH_NONE;
-      float IA3[3] = {0.f, 0.f, 0.f}, S3[3] = {0.f, 0.f, 0.f}, pAr = 0.f, Ur = 0.f;
+      float IA3[3] = {0.f, 0.f, 0.f}, pAr = 0.f, Ur = 0.f;
+      LvlB cb;
+      fetchB(d, cb);
       if (act) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { IA3[j] = s.IA[i][3 * k + j] + acc3[j]; S3[j] = s.S[i][mc + j]; }
-        pAr = s.pA[i][mr] + pacc;
-        const float up = IA3[0] * S3[0] + IA3[1] * S3[1] + IA3[2] * S3[2];
+        for (int j = 0; j < 3; ++j) IA3[j] = cur.ia[j] + acc3[j];
+        pAr = cur.pa + pacc;
+        const float up = IA3[0] * cur.s3[0] + IA3[1] * cur.s3[1] + IA3[2] * cur.s3[2];
         Ur = up + pair_swap(up);                    // U[mr] = row mr of IA times S
         s.U[i][mr] = Ur;                            // both lanes of the pair write the same value
-        TT(s)[i][mr] = s.S[i][mr] * pAr;
+        TT(s)[i][mr] = cur.smr * pAr;
       }
       WSYNC();
+      if (d > 0) fetch(d - 1, nxt);
       if (act) {
-        const int dj = ch_dof(cr, d);
         float U3[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) U3[j] = s.U[i][mc + j];
-        const float dp = S3[0] * U3[0] + S3[1] * U3[1] + S3[2] * U3[2];
-        const float D = (dp + pair_swap(dp)) + cr.arm[d];
-        // joint-limit stop (scaled by D): -kappa D/dt^2 viol - delta D/dt qd if moving further out
-        const float tau = s.tau[dj] - D * (kap_dt2 * s.viol[dj] + del_dt * s.limd[dj]);
         const float* t = TT(s)[i];
-        const float u = tau - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5]);
+        const float tsum = ((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5];
+        const float dp = cur.s3[0] * U3[0] + cur.s3[1] * U3[1] + cur.s3[2] * U3[2];
+        const float D = (dp + pair_swap(dp)) + cb.arm;
+        // joint-limit stop (scaled by D): -kappa D/dt^2 viol - delta D/dt qd if moving further out
+        const float tau = cb.tau - D * (kap_dt2 * cb.viol + del_dt * cb.limd);
+        const float u = tau - tsum;
         const float invD = rcpf(D);
         if (k == 0) { s.iD[i] = invD; s.u[i] = u; }
         float Ia3[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) Ia3[j] = IA3[j] - Ur * U3[j] * invD;     // (U_r U_c)/D: stays exactly symmetric
-        const float pp = Ia3[0] * s.c[i][mc] + Ia3[1] * s.c[i][mc + 1] + Ia3[2] * s.c[i][mc + 2];
+        const float pp = Ia3[0] * cb.c3[0] + Ia3[1] * cb.c3[1] + Ia3[2] * cb.c3[2];
         const float pa = pAr + (pp + pair_swap(pp)) + Ur * u * invD;         // component mr of pA + Ia c + U u/D
         if (d > 0) {
 #pragma unroll
@@ -550,6 +610,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
           s.pa1[chain][mr] = pa;
         }
       }
+      cur = nxt;
     }
   }
   WSYNC();
@@ -604,43 +665,64 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   // pass 3 and inverse articulated inertias, outward: the parent's K entries (K3) and acceleration component (apr)
   // travel down the chain in registers; one LDS hand-over per level (g = K_p U / D and the terms of U.(a_p + c)).
   {
+    // (operands requested one level ahead, as in pass 2: U, 1/D, u, S and c of the next body are not written by this pass)
+    struct Lvl { float u3[3], invD, cmr, umr; };
+    struct LvlB { float s3[3], sr, ui; };
+    auto fetch = [&](int d, Lvl& o) {
+      const ChainRegs cl = ch_here(cr);
+      const int i = ch_body(cl, d);
+      const int ii = i != CH_NONE ? i : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o.u3[j] = s.U[ii][mc + j];
+      o.invD = s.iD[ii]; o.cmr = s.c[ii][mr]; o.umr = s.U[ii][mr];
+    };
+    auto fetchB = [&](int d, LvlB& o) {
+      const ChainRegs cl = ch_here(cr);
+      const int i = ch_body(cl, d);
+      const int ii = i != CH_NONE ? i : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o.s3[j] = s.S[ii][mc + j];
+      o.sr = s.S[ii][mr]; o.ui = s.u[ii];
+    };
     float K3[3], apr = s.a[0][mr];
 #pragma unroll
     for (int j = 0; j < 3; ++j) K3[j] = s.IA[0][3 * k + j];
-#pragma unroll 1
-    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-      const int i = ch_body(cr, d);
-      const bool act = i != CH_NONE;
-      float U3[3] = {0.f, 0.f, 0.f}, gr = 0.f, apc = 0.f, invD = 0.f;
-      if (act) {
+    Lvl cur, nxt;
+    fetch(0, cur);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) U3[j] = s.U[i][mc + j];
-        invD = s.iD[i];
-        const float gp = K3[0] * U3[0] + K3[1] * U3[1] + K3[2] * U3[2];
-        gr = (gp + pair_swap(gp)) * invD;           // g[mr] = row mr of K_p times U / D
-        apc = apr + s.c[i][mr];
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
+      const int i = ch_body(ch_here(cr), d);
+      const bool act = i != CH_NONE;
+      float gr = 0.f, apc = 0.f;
+      LvlB cb;
+      fetchB(d, cb);
+      if (act) {
+        const float gp = K3[0] * cur.u3[0] + K3[1] * cur.u3[1] + K3[2] * cur.u3[2];
+        gr = (gp + pair_swap(gp)) * cur.invD;       // g[mr] = row mr of K_p times U / D
+        apc = apr + cur.cmr;
         GG(s)[i][mr] = gr;
-        TT(s)[i][mr] = s.U[i][mr] * apc;
+        TT(s)[i][mr] = cur.umr * apc;
       }
       WSYNC();
+      if (d + 1 < WBC_MAX_DEPTH) fetch(d + 1, nxt);
       if (act) {
-        float g3[3], S3[3];
+        float g3[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { g3[j] = GG(s)[i][mc + j]; S3[j] = s.S[i][mc + j]; }
+        for (int j = 0; j < 3; ++j) g3[j] = GG(s)[i][mc + j];
         const float* t = TT(s)[i];
-        const float qdd = (s.u[i] - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * invD;
-        const float ug = U3[0] * g3[0] + U3[1] * g3[1] + U3[2] * g3[2];
-        const float gam = (ug + pair_swap(ug)) * invD + invD;
-        const float sr = s.S[i][mr];
+        const float qdd = (cb.ui - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * cur.invD;
+        const float ug = cur.u3[0] * g3[0] + cur.u3[1] * g3[1] + cur.u3[2] * g3[2];
+        const float gam = (ug + pair_swap(ug)) * cur.invD + cur.invD;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          K3[j] = K3[j] - gr * S3[j] - sr * g3[j] + gam * sr * S3[j];
+          K3[j] = K3[j] - gr * cb.s3[j] - cb.sr * g3[j] + gam * cb.sr * cb.s3[j];
           s.IA[i][3 * k + j] = K3[j];
         }
-        apr = apc + sr * qdd;
+        apr = apc + cb.sr * qdd;
         s.a[i][mr] = apr;                           // after every lane's read of t (program order within the wavefront)
         if (k == 0) s.qdd[i] = qdd;
       }
+      cur = nxt;
     }
   }
   WSYNC();
@@ -891,6 +973,8 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
   if (lane < 6) { AD(s)[0][lane] = 0.f; s.bxa[lane] = 0.f; }
+  // the per-body contact wrenches pD (every active contact ADDS its own; zeroed again by the sweep that consumed them)
+  for (int t = lane; t < WBC_NB * 6; t += LANES) (&PD(s)[0][0])[t] = 0.f;
   WSYNC();
   STAMP(7);
   // dmax: deepest chain level that carries an active contact. Deeper levels see no contact wrench, so the inward
@@ -970,6 +1054,22 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         // damped block-Jacobi: the active contacts acting on one body share the correction
         clamr = clamr + (mk3(lam[0], lam[1], lam[2]) - clamr) * com;
         st3(s.ctc.clam[lane], clamr);
+        // this contact's wrench about F's origin, added to its bodies' pD = -f_ext (the partner body of a pair receives the opposite
+        // wrench; the free box is not part of the tree): LDS float adds from the contact's own lane -- the solver's dependent chain
+        // goes solve -> sweep without a per-body gather loop and its second hand-over in between
+        if (any_tree) {
+          const f3 f = clamr * idt, mom = cross(cxcr, f);
+          if (!onbox) {
+            float* pd = PD(s)[cpb];
+            lds_add(&pd[0], -mom.x); lds_add(&pd[1], -mom.y); lds_add(&pd[2], -mom.z);
+            lds_add(&pd[3], -f.x); lds_add(&pd[4], -f.y); lds_add(&pd[5], -f.z);
+          }
+          if (cpb2 >= 0 && !p2box) {
+            float* pd = PD(s)[cpb2];
+            lds_add(&pd[0], mom.x); lds_add(&pd[1], mom.y); lds_add(&pd[2], mom.z);
+            lds_add(&pd[3], f.x); lds_add(&pd[4], f.y); lds_add(&pd[5], f.z);
+          }
+        }
       }
       WSYNC();
       if (it == 0) STAMP(20);
@@ -984,27 +1084,6 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         if (lane == 47) { st3(&s.bxa[0], mk3(nx, ny, nz) * s.bxiI); st3(&s.bxa[3], mk3(fx, fy, fz) * s.bxim); }
       }
       if (any_tree) {
-        // gather contact wrenches per body (ascending contact index), pD = -f_ext; the partner body of a pair receives the opposite wrench
-        if (lane < WBC_NB) {
-          float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            if (half && abhi == 0u) break;                // (scalar) nothing active in the upper slots: the usual case
-            const uint2 gm = half ? s.k_gmhi[lane] : s.k_gmlo[lane];
-            uint32_t mask = (gm.x | gm.y) & (half ? abhi : ablo);
-            while (mask) {
-              const int kb = __ffs(mask) - 1, kc = kb + 32 * half;
-              mask &= mask - 1;
-              const float sg = ((gm.x >> kb) & 1u) ? idt : -idt;
-              const f3 f = ld3(s.ctc.clam[kc]) * sg;
-              const f3 mom = cross(ld3(s.ctc.cxc[kc]), f);
-              acc[0] -= mom.x; acc[1] -= mom.y; acc[2] -= mom.z; acc[3] -= f.x; acc[4] -= f.y; acc[5] -= f.z;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 6; ++j) PD(s)[lane][j] = acc[j];
-        }
-        WSYNC();
         if (it == 0) STAMP(21);
         {   // inward: lane (sg, sk) carries component sk of the accumulated wrench in a register. The segments' own wrenches are
             // requested at once; levels that carry no contact are skipped by scalar tests (their uD stays 0).
@@ -1067,6 +1146,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
           const bool last = it == iters - 1;
           const int nA = last ? 3 : nlA, nB = last ? 3 : nlB;
           float adk = (sk < 6) ? AD(s)[0][sk] : 0.f;
+          if (!last) for (int t = lane; t < WBC_NB * 6; t += LANES) (&PD(s)[0][0])[t] = 0.f;     // (every read of pD is behind us: the next sweep's adds start from zero)
 #pragma unroll
           for (int l = 0; l < 3; ++l) {
             if (l < nA) {
@@ -1249,7 +1329,9 @@ __device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int ch
     for (int j = 0; j < 4; ++j) s.post.quatB[0][j] = s.root[3 + j];
   }
   joint_pre_pass<true>(s, C);
-  fk_pass(s, C, cr, chain, k);
+  WSYNC();
+  kin_walk<true>(s, lane);
+  WSYNC();
   // per body, in parallel (lane (chain, d<6) = the chain's body at depth d): world-frame lever from the parent's
   // origin and the joint's angular-velocity contribution, parked in voB / omB
   if (k < WBC_MAX_DEPTH) {
@@ -1569,48 +1651,95 @@ __device__ __forceinline__ void reward_accumulate(Smem& s, CP C, float lsc, floa
   }
 }
 
-// Load one env's state from HBM into LDS (consecutive lanes read consecutive words).
-template <class TT> __device__ void load_env(Smem& s, const TT& T, CP C, int env) {
-  const int lane = threadIdx.x;
-  if (lane < 13) { s.root[lane] = ROW(T.root, env, 26)[lane]; s.box[lane] = ROW(T.root, env, 26)[13 + lane]; }
-  if (lane < 40) { const float v = ROW(T.dof, env, 40)[lane]; if (lane & 1) s.qd[lane >> 1] = v; else s.q[lane >> 1] = v; }
-  if (lane < 20) s.bp[lane] = ROW(T.body_params, env, 20)[lane];
-  if (lane < WBC_NACT) s.motor[lane] = ROW(T.motor, env, WBC_NACT)[lane];
-  if (lane < 24) s.goal[lane] = ROW(T.goal, env, 24)[lane];
-  if (lane < 3) s.cmd[lane] = ROW(T.commands, env, 3)[lane];
-  if (lane < WBC_NREW) s.ep_sums[lane] = ROW(T.ep_sums, env, WBC_NREW)[lane];
-  if (lane < WBC_NMETRIC) s.met_sums[lane] = ROW(T.met_sums, env, WBC_NMETRIC)[lane];
-  if (lane == 0) {
-    s.friction = G(T.friction)[env];
-    const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
-    s.mu[0] = fmaxf(0.5f * (s.friction + tf), 0.f); s.mu[1] = fmaxf(s.friction, 0.f);
-    s.mu[2] = fmaxf(0.5f * (bf + tf), 0.f); s.mu[3] = fmaxf(0.5f * (bf + s.friction), 0.f);
-    s.bxtimer = (int)G(T.box_timer)[env];
-    const float bm = G(T.box_mass)[env], bh = C->model.box_half;
-    s.bxim = 1.f / bm; s.bxiI = 1.f / (bm * (2.f / 3.f) * bh * bh);
-    s.ep_len = (int)G(T.ep_len)[env];
-  }
-}
+// policy order -> simulator order of the 18 actions (POLICY_PERM for lane < 18, as arithmetic: the leg pairs FL<->FR, RL<->RR swap)
+__device__ __forceinline__ int policy_perm18(int j) { return j < 12 ? ((j / 3) ^ 1) * 3 + j % 3 : j; }
 
-__device__ void make_chain_regs(Smem& s, ChainRegs& cr, CP C, int chain) {
+// The kernel's prologue: the model constants the dependent chains index per lane (constant block -> LDS), this lane's chain registers,
+// one env's state (HBM -> LDS; consecutive lanes read consecutive words) and -- STEP -- the action with its reorder, clip and delay
+// FIFO (WG:1162-1168). EVERY load is issued before the first store: ~30 independent requests, one wait. (Written phase by phase --
+// `if (lane < n) s.x[lane] = row[lane]` -- each masked region loads, waits and stores before the next one's pointer is even
+// fetched: twenty global round trips in a row, 8.7 k cycles at the head of every wave's step.) Loads are unmasked with clamped
+// indices; only the LDS stores are masked.
+template <bool STEP, class TT>
+__device__ __forceinline__ void prologue(Smem& s, ChainRegs& cr, const TT& T, CP C, int env, int chain, const float* __restrict__ actions) {
   const int lane = threadIdx.x;
-  if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = (&C->model.joint_xyz[0][0])[lane];
-  if (lane < WBC_NB) s.k_body[lane] = C->body_pack[lane];
-  if (lane < WBC_NB) {
-    const uint64_t m1 = C->body_cp_mask[lane], m2 = C->body_cp2_mask[lane];
-    s.k_gmlo[lane] = make_uint2((uint32_t)m1, (uint32_t)m2); s.k_gmhi[lane] = make_uint2((uint32_t)(m1 >> 32), (uint32_t)(m2 >> 32));
-  }
-  if (lane == 0) s.dyn_dirty = 0;
-  s.k_prk[lane] = C->pr_pack[lane];
-  if (lane < WBC_NDOF) s.k_qdlim[lane] = C->model.qd_limit[lane];
-  if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) {
-    const int ch = lane / WBC_MAX_DEPTH, d = lane % WBC_MAX_DEPTH;
-    const int dj = (C->chain_pack_dof[ch] >> (5 * d)) & 31;
-    const bool have = ((C->chain_pack_body[ch] >> (5 * d)) & 31) != CH_NONE;
-    s.ct_arm[ch][d] = (have && dj < WBC_NACT) ? C->cfg.joint_armature[dj] : 0.f;
-  }
+  // ---- loads: constants
+  const float c_jxyz = (&C->model.joint_xyz[0][0])[min(lane, WBC_NB * 3 - 1)];
+  const int lb = min(lane, WBC_NB - 1);
+  const uint32_t c_body = C->body_pack[lb];
+  const uint64_t c_m1 = C->body_cp_mask[lb], c_m2 = C->body_cp2_mask[lb];
+  const uint32_t c_prk = C->pr_pack[lane];
+  const float c_qdlim = C->model.qd_limit[min(lane, WBC_NDOF - 1)];
+  const float c_arm = (&C->chain_arm[0][0])[min(lane, (WBC_NCHAIN + 1) * WBC_MAX_DEPTH - 1)];
+  const int qt = min(lane >> 3, 2), qq = min(lane & 7, WBC_NCHAIN);
+  const uint32_t c_qpack = (qt == 0 ? C->chain_pack_body : (qt == 1 ? C->chain_pack_dof : C->chain_pack_ax))[qq];
   const int ch = chain < WBC_NCHAIN ? chain : WBC_NCHAIN;
   cr.body = C->chain_pack_body[ch]; cr.dof = C->chain_pack_dof[ch]; cr.ax = C->chain_pack_ax[ch]; cr.arm = s.ct_arm[ch];
+  // ---- loads: the env's state
+  const float e_root = ROW(T.root, env, 26)[min(lane, 25)];
+  const float e_dof = ROW(T.dof, env, 40)[min(lane, 39)];
+  const float e_bp = ROW(T.body_params, env, 20)[min(lane, 19)];
+  const float e_motor = ROW(T.motor, env, WBC_NACT)[min(lane, WBC_NACT - 1)];
+  const float e_goal = ROW(T.goal, env, 24)[min(lane, 23)];
+  const float e_cmd = ROW(T.commands, env, 3)[min(lane, 2)];
+  const float e_eps = ROW(T.ep_sums, env, WBC_NREW)[min(lane, WBC_NREW - 1)];
+  const float e_met = ROW(T.met_sums, env, WBC_NMETRIC)[min(lane, WBC_NMETRIC - 1)];
+  const float e_fric = G(T.friction)[env], e_bxt = G(T.box_timer)[env], e_bxm = G(T.box_mass)[env];
+  const int e_eplen = (int)G(T.ep_len)[env];
+  // ---- loads: the action and its FIFO
+  float a_new = 0.f, a_h[WBC_ADELAY_LEN];
+  if (STEP) {
+    const int la = min(lane, WBC_NACT - 1);
+    a_new = ROW(actions, env, WBC_NACT)[policy_perm18(la)];
+    auto ah = ROW(T.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT));
+#pragma unroll
+    for (int r = 0; r < WBC_ADELAY_LEN - 1; ++r) a_h[r] = ah[(r + 1) * WBC_NACT + la];
+  }
+  // ---- stores
+  if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = c_jxyz;
+  if (lane < WBC_NB) {
+    s.k_body[lane] = c_body;
+    s.k_gmlo[lane] = make_uint2((uint32_t)c_m1, (uint32_t)c_m2); s.k_gmhi[lane] = make_uint2((uint32_t)(c_m1 >> 32), (uint32_t)(c_m2 >> 32));
+  }
+  s.k_prk[lane] = c_prk;
+  if (lane < WBC_NDOF) s.k_qdlim[lane] = c_qdlim;
+  if (lane < (WBC_NCHAIN + 1) * WBC_MAX_DEPTH) (&s.ct_arm[0][0])[lane] = c_arm;
+  if (lane < 24) (&s.k_qpack[0][0])[lane] = c_qpack;
+  if (lane < 26) (&s.root[0])[lane] = e_root;                    // (root[13], box[13]: contiguous)
+  if (lane < 40) { if (lane & 1) s.qd[lane >> 1] = e_dof; else s.q[lane >> 1] = e_dof; }
+  if (lane < 20) s.bp[lane] = e_bp;
+  if (lane < WBC_NACT) s.motor[lane] = e_motor;
+  if (lane < 24) s.goal[lane] = e_goal;
+  if (lane < 3) s.cmd[lane] = e_cmd;
+  if (lane < WBC_NREW) s.ep_sums[lane] = e_eps;
+  if (lane < WBC_NMETRIC) s.met_sums[lane] = e_met;
+  if (lane == 0) {
+    s.dyn_dirty = 0;
+    s.friction = e_fric;
+    const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
+    s.mu[0] = fmaxf(0.5f * (e_fric + tf), 0.f); s.mu[1] = fmaxf(e_fric, 0.f);
+    s.mu[2] = fmaxf(0.5f * (bf + tf), 0.f); s.mu[3] = fmaxf(0.5f * (bf + e_fric), 0.f);
+    s.bxtimer = (int)e_bxt;
+    const float bh = C->model.box_half;
+    s.bxim = 1.f / e_bxm; s.bxiI = 1.f / (e_bxm * (2.f / 3.f) * bh * bh);
+    s.ep_len = e_eplen;
+  }
+  if (STEP && lane < WBC_NACT) {
+    // action reorder, clip and delay FIFO (WG:1162-1168)
+    const float clipa = C->cfg.clip_actions;
+    const float a = clampf(a_new, -clipa, clipa);
+    auto ah = ROW(T.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT));
+    float used = a;
+    if (C->cfg.action_delay != -1) {
+      a_h[WBC_ADELAY_LEN - 1] = a;
+      const int sel = WBC_ADELAY_LEN - C->cfg.action_delay - 1;
+      used = a_h[0];
+#pragma unroll
+      for (int r = 0; r < WBC_ADELAY_LEN; ++r) { ah[r * WBC_NACT + lane] = a_h[r]; used = (r == sel) ? a_h[r] : used; }
+    }
+    s.act[lane] = used;
+    s.act_last[lane] = a;
+  }
   WSYNC();
 }
 
@@ -1787,28 +1916,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const long long wave_t0 = clock64();
 #endif
   STAMP(11);
-  make_chain_regs(s, cr, C, chain);
-  load_env(s, T, C, env);
-  // action reorder, clip and delay FIFO (WG:1162-1168)
-  if (lane < WBC_NACT) {
-    const float clipa = C->cfg.clip_actions;
-    const float a = clampf(ROW(actions, env, WBC_NACT)[POLICY_PERM[lane]], -clipa, clipa);
-    auto ah = ROW(T.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT));
-    float used = a;
-    if (C->cfg.action_delay != -1) {
-      float h[WBC_ADELAY_LEN];
-#pragma unroll
-      for (int r = 0; r < WBC_ADELAY_LEN - 1; ++r) h[r] = ah[(r + 1) * WBC_NACT + lane];
-      h[WBC_ADELAY_LEN - 1] = a;
-      const int sel = WBC_ADELAY_LEN - C->cfg.action_delay - 1;
-      used = h[0];
-#pragma unroll
-      for (int r = 0; r < WBC_ADELAY_LEN; ++r) { ah[r * WBC_NACT + lane] = h[r]; used = (r == sel) ? h[r] : used; }
-    }
-    s.act[lane] = used;
-    s.act_last[lane] = a;
-  }
-  WSYNC();
+  prologue<true>(s, cr, T, C, env, chain, actions);
   const int dec = C->cfg.decimation;
   STAMP(12);
   for (int t = 0; t < dec; ++t) {
@@ -1938,8 +2046,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_reset_kernel(DevTensors 
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(s, cr, C, chain);
-  load_env(s, T, C, env);
+  prologue<false>(s, cr, T, C, env, chain, nullptr);
   if (lane == 0) { s.time_out = 0; s.reset_flag = 0; }
   WSYNC();
   float yaw = 0.f;
@@ -1977,8 +2084,7 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(s, cr, C, chain);
-  load_env(s, T, C, env);
+  prologue<false>(s, cr, T, C, env, chain, nullptr);
   if (lane < WBC_NDOF) s.tau[lane] = ROW(T.torques, env, WBC_NDOF)[lane];
   WSYNC();
   physics_substep(s, C, cr, chain, k, true);
@@ -2004,14 +2110,14 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_fk_kernel(DevTensors T, 
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-  make_chain_regs(s, cr, C, chain);
-  load_env(s, T, C, env);
+  prologue<false>(s, cr, T, C, env, chain, nullptr);
   WSYNC();
   rigid_body_pass(s, C, cr, chain, k);
   for (int e = lane; e < WBC_NRB_ENV * 13; e += LANES) ROW(T.rb, env, (WBC_NRB_ENV * 13))[e] = (&s.post.out_rb[0][0])[e];
 }
 
 static_assert(sizeof(PostBuf) <= sizeof(float) * WBC_NB * 36, "post-physics staging must fit in the IA region");
+static_assert(offsetof(Smem, vb) == offsetof(Smem, wb) + 12 && offsetof(Smem, gF) == offsetof(Smem, wb) + 24, "wb, vb, gF are written as one 9-float row");
 static_assert(sizeof(float) * (36 + WBC_NCP * 3) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
 static_assert(sizeof(float) * (WBC_NRB_ENV * 3 + WBC_NFEET * 6) <= sizeof(float) * WBC_NB * 6, "contact outputs alias U");
 static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");

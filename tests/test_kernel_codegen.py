@@ -21,7 +21,10 @@ def step_kernel_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
     out = str(tmp_path_factory.mktemp("asm") / "step.s")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]          # the build's flags (__graft_entry__.build)
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    flags = [f for f in g.COMMON_FLAGS if f != "-fPIC"] + g.EXTRA_FLAGS.get("wbc_step_kernel.hip", [])     # the build's flags for this source
     subprocess.check_call([HIPCC] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), "-o", out, SRC],
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
