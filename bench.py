@@ -41,12 +41,28 @@ _LAYERS = [(24, 64), (64, 20), (96, 128), (128, 128), (128, 128), (128, 12), (12
 UPDATE_FLOPS_PER_ROW = sum(2 * i * o * (3 if k not in (0, 9) else 2) for k, (i, o) in enumerate(_LAYERS))
 
 
+def _code_only(text):
+    """C / C++ source without comments and without whitespace: what the compiler sees (string literals in these sources hold no
+    comment markers)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", "", text)
+
+
 def step_kernel_sha16():
-    """First 16 hex digits of sha256 over the step kernel's sources: ties profiles/step_kernel_counters.json to the build it measured."""
+    """First 16 hex digits of sha256 over the CODE of the step kernel's sources (comments and whitespace stripped: documentation may be
+    corrected without orphaning the committed counters) and the flags it is built with: ties profiles/step_kernel_counters.json to
+    the build it measured."""
     import hashlib
     h = hashlib.sha256()
     for fn in ("deep-whole-body-control_amd/csrc/wbc_step_kernel.hip", "deep-whole-body-control_amd/csrc/wbc_device.h", "include/wbc_sim.h"):
-        h.update(open(os.path.join(ROOT, fn), "rb").read())
+        h.update(_code_only(open(os.path.join(ROOT, fn)).read()).encode())
+    try:
+        import __graft_entry__ as g
+        h.update(" ".join(g.COMMON_FLAGS + g.EXTRA_FLAGS.get("wbc_step_kernel.hip", [])).encode())
+    except Exception:      # noqa: BLE001
+        pass
     return h.hexdigest()[:16]
 
 

@@ -101,6 +101,7 @@ struct DevTensors {
   float* box_timer;   // [N]
   float* feet_air_time; // [N,4]
   float* last_contacts; // [N,4]
+  float* dropped;       // [N]
 };
 
 #define WBC_PI 3.14159265358979323846f

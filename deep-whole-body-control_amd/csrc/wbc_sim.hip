@@ -48,7 +48,7 @@ static const TensorSpec kSpecs[WBC_T_COUNT] = {
     {{3, 0, 0}, 1, WBC_F32},  {{3, 0, 0}, 1, WBC_F32},  {{5, 0, 0}, 1, WBC_F32},   {{0, 0, 0}, 0, WBC_F32},
     {{18, 0, 0}, 1, WBC_F32}, {{3, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},   {{20, 0, 0}, 1, WBC_F32},
     {{2, 0, 0}, 1, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},  {{0, 0, 0}, 0, WBC_F32},  {{WBC_NFEET, 0, 0}, 1, WBC_F32},
-    {{WBC_NFEET, 0, 0}, 1, WBC_F32}};
+    {{WBC_NFEET, 0, 0}, 1, WBC_F32}, {{0, 0, 0}, 0, WBC_F32}};
 
 static size_t spec_elems(const TensorSpec& s) {
   size_t n = 1;
@@ -313,6 +313,7 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   T.body_params = (float*)s->ptr[WBC_T_BODY_PARAMS]; T.reset_travel = (float*)s->ptr[WBC_T_RESET_TRAVEL];
   T.box_mass = (float*)s->ptr[WBC_T_BOX_MASS]; T.box_timer = (float*)s->ptr[WBC_T_BOX_SLEEP_TIMER];
   T.feet_air_time = (float*)s->ptr[WBC_T_FEET_AIR_TIME]; T.last_contacts = (float*)s->ptr[WBC_T_LAST_CONTACTS];
+  T.dropped = (float*)s->ptr[WBC_T_DROPPED_HITS];
   // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
   {
     const int n = num_envs;

@@ -133,6 +133,7 @@ struct __align__(16) Smem {
   float sph[WBC_NSPH][3];
   uint32_t k_prk[WBC_NCP];       // DevConst::pr_pack: every lane's pair descriptor
   int dyn_dirty;                 // the per-body contact masks below carry bits of dynamic slots (restored before they are used again)
+  int dropped;                   // broad-phase hits of this launch that found no free dynamic slot (WBC_T_DROPPED_HITS)
   float goal[24], cmd[3], blv[3], bav[3];
   float act_last[WBC_NACT];      // newest (undelayed) action, sim order
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
@@ -191,10 +192,10 @@ __device__ __forceinline__ float quad_rot2(float x) { return __int_as_float(__bu
 // (q = lane >> 2 < 5), lane `row` = lane & 3 < 3 of it holds ROW `row` of the current body's rotation E (3 registers), component
 // `row` of its origin and of its spatial velocity. E_i = E_p Rot(axis, q) touches only the lane's own row (a rotation about a
 // coordinate axis mixes two columns), the origin needs the parent's row times the joint offset: a level of forward kinematics has no
-// cross-lane step at all. The joint screw S = (axis; origin x axis), the velocity v_i = v_p + S qd and the velocity-product term
-// c = v x (S qd) need the other two rows' components: DPP rotations within the quad. Every operand of every level (sin / cos, joint
-// offset, joint velocity) is requested before the walk starts; everything later phases read goes to LDS as it is produced (E, pos,
-// S, v, c: the layouts they had); nothing is read back. (Rounds 1-5 ran this as four phases -- a 12-lane-per-chain forward
+// cross-lane step at all. The joint screw S = (axis; origin x axis) needs the other two rows' components (DPP rotations within the
+// quad), the velocity v_i = v_p + S qd follows in the lane. Every operand of every level (sin / cos, joint offset, joint velocity) is
+// requested before the walk starts; everything later phases read goes to LDS as it is produced (E, pos, S, v: the layouts they
+// had); nothing is read back. (The velocity-product term c = v x (S qd) is formed with the spatial inertias, one body per lane.) (Rounds 1-5 ran this as four phases -- a 12-lane-per-chain forward
 // kinematics with an LDS hand-over per level, then S, v and c as 108-entry maps with a hand-over between them: 6.7 k cycles of a
 // wave's dependent chain per substep, 540 vector instructions.)
 // POST: frames only (the rigid-body pass after the last substep). All 64 lanes run the same instructions (the DPP steps must not
@@ -238,22 +239,16 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
     const float axw = ax0 ? e0 : (ax1 ? e1 : e2);                 // the joint axis in F, component row
     const float n1 = cq[d] * ea1 + sq[d] * ea2, n2 = cq[d] * ea2 - sq[d] * ea1;
     e0 = ax0 ? e0 : (ax1 ? n2 : n1); e1 = ax0 ? n1 : (ax1 ? e1 : n2); e2 = ax0 ? n2 : (ax1 ? n1 : e2);
-    float lin = 0.f, cang = 0.f, clin = 0.f;
+    float lin = 0.f;
     if (!POST) {
-      const float x1 = quad_rot1(axw), x2 = quad_rot2(axw);
-      lin = quad_rot1(pos) * x2 - quad_rot2(pos) * x1;                        // (origin x axis)[row]
-      const float ja = axw * qd[d], jl = lin * qd[d], ja1 = x1 * qd[d], ja2 = x2 * qd[d];
-      w += ja; vl += jl;
-      const float w1 = quad_rot1(w), w2 = quad_rot2(w);
-      cang = w1 * ja2 - w2 * ja1;                                             // (w x ja)[row]
-      clin = (w1 * quad_rot2(jl) - w2 * quad_rot1(jl)) + (quad_rot1(vl) * ja2 - quad_rot2(vl) * ja1);   // (w x jl + vl x ja)[row]
+      lin = quad_rot1(pos) * quad_rot2(axw) - quad_rot2(pos) * quad_rot1(axw);   // (origin x axis)[row]
+      w += axw * qd[d]; vl += lin * qd[d];
     }
     if (act) {
       s.E[i][3 * row] = e0; s.E[i][3 * row + 1] = e1; s.E[i][3 * row + 2] = e2; s.pos[i][row] = pos;
       if (!POST) {
         s.S[i][row] = axw; s.S[i][3 + row] = lin;
         s.v[i][row] = w; s.v[i][3 + row] = vl;
-        s.c[i][row] = cang; s.c[i][3 + row] = clin;
       }
     }
   }
@@ -528,6 +523,13 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     const f3 nn = mat_mul(Ir, w) + cross(h, vl), ff = vl * m - cross(h, w);
     st3(&s.pA[i][0], cross(w, nn) + cross(vl, ff));
     st3(&s.pA[i][3], cross(w, ff));
+    // velocity-product acceleration c = v x (S qd) = (w x ja; w x jl + vl x ja), (ja; jl) = S qd (the root's is zero: kin_walk)
+    if (i > 0) {
+      const float qd = s.qd[(s.k_body[i] >> 2) & 31];
+      const f3 ja = ld3(&s.S[i][0]) * qd, jl = ld3(&s.S[i][3]) * qd;
+      st3(&s.c[i][0], cross(w, ja));
+      st3(&s.c[i][3], cross(w, jl) + cross(vl, ja));
+    }
   }
   WSYNC();
   STAMP(3);
@@ -542,69 +544,61 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     // terms, armature, c) are requested one level AHEAD, right after the previous level's hand-over: the pass never writes them, and
     // their LDS latency runs under that level's arithmetic instead of heading this one's dependent chain (levels unrolled: the
     // operand sets are plain registers).
-    struct Lvl { float ia[3], s3[3], smr, pa; };
-    struct LvlB { float tau, viol, limd, arm, c3[3]; };
+    // Lanes whose chain has no body at a level (the legs below level 3, the four spare lanes) run the same arithmetic on whatever
+    // their reads return (a "none" body index stays inside this workgroup's LDS): only the stores are masked.
+    struct Lvl { float ia[3], s3[3], smr, pa; int i, dj; };
     auto fetch = [&](int d, Lvl& o) {
       const ChainRegs cl = ch_here(cr);
-      const int i = ch_body(cl, d);
-      const int ii = i != CH_NONE ? i : 0;
+      o.i = ch_body(cl, d); o.dj = ch_dof(cl, d);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { o.ia[j] = s.IA[ii][3 * k + j]; o.s3[j] = s.S[ii][mc + j]; }
-      o.smr = s.S[ii][mr]; o.pa = s.pA[ii][mr];
-    };
-    auto fetchB = [&](int d, LvlB& o) {       // what the second half of a level needs: requested at the level's start
-      const ChainRegs cl = ch_here(cr);
-      const int i = ch_body(cl, d);
-      const bool have = i != CH_NONE;
-      const int ii = have ? i : 0, dj = have ? ch_dof(cl, d) : 0;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) o.c3[j] = s.c[ii][mc + j];
-      o.tau = s.tau[dj]; o.viol = s.viol[dj]; o.limd = s.limd[dj]; o.arm = cr.arm[d];
+      for (int j = 0; j < 3; ++j) { o.ia[j] = s.IA[o.i][3 * k + j]; o.s3[j] = s.S[o.i][mc + j]; }
+      o.smr = s.S[o.i][mr]; o.pa = s.pA[o.i][mr];
     };
     float acc3[3] = {0.f, 0.f, 0.f}, pacc = 0.f;
     Lvl cur, nxt;
     fetch(WBC_MAX_DEPTH - 1, cur);
 #pragma unroll
     for (int d = WBC_MAX_DEPTH - 1; d >= 0; --d) {
-      const int i = ch_body(ch_here(cr), d);
+      const int i = cur.i, dj = cur.dj;
       const bool act = i != CH_NONE;
-      float IA3[3] = {0.f, 0.f, 0.f}, pAr = 0.f, Ur = 0.f;
-      LvlB cb;
-      fetchB(d, cb);
-      if (act) {
+      // what the second half of the level needs, requested at its start
+      const float c30 = s.c[i][mc], c31 = s.c[i][mc + 1], c32 = s.c[i][mc + 2];
+      const float jtau = s.tau[dj], jviol = s.viol[dj], jlimd = s.limd[dj], jarm = cr.arm[d];
+      float IA3[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) IA3[j] = cur.ia[j] + acc3[j];
-        pAr = cur.pa + pacc;
-        const float up = IA3[0] * cur.s3[0] + IA3[1] * cur.s3[1] + IA3[2] * cur.s3[2];
-        Ur = up + pair_swap(up);                    // U[mr] = row mr of IA times S
+      for (int j = 0; j < 3; ++j) IA3[j] = cur.ia[j] + acc3[j];
+      const float pAr = cur.pa + pacc;
+      const float up = IA3[0] * cur.s3[0] + IA3[1] * cur.s3[1] + IA3[2] * cur.s3[2];
+      const float Ur = up + pair_swap(up);          // U[mr] = row mr of IA times S
+      if (act) {
         s.U[i][mr] = Ur;                            // both lanes of the pair write the same value
         TT(s)[i][mr] = cur.smr * pAr;
       }
       WSYNC();
       if (d > 0) fetch(d - 1, nxt);
-      if (act) {
+      {
         float U3[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) U3[j] = s.U[i][mc + j];
         const float* t = TT(s)[i];
         const float tsum = ((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5];
         const float dp = cur.s3[0] * U3[0] + cur.s3[1] * U3[1] + cur.s3[2] * U3[2];
-        const float D = (dp + pair_swap(dp)) + cb.arm;
+        const float D = (dp + pair_swap(dp)) + jarm;
         // joint-limit stop (scaled by D): -kappa D/dt^2 viol - delta D/dt qd if moving further out
-        const float tau = cb.tau - D * (kap_dt2 * cb.viol + del_dt * cb.limd);
+        const float tau = jtau - D * (kap_dt2 * jviol + del_dt * jlimd);
         const float u = tau - tsum;
         const float invD = rcpf(D);
-        if (k == 0) { s.iD[i] = invD; s.u[i] = u; }
+        if (act && k == 0) { s.iD[i] = invD; s.u[i] = u; }
         float Ia3[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) Ia3[j] = IA3[j] - Ur * U3[j] * invD;     // (U_r U_c)/D: stays exactly symmetric
-        const float pp = Ia3[0] * cb.c3[0] + Ia3[1] * cb.c3[1] + Ia3[2] * cb.c3[2];
+        const float pp = Ia3[0] * c30 + Ia3[1] * c31 + Ia3[2] * c32;
         const float pa = pAr + (pp + pair_swap(pp)) + Ur * u * invD;         // component mr of pA + Ia c + U u/D
         if (d > 0) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc3[j] = Ia3[j];
-          pacc = pa;
-        } else {
+          for (int j = 0; j < 3; ++j) acc3[j] = act ? Ia3[j] : 0.f;
+          pacc = act ? pa : 0.f;
+        } else if (act) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) s.IA[i][3 * k + j] = Ia3[j];           // depth-1 contribution to the root
           s.pa1[chain][mr] = pa;
@@ -666,23 +660,12 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   // travel down the chain in registers; one LDS hand-over per level (g = K_p U / D and the terms of U.(a_p + c)).
   {
     // (operands requested one level ahead, as in pass 2: U, 1/D, u, S and c of the next body are not written by this pass)
-    struct Lvl { float u3[3], invD, cmr, umr; };
-    struct LvlB { float s3[3], sr, ui; };
+    struct Lvl { float u3[3], invD, cmr, umr; int i; };
     auto fetch = [&](int d, Lvl& o) {
-      const ChainRegs cl = ch_here(cr);
-      const int i = ch_body(cl, d);
-      const int ii = i != CH_NONE ? i : 0;
+      o.i = ch_body(ch_here(cr), d);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) o.u3[j] = s.U[ii][mc + j];
-      o.invD = s.iD[ii]; o.cmr = s.c[ii][mr]; o.umr = s.U[ii][mr];
-    };
-    auto fetchB = [&](int d, LvlB& o) {
-      const ChainRegs cl = ch_here(cr);
-      const int i = ch_body(cl, d);
-      const int ii = i != CH_NONE ? i : 0;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) o.s3[j] = s.S[ii][mc + j];
-      o.sr = s.S[ii][mr]; o.ui = s.u[ii];
+      for (int j = 0; j < 3; ++j) o.u3[j] = s.U[o.i][mc + j];
+      o.invD = s.iD[o.i]; o.cmr = s.c[o.i][mr]; o.umr = s.U[o.i][mr];
     };
     float K3[3], apr = s.a[0][mr];
 #pragma unroll
@@ -691,36 +674,37 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     fetch(0, cur);
 #pragma unroll
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-      const int i = ch_body(ch_here(cr), d);
+      const int i = cur.i;
       const bool act = i != CH_NONE;
-      float gr = 0.f, apc = 0.f;
-      LvlB cb;
-      fetchB(d, cb);
+      // (lanes without a body at this level: the same arithmetic on whatever they read, only the stores are masked)
+      const float s30 = s.S[i][mc], s31 = s.S[i][mc + 1], s32 = s.S[i][mc + 2], sr = s.S[i][mr], ui = s.u[i];
+      const float gp = K3[0] * cur.u3[0] + K3[1] * cur.u3[1] + K3[2] * cur.u3[2];
+      const float gr = (gp + pair_swap(gp)) * cur.invD;       // g[mr] = row mr of K_p times U / D
+      const float apc = apr + cur.cmr;
       if (act) {
-        const float gp = K3[0] * cur.u3[0] + K3[1] * cur.u3[1] + K3[2] * cur.u3[2];
-        gr = (gp + pair_swap(gp)) * cur.invD;       // g[mr] = row mr of K_p times U / D
-        apc = apr + cur.cmr;
         GG(s)[i][mr] = gr;
         TT(s)[i][mr] = cur.umr * apc;
       }
       WSYNC();
       if (d + 1 < WBC_MAX_DEPTH) fetch(d + 1, nxt);
-      if (act) {
+      {
         float g3[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) g3[j] = GG(s)[i][mc + j];
         const float* t = TT(s)[i];
-        const float qdd = (cb.ui - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * cur.invD;
+        const float qdd = (ui - (((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5])) * cur.invD;
         const float ug = cur.u3[0] * g3[0] + cur.u3[1] * g3[1] + cur.u3[2] * g3[2];
         const float gam = (ug + pair_swap(ug)) * cur.invD + cur.invD;
+        const float s3[3] = {s30, s31, s32};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          K3[j] = K3[j] - gr * cb.s3[j] - cb.sr * g3[j] + gam * cb.sr * cb.s3[j];
-          s.IA[i][3 * k + j] = K3[j];
+        for (int j = 0; j < 3; ++j) K3[j] = K3[j] - gr * s3[j] - sr * g3[j] + gam * sr * s3[j];
+        apr = apc + sr * qdd;
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) s.IA[i][3 * k + j] = K3[j];
+          s.a[i][mr] = apr;                         // after every lane's read of t (program order within the wavefront)
+          if (k == 0) s.qdd[i] = qdd;
         }
-        apr = apc + cb.sr * qdd;
-        s.a[i][mr] = apr;                           // after every lane's read of t (program order within the wavefront)
-        if (k == 0) s.qdd[i] = qdd;
       }
       cur = nxt;
     }
@@ -785,12 +769,15 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       h &= h - 1; pool &= pool - 1;
       cand = (lane == d) ? c : cand;
     }
+    int ndrop = __popcll(h);
     h = nearbits & Cc->cand_box_mask; pool = Cc->dyn_box_mask;
     while (h != 0ull && pool != 0ull) {
       const int c = __ffsll((unsigned long long)h) - 1, d = __ffsll((unsigned long long)pool) - 1;
       h &= h - 1; pool &= pool - 1;
       cand = (lane == d) ? c : cand;
     }
+    ndrop += __popcll(h);
+    if (ndrop != 0 && lane == 0) s.dropped += ndrop;                     // (scalar test: hits that found no free slot -- WBC_T_DROPPED_HITS)
   }
   // (a wave that promotes has the exact limb tests ahead of it -- the longer way to go: it takes the SIMD's issue slots first, as a
   // wave in contact does)
@@ -1714,7 +1701,7 @@ __device__ __forceinline__ void prologue(Smem& s, ChainRegs& cr, const TT& T, CP
   if (lane < WBC_NREW) s.ep_sums[lane] = e_eps;
   if (lane < WBC_NMETRIC) s.met_sums[lane] = e_met;
   if (lane == 0) {
-    s.dyn_dirty = 0;
+    s.dyn_dirty = 0; s.dropped = 0;
     s.friction = e_fric;
     const float tf = C->cfg.terrain_friction, bf = C->model.box_friction;      // PhysX default combine: the average, not below 0
     s.mu[0] = fmaxf(0.5f * (e_fric + tf), 0.f); s.mu[1] = fmaxf(e_fric, 0.f);
@@ -1924,7 +1911,10 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     WSYNC();
     physics_substep(s, C, cr, chain, k, t == dec - 1);
   }
-  if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
+  if (lane == 0) {
+    G(T.box_timer)[env] = (float)s.bxtimer;
+    if (s.dropped != 0) G(T.dropped)[env] += (float)s.dropped;
+  }
   STAMP(13);
 #ifdef WBC_STEP_TIMING
   const long long wave_t13 = clock64();
@@ -2089,7 +2079,10 @@ extern "C" __global__ void __launch_bounds__(LANES) wbc_simulate_kernel(DevTenso
   WSYNC();
   physics_substep(s, C, cr, chain, k, true);
   if (lane < 13) { ROW(T.root, env, 26)[lane] = s.root[lane]; ROW(T.root, env, 26)[13 + lane] = s.box[lane]; }
-  if (lane == 0) G(T.box_timer)[env] = (float)s.bxtimer;
+  if (lane == 0) {
+    G(T.box_timer)[env] = (float)s.bxtimer;
+    if (s.dropped != 0) G(T.dropped)[env] += (float)s.dropped;
+  }
   {   // (a laundered lane index: left alone, the compiler keeps lane & 1 and lane >> 1 of load_env's dof rows alive across the whole
       // kernel for this store -- two VGPRs the substeps cannot spare)
     int l2 = threadIdx.x;

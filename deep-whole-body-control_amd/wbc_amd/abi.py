@@ -105,7 +105,7 @@ TENSOR_IDS = [
     "OBS_HISTORY", "ACTION_HISTORY", "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_ROOT_VEL", "COMMANDS",
     "GOAL_STATE", "REW_BUF", "ARM_REW_BUF", "RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH", "EPISODE_SUMS",
     "METRIC_SUMS", "EPISODE_SUMS_DONE", "METRIC_SUMS_DONE", "BASE_LIN_VEL", "BASE_ANG_VEL", "MASS_PARAMS",
-    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS", "RESET_TRAVEL", "BOX_MASS", "BOX_SLEEP_TIMER", "FEET_AIR_TIME", "LAST_CONTACTS"]
+    "FRICTION", "MOTOR_STRENGTH", "ENV_ORIGINS", "BOX_DELTA_Y", "BODY_PARAMS", "RESET_TRAVEL", "BOX_MASS", "BOX_SLEEP_TIMER", "FEET_AIR_TIME", "LAST_CONTACTS", "DROPPED_HITS"]
 T = {name: i for i, name in enumerate(TENSOR_IDS)}
 # per-env shapes (without the leading N) and dtypes, as the header documents them
 TENSOR_SHAPES = {
@@ -116,7 +116,7 @@ TENSOR_SHAPES = {
     "RESET_BUF": (), "TIME_OUT_BUF": (), "EPISODE_LENGTH": (), "EPISODE_SUMS": (NREW,), "METRIC_SUMS": (10,),
     "EPISODE_SUMS_DONE": (NREW,), "METRIC_SUMS_DONE": (10,), "BASE_LIN_VEL": (3,), "BASE_ANG_VEL": (3,),
     "MASS_PARAMS": (5,), "FRICTION": (), "MOTOR_STRENGTH": (18,), "ENV_ORIGINS": (3,), "BOX_DELTA_Y": (),
-    "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,), "BOX_MASS": (), "BOX_SLEEP_TIMER": (), "FEET_AIR_TIME": (4,), "LAST_CONTACTS": (4,)}
+    "BODY_PARAMS": (20,), "RESET_TRAVEL": (2,), "BOX_MASS": (), "BOX_SLEEP_TIMER": (), "FEET_AIR_TIME": (4,), "LAST_CONTACTS": (4,), "DROPPED_HITS": ()}
 TENSOR_DTYPES = {name: "f32" for name in TENSOR_IDS}
 TENSOR_DTYPES.update(RESET_BUF="i64", EPISODE_LENGTH="i64", TIME_OUT_BUF="u8")
 

@@ -86,14 +86,15 @@ typedef struct {
    * per-body loops walk the slots below 32 and those from 48 separately.
    *
    * Self-collision as configured (asset.self_collisions = 0: every pair of non-adjacent links collides): the pairs that can touch
-   * inside the URDF's joint limits (tools/self_collision_reach.py: 47 of 59; the legs never reach the trunk box, the front and
-   * rear thighs never meet) are too many for one lane each, and almost never active. They are CANDIDATES: every lane carries one
+   * inside the URDF's joint limits (tools/self_collision_reach.py: 44 limb pairs and 12 robot spheres against the free box; the legs
+   * never reach the trunk box, the front and rear thighs never meet) are too many for one lane each, and almost never active. They are CANDIDATES: every lane carries one
    * pair descriptor (pr_*) -- its own pair for a static pair slot, otherwise a candidate -- and tests it against bounding spheres
    * in the same instructions (the broad phase; a limb pair that passes -- two legs standing side by side always do -- is then tested
    * segment against segment with the generous radius WBC_LIMB_RSUM_MAX before it counts as a hit). A candidate that passes is promoted into a free DYNAMIC slot (kind
    * WBC_CP_DYNAMIC: robot-vs-robot hits into the dynamic slots outside 32..47, in ascending order of candidate and slot;
    * robot-vs-free-box hits into the dynamic slots of the box row), where the exact test runs and, if the gap is inside the contact
-   * margin, the contact is solved like any other pair. Hits beyond the free slots (14 + 3) are dropped.
+   * margin, the contact is solved like any other pair. Hits beyond the free slots (17 outside the box row + 3 inside it) are dropped
+   * and COUNTED (tensor WBC_T_DROPPED_HITS: per env, accumulated over the substeps; the tests assert it stays 0).
    * Primitives of the candidates, all in frame F from the cached sphere centres (cp_sph: the compact index of a robot sphere):
    *   limbs -- capsules between two sphere centres (thigh: hip-side end to knee, r 0.017; calf: knee to foot, r 0.008, with its end
    *   spheres knee r 0.02 / foot r 0.02; upper arm: shoulder joint to elbow, forearm: elbow to wrist, r 0.025; hand: wrist to gripper
@@ -284,6 +285,8 @@ enum wbc_tensor_id {
   WBC_T_BOX_SLEEP_TIMER,   /* f32 [N]    substeps the box actor has been at rest (asleep from box_sleep_time / sim_dt on) */
   WBC_T_FEET_AIR_TIME,     /* f32 [N,4]  feet_air_time (WG:633, LR:898-909), zeroed on reset (WG:734) */
   WBC_T_LAST_CONTACTS,     /* f32 [N,4]  last_contacts as 0 / 1 (WG:626, LR:902-903) */
+  WBC_T_DROPPED_HITS,      /* f32 [N]    broad-phase hits that found no free dynamic contact slot, accumulated over all substeps since the sim was
+                              created (diagnostic: a non-zero value means a self-collision / box contact was not simulated) */
   WBC_T_COUNT
 };
 enum wbc_dtype { WBC_F32 = 0, WBC_I64 = 1, WBC_U8 = 2 };

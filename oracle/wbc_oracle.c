@@ -175,6 +175,7 @@ typedef struct {
   REAL reset_travel[2];      /* ||root_xy - origin_xy||, ||commands[:2]|| at the moment of reset (LR:431-435) */
   REAL box_mass;             /* total mass of the box actor (WG:458-466) */
   REAL box_timer;            /* substeps the box has been at rest (asleep from box_sleep_time / sim_dt on) */
+  REAL dropped_hits;         /* broad-phase hits that found no free dynamic slot (WBC_T_DROPPED_HITS: diagnostic, accumulated) */
   REAL feet_air_time[WBC_NFEET], last_contacts[WBC_NFEET];   /* LR:898-909 (WG:626,633) */
 } ora_env;
 
@@ -608,10 +609,10 @@ static void physics_substep(const ora_sim* s, ora_env* e) {
       if (!near[k] || md->pr_kind[k] == WBC_PR_STATIC) continue;
       if (md->pr_kind[k] == WBC_PR_LIMBS) {
         while (ds < md->ncp && !(md->cp_kind[ds] == WBC_CP_DYNAMIC && (ds < 32 || ds > 47))) ++ds;
-        if (ds < md->ncp) src[ds++] = k;
+        if (ds < md->ncp) src[ds++] = k; else e->dropped_hits += 1;
       } else {
         while (db < 48 && db < md->ncp && md->cp_kind[db] != WBC_CP_DYNAMIC) ++db;
-        if (db < 48 && db < md->ncp) src[db++] = k;
+        if (db < 48 && db < md->ncp) src[db++] = k; else e->dropped_hits += 1;
       }
     }
   }
@@ -1414,6 +1415,7 @@ static int field_ptr(ora_env* e, int id, REAL** p, int* n) {
     case WBC_T_BOX_SLEEP_TIMER: *p = &e->box_timer; *n = 1; return 0;
     case WBC_T_FEET_AIR_TIME: *p = e->feet_air_time; *n = WBC_NFEET; return 0;
     case WBC_T_LAST_CONTACTS: *p = e->last_contacts; *n = WBC_NFEET; return 0;
+    case WBC_T_DROPPED_HITS: *p = &e->dropped_hits; *n = 1; return 0;
     default: return -1;
   }
 }

@@ -56,10 +56,12 @@ def test_step_kernel_reads_constants_through_the_scalar_path(step_kernel_asm):
     body, meta, text = step_kernel_asm
     assert not re.search(r"\bflat_(load|store|atomic)", body)
     assert len(re.findall(r"\bs_load_dword", body)) > 60          # constants and tensor pointers arrive by scalar loads
-    # the per-env rows are (scalar base) + (32-bit lane offset): most stores use the SGPR-base form
-    stores = re.findall(r"\bglobal_store_\w+\s+([^\n]*)", body)
-    sgpr_base = [s for s in stores if re.search(r",\s*s\[\d+:\d+\]", s)]
-    assert len(stores) > 40 and len(sgpr_base) >= 0.8 * len(stores)
+    # the per-env rows are (scalar base) + (32-bit lane offset), or ONE 64-bit lane address per row with immediate offsets for the
+    # row's accesses (which of the two the instruction selector picks changed with the build flags in round 6): either way there is
+    # well under one 64-bit address computation per global access
+    accesses = re.findall(r"\bglobal_(?:store|load)_\w+", body)
+    addr64 = re.findall(r"\bv_lshl_add_u64\b|\bv_add_co_u32\b", body)
+    assert len(accesses) > 100 and len(addr64) <= 0.7 * len(accesses)
 
 
 @pytest.mark.parametrize("src, kernel, max_vgpr", [
