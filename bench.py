@@ -235,6 +235,14 @@ def _self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def _phase(hist, pred):
+    sel = [h for h in hist if pred(h)]
+    if not sel:
+        return None
+    return {"count": len(sel), "collection_ms": 1e3 * sum(h["collection_time"] for h in sel) / len(sel),
+            "learn_ms": 1e3 * sum(h["learn_time"] for h in sel) / len(sel)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +266,10 @@ def main():
                          "grid = the base class's sub-terrain grid with the terrain-level curriculum (configs[2])")
     ap.add_argument("--contact-iters", type=int, default=0,
                     help="override sim.physx.num_position_iterations (the contact solver's sweeps per substep; the reference ships 4 = the default)")
+    ap.add_argument("--dagger-every", type=int, default=0,
+                    help="override algorithm.dagger_update_freq (widowGo1_config.py:365 ships 20): every N-th iteration collects with the history "
+                         "encoder's latent and runs PPO.update_dagger() (ppo.py:265-291) instead of update(); 1 = the teacher -> student "
+                         "distillation regime of BASELINE.json configs[4]")
     ap.add_argument("--regime", choices=["default", "standing"], default="default",
                     help="default = random-init policy under the shipped thresholds (13 %% of the envs reset per step, most robots airborne); "
                          "standing = what a trained run looks like to the step kernel: every robot on its feet, 500-step episodes "
@@ -350,6 +362,9 @@ def main():
     torch.manual_seed(train_cfg.seed)                 # identical replicas; env RNG differs per rank
     env = WidowGo1(cfg, sim_device=device, seed=train_cfg.seed + rank)
     train = class_to_dict(train_cfg)
+    if args.dagger_every:
+        train["algorithm"]["dagger_update_freq"] = args.dagger_every
+    dagger_freq = int(train["algorithm"]["dagger_update_freq"])
     log_dir = None
     if args.log:                                       # the logged loop (train.py): text goes to /dev/null, checkpoints to a scratch directory
         import tempfile
@@ -523,7 +538,7 @@ def main():
             "dtype": "f32", "data": f"synthetic (random-init policy, seeded domain randomisation, {terrain_name} terrain)",
             "config": {"workload": f"widowGo1 {terrain_name} terrain, {args.envs_per_gpu} envs per GPU, PPO fp32 "
                                    f"(BASELINE.json configs[{cfg_idx}]); T={T} steps/iteration, 5 epochs x 4 minibatches, "
-                                   f"DAgger every 20th iteration; contact solver {int(env.tcfg.contact_iters)} sweeps per substep "
+                                   f"DAgger (update_dagger) every {dagger_freq}{'th' if dagger_freq != 1 else 'st'} iteration; contact solver {int(env.tcfg.contact_iters)} sweeps per substep "
                                    f"(sim.physx.num_position_iterations, reference: 4); regime: "
                                    + ("random-init policy, shipped thresholds" if args.regime == "default" else
                                       "STANDING (z_threshold 0.25, zero-mean policy at the std floor: every robot on its feet, 500-step episodes)"),
@@ -536,8 +551,12 @@ def main():
                        "backend": args.backend if use_dist else None, "same_device": bool(args.same_device),
                        "logged": bool(args.log), "end_of_learn_checkpoint_ms": checkpoint_ms,
                        "grad_allreduce_us": allreduce_us,
+                       "dagger_update_freq": dagger_freq,
                        "collection_ms": 1e3 * sum(h["collection_time"] for h in hist) / len(hist),
-                       "learn_ms": 1e3 * sum(h["learn_time"] for h in hist) / len(hist)},
+                       "learn_ms": 1e3 * sum(h["learn_time"] for h in hist) / len(hist),
+                       # the two kinds of iteration apart (a DAgger iteration: rollout through the history encoder, update_dagger)
+                       "ppo_iterations": _phase(hist, lambda h: h["it"] % dagger_freq != 0),
+                       "dagger_iterations": _phase(hist, lambda h: h["it"] % dagger_freq == 0)},
             "roofline": {"kernel": "wbc_step_kernel", "bound": "hbm",
                          "limiter": "vector-instruction issue + the slowest wave's dependent chain, not HBM (SURVEY.md section 8d: the 40 % HBM target is "
                                     "not meaningful for this kernel at this size; 'bound' = the roofline the contract prices it against)",

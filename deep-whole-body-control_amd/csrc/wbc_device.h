@@ -28,7 +28,8 @@ struct DevConst {
   // The solver sweeps' layout: eight groups of 8 lanes, each walks a segment of up to three levels of one chain with its operands in
   // registers. A chain deeper than three levels takes two groups of one 16-lane DPP row (even group: levels 1..3, odd group: 4..6;
   // the hand-over between them is one DPP row shift). 3 x 5 bits: the segment's bodies (31 = none) | chain << 15 (7 = unused group)
-  // | 1 << 18: the deep half of its chain | 1 << 19: its chain has a deep half (in the next group)
+  // | 1 << 18: the deep half of its chain | 1 << 19: its chain has a deep half (in the next group) | 1 << 20: the group that adds the
+  // root's own contact wrench to the sum over the groups and stores the root's response
   uint32_t sweep_pack[8];
   float chain_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];  // cfg.joint_armature of the joint at (chain, depth-1); 0 where there is none (row WBC_NCHAIN: idle)
   uint64_t out_cp_mask[32];                        // [rb]: contacts whose force net_contact_force row rb receives ...

@@ -133,6 +133,7 @@ static int build_chains(DevConst& hc) {
       if (g + 1 > 8) return -1;
       hc.sweep_pack[g++] = seg(c, 0) | (uint32_t)c << 15;
     }
+    hc.sweep_pack[0] |= 1u << 20;       // (group 0 is never a deep half)
   }
   // collision set: every contact has a sphere on a moving body (or on the free box actor); a pair also a partner body
   static_assert(WBC_NCP <= 64 && WBC_NRB_ENV <= 32, "contact sets are 64-bit masks (one lane per contact, ballot of the active ones)");

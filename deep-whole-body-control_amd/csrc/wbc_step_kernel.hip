@@ -37,7 +37,8 @@ template <class X> __device__ __forceinline__ X* G(X* p) { return p; }
 #define LANES 64
 static_assert(LANES == 64, "one wavefront per robot: cross-lane hand-overs rest on wavefront-scope ordering");
 
-// development aid: phase timestamps of block 0 (tools/time_step.py builds a variant with -DWBC_STEP_TIMING)
+// development aid: phase timestamps of block 0 (tools/time_step.py builds a variant with -DWBC_STEP_TIMING); -DWBC_WAVE_TIMING: only
+// every wave's own start / end / phase stamps (tools/wave_spread.py), without the phase stamps' pointer checks in the instruction stream
 __device__ long long* g_step_dbg = nullptr;
 __device__ long long* g_wave_dbg = nullptr;      // timing builds: per env {start, end, reset | HW_ID << 8} of the step kernel's wave
 #ifdef WBC_STEP_TIMING
@@ -77,6 +78,28 @@ __device__ __forceinline__ float sum8(float x) {
   return x;
 }
 
+// Sum over the eight lanes that share (lane & 7), one in every aligned group of 8, every lane gets the total: the other group of the
+// 16-lane row by a DPP row rotation, the other rows by the two gfx950 row swaps (v_permlane16_swap / v_permlane32_swap). Vector-ALU
+// speed, no LDS, a fixed tree (the same bits in all eight lanes).
+__device__ __forceinline__ float sum_groups8(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true));     // row_ror:8
+  auto p = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(x), false, false);     // {rows 0,0,2,2 | rows 1,1,3,3}
+  x = __int_as_float(p[0]) + __int_as_float(p[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(x), false, false);     // {lower half twice | upper half twice}
+  return __int_as_float(q[0]) + __int_as_float(q[1]);
+}
+// x of lane (lane ^ m) within the aligned group of 8, m = 1..7: quad permutations and the half-row mirror (lane -> 7 - lane)
+template <int M> __device__ __forceinline__ float xor8(float x) {
+  static_assert(M >= 1 && M <= 7, "within a group of 8");
+  constexpr int Q = M & 3;
+  if (M >= 4) x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror: ^ 7
+  constexpr int R = M >= 4 ? (Q ^ 3) : Q;          // what is left to apply inside the quad
+  if (R == 1) x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+  if (R == 2) x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+  if (R == 3) x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x1B, 0xF, 0xF, true));
+  return x;
+}
+
 // Inclusive sum along a 16-lane row (DPP row_shr 1, 2, 4, 8 with zero fill): the row's last lane ends up with the row total.
 // Fixed order, VALU speed, no LDS.
 __device__ __forceinline__ float row_scan16(float x) {
@@ -100,8 +123,7 @@ struct __align__(16) Smem {
     PostBuf post;
     struct {                     // contact iterations: K of the bodies 1.. is dead once every active contact has built its Delassus
       float K0[36];              // block (the sweeps only apply the root's K), so the per-contact data of the iterations lives there:
-      float clam[WBC_NCP][3];    // the impulse, gathered per body by other lanes
-      float cxc[WBC_NCP][3];     // the contact point (frame F)
+      float clam[WBC_NCP][3];    // the impulse (read by the force outputs; the contact point stays in the owning lane's registers)
     } ctc;
   };
   float E[WBC_NB][9];
@@ -123,7 +145,7 @@ struct __align__(16) Smem {
   // 1/m and 1/Ic, and its response to the contact impulses of the current sweep (centre acceleration, angular acceleration)
   float bxRb[9], bxc[3], bxE[9], bxv[3], bxw[3], bxim, bxiI, bxa[6];
   int bxtimer;                   // substeps the box has been at rest (asleep from box_sleep_time / sim_dt on)
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   int dbg_ncon;                  // timing builds: active contacts | deepest active level << 8 of the last substep
 #endif
   // contacts (one per lane): what OTHER lanes read -- the contact point and the impulse -- lives in ctc; normal, free velocity and
@@ -215,7 +237,6 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
     sq[d] = s.sq[dj]; cq[d] = s.cq[dj]; qd[d] = POST ? 0.f : s.qd[dj];
     jx[d] = s.k_jxyz[ii][0]; jy[d] = s.k_jxyz[ii][1]; jz[d] = s.k_jxyz[ii][2];
   }
-  if (!POST) XSTAMP(27);
   if (!POST) {
     // the root's velocity in F: component row of R^T omega, R^T v
     const float r0 = s.R[r3], r1 = s.R[3 + r3], r2 = s.R[6 + r3];
@@ -230,7 +251,6 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     const int i = (pb >> (5 * d)) & 31, ax = (pa >> (2 * d)) & 3;
     const bool act = on && i != CH_NONE;
-    if (!POST && d == 3) XSTAMP(28);
     // origin: the parent's row times the joint offset
     pos = pos + e0 * jx[d] + e1 * jy[d] + e2 * jz[d];
     // E_i = E_p Rot(ax, q): column ax stays, columns a1 = ax + 1, a2 = ax + 2 (mod 3) mix: new a1 = c a1 + s a2, new a2 = c a2 - s a1
@@ -447,7 +467,6 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     const float x0 = which == 2 ? C->cfg.gravity[0] : s.root[src], x1 = which == 2 ? C->cfg.gravity[1] : s.root[src + 1], x2 = which == 2 ? C->cfg.gravity[2] : s.root[src + 2];
     s.wb[e] = s.R[j] * x0 + s.R[3 + j] * x1 + s.R[6 + j] * x2;
   }
-  XSTAMP(25);
   // the free box in frame F (oracle: box_ws), 18 entries on otherwise idle lanes: out = sum_j R[j][r] x_j with x = a column of the
   // box's rotation (bxE = R^T Rb), its position relative to the base, its velocity, its spin
   if (lane >= 44 && lane < 62) {
@@ -463,10 +482,8 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     float* dst = isE ? &s.bxE[e] : (which == 0 ? &s.bxc[r] : (which == 1 ? &s.bxv[r] : &s.bxw[r]));
     *dst = acc;
   }
-  XSTAMP(26);
   // frames, joint screws, velocities and velocity-product terms: one walk per chain, in registers
   kin_walk<false>(s, lane);
-  XSTAMP(29);
   WSYNC();
   STAMP(1);
   STAMP(2);
@@ -726,11 +743,17 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     const f3 xk = ld3(pb) + mat_mul(Eb, mk3(cpp[0], cpp[1], cpp[2]));
     const int own = (prk >> 2) & 31;
     if (own < WBC_NSPH) st3(s.sph[own], xk);
-    const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
-    float h; f3 nw;
-    terrain_query(C, Xw.x, Xw.y, &h, &nw);
-    cgap = (Xw.z - h) * nw.z - cpr;
-    cn = matT_mul(s.R, nw);
+    if (!C->hf) {
+      // the ground plane (a wave-uniform branch): only the height of the centre is needed, the normal is the world's z axis in F
+      cn = mk3(s.R[6], s.R[7], s.R[8]);
+      cgap = ((s.root[2] + dot(cn, xk)) - C->cfg.ground_z) - cpr;
+    } else {
+      const f3 Xw = ld3(&s.root[0]) + mat_mul(s.R, xk);
+      float h; f3 nw;
+      terrain_query(C, Xw.x, Xw.y, &h, &nw);
+      cgap = (Xw.z - h) * nw.z - cpr;
+      cn = matT_mul(s.R, nw);
+    }
     cxcr = xk - cn * cpr;
   }
   WSYNC();
@@ -740,22 +763,33 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   bool near = false;
   {
     const int pk = prk & 3;
-    const f3 ca = (ld3(s.sph[(prk >> 7) & 31]) + ld3(s.sph[(prk >> 12) & 31])) * 0.5f;
-    const f3 cbl = (ld3(s.sph[(prk >> 17) & 31]) + ld3(s.sph[(prk >> 22) & 31])) * 0.5f;
+    const f3 a0 = ld3(s.sph[(prk >> 7) & 31]), a1 = ld3(s.sph[(prk >> 12) & 31]), b0 = ld3(s.sph[(prk >> 17) & 31]), b1 = ld3(s.sph[(prk >> 22) & 31]);
+    const f3 ca = (a0 + a1) * 0.5f;
+    const f3 cbl = (b0 + b1) * 0.5f;
     const int bsel = (prk >> 27) & 3;
     const f3 cb = bsel == 0 ? cbl : (bsel == 1 ? mk3(C->trunk_c[0], C->trunk_c[1], C->trunk_c[2]) : ld3(s.bxc));
     const float reach = (float)((prk >> 29) + 1u) * WBC_REACH_STEP + C->cfg.contact_margin + 1e-3f;
     const f3 dc = ca - cb;
-    near = pk != WBC_PR_NONE && dot(dc, dc) < reach * reach;
+    const float dcc = dot(dc, dc);
+    near = pk != WBC_PR_NONE && dcc < reach * reach;
     // second stage for the limb pairs that pass (two legs standing side by side always do): the two shafts' segments against a generous
-    // common radius -- one segment-segment distance on those lanes instead of a promotion and nine feature pairs every substep
-    const bool limbs = near && pk == WBC_PR_LIMBS;
-    if (__ballot(limbs) != 0ull && limbs) {
-      f3 pa, pb;
-      seg_seg_closest(ld3(s.sph[(prk >> 7) & 31]), ld3(s.sph[(prk >> 12) & 31]), ld3(s.sph[(prk >> 17) & 31]), ld3(s.sph[(prk >> 22) & 31]), &pa, &pb);
-      const f3 dd = pa - pb;
+    // common radius -- one segment-segment distance on those lanes instead of a promotion and nine feature pairs every substep. Before it,
+    // in a dozen instructions: the separation of the two segments ALONG the line of their midpoints, |dc| - (|dc.hA| + |dc.hB|) / |dc|
+    // with hA, hB the half segments, is a lower bound of their distance; parallel legs side by side (dc across the shafts) fail it at
+    // once, and the segment-segment code runs only for the pairs it cannot exclude (it would have excluded the same ones: same radius).
+    bool limbs = near && pk == WBC_PR_LIMBS;
+    if (__ballot(limbs) != 0ull) {
       const float r2 = WBC_LIMB_RSUM_MAX + Cc->model.pair_rest_offset + C->cfg.contact_margin + 1e-3f;
-      near = dot(dd, dd) < r2 * r2;
+      if (limbs) {
+        const float sepn = dcc - (fabsf(dot(dc, a1 - ca)) + fabsf(dot(dc, b1 - cbl)));      // |dc| x the separation
+        if (sepn > 0.f && sepn * sepn > 1.002f * (r2 * r2) * dcc) { limbs = false; near = false; }
+      }
+      if (__ballot(limbs) != 0ull && limbs) {
+        f3 pa, pb;
+        seg_seg_closest(a0, a1, b0, b1, &pa, &pb);
+        const f3 dd = pa - pb;
+        near = dot(dd, dd) < r2 * r2;
+      }
     }
   }
   const uint64_t nearbits = __ballot(near);
@@ -956,7 +990,6 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   WSYNC();
   if (cact) {
     s.ctc.clam[lane][0] = s.ctc.clam[lane][1] = s.ctc.clam[lane][2] = 0.f;
-    st3(s.ctc.cxc[lane], cxcr);
   }
   if (lane < WBC_NB) s.qddD[lane] = 0.f;
   if (lane < 6) { AD(s)[0][lane] = 0.f; s.bxa[lane] = 0.f; }
@@ -978,7 +1011,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
 #pragma unroll
   for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
   dmax = max(dmax, ddmax);
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   if (lane == 0) s.dbg_ncon = __popcll(abits) | (dmax << 8) | (__popcll(abits & 0x3F800000ull) << 16);
 #endif
   // damped block-Jacobi: relaxation 1 / (number of active contacts acting on the busier of the contact's two bodies)
@@ -1018,7 +1051,8 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     }
     const bool sdeep = ((sbody >> 18) & 1u) != 0u, shasdeep = ((sbody >> 19) & 1u) != 0u;
     float sS[3] = {0.f, 0.f, 0.f}, sU[3] = {0.f, 0.f, 0.f}, siD[3] = {0.f, 0.f, 0.f}, suD[3] = {0.f, 0.f, 0.f};
-    float k0e = 0.f;                                  // the root's 6 x 8 grid: K0[lane >> 3][sk]
+    const bool sroot = ((sbody >> 20) & 1u) != 0u;    // the group that adds the root's own wrench and stores the root's response
+    float k0p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // row sk of K0 in the order the group's lanes are gathered: K0[sk][sk ^ p]
     if (any_tree) {
 #pragma unroll
       for (int l = 0; l < 3; ++l) {
@@ -1028,11 +1062,18 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         const float vs = s.S[ii][kk], vu = s.U[ii][kk], vd = s.iD[ii];
         sS[l] = act ? vs : 0.f; sU[l] = act ? vu : 0.f; siD[l] = act ? vd : 0.f;
       }
-      if (lane < 48 && sk < 6) k0e = s.ctc.K0[(lane >> 3) * 6 + sk];
+#pragma unroll
+      for (int p2 = 0; p2 < 8; ++p2) {
+        const int c = sk ^ p2;
+        const bool ok = sk < 6 && c < 6;
+        const float v = s.ctc.K0[ok ? sk * 6 + c : 0];
+        k0p[p2] = ok ? v : 0.f;
+      }
     }
     // levels a sweep has to reach: the shallow segments' (nlA) and, for a contact below level 3, the deep segments' (nlB)
     const int nlA = min(dmax, 3), nlB = max(dmax - 3, 0);
     for (int it = 0; it < iters; ++it) {
+      if (it == 1) XSTAMP(25);
       if (cact) {
         const f3 own = sym_mul(cW, clamr);
         const f3 vref = cvfree + cdvr - own;
@@ -1060,21 +1101,28 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       }
       WSYNC();
       if (it == 0) STAMP(20);
+      if (it == 1) XSTAMP(26);
       // the free box: its contacts fill the 16-lane row 32..47 (corners: + the impulse; a robot sphere against it: - the impulse);
       // every lane of the row forms its wrench about the box centre (3 m from F's origin: no cancellation in fp32), a row reduction
       // sums them, the row's last lane turns the sum into the box's response (angular acceleration n / Ic, centre acceleration F / m)
       if ((abhi & 0xFFFFu) != 0u && (lane >> 4) == 2) {
         const f3 f = cact ? clamr * (onbox ? idt : -idt) : mk3(0.f, 0.f, 0.f);
-        const f3 mom = cross((cact ? ld3(s.ctc.cxc[lane]) : ld3(s.bxc)) - ld3(s.bxc), f);
+        const f3 mom = cross(cact ? cxcr - ld3(s.bxc) : mk3(0.f, 0.f, 0.f), f);
         const float nx = row_scan16(mom.x), ny = row_scan16(mom.y), nz = row_scan16(mom.z);
         const float fx = row_scan16(f.x), fy = row_scan16(f.y), fz = row_scan16(f.z);
         if (lane == 47) { st3(&s.bxa[0], mk3(nx, ny, nz) * s.bxiI); st3(&s.bxa[3], mk3(fx, fy, fz) * s.bxim); }
       }
       if (any_tree) {
         if (it == 0) STAMP(21);
+        if (it == 1) XSTAMP(27);
         {   // inward: lane (sg, sk) carries component sk of the accumulated wrench in a register. The segments' own wrenches are
             // requested at once; levels that carry no contact are skipped by scalar tests (their uD stays 0).
           float pd[3];
+          float pd0 = 0.f;                      // the root's own wrench (on the lanes of ONE group)
+          {
+            const float v = PD(s)[0][sk < 6 ? sk : 0];
+            pd0 = (sroot && sk < 6) ? v : 0.f;
+          }
 #pragma unroll
           for (int l = 0; l < 3; ++l) {
             pd[l] = 0.f;
@@ -1108,31 +1156,24 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
               carry = pk + sU[l] * (uD * siD[l]);
             }
           }
-          const int sc = (sbody >> 15) & 7;
-          if (sc < WBC_NCHAIN && !sdeep && sk < 6) s.pa1[sc][sk] = carry;
-          WSYNC();
-        }
-        if (it == 0) STAMP(22);
-        {   // root: a0 = -K0 pD0, pD0 = its own wrench + the depth-1 contributions (fixed order). Lane (r, c) of a 6 x 8 grid forms
-            // K0[r][c] pD0[c], an 8-lane DPP sum finishes row r: one LDS round trip instead of 42 dependent reads on six lanes
-          float t = 0.f;
-          if (lane < 48 && sk < 6) {
-            float acc = PD(s)[0][sk];
-  #pragma unroll
-            for (int ch = 0; ch < WBC_NCHAIN; ++ch) acc += s.pa1[ch][sk];
-            t = k0e * acc;
-          }
-          const float a0r = -sum8(t);
-          if (lane < 48 && sk == 0) AD(s)[0][lane >> 3] = a0r;
-        }
-        WSYNC();
-        if (it == 0) STAMP(23);
-        {   // outward: component sk of the parent's acceleration change travels in a register. The sweeps before the last one stop at
-            // the deepest level that carries a contact (only the contact points' responses are read); the last one yields every joint's
-            // acceleration change.
+          // root, still in registers: pD0 = its own wrench + the chains' depth-1 contributions (summed over the eight groups by row
+          // rotation / row swaps: every lane gets component sk), a0 = -K0 pD0 (the group's lanes gather pD0, each forms its own row)
+          const float p0 = sum_groups8((sdeep ? 0.f : carry) + pd0);
+          float a0 = k0p[0] * p0;
+          a0 += k0p[1] * xor8<1>(p0); a0 += k0p[2] * xor8<2>(p0); a0 += k0p[3] * xor8<3>(p0);
+          a0 += k0p[4] * xor8<4>(p0); a0 += k0p[5] * xor8<5>(p0); a0 += k0p[6] * xor8<6>(p0); a0 += k0p[7] * xor8<7>(p0);
+          a0 = -a0;
+          if (sroot && sk < 6) AD(s)[0][sk] = a0;       // (read by the contact points on the root body and by the integrator)
+          if (it == 0) STAMP(22);
+          if (it == 1) XSTAMP(28);
+          if (it == 0) STAMP(23);
+          if (it == 1) XSTAMP(29);
+          // outward: component sk of the parent's acceleration change travels in a register. The sweeps before the last one stop at
+          // the deepest level that carries a contact (only the contact points' responses are read); the last one yields every joint's
+          // acceleration change.
           const bool last = it == iters - 1;
           const int nA = last ? 3 : nlA, nB = last ? 3 : nlB;
-          float adk = (sk < 6) ? AD(s)[0][sk] : 0.f;
+          float adk = a0;
           if (!last) for (int t = lane; t < WBC_NB * 6; t += LANES) (&PD(s)[0][0])[t] = 0.f;     // (every read of pD is behind us: the next sweep's adds start from zero)
 #pragma unroll
           for (int l = 0; l < 3; ++l) {
@@ -1171,8 +1212,9 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         WSYNC();
       }
       if (it == 0) STAMP(24);
+      if (it == 1) XSTAMP(30);
       if (it < iters - 1 && cact) {      // the last sweep's contact-point response is not used
-        const f3 xc = ld3(s.ctc.cxc[lane]);
+        const f3 xc = cxcr;
         // response of a body at the contact point: (angular; linear) acceleration change, lever from F's origin (tree) / from the
         // box centre (free box)
         const float* ad1 = onbox ? s.bxa : AD(s)[onbox ? 0 : cpb];
@@ -1186,6 +1228,7 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         cdvr = dvv;
       }
       WSYNC();
+      if (it == 1) XSTAMP(31);
     }
   }
   STAMP(8);
@@ -1899,7 +1942,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
   ChainRegs cr;
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   const long long wave_t0 = clock64();
 #endif
   STAMP(11);
@@ -1916,7 +1959,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     if (s.dropped != 0) G(T.dropped)[env] += (float)s.dropped;
   }
   STAMP(13);
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   const long long wave_t13 = clock64();
 #endif
   // Everything after the substeps reads its tensor / constant pointers through laundered copies of the two kernel arguments: the
@@ -2003,7 +2046,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   reward_accumulate(s, Cq, rsc_leg, rsc_arm);
   WSYNC();
   STAMP(15);
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   const long long wave_t15 = clock64();
 #endif
   const bool do_reset = s.reset_flag != 0;
@@ -2013,12 +2056,12 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane + LANES] = 0.f;
   }
   STAMP(16);
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   const long long wave_t16 = clock64();
 #endif
   observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
   STAMP(17);
-#ifdef WBC_STEP_TIMING
+#if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   if (g_wave_dbg && lane == 0) {
     g_wave_dbg[6 * (size_t)env] = wave_t0; g_wave_dbg[6 * (size_t)env + 1] = clock64();
     g_wave_dbg[6 * (size_t)env + 3] = wave_t13; g_wave_dbg[6 * (size_t)env + 4] = wave_t15; g_wave_dbg[6 * (size_t)env + 5] = wave_t16;

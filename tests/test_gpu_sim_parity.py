@@ -534,22 +534,50 @@ def test_box_actor_matches_oracle(robot):
         foot_hits = grip_hits = box_steps = slept = 0
         for step in range(6):
             helpers.sync_oracle_from_gpu(o, g)
+            root_before = _t(g, "ROOT_STATES").astype(np.float64)
             a = (0.3 * rng.normal(size=(n, 18))).astype(np.float32)
             g.step(torch.from_numpy(a).cuda()); o.step(a)
             tag = f"box actor ({'grid' if use_hf else 'plane'}), step {step}"
             for name in ("RESET_BUF", "TIME_OUT_BUF", "EPISODE_LENGTH"):
                 np.testing.assert_array_equal(_t(g, name), o.get(name), err_msg=f"{tag} {name}")
             fo, fg = o.get("NET_CONTACT_FORCE"), _t(g, "NET_CONTACT_FORCE")
-            _assert_close_bulk(fg, fo, 0.08, 5e-3, f"{tag} NET_CONTACT_FORCE", frac=4e-3, slack=1e9)
             ro, rg = o.get("ROOT_STATES"), _t(g, "ROOT_STATES")
+            # Rows are split by whether kernel and oracle ended the step with the SAME set of rigid bodies in contact. Same set: every
+            # element within 10 x its tolerance (and all but the stated fraction within it). Different set -- a box corner or a foot that
+            # touches one substep apart in fp32 and in fp64 --: a stated fraction of the rows at most, and what they may differ by is
+            # bounded physically: one of the two has applied an impact the other has not yet, i.e. a velocity change of at most the
+            # box's closing speed before the step (|v| + |omega| x half diagonal, the robot's base speed for the foot pair) plus one
+            # depenetration step, over at most one policy step of travel.
+            same = ((np.abs(fg).sum(-1) > 0) == (np.abs(fo).sum(-1) > 0)).all(1)
+            ndiff = int((~same).sum())
+            assert ndiff <= 0.03 * n, f"{tag}: contact sets differ in {ndiff} of {n} envs"
+            vclose = (np.linalg.norm(root_before[:, 1, 7:10], axis=1) + 0.0866 * np.linalg.norm(root_before[:, 1, 10:13], axis=1)
+                      + np.linalg.norm(root_before[:, 0, 7:10], axis=1) + float(tc.max_depenetration_vel) + 9.81 * 0.02)
+            worst = {}
+
+            def split(name, got, want, atol, rtol, frac, dbound):
+                got, want = np.asarray(got, np.float64).reshape(n, -1), np.asarray(want, np.float64).reshape(n, -1)
+                if same.any():
+                    _assert_close_bulk(got[same], want[same], atol, rtol, f"{tag} {name} (same contact set)", frac=frac, slack=10.0)
+                if ndiff:
+                    err = np.abs(got[~same] - want[~same]).max(1)
+                    lim = np.broadcast_to(np.asarray(dbound, np.float64), (n,))[~same] if np.ndim(dbound) else np.full(ndiff, float(dbound))
+                    worst[name] = float((err / lim).max())
+                    assert (err <= lim).all(), f"{tag} {name} (different contact set): {err.max():.3e} against the bound {lim[err.argmax()]:.3e}"
+            wmax = float(np.abs(fo).max(initial=1.0))
+            split("NET_CONTACT_FORCE", fg, fo, 0.08, 5e-3, 4e-3, 2.0 * wmax + 50.0)             # (a contact more or less: up to the largest force in the batch)
             _assert_close_bulk(rg[:, 0], ro[:, 0], 4e-4, 5e-4, f"{tag} ROOT_STATES robot", frac=2e-3)
             # the box: 1 kg on 0.1 m -- a corner that touches one substep apart in fp32 moves it visibly: the bulk must be tight
-            _assert_close_bulk(rg[:, 1, :7], ro[:, 1, :7], 4e-4, 5e-4, f"{tag} box pose", frac=1e-2, slack=1e9)
-            _assert_close_bulk(rg[:, 1, 7:10], ro[:, 1, 7:10], 2e-3, 2e-3, f"{tag} box velocity", frac=2e-2, slack=1e9)
-            _assert_close_bulk(rg[:, 1, 10:], ro[:, 1, 10:], 3e-2, 5e-3, f"{tag} box spin", frac=2e-2, slack=1e9)
+            split("box pose", rg[:, 1, :7], ro[:, 1, :7], 4e-4, 5e-4, 1e-2, 0.02 * vclose + 0.05)
+            split("box velocity", rg[:, 1, 7:10], ro[:, 1, 7:10], 2e-3, 2e-3, 2e-2, vclose)
+            split("box spin", rg[:, 1, 10:], ro[:, 1, 10:], 3e-2, 5e-3, 2e-2, vclose / 0.05 + 1.0)
             np.testing.assert_allclose(_t(g, "RIGID_BODY_STATE")[:, 27], rg[:, 1], atol=1e-6)
-            for name, atol, rtol in (("DOF_STATE", 6e-4, 1e-3), ("FORCE_SENSOR", 0.08, 5e-3), ("OBS_BUF", 3e-3, 1e-3), ("REW_BUF", 2e-4, 2e-3)):
-                _assert_close_bulk(_t(g, name), o.get(name), atol, rtol, f"{tag} {name}", frac=4e-3, slack=1e9)
+            split("DOF_STATE", _t(g, "DOF_STATE"), o.get("DOF_STATE"), 6e-4, 1e-3, 4e-3, 2.0)       # (a 1 kg box against a 12 kg robot's limb)
+            split("FORCE_SENSOR", _t(g, "FORCE_SENSOR"), o.get("FORCE_SENSOR"), 0.08, 5e-3, 4e-3, 2.0 * wmax + 50.0)
+            split("OBS_BUF", _t(g, "OBS_BUF"), o.get("OBS_BUF"), 3e-3, 1e-3, 4e-3, 2.0)
+            split("REW_BUF", _t(g, "REW_BUF"), o.get("REW_BUF"), 2e-4, 2e-3, 4e-3, 0.05)
+            if ndiff:
+                print(f"{tag}: {ndiff} envs with different contact sets; worst error / physical bound:", {k: round(v, 3) for k, v in worst.items()})
             to, tg = o.get("BOX_SLEEP_TIMER"), _t(g, "BOX_SLEEP_TIMER")
             assert (to != tg).mean() < 0.01, f"{tag} BOX_SLEEP_TIMER: {(to != tg).sum()} differ"
             frozen = (to == 80) & (np.abs(fo[:, 27]).sum(-1) == 0)

@@ -3,7 +3,8 @@ launch (= its slowest SIMD) from the mean wave, and what do the slow waves have 
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["WBC_AMD_LIB"] = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_timing.so")
+_w = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_wavetiming.so")      # tools/build_variant.py wavetiming -DWBC_WAVE_TIMING
+os.environ["WBC_AMD_LIB"] = _w if os.path.exists(_w) else os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_timing.so")
 import numpy as np, torch
 import helpers
 from wbc_amd import abi
