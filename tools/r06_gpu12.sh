@@ -1,3 +1,3 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-for V in base nocontact dec1 noreset; do echo "== insts $V"; bash tools/r06_pmc_insts.sh 4096 $V; done
+for V in dec0 dec2 dec8; do echo "== insts $V"; bash tools/r06_pmc_insts.sh 4096 $V 2>&1 | grep wbc_step; done
