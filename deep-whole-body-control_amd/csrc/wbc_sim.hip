@@ -150,6 +150,7 @@ static int build_chains(DevConst& hc) {
     const uint64_t bit = 1ull << k;
     if (kind == WBC_CP_NONE) continue;                          // unused slot
     if (kind == WBC_CP_DYNAMIC) {                               // a free slot of the dynamic pool: the box row's belong to the free box
+      if (b == WBC_BOX_BODY) return -1;                         // (the step kernel derives `onbox` from cp_body: a dynamic slot must not claim the box)
       if (k >= 32 && k <= 47) { hc.dyn_box_mask |= bit; hc.box_pair_mask |= bit; } else hc.dyn_self_mask |= bit;
       continue;
     }
@@ -208,6 +209,10 @@ static int build_chains(DevConst& hc) {
       const int la = m.pr_a[k], lb = m.pr_b[k];
       if (la < 0 || la >= m.nlimb || lb < 0 || lb >= m.nlimb || m.limb_body[la] == m.limb_body[lb]) return -1;
       a0 = m.limb_s0[la]; a1 = m.limb_s1[la]; b0 = m.limb_s0[lb]; b1 = m.limb_s1[lb];
+      // the second stage of the broad phase tests the two shafts against WBC_LIMB_RSUM_MAX: a pair with a larger radius sum would
+      // silently lose contacts there
+      const float ra = fmaxf(m.limb_radius[la], fmaxf(m.limb_cap0[la], m.limb_cap1[la])), rb = fmaxf(m.limb_radius[lb], fmaxf(m.limb_cap0[lb], m.limb_cap1[lb]));
+      if (ra + rb > WBC_LIMB_RSUM_MAX + 1e-6f) return -3;
       hc.cand_self_mask |= bit;
     } else if (pk == WBC_PR_SPHERE_BOX) {
       if (m.pr_a[k] < 0 || m.pr_a[k] >= WBC_NSPH || hc.sph_slot[m.pr_a[k]] < 0) return -1;
@@ -280,7 +285,8 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   s->hc.model = *model; s->hc.cfg = *cfg;
   if (const int rc = build_chains(s->hc)) {
     delete s;
-    return fail(-1, rc == -2 ? "wbc_sim_create: contact slots 32..47 are the free box's row (its corners, robot spheres against it) and nothing else"
+    return fail(-1, rc == -3 ? "wbc_sim_create: a candidate limb pair's radii add up to more than WBC_LIMB_RSUM_MAX (the broad phase's second stage would miss its contacts)" :
+                    rc == -2 ? "wbc_sim_create: contact slots 32..47 are the free box's row (its corners, robot spheres against it) and nothing else"
                              : "wbc_sim_create: topology must be a root with 5 serial chains of depth <= 6, contacts on valid bodies");
   }
   const size_t need = wbc_sim_arena_bytes(num_envs);

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import json
 import os
 from typing import Optional
 
@@ -153,7 +154,21 @@ KNEE_RADIUS, FOOT_RADIUS, ELBOW_RADIUS, WRIST_RADIUS, GRIP_RADIUS = 0.02, 0.02, 
 HAND_RADIUS = 0.02                                        # gripper body + fingers (a 4 cm bar) as a capsule from the wrist to the tip
 UPPER_ARM_LEN = math.hypot(0.25, 0.04975)                 # shoulder joint .. elbow: the L-shaped upper-arm link (urdf:512-530) as the straight capsule between its joints
 FOREARM_LEN, HAND_LEN = 0.25, 0.1586                       # elbow .. wrist (0.175 + 0.075) and wrist .. gripper tip (0.065 + 0.0936) along the arm (urdf:531-700)
-LIMB_RSUM_MAX = 0.045     # WBC_LIMB_RSUM_MAX (include/wbc_sim.h): bounds the radius sums of all candidate limb pairs
+LIMB_RSUM_MAX = 0.060     # WBC_LIMB_RSUM_MAX (include/wbc_sim.h): bounds the radius sums of all candidate limb pairs
+
+
+def _arm_limb_fit():
+    """Shaft / end-sphere radii of the arm's three limbs, FITTED to the convex hulls of the STL meshes the URDF names as collision
+    geometry (widowGo1.urdf:504-819; tools/fit_arm_primitives.py --apply writes assets/arm_primitives.json): the radii that minimise
+    max(under-, over-approximation) of capsule + end spheres against each hull -- 28.7 / 13.7 / 24.2 mm for upper arm / forearm / hand
+    (a straight capsule against the cone-like hull of an L-shaped link; the file also holds the `under <= 10 mm` variant and its
+    46 / 19 / 39 mm over-approximation). Rounds 3-5 had 25 / 25 / 20 mm typed in by hand (42 mm under on the upper arm)."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "arm_primitives.json")) as f:
+        d = json.load(f)["limbs"]
+    return {k: tuple(round(float(d[k]["balanced"][q]), 4) for q in ("radius", "cap0", "cap1")) for k in ("upper_arm", "forearm", "hand")}
+
+
+ARM_LIMB_FIT = _arm_limb_fit()
 STATIC_SELF_SLOT0, BOX_ROW, SHANK0 = 23, 32, 48
 # dynamic slots: what the self-collision broad phase promotes its hits into (robot-vs-robot: outside the box row; robot-vs-box: inside)
 SHOULDER_SLOT = 26
@@ -255,11 +270,12 @@ def collision_set(m: RobotModel, foot_name: str = "foot", gripper_name: str = "w
         # and finger links, about the wrist-rotate axis) as capsules. (The arm's own links do not collide with each other: the one pair
         # that could, hand vs upper arm, is the stated exception.)
         rbi = {n: i for i, n in enumerate(rbn)}
-        limbs.append(dict(name="upper_arm", s0=NSPH - 1, s1=k_elbow, radius=ELBOW_RADIUS, cap0=0.0, cap1=0.0, length=UPPER_ARM_LEN,
+        fit = ARM_LIMB_FIT
+        limbs.append(dict(name="upper_arm", s0=NSPH - 1, s1=k_elbow, radius=fit["upper_arm"][0], cap0=fit["upper_arm"][1], cap1=fit["upper_arm"][2], length=UPPER_ARM_LEN,
                           body=cps[k_shoulder]["body"], rb=cps[k_shoulder]["rb"], rb0=cps[k_shoulder]["rb"], rb1=cps[k_shoulder]["rb"]))
-        limbs.append(dict(name="forearm", s0=k_elbow, s1=k_wrist, radius=ELBOW_RADIUS, cap0=0.0, cap1=0.0, length=FOREARM_LEN,
+        limbs.append(dict(name="forearm", s0=k_elbow, s1=k_wrist, radius=fit["forearm"][0], cap0=fit["forearm"][1], cap1=fit["forearm"][2], length=FOREARM_LEN,
                           body=cps[k_elbow]["body"], rb=cps[k_elbow]["rb"], rb0=cps[k_elbow]["rb"], rb1=cps[k_wrist]["rb"]))
-        limbs.append(dict(name="hand", s0=k_wrist, s1=k_grip, radius=HAND_RADIUS, cap0=0.0, cap1=0.0, length=HAND_LEN,
+        limbs.append(dict(name="hand", s0=k_wrist, s1=k_grip, radius=fit["hand"][0], cap0=fit["hand"][1], cap1=fit["hand"][2], length=HAND_LEN,
                           body=cps[k_grip]["body"], rb=rbi["wx250s/gripper_link"], rb0=rbi["wx250s/gripper_link"], rb1=rbi["wx250s/gripper_link"]))
         assert len(limbs) <= NLIMB
         L = {l["name"]: i for i, l in enumerate(limbs)}

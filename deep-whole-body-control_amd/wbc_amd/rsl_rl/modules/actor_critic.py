@@ -311,7 +311,13 @@ class ActorCritic(nn.Module):
     param_version = 0      # bump (mark_params_changed) whenever parameters are modified: the fused kernels cache a packed copy
 
     def mark_params_changed(self):
+        """Bump the version the packed weight copies follow AND tell the library that whatever weight streams it keeps current for
+        the update kernels (wbc_ppo_minibatch_grad_packed trusts them by pointer, csrc/wbc_ppo_kernel.hip) are stale: an in-place
+        write -- load_state_dict, enforce_min_std, a broadcast -- keeps every pointer, so only the caller can know."""
         self.param_version += 1
+        if any(p.is_cuda for p in self.parameters()):
+            from ... import native
+            native.lib().wbc_ppo_pack_invalidate(None)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

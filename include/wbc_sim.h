@@ -40,7 +40,7 @@ extern "C" {
                             that the self-collision broad phase promotes its hits into */
 #define WBC_NSPH 28      /* the robot's contact spheres (their centres in frame F are cached once per substep) */
 #define WBC_NLIMB 11     /* capsules of the self-collision broad phase: 4 thighs, 4 calves, upper arm, forearm, hand */
-#define WBC_LIMB_RSUM_MAX 0.045f   /* an upper bound of (largest radius of limb a) + (largest radius of limb b) over all candidate pairs (second
+#define WBC_LIMB_RSUM_MAX 0.060f   /* an upper bound of (largest radius of limb a) + (largest radius of limb b) over all candidate pairs (second
                                       stage of the broad phase: the distance between the two shafts' segments against this + rest + margin) */
 #define WBC_BOX_BODY WBC_NB   /* pseudo body index of the free box actor (WG:321-325,384) in cp_body / cp_body2 */
 #define WBC_BOX_RB WBC_NRB    /* its row in the [N,28,...] rigid-body tensors (WG:544-548: the last one) */

@@ -48,9 +48,10 @@ def primitives(rb, names):
            "gripper": (P["wx250s/ee_gripper_link"], abi.GRIP_RADIUS)}
     # the arm's links between those spheres, as the legs meet them: upper arm (shoulder joint .. elbow: the L-shaped link as the straight
     # capsule between its two joints), forearm and hand capsules
-    limbs["upper_arm"] = (P["wx250s/upper_arm_link"], P["wx250s/upper_forearm_link"], abi.ELBOW_RADIUS, 0.0, 0.0)
-    limbs["forearm"] = (P["wx250s/upper_forearm_link"], P["wx250s/wrist_link"], abi.ELBOW_RADIUS, 0.0, 0.0)
-    limbs["hand"] = (P["wx250s/wrist_link"], P["wx250s/ee_gripper_link"], abi.HAND_RADIUS, 0.0, 0.0)
+    # (the arm limbs' radii: fitted to the URDF meshes' convex hulls, tools/fit_arm_primitives.py -> abi.ARM_LIMB_FIT)
+    limbs["upper_arm"] = (P["wx250s/upper_arm_link"], P["wx250s/upper_forearm_link"]) + abi.ARM_LIMB_FIT["upper_arm"]
+    limbs["forearm"] = (P["wx250s/upper_forearm_link"], P["wx250s/wrist_link"]) + abi.ARM_LIMB_FIT["forearm"]
+    limbs["hand"] = (P["wx250s/wrist_link"], P["wx250s/ee_gripper_link"]) + abi.ARM_LIMB_FIT["hand"]
     ti = names.index("trunk")
     return limbs, arm, (rotm(rb[:, ti, 3:7]), rb[:, ti, :3], np.array(abi.TRUNK_HALF))
 

@@ -182,16 +182,16 @@ def main():
     # upper arm: shoulder joint .. elbow joint (one link, L-shaped)
     p = subtree_points(links, joints, "wx250s/upper_arm_link", fq)
     limb_geoms.append(("upper_arm", p, np.zeros(3), J("wx250s/upper_forearm_link")))
-    out["upper_arm_radius"] = report("upper arm (shoulder joint .. elbow)", p, np.zeros(3), J("wx250s/upper_forearm_link"), abi.ELBOW_RADIUS)
+    out["upper_arm_radius"] = report("upper arm (shoulder joint .. elbow)", p, np.zeros(3), J("wx250s/upper_forearm_link"), abi.ARM_LIMB_FIT["upper_arm"][0])
     # forearm: elbow .. wrist = upper_forearm_link + lower_forearm_link (roll about the forearm axis)
     p = np.concatenate([subtree_points(links, joints, "wx250s/upper_forearm_link", fq), subtree_points(links, joints, "wx250s/lower_forearm_link", fq) + J("wx250s/lower_forearm_link")], 0)
     limb_geoms.append(("forearm", p, np.zeros(3), J("wx250s/lower_forearm_link") + J("wx250s/wrist_link")))
-    out["forearm_radius"] = report("forearm (elbow .. wrist)", p, np.zeros(3), J("wx250s/lower_forearm_link") + J("wx250s/wrist_link"), abi.ELBOW_RADIUS)
+    out["forearm_radius"] = report("forearm (elbow .. wrist)", p, np.zeros(3), J("wx250s/lower_forearm_link") + J("wx250s/wrist_link"), abi.ARM_LIMB_FIT["forearm"][0])
     # hand: wrist .. gripper tip = wrist_link + gripper_link and what is fixed to it (prop, bar, fingers)
     tip = J("wx250s/gripper_link") + J("wx250s/ee_arm_link") + J("wx250s/gripper_bar_link") + J("wx250s/fingers_link") + J("wx250s/ee_gripper_link")
     p = np.concatenate([subtree_points(links, joints, "wx250s/wrist_link", fq), subtree_points(links, joints, "wx250s/gripper_link", fq) + J("wx250s/gripper_link")], 0)
     limb_geoms.append(("hand", p, np.zeros(3), tip))
-    out["hand_radius"] = report("hand (wrist .. gripper tip)", p, np.zeros(3), tip, abi.HAND_RADIUS)
+    out["hand_radius"] = report("hand (wrist .. gripper tip)", p, np.zeros(3), tip, abi.ARM_LIMB_FIT["hand"][0])
     out["hand_len"] = float(np.linalg.norm(tip))
     # shoulder link (waist joint .. shoulder joint): the sphere at the shoulder joint stands for it
     p = subtree_points(links, joints, "wx250s/shoulder_link", fq)
@@ -217,6 +217,14 @@ def main():
         path = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "assets", "arm_primitives.json")
         json.dump(json.loads(json.dumps(out, default=float)), open(path, "w"), indent=1)
         print("wrote", path)
+        # hull samples + facets as a test fixture (data: points on the hulls of the reference's meshes, in limb frames)
+        fx = {}
+        for name, p, a, b in limb_geoms:
+            smp, h = hull_samples(p)
+            fx[name + "_samples"], fx[name + "_facets"], fx[name + "_a"], fx[name + "_b"] = smp.astype(np.float32), h.equations.astype(np.float32), a, b
+        gpath = os.path.join(ROOT, "tests", "golden", "arm_hull_samples.npz")
+        np.savez_compressed(gpath, **fx)
+        print("wrote", gpath)
 
 
 if __name__ == "__main__":
