@@ -112,7 +112,7 @@ __device__ __forceinline__ float row_scan16(float x) {
 
 struct PostBuf {                  // post-physics staging; shares LDS with IA (dead once the substeps are done)
   float out_rb[WBC_NRB_ENV][13];
-  float quatB[WBC_NB][4], omB[WBC_NB][3], voB[WBC_NB][3];
+  float quatB[WBC_NB][4];
   float o76[WBC_NPROP];
 };
 #define WBC_NREW_WG 22             // the terms WG itself defines (the only ones with a metric side effect)
@@ -163,6 +163,7 @@ struct __align__(16) Smem {
   float rew, arm_rew, base_yaw, friction;
   float mu[4];                   // friction coefficients: robot-terrain, robot-robot, box-terrain, robot-box
   float rp[2];                   // base roll / pitch of the state the observation is built from (post-physics, or post-reset)
+  float eul[6];                  // Euler angles of the base [0..2] and of the gripper [3..5] after the physics (euler_batch: six lanes, one atan2)
   int reset_flag, time_out, ep_len;
   float sq[WBC_NDOF], cq[WBC_NDOF];      // sin/cos of the joint angles of this substep
   float viol[WBC_NDOF], limd[WBC_NDOF];  // joint-limit violation and (if moving further out) the joint velocity
@@ -220,8 +221,8 @@ __device__ __forceinline__ float quad_rot2(float x) { return __int_as_float(__bu
 // had); nothing is read back. (The velocity-product term c = v x (S qd) is formed with the spatial inertias, one body per lane.) (Rounds 1-5 ran this as four phases -- a 12-lane-per-chain forward
 // kinematics with an LDS hand-over per level, then S, v and c as 108-entry maps with a hand-over between them: 6.7 k cycles of a
 // wave's dependent chain per substep, 540 vector instructions.)
-// POST: frames only (the rigid-body pass after the last substep). All 64 lanes run the same instructions (the DPP steps must not
-// be masked); lanes without a body store nothing.
+// POST (the rigid-body pass after the last substep): frames and velocities only. All 64 lanes run the same instructions (the DPP steps
+// must not be masked); lanes without a body store nothing.
 template <bool POST>
 __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
   const int q = lane >> 2, row = lane & 3;
@@ -234,10 +235,10 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     const int i = (pb >> (5 * d)) & 31;
     const int ii = i != CH_NONE ? i : 0, dj = i != CH_NONE ? (int)((pd >> (5 * d)) & 31) : 0;
-    sq[d] = s.sq[dj]; cq[d] = s.cq[dj]; qd[d] = POST ? 0.f : s.qd[dj];
+    sq[d] = s.sq[dj]; cq[d] = s.cq[dj]; qd[d] = s.qd[dj];
     jx[d] = s.k_jxyz[ii][0]; jy[d] = s.k_jxyz[ii][1]; jz[d] = s.k_jxyz[ii][2];
   }
-  if (!POST) {
+  {
     // the root's velocity in F: component row of R^T omega, R^T v
     const float r0 = s.R[r3], r1 = s.R[3 + r3], r2 = s.R[6 + r3];
     w = r0 * s.root[10] + r1 * s.root[11] + r2 * s.root[12];
@@ -245,7 +246,8 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
   }
   if (q == 0 && row < 3) {
     s.E[0][3 * row] = e0; s.E[0][3 * row + 1] = e1; s.E[0][3 * row + 2] = e2; s.pos[0][row] = 0.f;
-    if (!POST) { s.v[0][row] = w; s.v[0][3 + row] = vl; s.S[0][row] = 0.f; s.S[0][3 + row] = 0.f; s.c[0][row] = 0.f; s.c[0][3 + row] = 0.f; }
+    s.v[0][row] = w; s.v[0][3 + row] = vl;
+    if (!POST) { s.S[0][row] = 0.f; s.S[0][3 + row] = 0.f; s.c[0][row] = 0.f; s.c[0][3 + row] = 0.f; }
   }
 #pragma unroll
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
@@ -259,17 +261,12 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
     const float axw = ax0 ? e0 : (ax1 ? e1 : e2);                 // the joint axis in F, component row
     const float n1 = cq[d] * ea1 + sq[d] * ea2, n2 = cq[d] * ea2 - sq[d] * ea1;
     e0 = ax0 ? e0 : (ax1 ? n2 : n1); e1 = ax0 ? n1 : (ax1 ? e1 : n2); e2 = ax0 ? n2 : (ax1 ? n1 : e2);
-    float lin = 0.f;
-    if (!POST) {
-      lin = quad_rot1(pos) * quad_rot2(axw) - quad_rot2(pos) * quad_rot1(axw);   // (origin x axis)[row]
-      w += axw * qd[d]; vl += lin * qd[d];
-    }
+    const float lin = quad_rot1(pos) * quad_rot2(axw) - quad_rot2(pos) * quad_rot1(axw);   // (origin x axis)[row]
+    w += axw * qd[d]; vl += lin * qd[d];
     if (act) {
       s.E[i][3 * row] = e0; s.E[i][3 * row + 1] = e1; s.E[i][3 * row + 2] = e2; s.pos[i][row] = pos;
-      if (!POST) {
-        s.S[i][row] = axw; s.S[i][3 + row] = lin;
-        s.v[i][row] = w; s.v[i][3 + row] = vl;
-      }
+      s.v[i][row] = w; s.v[i][3 + row] = vl;
+      if (!POST) { s.S[i][row] = axw; s.S[i][3 + row] = lin; }
     }
   }
 }
@@ -597,6 +594,8 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
         float U3[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) U3[j] = s.U[i][mc + j];
+        // (the six S.pA terms: summed by every lane. Tried in round 6: one LDS float add per lane pair into u[i] and one read -- fewer
+        // vector instructions, but six lanes adding to ONE address serialise in the LDS: 122 -> 135 us per launch)
         const float* t = TT(s)[i];
         const float tsum = ((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5];
         const float dp = cur.s3[0] * U3[0] + cur.s3[1] * U3[1] + cur.s3[2] * U3[2];
@@ -1355,45 +1354,25 @@ __device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int ch
   const int lane = threadIdx.x;
   if (lane == 0) {
     quat_to_mat(&s.root[3], s.R);
-    for (int j = 0; j < 3; ++j) { s.post.omB[0][j] = s.root[10 + j]; s.post.voB[0][j] = s.root[7 + j]; }
     for (int j = 0; j < 4; ++j) s.post.quatB[0][j] = s.root[3 + j];
   }
   joint_pre_pass<true>(s, C);
   WSYNC();
+  // frames and spatial velocities (frame F: the base's axes, origin at the base) of every body: one walk per chain
   kin_walk<true>(s, lane);
-  WSYNC();
-  // per body, in parallel (lane (chain, d<6) = the chain's body at depth d): world-frame lever from the parent's
-  // origin and the joint's angular-velocity contribution, parked in voB / omB
-  if (k < WBC_MAX_DEPTH) {
-    const int i = ch_body(cr, k);
-    if (i != CH_NONE) {
-      const int p = ch_par(cr, k), ax = ch_ax(cr, k);
-      st3(s.post.voB[i], mat_mul(s.R, ld3(s.pos[i]) - ld3(s.pos[p])));
-      st3(s.post.omB[i], mat_mul(s.R, mk3(s.E[i][ax], s.E[i][3 + ax], s.E[i][6 + ax])) * s.qd[ch_dof(cr, k)]);
-    }
-  }
-  WSYNC();
-  // two lanes per chain walk it with the running state in registers: k=0 velocities, k=1 orientation
-  if (k == 0) {
-    f3 om = ld3(s.post.omB[0]), vo = ld3(s.post.voB[0]);
-#pragma unroll 1
+  // orientations: one lane per chain multiplies the joint quaternions down its chain (half-angle sin / cos: joint_pre_pass<true>),
+  // every operand requested before the walk
+  if (k == 1) {
+    float qp[4] = {s.root[3], s.root[4], s.root[5], s.root[6]};
+    float sh[WBC_MAX_DEPTH], ch[WBC_MAX_DEPTH];
+#pragma unroll
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) { const int dj = ch_dof(cr, d); sh[d] = s.viol[dj]; ch[d] = s.limd[dj]; }
+#pragma unroll
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
       const int i = ch_body(cr, d);
       if (i != CH_NONE) {
-        vo = vo + cross(om, ld3(s.post.voB[i]));
-        om = om + ld3(s.post.omB[i]);
-        st3(s.post.voB[i], vo); st3(s.post.omB[i], om);
-      }
-    }
-  } else if (k == 1) {
-    float qp[4] = {s.post.quatB[0][0], s.post.quatB[0][1], s.post.quatB[0][2], s.post.quatB[0][3]};
-#pragma unroll 1
-    for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-      const int i = ch_body(cr, d);
-      if (i != CH_NONE) {
-        const int ax = ch_ax(cr, d), dj = ch_dof(cr, d);
-        const float sh = s.viol[dj], ch = s.limd[dj];
-        const float qa[4] = {(ax == 0) ? sh : 0.f, (ax == 1) ? sh : 0.f, (ax == 2) ? sh : 0.f, ch};
+        const int ax = ch_ax(cr, d);
+        const float qa[4] = {(ax == 0) ? sh[d] : 0.f, (ax == 1) ? sh[d] : 0.f, (ax == 2) ? sh[d] : 0.f, ch[d]};
         float qn[4];
         quat_mul(qp, qa, qn);
 #pragma unroll
@@ -1402,19 +1381,42 @@ __device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int ch
     }
   }
   WSYNC();
+  // rigid bodies: pose of the body's frame + the importer's offset; velocities from the body's spatial velocity (w; vl) in F: the point
+  // p moves with vl + w x p, the world sees R times that (the base's own velocity is part of every body's: v_0 = R^T of the root's)
   if (lane < WBC_NRB) {
     const int r = lane, b = C->model.rb_body[r];
     const f3 t = mat_mul(s.E[b], ld3(C->model.rb_offset[r]));
-    const f3 pw = mat_mul(s.R, ld3(s.pos[b]) + t);
-    const f3 offw = mat_mul(s.R, t);
-    st3(&s.post.out_rb[r][0], ld3(&s.root[0]) + pw);
+    const f3 pF = ld3(s.pos[b]) + t;
+    const f3 w = ld3(&s.v[b][0]), vl = ld3(&s.v[b][3]);
+    st3(&s.post.out_rb[r][0], ld3(&s.root[0]) + mat_mul(s.R, pF));
     for (int j = 0; j < 4; ++j) s.post.out_rb[r][3 + j] = s.post.quatB[b][j];
-    st3(&s.post.out_rb[r][7], ld3(s.post.voB[b]) + cross(ld3(s.post.omB[b]), offw));
-    st3(&s.post.out_rb[r][10], ld3(s.post.omB[b]));
+    st3(&s.post.out_rb[r][7], mat_mul(s.R, vl + cross(w, pF)));
+    st3(&s.post.out_rb[r][10], mat_mul(s.R, w));
   } else if (lane == WBC_NRB) {
     for (int j = 0; j < 13; ++j) s.post.out_rb[WBC_NRB][j] = s.box[j];
   }
   WSYNC();
+}
+
+// euler_from_quat of the base and of the gripper, the six angles on six lanes: roll and yaw are the same expression with the roles
+// of x and z exchanged (atan2(2 (w p + y r), 1 - 2 (p p + y y)), p = x | z, r = z | x), the pitch's arcsine is an atan2 as well -- ONE
+// evaluation of the 30-instruction arctangent instead of six on lane 0 (every instruction of a single-lane phase is a full
+// wavefront issue slot). Same float expressions as euler_from_quat (wbc_device.h).
+__device__ __forceinline__ void euler_batch(Smem& s, const float* q_root, const float* q_ee) {
+  const int lane = threadIdx.x;
+  if (lane < 6) {
+    const int c = lane < 3 ? lane : lane - 3;
+    const float* q = lane < 3 ? q_root : q_ee;
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float p = c == 2 ? z : x, r = c == 2 ? x : z;
+    float Y = 2 * (w * p + y * r), X = 1 - 2 * (p * p + y * y);
+    if (c == 1) {
+      float sp = 2 * (w * y - z * x);
+      sp = fminf(fmaxf(sp, -1.f), 1.f);
+      Y = sp; X = __builtin_amdgcn_sqrtf(fmaxf((1.f - sp) * (1.f + sp), 0.f));
+    }
+    s.eul[lane] = fast_atan2f(Y, X);
+  }
 }
 
 enum { G_START = 0, G_GOAL = 3, G_GOAL_CART = 6, G_CURR = 9, G_CURR_CART = 12, G_DORN = 15, G_ORN = 18,
@@ -1547,7 +1549,7 @@ template <class TT> __device__ void compute_reward(Smem& s, const TT& T, CP C, c
   const f3 tw = quat_rotate_inverse(yq_inv, ld3(&s.goal[G_CURR_CART]));
   const float ec = fabsf(ee_pos[0] - (s.root[0] + tw.x)) + fabsf(ee_pos[1] - (s.root[1] + tw.y)) + fabsf(ee_pos[2] - (cf.z_invariant_offset + tw.z));
   term[WBC_REW_TRACKING_EE_CART] = fast_expf(-ec * inv_ee_sig);
-  const f3 eul = euler_from_quat(ee_orn);
+  const f3 eul = ld3(&s.eul[3]);                    // euler_from_quat(ee_orn), computed by euler_batch
   const float eu[3] = {eul.x, eul.y, eul.z};
   float eo = 0.f, eo_ry = 0.f;
 #pragma unroll
@@ -1839,25 +1841,35 @@ template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C
                                   const float (&hist_in)[12]) {
   const int lane = threadIdx.x;
   const wbc_task_cfg& cf = C->cfg;
-  // proprio vector o76, one or two entries per lane
-  for (int e = lane; e < WBC_NPROP; e += LANES) {
+  // proprio vector o76: entry `lane` on every lane, entries 64..75 on the first twelve. (Two explicit parts instead of a two-trip loop
+  // over one if-chain: every divergent branch of the chain is paid once per trip, and the second trip only has the contact flags, the
+  // commands and the goal rows left. The policy order of the DoF entries is arithmetic, not a table load.)
+  {
+    const int e = lane;                               // 0..63
     float val;
     if (e < 2) val = s.rp[e];
     else if (e < 5) val = s.bav[e - 2] * cf.obs_scale_ang_vel;
-    else if (e < 25) {
-      const int sj = POLICY_PERM[e - 5];
-      float qw = s.q[sj];
-      if (sj == WBC_NDOF - 8) qw = wrap_to_pi(qw);
-      val = (qw - cf.default_dof_pos[sj]) * cf.obs_scale_dof_pos;
-    } else if (e < 45) val = s.qd[POLICY_PERM[e - 25]] * cf.obs_scale_dof_vel;
-    else if (e < 63) val = was_reset ? 0.f : s.act_last[POLICY_PERM[e - 45]];
-    else if (e < 67) {
-      const int f = e - 63;
-      const float* fs = s.out_sensor[f ^ 1];     // [1,0,3,2]
-      val = sqrtf(dot6(fs, fs)) > 1.5f ? 1.f : 0.f;
+    else if (e < 45) {
+      const bool isq = e < 25;
+      const int pj = isq ? e - 5 : e - 25, sj = pj < WBC_NACT ? policy_perm18(pj) : pj;
+      float x = isq ? s.q[sj] : s.qd[sj];
+      if (isq && sj == WBC_NDOF - 8) x = wrap_to_pi(x);
+      val = isq ? (x - cf.default_dof_pos[sj]) * cf.obs_scale_dof_pos : x * cf.obs_scale_dof_vel;
+    } else if (e < 63) val = was_reset ? 0.f : s.act_last[policy_perm18(e - 45)];
+    else {
+      const float* fs = s.out_sensor[1];              // entry 63: foot 0 reads sensor 1 ([1,0,3,2])
+      val = dot6(fs, fs) > 2.25f ? 1.f : 0.f;         // |wrench| > 1.5
+    }
+    s.post.o76[e] = val;
+  }
+  if (lane < WBC_NPROP - LANES) {
+    const int e = LANES + lane;                       // 64..75
+    float val;
+    if (e < 67) {
+      const float* fs = s.out_sensor[(e - 63) ^ 1];
+      val = dot6(fs, fs) > 2.25f ? 1.f : 0.f;
     } else if (e < 70) val = s.cmd[e - 67] * cf.commands_scale[e - 67];
-    else if (e < 73) val = s.goal[G_CURR + e - 70];
-    else val = s.goal[G_DORN + e - 73];
+    else val = s.goal[(e < 73 ? G_CURR - 70 : G_DORN - 73) + e];
     s.post.o76[e] = val;
   }
   WSYNC();
@@ -1984,6 +1996,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   float rsc_leg = 0.f, rsc_arm = 0.f;             // this lane's reward scales (consumed after the lane-0 task logic)
   if (lane < WBC_NREW) { rsc_leg = Cq->cur.leg_reward_scale[lane]; rsc_arm = Cq->cur.arm_reward_scale[lane]; }
   rigid_body_pass(s, Cq, cr, chain, k);
+  euler_batch(s, &s.root[3], &s.post.out_rb[Cq->model.gripper_rb][3]);      // (read by lane 0 below, after the wavefront fence before its block)
   STAMP(14);
   // check_termination's contact list (WG:940) and _reward_collision (LR:865-867): |net contact force| of every rigid body on its
   // own lane, the two conditions as wavefront ballots
@@ -2009,11 +2022,12 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     }
   }
   float base_yaw = 0.f;
+  WSYNC();
   if (lane == 0) {
     s.ep_len += 1;
     st3(s.blv, quat_rotate_inverse(&s.root[3], ld3(&s.root[7])));
     st3(s.bav, quat_rotate_inverse(&s.root[3], ld3(&s.root[10])));
-    const f3 rpy = euler_from_quat(&s.root[3]);
+    const f3 rpy = ld3(&s.eul[0]);                  // euler_from_quat(root), computed by euler_batch
     base_yaw = rpy.z;
     s.base_yaw = base_yaw;
     s.rp[0] = rpy.x; s.rp[1] = rpy.y;
