@@ -110,6 +110,13 @@ static int build_chains(DevConst& hc) {
     hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
   }
   if (nchain != WBC_NCHAIN) return -1;
+  {   // euler_from_quat (roll, pitch) of the reset pose
+    const float x = hc.cfg.base_init_state[3], y = hc.cfg.base_init_state[4], z = hc.cfg.base_init_state[5], w = hc.cfg.base_init_state[6];
+    float sp = 2 * (w * y - z * x);
+    sp = sp < -1.f ? -1.f : (sp > 1.f ? 1.f : sp);
+    hc.init_rp[0] = atan2f(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+    hc.init_rp[1] = asinf(sp);
+  }
   for (int c = 0; c <= WBC_NCHAIN; ++c) for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     const int b = c < WBC_NCHAIN ? hc.chain_body[c][d] : -1;
     const int dj = b >= 0 ? m.dof[b] : -1;

@@ -233,10 +233,10 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
   float sq[WBC_MAX_DEPTH], cq[WBC_MAX_DEPTH], qd[WBC_MAX_DEPTH], jx[WBC_MAX_DEPTH], jy[WBC_MAX_DEPTH], jz[WBC_MAX_DEPTH];
 #pragma unroll
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
-    const int i = (pb >> (5 * d)) & 31;
-    const int ii = i != CH_NONE ? i : 0, dj = i != CH_NONE ? (int)((pd >> (5 * d)) & 31) : 0;
+    // (a level without a body: index 31 / dof 0 -- reads that stay inside this workgroup's LDS and feed lanes that store nothing)
+    const int i = (pb >> (5 * d)) & 31, dj = (pd >> (5 * d)) & 31;
     sq[d] = s.sq[dj]; cq[d] = s.cq[dj]; qd[d] = s.qd[dj];
-    jx[d] = s.k_jxyz[ii][0]; jy[d] = s.k_jxyz[ii][1]; jz[d] = s.k_jxyz[ii][2];
+    jx[d] = s.k_jxyz[i][0]; jy[d] = s.k_jxyz[i][1]; jz[d] = s.k_jxyz[i][2];
   }
   {
     // the root's velocity in F: component row of R^T omega, R^T v
@@ -1821,7 +1821,7 @@ template <class TT> __device__ __forceinline__ void reset_env(Smem& s, const TT&
     s.box[1] = s.root[1] + G(T.box_dy)[env];
     s.box[2] = C->cfg.box_origin_z;
     for (int j = 0; j < 6; ++j) s.root[7 + j] = urange(-C->cfg.init_vel_perturb_range, C->cfg.init_vel_perturb_range, dr[SLOT_RESET_VEL - SLOT_RESET_XY + j]);
-    { const f3 e = euler_from_quat(&s.root[3]); s.rp[0] = e.x; s.rp[1] = e.y; }      // the observation of a reset env shows the new pose
+    s.rp[0] = C->init_rp[0]; s.rp[1] = C->init_rp[1];      // the observation of a reset env shows the new pose: roll / pitch of base_init_state (a constant: formed once on the host)
     if (start || s.time_out) resample_commands(s, C, dr[SLOT_RESET_CMD - SLOT_RESET_XY], dr[SLOT_RESET_CMD - SLOT_RESET_XY + 1]);
     goal_apply(s, C, SLOT_RESET_GOAL_ORN - SLOT_RESET_XY, base_yaw);
     s.ep_len = 0;
@@ -2171,6 +2171,7 @@ static_assert(offsetof(Smem, vb) == offsetof(Smem, wb) + 12 && offsetof(Smem, gF
 static_assert(sizeof(float) * (36 + WBC_NCP * 3) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
 static_assert(sizeof(float) * (WBC_NRB_ENV * 3 + WBC_NFEET * 6) <= sizeof(float) * WBC_NB * 6, "contact outputs alias U");
 static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");
+static_assert(offsetof(Smem, k_jxyz) + 32 * 12 <= sizeof(Smem), "a 'none' body index (31) must stay inside the workgroup's LDS where the passes read through it");
 
 extern "C" void wbc_debug_set_wave_timing(void* dev_buf) {
   long long* p = (long long*)dev_buf;

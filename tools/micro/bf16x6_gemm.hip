@@ -6,7 +6,10 @@
 //       ~2^-24 relative accuracy per product; (b3) the three products with i + j <= 3 for comparison (~2^-16).
 // Both variants share one tiling (a workgroup of 8 waves takes 128 rows x 128 columns x a 128-deep K chunk, the shared operand staged
 // through LDS, the per-wave operand straight from memory), so the difference is the matrix pipe and the splitting work, not the data
-// path. Reports time per GEMM and max / rms error against an fp64 reference. Not product code: a measurement.
+// path. Reports time per GEMM and max / rms error against an fp64 reference. One such GEMM over 40 960 x 128 activations is bound by
+// reading and writing them (42 MB), which the product's update kernels do not do per layer (a unit's activations stay on chip across
+// its layers): the matrix-side cost per layer is therefore measured as well, as the SLOPE of the time over `reps` repetitions of the
+// K loop on resident operands (for bf16 x 6 each repetition splits its activations again, as every layer would). Not product code.
 //   hipcc --offload-arch=gfx950 -O3 -o bf16x6_gemm bf16x6_gemm.hip && ./bf16x6_gemm
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -43,7 +46,7 @@ __device__ __forceinline__ void split3(float x, unsigned short& p1, unsigned sho
 
 // C[M x N] (+)= A[M x K] Bt[N x K]^T over the K chunk of this workgroup. grid = (M / MB, K / KC); partial results go to
 // Cpart[kchunk][M][N] (the caller reduces them when there is more than one chunk). A, Bt row-major fp32.
-__global__ void __launch_bounds__(512) gemm_f32(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ Cpart, int M, int K) {
+__global__ void __launch_bounds__(512) gemm_f32(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ Cpart, int M, int K, int reps) {
   __shared__ float sB[N * LDB32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.x * MB + wave * 16, k0 = blockIdx.y * KC;
@@ -57,12 +60,18 @@ __global__ void __launch_bounds__(512) gemm_f32(const float* __restrict__ A, con
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int li = lane & 15, lk = lane >> 4;
-  const float* Arow = A + (size_t)(m0 + li) * K + k0;
-#pragma unroll 4
-  for (int s = 0; s < KC / 4; ++s) {
-    const float a = Arow[4 * s + lk];
+  // (the sum over k does not care about its order: step s gives lane group lk the index k = 32 lk + s, on both operands, so that a
+  // lane's 32 values of A are contiguous)
+  const float* Arow = A + (size_t)(m0 + li) * K + k0 + 32 * lk;
+  float a[32];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sB[(16 * c + li) * LDB32 + 4 * s + lk], acc[c], 0, 0, 0);
+  for (int q = 0; q < 8; ++q) { const float4 v = *(const float4*)&Arow[4 * q]; a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], sB[(16 * c + li) * LDB32 + 32 * lk + s], acc[c], 0, 0, 0);
+    }
   }
   float* C = Cpart + (size_t)blockIdx.y * M * N;
 #pragma unroll
@@ -75,7 +84,7 @@ __global__ void __launch_bounds__(512) gemm_f32(const float* __restrict__ A, con
 // PRESPLIT: Bt arrives as three bf16 matrices Bp[3][N][K] (weights: split once per minibatch); otherwise it is split while it is staged.
 template <int NPROD, bool PRESPLIT>
 __global__ void __launch_bounds__(512) gemm_bf16x(const float* __restrict__ A, const float* __restrict__ Bt, const unsigned short* __restrict__ Bp,
-                                                  float* __restrict__ Cpart, int M, int K) {
+                                                  float* __restrict__ Cpart, int M, int K, int reps) {
   __shared__ unsigned short sB[3][N * LDB16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m0 = blockIdx.x * MB + wave * 16, k0 = blockIdx.y * KC;
@@ -103,33 +112,42 @@ __global__ void __launch_bounds__(512) gemm_bf16x(const float* __restrict__ A, c
   for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int li = lane & 15, lk = lane >> 4;
   const float* Arow = A + (size_t)(m0 + li) * K + k0;
-#pragma unroll 1
+  float x[KC / 32][8];                           // this lane's 8 consecutive k of its row in each of the four 32-deep steps
+#pragma unroll
   for (int s = 0; s < KC / 32; ++s) {
-    // this lane's 8 consecutive k of its row, split into the three pieces
     const float4 v0 = *(const float4*)&Arow[32 * s + 8 * lk], v1 = *(const float4*)&Arow[32 * s + 8 * lk + 4];
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    bf16x8 a1, a2, a3;
+    x[s][0] = v0.x; x[s][1] = v0.y; x[s][2] = v0.z; x[s][3] = v0.w; x[s][4] = v1.x; x[s][5] = v1.y; x[s][6] = v1.z; x[s][7] = v1.w;
+  }
+  for (int rep = 0; rep < reps; ++rep) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      unsigned short p1, p2, p3;
-      split3(x[j], p1, p2, p3);
-      a1[j] = (short)p1; a2[j] = (short)p2; a3[j] = (short)p3;
-    }
+    for (int s = 0; s < KC / 32; ++s) {
+      bf16x8 a1, a2, a3;                          // split again in every repetition: a layer's input is new every time
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int off = (16 * c + li) * LDB16 + 32 * s + 8 * lk;
-      const bf16x8 b1 = *(const bf16x8*)&sB[0][off], b2 = *(const bf16x8*)&sB[1][off];
-      // smallest products first
-      if (NPROD == 6) {
-        const bf16x8 b3 = *(const bf16x8*)&sB[2][off];
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[c], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+        unsigned short p1, p2, p3;
+        split3(x[s][j], p1, p2, p3);
+        a1[j] = (short)p1; a2[j] = (short)p2; a3[j] = (short)p3;
       }
-      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[c], 0, 0, 0);
-      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc[c], 0, 0, 0);
-      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int off = (16 * c + li) * LDB16 + 32 * s + 8 * lk;
+        const bf16x8 b1 = *(const bf16x8*)&sB[0][off], b2 = *(const bf16x8*)&sB[1][off];
+        // smallest products first
+        if (NPROD == 6) {
+          const bf16x8 b3 = *(const bf16x8*)&sB[2][off];
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[c], 0, 0, 0);
+        }
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[c], 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int s = 0; s < KC / 32; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(x[s][j]));      // (opaque: the split stays inside the repetition loop)
   }
   float* C = Cpart + (size_t)blockIdx.y * M * N;
 #pragma unroll
@@ -206,8 +224,8 @@ int main() {
     return ms * 1e3 / 50;
   };
   const double flops = 2.0 * R * D * D;
-  printf("one 128 x 128 layer, %d rows; errors against fp64 (output rms: Y %.3g, dX %.3g, dW %.3g)\n", R, 0.0, 0.0, 0.0);
-  printf("%-34s %10s %10s %12s %12s\n", "GEMM / variant", "us", "TFLOP/s", "max |err|", "rms err / rms");
+  printf("one 128 x 128 layer, %d rows; errors against fp64; 'us per pass' = slope of the time over repetitions of the K loop on resident operands\n", R);
+  printf("%-34s %10s %10s %12s %12s %12s %10s\n", "GEMM / variant", "us", "TFLOP/s", "max |err|", "rms err / rms", "us per pass", "TFLOP/s");
   struct Case { const char* name; const float* A; const float* Bt; const unsigned short* Bp; int M, K; const std::vector<double>* ref; };
   const Case cases[3] = {{"forward  Y = X W^T", dX_, dW_, dWp, R, D, &Yref}, {"dgrad   dX = dY W", ddY, dWt, dWtp, R, D, &dXref},
                          {"wgrad   dW = dY^T X", ddYt, dXt, nullptr, D, R, &dWref}};
@@ -219,18 +237,21 @@ int main() {
     auto fetch = [&](std::vector<float>& o) { HIP_OK(hipMemcpy(o.data(), dC, o.size() * 4, hipMemcpyDeviceToHost)); };
     std::vector<float>& o = splitk ? outw : out;
     for (int variant = 0; variant < 3; ++variant) {
-      double us;
-      if (variant == 0) us = timeit([&]() { gemm_f32<<<grid, 512>>>(c.A, c.Bt, target, c.M, c.K); finish(); });
-      else if (c.Bp) us = variant == 1 ? timeit([&]() { gemm_bf16x<6, true><<<grid, 512>>>(c.A, c.Bt, c.Bp, target, c.M, c.K); finish(); })
-                                       : timeit([&]() { gemm_bf16x<3, true><<<grid, 512>>>(c.A, c.Bt, c.Bp, target, c.M, c.K); finish(); });
-      else us = variant == 1 ? timeit([&]() { gemm_bf16x<6, false><<<grid, 512>>>(c.A, c.Bt, nullptr, target, c.M, c.K); finish(); })
-                             : timeit([&]() { gemm_bf16x<3, false><<<grid, 512>>>(c.A, c.Bt, nullptr, target, c.M, c.K); finish(); });
+      auto run = [&](int reps) {
+        if (variant == 0) gemm_f32<<<grid, 512>>>(c.A, c.Bt, target, c.M, c.K, reps);
+        else if (c.Bp) { if (variant == 1) gemm_bf16x<6, true><<<grid, 512>>>(c.A, c.Bt, c.Bp, target, c.M, c.K, reps); else gemm_bf16x<3, true><<<grid, 512>>>(c.A, c.Bt, c.Bp, target, c.M, c.K, reps); }
+        else { if (variant == 1) gemm_bf16x<6, false><<<grid, 512>>>(c.A, c.Bt, nullptr, target, c.M, c.K, reps); else gemm_bf16x<3, false><<<grid, 512>>>(c.A, c.Bt, nullptr, target, c.M, c.K, reps); }
+        finish();
+      };
+      const double us = timeit([&]() { run(1); });
       HIP_OK(hipDeviceSynchronize());
       fetch(o);
       const Err e = compare(o, *c.ref);
+      const double us17 = timeit([&]() { run(17); });
+      const double slope = (us17 - us) / 16.0;               // matrix-side time of one more pass over resident operands
       char nm[96];
       snprintf(nm, sizeof nm, "%s  %s", c.name, variant == 0 ? "fp32 MFMA" : (variant == 1 ? "bf16 x 6" : "bf16 x 3"));
-      printf("%-34s %10.1f %10.1f %12.3e %12.3e\n", nm, us, flops / us / 1e6, e.max_abs, e.rms / e.ref_rms);
+      printf("%-34s %10.1f %10.1f %12.3e %12.3e %12.1f %10.1f\n", nm, us, flops / us / 1e6, e.max_abs, e.rms / e.ref_rms, slope, flops / slope / 1e6);
     }
   }
   return 0;
