@@ -31,6 +31,7 @@ struct DevConst {
   // | 1 << 18: the deep half of its chain | 1 << 19: its chain has a deep half (in the next group) | 1 << 20: the group that adds the
   // root's own contact wrench to the sum over the groups and stores the root's response
   uint32_t sweep_pack[8];
+  int32_t lvl_ax[WBC_MAX_DEPTH];                    // the joint axis every chain with a body at depth d+1 shares (0 / 1 / 2), 3 where they differ
   float init_rp[2];                                // roll, pitch of cfg.base_init_state's quaternion (what a freshly reset env observes)
   float chain_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];  // cfg.joint_armature of the joint at (chain, depth-1); 0 where there is none (row WBC_NCHAIN: idle)
   uint64_t out_cp_mask[32];                        // [rb]: contacts whose force net_contact_force row rb receives ...

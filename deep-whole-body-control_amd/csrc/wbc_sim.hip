@@ -110,6 +110,14 @@ static int build_chains(DevConst& hc) {
     hc.chain_len[hc.body_chain[i]] = hc.body_depth[i];
   }
   if (nchain != WBC_NCHAIN) return -1;
+  for (int d = 0; d < WBC_MAX_DEPTH; ++d) {          // the kinematics walk's per-level axis
+    int ax = -1;
+    for (int c = 0; c < WBC_NCHAIN; ++c) if (hc.chain_body[c][d] >= 0) {
+      const int a = m.axis[hc.chain_body[c][d]];
+      ax = ax < 0 ? a : (ax == a ? ax : 3);
+    }
+    hc.lvl_ax[d] = ax < 0 ? 0 : ax;
+  }
   {   // euler_from_quat (roll, pitch) of the reset pose
     const float x = hc.cfg.base_init_state[3], y = hc.cfg.base_init_state[4], z = hc.cfg.base_init_state[5], w = hc.cfg.base_init_state[6];
     float sp = 2 * (w * y - z * x);

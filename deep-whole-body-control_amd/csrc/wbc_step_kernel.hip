@@ -66,6 +66,8 @@ __device__ __forceinline__ float pair_swap(float x) {
 
 // LDS float add without a return value (ds_add_f32). One wavefront per workgroup: lanes that hit one address are served in lane order.
 __device__ __forceinline__ void lds_add(float* p, float v) {
+  // (measured in round 6 with plain stores in their place -- wrong physics, timing only: the contacts' adds cost nothing measurable,
+  // 83.0 vs 83.6 us at 1024 envs, 117.7 vs 117.8 at 4096; six lanes adding to one address in EVERY level of pass 2 did: section 2.1)
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
@@ -165,10 +167,12 @@ struct __align__(16) Smem {
   float rp[2];                   // base roll / pitch of the state the observation is built from (post-physics, or post-reset)
   float eul[6];                  // Euler angles of the base [0..2] and of the gripper [3..5] after the physics (euler_batch: six lanes, one atan2)
   int reset_flag, time_out, ep_len;
-  float sq[WBC_NDOF], cq[WBC_NDOF];      // sin/cos of the joint angles of this substep
-  float viol[WBC_NDOF], limd[WBC_NDOF];  // joint-limit violation and (if moving further out) the joint velocity
+  // per DoF, written by joint_pre_pass as one 16-byte row: {sin q, cos q, joint-limit violation, the joint velocity if it moves further
+  // out} (post-physics: {sin q, cos q, sin q/2, cos q/2}) -- the walk and pass 2 read a pair with ONE 8-byte LDS read (a lone wave pays
+  // ~10 cycles per LDS instruction, whatever its width)
+  alignas(16) float jt[WBC_NDOF][4];
   // model constants the dependent chains index per lane (LDS instead of a global load on the critical path)
-  float k_jxyz[WBC_NB][3];
+  alignas(16) float k_jxyz[WBC_NB][4];   // joint origin in the parent frame (x, y, z, -): one 16-byte read
   uint32_t k_body[WBC_NB];               // DevConst::body_pack
   float k_qdlim[WBC_NDOF];
   float ct_arm[WBC_NCHAIN + 1][WBC_MAX_DEPTH];   // joint armature at (chain, depth); row WBC_NCHAIN is the idle row
@@ -223,20 +227,31 @@ __device__ __forceinline__ float quad_rot2(float x) { return __int_as_float(__bu
 // wave's dependent chain per substep, 540 vector instructions.)
 // POST (the rigid-body pass after the last substep): frames and velocities only. All 64 lanes run the same instructions (the DPP steps
 // must not be masked); lanes without a body store nothing.
+// one level's rotation with the joint axis known at compile time: no selects
+template <int A>
+__device__ __forceinline__ float rot_axis(float (&e)[3], float cq, float sq) {
+  constexpr int a1 = (A + 1) % 3, a2 = (A + 2) % 3;
+  const float n1 = cq * e[a1] + sq * e[a2], n2 = cq * e[a2] - sq * e[a1];
+  e[a1] = n1; e[a2] = n2;
+  return e[A];
+}
+
 template <bool POST>
-__device__ __forceinline__ void kin_walk(Smem& s, int lane) {
+__device__ __forceinline__ void kin_walk(Smem& s, CP C, int lane) {
   const int q = lane >> 2, row = lane & 3;
   const bool on = q < WBC_NCHAIN && row < 3;
   const uint32_t pb = s.k_qpack[0][q & 7], pd = s.k_qpack[1][q & 7], pa = s.k_qpack[2][q & 7];   // (rows >= WBC_NCHAIN: no bodies)
   const int r3 = row < 3 ? row : 0;
-  float e0 = row == 0 ? 1.f : 0.f, e1 = row == 1 ? 1.f : 0.f, e2 = row == 2 ? 1.f : 0.f, pos = 0.f, w = 0.f, vl = 0.f;
+  float e[3] = {row == 0 ? 1.f : 0.f, row == 1 ? 1.f : 0.f, row == 2 ? 1.f : 0.f}, pos = 0.f, w = 0.f, vl = 0.f;
   float sq[WBC_MAX_DEPTH], cq[WBC_MAX_DEPTH], qd[WBC_MAX_DEPTH], jx[WBC_MAX_DEPTH], jy[WBC_MAX_DEPTH], jz[WBC_MAX_DEPTH];
 #pragma unroll
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     // (a level without a body: index 31 / dof 0 -- reads that stay inside this workgroup's LDS and feed lanes that store nothing)
     const int i = (pb >> (5 * d)) & 31, dj = (pd >> (5 * d)) & 31;
-    sq[d] = s.sq[dj]; cq[d] = s.cq[dj]; qd[d] = s.qd[dj];
-    jx[d] = s.k_jxyz[i][0]; jy[d] = s.k_jxyz[i][1]; jz[d] = s.k_jxyz[i][2];
+    const float2 sc = *reinterpret_cast<const float2*>(&s.jt[dj][0]);
+    const float4 jo = *reinterpret_cast<const float4*>(&s.k_jxyz[i][0]);
+    sq[d] = sc.x; cq[d] = sc.y; qd[d] = s.qd[dj];
+    jx[d] = jo.x; jy[d] = jo.y; jz[d] = jo.z;
   }
   {
     // the root's velocity in F: component row of R^T omega, R^T v
@@ -244,8 +259,9 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
     w = r0 * s.root[10] + r1 * s.root[11] + r2 * s.root[12];
     vl = r0 * s.root[7] + r1 * s.root[8] + r2 * s.root[9];
   }
+  if (!POST) XSTAMP(27);
   if (q == 0 && row < 3) {
-    s.E[0][3 * row] = e0; s.E[0][3 * row + 1] = e1; s.E[0][3 * row + 2] = e2; s.pos[0][row] = 0.f;
+    s.E[0][3 * row] = e[0]; s.E[0][3 * row + 1] = e[1]; s.E[0][3 * row + 2] = e[2]; s.pos[0][row] = 0.f;
     s.v[0][row] = w; s.v[0][3 + row] = vl;
     if (!POST) { s.S[0][row] = 0.f; s.S[0][3 + row] = 0.f; s.c[0][row] = 0.f; s.c[0][3 + row] = 0.f; }
   }
@@ -253,18 +269,29 @@ __device__ __forceinline__ void kin_walk(Smem& s, int lane) {
   for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
     const int i = (pb >> (5 * d)) & 31, ax = (pa >> (2 * d)) & 3;
     const bool act = on && i != CH_NONE;
+    if (!POST && d == 3) XSTAMP(28);
     // origin: the parent's row times the joint offset
-    pos = pos + e0 * jx[d] + e1 * jy[d] + e2 * jz[d];
-    // E_i = E_p Rot(ax, q): column ax stays, columns a1 = ax + 1, a2 = ax + 2 (mod 3) mix: new a1 = c a1 + s a2, new a2 = c a2 - s a1
-    const bool ax0 = ax == 0, ax1 = ax == 1;
-    const float ea1 = ax0 ? e1 : (ax1 ? e2 : e0), ea2 = ax0 ? e2 : (ax1 ? e0 : e1);
-    const float axw = ax0 ? e0 : (ax1 ? e1 : e2);                 // the joint axis in F, component row
-    const float n1 = cq[d] * ea1 + sq[d] * ea2, n2 = cq[d] * ea2 - sq[d] * ea1;
-    e0 = ax0 ? e0 : (ax1 ? n2 : n1); e1 = ax0 ? n1 : (ax1 ? e1 : n2); e2 = ax0 ? n2 : (ax1 ? n1 : e2);
+    pos = pos + e[0] * jx[d] + e[1] * jy[d] + e[2] * jz[d];
+    // E_i = E_p Rot(ax, q): column ax stays, columns a1 = ax + 1, a2 = ax + 2 (mod 3) mix: new a1 = c a1 + s a2, new a2 = c a2 - s a1.
+    // Where every chain that has a body at this level turns about the SAME axis (DevConst::lvl_ax: five of widowGo1's six levels) a
+    // scalar branch picks the code for that axis -- register renaming instead of twelve selects on the runtime axis.
+    float axw;                                                    // the joint axis in F, component row
+    const int la = C->lvl_ax[d];
+    if (la == 0) axw = rot_axis<0>(e, cq[d], sq[d]);
+    else if (la == 1) axw = rot_axis<1>(e, cq[d], sq[d]);
+    else if (la == 2) axw = rot_axis<2>(e, cq[d], sq[d]);
+    else {
+      const bool ax0 = ax == 0, ax1 = ax == 1;
+      const float ea1 = ax0 ? e[1] : (ax1 ? e[2] : e[0]), ea2 = ax0 ? e[2] : (ax1 ? e[0] : e[1]);
+      axw = ax0 ? e[0] : (ax1 ? e[1] : e[2]);
+      const float n1 = cq[d] * ea1 + sq[d] * ea2, n2 = cq[d] * ea2 - sq[d] * ea1;
+      const float f0 = ax0 ? e[0] : (ax1 ? n2 : n1), f1 = ax0 ? n1 : (ax1 ? e[1] : n2), f2 = ax0 ? n2 : (ax1 ? n1 : e[2]);
+      e[0] = f0; e[1] = f1; e[2] = f2;
+    }
     const float lin = quad_rot1(pos) * quad_rot2(axw) - quad_rot2(pos) * quad_rot1(axw);   // (origin x axis)[row]
     w += axw * qd[d]; vl += lin * qd[d];
     if (act) {
-      s.E[i][3 * row] = e0; s.E[i][3 * row + 1] = e1; s.E[i][3 * row + 2] = e2; s.pos[i][row] = pos;
+      s.E[i][3 * row] = e[0]; s.E[i][3 * row + 1] = e[1]; s.E[i][3 * row + 2] = e[2]; s.pos[i][row] = pos;
       s.v[i][row] = w; s.v[i][3 + row] = vl;
       if (!POST) { s.S[i][row] = axw; s.S[i][3 + row] = lin; }
     }
@@ -341,18 +368,18 @@ __device__ __forceinline__ void joint_pre_pass(Smem& s, CP C) {
     const float qq = s.q[j], qdv = s.qd[j];
     float sq, cq;
     fast_sincosf(qq, &sq, &cq);
-    s.sq[j] = sq; s.cq[j] = cq;
+    float2 lim;
     if (HALF) {
       float sh, ch;
       fast_sincosf(0.5f * qq, &sh, &ch);
-      s.viol[j] = sh; s.limd[j] = ch;
+      *reinterpret_cast<float4*>(&s.jt[j][0]) = make_float4(sq, cq, sh, ch);
       return;
     }
     const float lo = C->model.q_lower[j], hi = C->model.q_upper[j];
     float viol = 0.f;
     if (lo < hi) { if (qq > hi) viol = qq - hi; else if (qq < lo) viol = qq - lo; }
-    s.viol[j] = viol;
-    s.limd[j] = (qdv * viol > 0.f) ? qdv : 0.f;
+    lim = make_float2(viol, (qdv * viol > 0.f) ? qdv : 0.f);
+    *reinterpret_cast<float4*>(&s.jt[j][0]) = make_float4(sq, cq, lim.x, lim.y);
   }
 }
 
@@ -480,7 +507,9 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
     *dst = acc;
   }
   // frames, joint screws, velocities and velocity-product terms: one walk per chain, in registers
-  kin_walk<false>(s, lane);
+  XSTAMP(25);
+  kin_walk<false>(s, C, lane);
+  XSTAMP(26);
   WSYNC();
   STAMP(1);
   STAMP(2);
@@ -577,7 +606,8 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       const bool act = i != CH_NONE;
       // what the second half of the level needs, requested at its start
       const float c30 = s.c[i][mc], c31 = s.c[i][mc + 1], c32 = s.c[i][mc + 2];
-      const float jtau = s.tau[dj], jviol = s.viol[dj], jlimd = s.limd[dj], jarm = cr.arm[d];
+      const float2 jl = *reinterpret_cast<const float2*>(&s.jt[dj][2]);
+      const float jtau = s.tau[dj], jviol = jl.x, jlimd = jl.y, jarm = cr.arm[d];
       float IA3[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) IA3[j] = cur.ia[j] + acc3[j];
@@ -1359,14 +1389,14 @@ __device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int ch
   joint_pre_pass<true>(s, C);
   WSYNC();
   // frames and spatial velocities (frame F: the base's axes, origin at the base) of every body: one walk per chain
-  kin_walk<true>(s, lane);
+  kin_walk<true>(s, C, lane);
   // orientations: one lane per chain multiplies the joint quaternions down its chain (half-angle sin / cos: joint_pre_pass<true>),
   // every operand requested before the walk
   if (k == 1) {
     float qp[4] = {s.root[3], s.root[4], s.root[5], s.root[6]};
     float sh[WBC_MAX_DEPTH], ch[WBC_MAX_DEPTH];
 #pragma unroll
-    for (int d = 0; d < WBC_MAX_DEPTH; ++d) { const int dj = ch_dof(cr, d); sh[d] = s.viol[dj]; ch[d] = s.limd[dj]; }
+    for (int d = 0; d < WBC_MAX_DEPTH; ++d) { const float2 h = *reinterpret_cast<const float2*>(&s.jt[ch_dof(cr, d)][2]); sh[d] = h.x; ch[d] = h.y; }
 #pragma unroll
     for (int d = 0; d < WBC_MAX_DEPTH; ++d) {
       const int i = ch_body(cr, d);
@@ -1728,7 +1758,7 @@ __device__ __forceinline__ void prologue(Smem& s, ChainRegs& cr, const TT& T, CP
     for (int r = 0; r < WBC_ADELAY_LEN - 1; ++r) a_h[r] = ah[(r + 1) * WBC_NACT + la];
   }
   // ---- stores
-  if (lane < WBC_NB * 3) (&s.k_jxyz[0][0])[lane] = c_jxyz;
+  if (lane < WBC_NB * 3) s.k_jxyz[lane / 3][lane % 3] = c_jxyz;
   if (lane < WBC_NB) {
     s.k_body[lane] = c_body;
     s.k_gmlo[lane] = make_uint2((uint32_t)c_m1, (uint32_t)c_m2); s.k_gmhi[lane] = make_uint2((uint32_t)(c_m1 >> 32), (uint32_t)(c_m2 >> 32));
@@ -2171,7 +2201,7 @@ static_assert(offsetof(Smem, vb) == offsetof(Smem, wb) + 12 && offsetof(Smem, gF
 static_assert(sizeof(float) * (36 + WBC_NCP * 3) <= sizeof(float) * WBC_NB * 36, "per-contact iteration data must fit in the IA region");
 static_assert(sizeof(float) * (WBC_NRB_ENV * 3 + WBC_NFEET * 6) <= sizeof(float) * WBC_NB * 6, "contact outputs alias U");
 static_assert(sizeof(Smem) <= 10240, "16 robots per CU (160 KB of LDS): all 4096 envs of the bench resident at once");
-static_assert(offsetof(Smem, k_jxyz) + 32 * 12 <= sizeof(Smem), "a 'none' body index (31) must stay inside the workgroup's LDS where the passes read through it");
+static_assert(offsetof(Smem, k_jxyz) + 32 * 16 <= sizeof(Smem), "a 'none' body index (31) must stay inside the workgroup's LDS where the passes read through it");
 
 extern "C" void wbc_debug_set_wave_timing(void* dev_buf) {
   long long* p = (long long*)dev_buf;

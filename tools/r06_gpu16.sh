@@ -1,0 +1,8 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 1500 python -m pytest tests/test_gpu_sim_parity.py tests/test_gpu_contact_physics.py tests/test_wg_golden.py tests/test_gpu_env_runner.py tests/test_standalone_abi.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" | tail -5
+for N in 1024 2048 4096; do
+  echo "== product N=$N"; python tools/time_step.py $N 200 base 2>&1 | grep "step kernel" | cut -c1-200
+done
+echo "== timing N=1024"; WBC_STAMPS=1 python tools/time_step.py 1024 100 base 2>&1 | grep "phase cycles\|contact detail" | cut -c1-700
+echo "== insts"; bash tools/r06_pmc_insts.sh 4096 2>&1 | grep wbc_step

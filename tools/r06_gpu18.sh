@@ -1,0 +1,7 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 1500 python -m pytest tests/test_gpu_sim_parity.py tests/test_gpu_contact_physics.py tests/test_wg_golden.py tests/test_gpu_env_runner.py tests/test_standalone_abi.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" | tail -5
+for N in 1024 2048 4096; do
+  echo "== product N=$N"; python tools/time_step.py $N 200 base 2>&1 | grep "step kernel" | cut -c1-200
+done
+echo "== walk stamps (timing)"; WBC_XSTAMPS=walk WBC_STAMPS=1 python tools/time_step.py 1024 100 base 2>&1 | grep "walk stamps\|phase cycles" | cut -c1-500

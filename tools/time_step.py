@@ -65,7 +65,8 @@ g.simulate(); torch.cuda.synchronize()
 t = buf.cpu().numpy()
 names = ["fk", "S,v,c", "inertia", "pass2", "root inv", "pass3+K", "contact detect", "contact iters", "outputs", "integrate"]
 print("substep phase cycles (block 0):", {names[i]: int(t[i+1]-t[i]) for i in range(10)}, "total", int(t[10]-t[0]))
-if os.environ.get("WBC_XSTAMPS"): print("  second solver sweep (stamps 25..31: start | solve+adds | box row | inward | root | outward | response), cycles between:", [int(t[i + 1] - t[i]) for i in range(25, 31)])
+if os.environ.get("WBC_XSTAMPS") == "walk": print("  walk stamps: 25 before, 27 after prefetch, 28 before level 3, 26 after:", [int(t[i] - t[25]) for i in (27, 28, 26)])
+elif os.environ.get("WBC_XSTAMPS"): print("  second solver sweep (stamps 25..31: start | solve+adds | box row | inward | root | outward | response), cycles between:", [int(t[i + 1] - t[i]) for i in range(25, 31)])
 print("  contact detail: narrow phase", int(t[18]-t[6]), "set-up", int(t[7]-t[18]), "| first iteration: solve", int(t[20]-t[7]), "gather", int(t[21]-t[20]),
       "inward", int(t[22]-t[21]), "root", int(t[23]-t[22]), "outward", int(t[24]-t[23]))
 g.step(acts[0]); torch.cuda.synchronize()
