@@ -13,7 +13,10 @@
 // Backward layer by layer in LDS, every activation buffer overwritten in place by its pre-activation gradient
 // (ELU'(z) = h > 0 ? 1 : h + 1 needs only the output). Weight gradients never leave registers inside a launch: every thread
 // owns a fixed set of entries of the small layers (plain FMAs over the 24 rows of a group), the 30 x 76 projection gradient
-// is an MFMA GEMM over the 240 (row, time step) pairs of a group with B operands re-read from obs (L2). At the end each
+// is an MFMA GEMM over the 240 (row, time step) pairs of a group with B operands re-read from obs (L2). Since round 6 the two largest
+// backward stages of conv1 -- its weight gradient (a 20 x 96 x 30 GEMM per tap, one tap per wave) and its input gradient dz1 (one
+// 120 x 40 x 30 GEMM per parity of the time step) -- run on the matrix pipe too: as plain FMAs with two LDS reads each they were
+// three quarters of the kernel's LDS traffic (21 M LDS instructions per launch, MFMA pipe 19 % busy: profiles/r02_pmc_hist_train.txt). At the end each
 // workgroup writes ONE partial gradient vector; hist_reduce_kernel sums them in workgroup order (deterministic).
 #include <hip/hip_runtime.h>
 #include "wbc_stream_guard.h"
@@ -45,6 +48,18 @@
 #define PRIV_N 24
 #define PRIV_H 64
 
+// development aid (-DWBC_HIST_TIMING): cycle stamps of workgroup 0's first group at the phase boundaries (tools/time_hist_train.py)
+__device__ long long* g_hist_dbg = nullptr;
+#ifdef WBC_HIST_TIMING
+#define HSTAMP(i) do { if (g_hist_dbg && blockIdx.x == 0 && threadIdx.x == 0 && group == 0) g_hist_dbg[i] = clock64(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
+extern "C" void wbc_debug_set_hist_timing(void* dev_buf) {
+  long long* pp = (long long*)dev_buf;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hist_dbg), &pp, sizeof(pp));
+}
+
 struct HistParams { const float *enc_w, *enc_b, *c1_w, *c1_b, *c2_w, *c2_b, *lin_w, *lin_b; };
 
 static __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
@@ -63,6 +78,10 @@ struct TrainSmem {
   float w_lin[H_OUT][H_C1];
   float b_enc[H_C1], b_c1[H_C2], b_c2[H_C3], b_lin[H_OUT];
   long long ridx[G_ROWS];               // gathered row of obs / target, -1 past the end of the minibatch
+  // conv1 / conv2 weight gradients of the whole launch (every element owned by one lane of one wave: plain read-add-write per group;
+  // as register tiles they were 20 more VGPRs held across the forward pass, which sits at the 256-register limit)
+  float gW1[H_C2][4][H_C1];             // [co][tap][ci]
+  float gW2[H_C3][H_C2 * 2];            // [co][(ci, tap)]
 };
 
 extern "C" __global__ void __launch_bounds__(G_THREADS, 2)
@@ -86,10 +105,8 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
 #pragma unroll
   for (int i = 0; i < 3; ++i) accE[i] = (f32x4h){0.f, 0.f, 0.f, 0.f};
   float accL[3] = {0.f, 0.f, 0.f};      // linear_output weight entries tid + 256 i (< 600)
-  float accC2[2] = {0.f, 0.f};          // conv2 weight entries tid + 256 i (< 400)
-  float accC1[10];                      // conv1 weight entries tid + 256 i (< 2400)
-#pragma unroll
-  for (int i = 0; i < 10; ++i) accC1[i] = 0.f;
+  for (int e = tid; e < H_C2 * 4 * H_C1; e += G_THREADS) (&s.gW1[0][0][0])[e] = 0.f;
+  for (int e = tid; e < H_C3 * H_C2 * 2; e += G_THREADS) (&s.gW2[0][0])[e] = 0.f;
   float accB = 0.f;                     // bias entry tid (< 80): enc 0..29, conv1 30..49, conv2 50..59, linear 60..79
   float loss_acc = 0.f;
   const float inv_rows = 1.f / (float)rows;
@@ -109,9 +126,15 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     if (tid < G_ROWS) s.ridx[tid] = (row0 + tid < rows) ? idx[row0 + tid] : -1;
     int opaque = 0;
     asm volatile("" : "+v"(opaque));                    // keeps the weight fetches inside the loop (no hoisting)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));                        // the thread index likewise: the index arithmetic of the per-thread phases (e / 30, e % 30, LDS
+                                                        // addresses ...) is redone per group instead of being held in ~100 registers across the loop (and spilled)
+    const int wave = tl >> 6, p = tl & 15, g = (tl >> 4) & 3;   // (shadow the launch-wide copies inside the loop for the same reason)
+    HSTAMP(0);
     // ---- forward: per-step projection 76 -> 30 + ELU -> h1
-    float4 a0[5], a1[5];
+    float4 a0[5], a1[5], a2[5];                       // the rows of this wave's blocks mb, mb + 4, mb + 8: requested two blocks ahead
     fetch(a0, row0, wave);
+    if (wave + 4 < G_PAIRS / 16) fetch(a1, row0, wave + 4);
     float wA[40];
     {
       const float* ew = P.enc_w + opaque;
@@ -124,7 +147,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     }
 #pragma unroll 1
     for (int mb = wave; mb < G_PAIRS / 16; mb += 4) {
-      if (mb + 4 < G_PAIRS / 16) fetch(a1, row0, mb + 4);
+      if (mb + 8 < G_PAIRS / 16) fetch(a2, row0, mb + 8);
       f32x4h acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
@@ -142,9 +165,10 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
         if (p + 16 < H_C1) s.h1[q][p + 16] = elu1(acc1[r4] + s.b_enc[p + 16]);
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) a0[j] = a1[j];
+      for (int j = 0; j < 5; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
     }
     __syncthreads();
+    HSTAMP(1);
     // ---- conv1 (30 -> 20, k4 s2) + ELU -> h2
     float wB[60];
     {
@@ -174,18 +198,31 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       }
     }
     __syncthreads();
+    HSTAMP(2);
     // ---- conv2 (20 -> 10, k2 s1) + ELU, channel-major flatten -> h3
-    for (int e = tid; e < G_ROWS * 3 * H_C3; e += G_THREADS) {
-      const int rr = e / (3 * H_C3), rem = e - rr * (3 * H_C3), l = rem / H_C3, co = rem - l * H_C3;
-      float acc = s.b_c2[co];
-      const float* wr = s.w_c2[co];
+    // (matrix pipe since round 6: rows u = (row, l) -- 72, five tiles of 16 --, K = (ci, tap) = 40, columns co = 10)
+#pragma unroll 1
+    for (int tile = wave; tile < 5; tile += 4) {
+      const int u = tile * 16 + p, urr = u / 3, ul = u - 3 * urr;
+      const bool uok = u < G_ROWS * 3;
+      f32x4h d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ci = 0; ci < H_C2; ++ci) acc += s.h2[rr][l][ci] * wr[ci * 2] + s.h2[rr][l + 1][ci] * wr[ci * 2 + 1];
-      s.h3[rr][co * 3 + l] = elu1(acc);
+      for (int st = 0; st < (H_C2 * 2) / 4; ++st) {
+        const int K = 4 * st + g, ci = K >> 1, k = K & 1;
+        const float av = uok ? s.h2[urr][ul + k][ci] : 0.f;
+        const float bv = p < H_C3 ? s.w_c2[p][K] : 0.f;
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, d, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int u2 = tile * 16 + 4 * g + r4;
+        if (u2 < G_ROWS * 3 && p < H_C3) { const int rr = u2 / 3, l = u2 - 3 * rr; s.h3[rr][p * 3 + l] = elu1(d[r4] + s.b_c2[p]); }
+      }
     }
     __syncthreads();
+    HSTAMP(3);
     // ---- linear_output (30 -> 20) + ELU -> y
-    for (int e = tid; e < G_ROWS * H_OUT; e += G_THREADS) {
+    for (int e = tl; e < G_ROWS * H_OUT; e += G_THREADS) {
       const int rr = e / H_OUT, j = e - rr * H_OUT;
       float acc = s.b_lin[j];
 #pragma unroll 15
@@ -193,29 +230,31 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       s.y[rr][j] = elu1(acc);
     }
     __syncthreads();
+    HSTAMP(4);
     // ---- loss and dz4 = dL/dy * ELU'(y): one lane per row (||priv - hist||_2, mean over the minibatch's rows)
-    if (tid < G_ROWS) {
-      const long long gi = s.ridx[tid];
+    if (tl < G_ROWS) {
+      const long long gi = s.ridx[tl];
       if (gi >= 0) {
         const float* tg = target + (size_t)gi * H_OUT;
         float d[H_OUT], n2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < H_OUT; ++j) { d[j] = s.y[tid][j] - tg[j]; n2 += d[j] * d[j]; }
+        for (int j = 0; j < H_OUT; ++j) { d[j] = s.y[tl][j] - tg[j]; n2 += d[j] * d[j]; }
         const float nrm = sqrtf(n2);
         loss_acc += nrm;
         const float sc = nrm > 0.f ? inv_rows / nrm : 0.f;
 #pragma unroll
-        for (int j = 0; j < H_OUT; ++j) s.y[tid][j] = d[j] * sc * delu_from_out(s.y[tid][j]);
+        for (int j = 0; j < H_OUT; ++j) s.y[tl][j] = d[j] * sc * delu_from_out(s.y[tl][j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < H_OUT; ++j) s.y[tid][j] = 0.f;
+        for (int j = 0; j < H_OUT; ++j) s.y[tl][j] = 0.f;
       }
     }
     __syncthreads();
+    HSTAMP(5);
     // ---- backward linear_output: weight / bias gradients, dz3 (held in registers until h3 has been read by everyone)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int e = tid + G_THREADS * i;
+      const int e = tl + G_THREADS * i;
       if (e < H_OUT * H_C1) {
         const int j = e / H_C1, i3 = e - j * H_C1;
         float a = 0.f;
@@ -224,15 +263,15 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
         accL[i] += a;
       }
     }
-    if (tid >= 60 && tid < 80) {
+    if (tl >= 60 && tl < 80) {
       float a = 0.f;
-      for (int rr = 0; rr < G_ROWS; ++rr) a += s.y[rr][tid - 60];
+      for (int rr = 0; rr < G_ROWS; ++rr) a += s.y[rr][tl - 60];
       accB += a;
     }
     float dz3r[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int e = tid + G_THREADS * i;
+      const int e = tl + G_THREADS * i;
       dz3r[i] = 0.f;
       if (e < G_ROWS * H_C1) {
         const int rr = e / H_C1, i3 = e - rr * H_C1;
@@ -245,106 +284,171 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int e = tid + G_THREADS * i;
+      const int e = tl + G_THREADS * i;
       if (e < G_ROWS * H_C1) s.h3[e / H_C1][e % H_C1] = dz3r[i];
     }
     __syncthreads();
+    HSTAMP(6);
     // ---- backward conv2: weight / bias gradients, dz2
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + G_THREADS * i;
-      if (e < H_C3 * H_C2 * 2) {
-        const int co = e / (H_C2 * 2), rem = e - co * (H_C2 * 2), ci = rem >> 1, k = rem & 1;
-        float a = 0.f;
+    // (matrix pipe since round 6) weight gradient dW2[co][(ci, k)] = sum over the 72 (row, l) pairs of dz3[row][co 3 + l] h2[row][l + k][ci]:
+    // column tile nt = this wave (three tiles of the 40 (ci, k) columns), 18 steps of 4 pairs
+    if (wave < 3) {
+      const int Kc = wave * 16 + p, ci = Kc >> 1, k = Kc & 1;
+      const bool bok = Kc < H_C2 * 2;
+      f32x4h accW2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 6
-        for (int rr = 0; rr < G_ROWS; ++rr) {
+      for (int st = 0; st < (G_ROWS * 3) / 4; ++st) {
+        const int m = 4 * st + g, rr = m / 3, l = m - 3 * rr;
+        const float av = p < H_C3 ? s.h3[rr][p * 3 + l] : 0.f;
+        const float bv = bok ? s.h2[rr][l + k][ci] : 0.f;
+        accW2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accW2, 0, 0, 0);
+      }
 #pragma unroll
-          for (int l = 0; l < 3; ++l) a += s.h3[rr][co * 3 + l] * s.h2[rr][l + k][ci];
-        }
-        accC2[i] += a;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int co = 4 * g + r4;
+        if (co < H_C3 && bok) s.gW2[co][Kc] += accW2[r4];
       }
     }
-    if (tid >= 50 && tid < 60) {
+    if (tl >= 50 && tl < 60) {
       float a = 0.f;
-      for (int rr = 0; rr < G_ROWS; ++rr) a += s.h3[rr][(tid - 50) * 3] + s.h3[rr][(tid - 50) * 3 + 1] + s.h3[rr][(tid - 50) * 3 + 2];
+      for (int rr = 0; rr < G_ROWS; ++rr) a += s.h3[rr][(tl - 50) * 3] + s.h3[rr][(tl - 50) * 3 + 1] + s.h3[rr][(tl - 50) * 3 + 2];
       accB += a;
     }
-    for (int e = tid; e < G_ROWS * 4 * H_C2; e += G_THREADS) {
-      const int rr = e / (4 * H_C2), rem = e - rr * (4 * H_C2), lp = rem / H_C2, ci = rem - lp * H_C2;
-      float a = 0.f;
+    // dz2 = (conv2^T dz3) * ELU'(h2) on the matrix pipe: rows u = (row, lp) -- 96, six tiles --, K = (co, tap) = 20, columns ci = 20 (two tiles)
+#pragma unroll 1
+    for (int tile = wave; tile < 6; tile += 4) {
+      const int u = tile * 16 + p, urr = u >> 2, ulp = u & 3;
+      f32x4h d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int l = lp - k;
-        if (l >= 0 && l < 3) {
-#pragma unroll
-          for (int co = 0; co < H_C3; ++co) a += s.w_c2[co][ci * 2 + k] * s.h3[rr][co * 3 + l];
-        }
+      for (int st = 0; st < (H_C3 * 2) / 4; ++st) {
+        const int K = 4 * st + g, co = K >> 1, k = K & 1, l = ulp - k;
+        const float av = (l >= 0 && l < 3) ? s.h3[urr][co * 3 + (l < 0 ? 0 : (l > 2 ? 2 : l))] : 0.f;
+        const float bv0 = s.w_c2[co][p * 2 + k];
+        const float bv1 = (p + 16 < H_C2) ? s.w_c2[co][(p + 16) * 2 + k] : 0.f;
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv0, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv1, d1, 0, 0, 0);
       }
-      s.dz2[rr][lp][ci] = a * delu_from_out(s.h2[rr][lp][ci]);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int u2 = tile * 16 + 4 * g + r4, rr = u2 >> 2, lp = u2 & 3;
+        s.dz2[rr][lp][p] = d0[r4] * delu_from_out(s.h2[rr][lp][p]);
+        if (p + 16 < H_C2) s.dz2[rr][lp][p + 16] = d1[r4] * delu_from_out(s.h2[rr][lp][p + 16]);
+      }
     }
     __syncthreads();
-    // ---- backward conv1: weight / bias gradients (h1 still holds the activations)
+    HSTAMP(7);
+    // ---- backward conv1: weight / bias gradients (h1 still holds the activations). The weight gradient runs on the matrix pipe
+    // (round 6; as 2400 thread-owned entries x 96 plain FMAs with two LDS reads each it was the kernel's largest LDS-bound phase):
+    // tap k = this wave, dW1_k[co][ci] = sum over the 96 (row, l) pairs m of dz2[m][co] h1[row * 10 + 2 l + k][ci] -- a 20 x 96 x 30
+    // GEMM, A = dz2^T, B = the tap's rows of h1, 24 steps of 4 pairs, four 16 x 16 tiles.
+    {
+      const bool a1ok = (p + 16) < H_C2, b1ok = (p + 16) < H_C1;
+      f32x4h accW1[2][2];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int e = tid + G_THREADS * i;
-      if (e < H_C2 * H_C1 * 4) {                       // thread entries in (co, tap k, ci) order: consecutive lanes = consecutive ci (LDS banks)
-        const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4), k = rem / H_C1, ci = rem - k * H_C1;
-        float a = 0.f;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accW1[i][j] = (f32x4h){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int rr = 0; rr < G_ROWS; ++rr) {
-#pragma unroll
-          for (int l = 0; l < 4; ++l) a += s.dz2[rr][l][co] * s.h1[rr * H_T + 2 * l + k][ci];
-        }
-        accC1[i] += a;
+      for (int st = 0; st < (G_ROWS * 4) / 4; ++st) {
+        const int m = 4 * st + g, rr = m >> 2, l = m & 3;
+        const float* zr = s.dz2[rr][l];
+        const float* hr = s.h1[rr * H_T + 2 * l + wave];
+        const float av0 = zr[p], av1 = a1ok ? zr[p + 16] : 0.f;
+        const float bv0 = hr[p], bv1 = b1ok ? hr[p + 16] : 0.f;
+        accW1[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0, accW1[0][0], 0, 0, 0);
+        accW1[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv1, accW1[0][1], 0, 0, 0);
+        accW1[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv0, accW1[1][0], 0, 0, 0);
+        accW1[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1, accW1[1][1], 0, 0, 0);
       }
+#pragma unroll
+      for (int cot = 0; cot < 2; ++cot)
+#pragma unroll
+        for (int cit = 0; cit < 2; ++cit)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int co = cot * 16 + 4 * g + r4, ci = cit * 16 + p;       // D[row = 4g + r][col = p]
+            if (co < H_C2 && ci < H_C1) s.gW1[co][wave][ci] += accW1[cot][cit][r4];
+          }
     }
-    if (tid >= 30 && tid < 50) {
+    if (tl >= 30 && tl < 50) {
       float a = 0.f;
-      for (int rr = 0; rr < G_ROWS; ++rr) a += s.dz2[rr][0][tid - 30] + s.dz2[rr][1][tid - 30] + s.dz2[rr][2][tid - 30] + s.dz2[rr][3][tid - 30];
+      for (int rr = 0; rr < G_ROWS; ++rr) a += s.dz2[rr][0][tl - 30] + s.dz2[rr][1][tl - 30] + s.dz2[rr][2][tl - 30] + s.dz2[rr][3][tl - 30];
       accB += a;
     }
     __syncthreads();
-    // ---- dz1 = (conv1^T dz2) * ELU'(h1), in place (each element read and written by one thread)
-    for (int e = tid; e < G_PAIRS * H_C1; e += G_THREADS) {
-      const int q = e / H_C1, ci = e - q * H_C1, rr = q / H_T, t = q - rr * H_T;
-      float a = 0.f;
+    HSTAMP(8);
+    // ---- dz1 = (conv1^T dz2) * ELU'(h1), in place, on the matrix pipe (round 6): time step t = 2 m + par receives tap par from l = m
+    // and tap par + 2 from l = m - 1, so each parity is ONE GEMM over K = (co, j) = 40: rows u = (row, m) (120, eight tiles of 16),
+    // A[u][(co, j)] = dz2[row][m - j][co] (0 outside l = 0..3), B[(co, j)][ci] = w1[co][par + 2 j][ci]; every element of h1 is
+    // read (its ELU') and written by one lane. A wave takes row tiles 2 wave, 2 wave + 1 of both parities.
+    {
+      const bool b1ok = (p + 16) < H_C1;
+#pragma unroll 1
+      for (int pt = 0; pt < 4; ++pt) {
+        const int par = pt >> 1, rt = 2 * wave + (pt & 1);
+        const int u = rt * 16 + p, urr = u / 5, um = u - 5 * urr;
+        const bool uok = u < G_ROWS * 5;
+        f32x4h d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 5
+        for (int st = 0; st < (H_C2 * 2) / 4; ++st) {
+          const int K = 4 * st + g, co = K >> 1, j = K & 1, tap = par + 2 * j, l = um - j;
+          const float av = (uok && l >= 0 && l <= 3) ? s.dz2[uok ? urr : 0][l < 0 ? 0 : (l > 3 ? 3 : l)][co] : 0.f;
+          const float* wr = s.w1[co * 4 + tap];
+          const float bv0 = wr[p], bv1 = b1ok ? wr[p + 16] : 0.f;
+          d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv0, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv1, d1, 0, 0, 0);
+        }
 #pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        const int k = t - 2 * l;
-        if (k >= 0 && k < 4) {
-#pragma unroll
-          for (int co = 0; co < H_C2; ++co) a += s.w1[co * 4 + k][ci] * s.dz2[rr][l][co];
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int u2 = rt * 16 + 4 * g + r4;
+          if (u2 < G_ROWS * 5) {
+            const int rr = u2 / 5, m = u2 - 5 * rr, q = rr * H_T + 2 * m + par;
+            s.h1[q][p] = d0[r4] * delu_from_out(s.h1[q][p]);
+            if (b1ok) s.h1[q][p + 16] = d1[r4] * delu_from_out(s.h1[q][p + 16]);
+          }
         }
       }
-      s.h1[q][ci] = a * delu_from_out(s.h1[q][ci]);
     }
     __syncthreads();
+    HSTAMP(9);
     // ---- projection weight gradient dW[c][j] += sum_q dz1[q][c] x[q][j]: MFMA, A = dz1 (LDS), B = x (obs, L2)
     {
       const int jt0 = wave;                                      // this wave's column tile(s): jt0 for both ct, plus (ct = wave, jt = 4) for wave < 2
       const bool third = wave < 2;
       const bool a1ok = (p + 16) < H_C1;
       const bool b4ok = (64 + p) < H_NP;
-#pragma unroll 2
-      for (int ks = 0; ks < G_PAIRS / 4; ++ks) {
-        const int q = 4 * ks + g, rr = q / H_T, t = q - rr * H_T;
-        const long long gi = s.ridx[rr];
-        const float* xr = obs + (size_t)(gi < 0 ? 0 : gi) * H_OBS + H_OFF + t * H_NP;
-        const float bx = xr[jt0 * 16 + p];
-        const float b4 = (third && b4ok) ? xr[64 + p] : 0.f;
-        const float av0 = s.h1[q][p];
-        const float av1 = a1ok ? s.h1[q][p + 16] : 0.f;
-        accE[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bx, accE[0], 0, 0, 0);
-        accE[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bx, accE[1], 0, 0, 0);
-        if (third) accE[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wave == 0 ? av0 : av1, b4, accE[2], 0, 0, 0);
+      // (the B operands come from obs through L2: requested twelve steps at a time BEFORE those steps' MFMAs -- one step at a time, each
+      // step waited a full global round trip for its own row: 56 k of the group's 160 k cycles, round 6's stamps)
+      constexpr int CH = 12;
+#pragma unroll 1
+      for (int c0 = 0; c0 < G_PAIRS / 4; c0 += CH) {
+        float bxv[CH], b4v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int q = 4 * (c0 + i) + g, rr = q / H_T, t = q - rr * H_T;
+          const long long gi = s.ridx[rr];
+          const float* xr = obs + (size_t)(gi < 0 ? 0 : gi) * H_OBS + H_OFF + t * H_NP;
+          bxv[i] = xr[jt0 * 16 + p];
+          b4v[i] = (third && b4ok) ? xr[64 + p] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int q = 4 * (c0 + i) + g;
+          const float av0 = s.h1[q][p];
+          const float av1 = a1ok ? s.h1[q][p + 16] : 0.f;
+          accE[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bxv[i], accE[0], 0, 0, 0);
+          accE[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bxv[i], accE[1], 0, 0, 0);
+          if (third) accE[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wave == 0 ? av0 : av1, b4v[i], accE[2], 0, 0, 0);
+        }
       }
     }
-    if (tid < H_C1) {
+    if (tl < H_C1) {
       float a = 0.f;
-      for (int q = 0; q < G_PAIRS; ++q) a += s.h1[q][tid];
+      for (int q = 0; q < G_PAIRS; ++q) a += s.h1[q][tl];
       accB += a;
     }
     __syncthreads();                                   // h1 / ridx are rewritten by the next group
+    HSTAMP(10);
   }
   // ---- write this workgroup's partial gradient vector
   float* out = partial + (size_t)blockIdx.x * N_PART;
@@ -358,16 +462,11 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       if (c < H_C1) out[O_ENC_W + c * H_NP + 64 + p] = accE[2][r4];
     }
   }
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const int e = tid + G_THREADS * i;
-    if (e < H_C2 * H_C1 * 4) {
-      const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4), k = rem / H_C1, ci = rem - k * H_C1;
-      out[O_C1_W + co * (H_C1 * 4) + ci * 4 + k] = accC1[i];              // back to conv_layers.0.weight's [co][ci][k]
-    }
+  for (int e = tid; e < H_C2 * H_C1 * 4; e += G_THREADS) {                   // conv_layers.0.weight's [co][ci][k]
+    const int co = e / (H_C1 * 4), rem = e - co * (H_C1 * 4), ci = rem >> 2, k = rem & 3;
+    out[O_C1_W + e] = s.gW1[co][k][ci];
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { const int e = tid + G_THREADS * i; if (e < H_C3 * H_C2 * 2) out[O_C2_W + e] = accC2[i]; }
+  for (int e = tid; e < H_C3 * H_C2 * 2; e += G_THREADS) out[O_C2_W + e] = (&s.gW2[0][0])[e];     // conv_layers.2.weight's [co][ci][k] = co * 40 + (ci, k)
 #pragma unroll
   for (int i = 0; i < 3; ++i) { const int e = tid + G_THREADS * i; if (e < H_OUT * H_C1) out[O_LIN_W + e] = accL[i]; }
   if (tid < 30) out[O_ENC_B + tid] = accB;

@@ -5,6 +5,9 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-whole-body-control_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+_timing_lib = os.path.join(ROOT, "deep-whole-body-control_amd", "wbc_amd", "libwbc_amd_histtiming.so")   # tools/build_variant.py histtiming -DWBC_HIST_TIMING
+if os.path.exists(_timing_lib) and os.environ.get("WBC_STAMPS"):
+    os.environ["WBC_AMD_LIB"] = _timing_lib
 import torch
 import golden_procedure as gp
 from wbc_amd.native import check, lib
@@ -45,3 +48,13 @@ t_grad = ev(lambda: check(L.wbc_hist_train_grad(table, obs.data_ptr(), priv.data
 flops = 2 * 80e3 * B
 print(f"priv_latent {TN} rows: {t_priv:.1f} us; hist_train_grad (+reduce) {B} rows: {t_grad:.1f} us = {flops / t_grad / 1e6:.1f} TFLOP/s, "
       f"{B * 3040 / t_grad / 1e3:.1f} GB/s of history rows")
+
+if os.environ.get("WBC_STAMPS") and hasattr(L, "wbc_debug_set_hist_timing"):
+    L.wbc_debug_set_hist_timing.argtypes = [C.c_void_p]
+    buf = torch.zeros(16, dtype=torch.int64, device="cuda")
+    L.wbc_debug_set_hist_timing(buf.data_ptr())
+    check(L.wbc_hist_train_grad(table, obs.data_ptr(), priv.data_ptr(), idx.data_ptr(), B, ws.data_ptr(), grad.data_ptr(), st)); torch.cuda.synchronize()
+    t = buf.cpu().numpy()
+    names = ["projection fwd", "conv1 fwd", "conv2 fwd", "linear fwd", "loss", "linear bwd", "conv2 bwd", "conv1 wgrad", "dz1", "projection wgrad"]
+    print("hist_train phase cycles (workgroup 0, first group):", {names[i]: int(t[i + 1] - t[i]) for i in range(10)}, "total", int(t[10] - t[0]))
+    L.wbc_debug_set_hist_timing(None)
