@@ -132,9 +132,11 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     const int wave = tl >> 6, p = tl & 15, g = (tl >> 4) & 3;   // (shadow the launch-wide copies inside the loop for the same reason)
     HSTAMP(0);
     // ---- forward: per-step projection 76 -> 30 + ELU -> h1
-    float4 a0[5], a1[5], a2[5];                       // the rows of this wave's blocks mb, mb + 4, mb + 8: requested two blocks ahead
-    fetch(a0, row0, wave);
-    if (wave + 4 < G_PAIRS / 16) fetch(a1, row0, wave + 4);
+    float4 a0[5], a1[5], a2[5], a3[5];                // the rows of ALL of this wave's blocks (mb = wave, wave + 4, + 8, + 12) are requested up front:
+    fetch(a0, row0, wave);                            // the gathered rows come from HBM, and a wave that asks block by block waits a full
+    fetch(a1, row0, wave + 4);                        // round trip per block (the projection was 30 k of a group's 137 k cycles)
+    fetch(a2, row0, wave + 8);
+    if (wave + 12 < G_PAIRS / 16) fetch(a3, row0, wave + 12);
     float wA[40];
     {
       const float* ew = P.enc_w + opaque;
@@ -147,7 +149,6 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
     }
 #pragma unroll 1
     for (int mb = wave; mb < G_PAIRS / 16; mb += 4) {
-      if (mb + 8 < G_PAIRS / 16) fetch(a2, row0, mb + 8);
       f32x4h acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
@@ -165,7 +166,7 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
         if (p + 16 < H_C1) s.h1[q][p + 16] = elu1(acc1[r4] + s.b_enc[p + 16]);
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; }
+      for (int j = 0; j < 5; ++j) { a0[j] = a1[j]; a1[j] = a2[j]; a2[j] = a3[j]; }
     }
     __syncthreads();
     HSTAMP(1);
@@ -417,9 +418,9 @@ hist_train_kernel(HistParams P, const float* __restrict__ obs, const float* __re
       const bool third = wave < 2;
       const bool a1ok = (p + 16) < H_C1;
       const bool b4ok = (64 + p) < H_NP;
-      // (the B operands come from obs through L2: requested twelve steps at a time BEFORE those steps' MFMAs -- one step at a time, each
+      // (the B operands come from obs through L2: requested twenty steps at a time BEFORE those steps' MFMAs -- one step at a time, each
       // step waited a full global round trip for its own row: 56 k of the group's 160 k cycles, round 6's stamps)
-      constexpr int CH = 12;
+      constexpr int CH = 20;
 #pragma unroll 1
       for (int c0 = 0; c0 < G_PAIRS / 4; c0 += CH) {
         float bxv[CH], b4v[CH];
