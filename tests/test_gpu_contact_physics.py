@@ -19,6 +19,7 @@ def gpu(wmodel, tcfg, n, seed=1):
 @pytest.mark.parametrize("terrain_friction,tan_theta", [(1.0, 0.5), (0.2, 0.5), (-0.6, 0.1)])
 def test_box_sticks_below_the_friction_angle_on_the_kernel(robot, terrain_friction, tan_theta):
     r = pc.box_on_incline(robot, tan_theta, terrain_friction, make_sim=gpu)
+    print(f"box sticks: terrain_friction {terrain_friction} tan {tan_theta}: acc {r['acc']:+.5f} v_end {r['v_end']:+.5f}")
     assert r["sticks_expected"] and abs(r["acc"]) < 0.02 and abs(r["v_end"]) < 0.05, r
 
 
@@ -33,6 +34,7 @@ def test_box_slides_at_the_coulomb_rate_on_the_kernel(robot, terrain_friction, t
 @pytest.mark.parametrize("mu_env,terrain_friction,tan_theta", [(-0.5, 1.0, 0.2), (0.0, 1.0, 0.4), (1.0, 1.0, 0.6)])
 def test_robot_on_its_trunk_sticks_on_the_kernel(robot, mu_env, terrain_friction, tan_theta):
     r = pc.robot_on_incline(robot, tan_theta, mu_env, terrain_friction, t_settle=1.2, t_measure=0.4, make_sim=gpu)
+    print(f"trunk sticks: mu_env {mu_env} terrain_friction {terrain_friction} tan {tan_theta}: acc {r['acc']:+.5f} v_end {r['v_end']:+.5f}")
     assert r["sticks_expected"] and abs(r["acc"]) < 0.03 and abs(r["v_end"]) < 0.04, r
 
 
