@@ -105,7 +105,10 @@ struct DevTensors {
   float* feet_air_time; // [N,4]
   float* last_contacts; // [N,4]
   float* dropped;       // [N]
+  // balanced dealing of the step kernel's workgroups (wbc_step_kernel's header comment; allocated apart from the tensor arena)
+  uint64_t* deal_flags; // [2][8][2][WBC_DEAL_WORDS]: per launch parity and XCD, two bit planes with one bit per env of the XCD's range: "expected in contact" / "expected to lie on the ground or to touch itself"
 };
+#define WBC_DEAL_WORDS 8
 
 #define WBC_PI 3.14159265358979323846f
 

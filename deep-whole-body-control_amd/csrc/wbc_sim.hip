@@ -15,7 +15,7 @@
 #include "wbc_stream_guard.h"
 
 extern "C" __global__ void wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ C, const float* __restrict__ actions, int num_envs,
-                                           uint64_t seed, uint64_t step, StepOut so);
+                                           uint64_t seed, uint64_t step, StepOut so, uint32_t deal);
 extern "C" __global__ void wbc_reset_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs, uint64_t seed, uint64_t step);
 extern "C" __global__ void wbc_simulate_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
 extern "C" __global__ void wbc_fk_kernel(DevTensors T, const DevConst* __restrict__ C, int num_envs);
@@ -71,6 +71,11 @@ struct wbc_sim {
   bool own_arena = false;
   size_t arena_bytes = 0;
   int16_t* hf_dev = nullptr;
+  // balanced dealing of the step kernel's workgroups (wbc_step_kernel): on when every robot is resident at once and an XCD's range is
+  // whole flag words (N a multiple of 512, at most 4096); WBC_NO_DEAL=1 in the environment switches it off (A/B runs)
+  char* deal_mem = nullptr;
+  bool deal_on = false;
+  int64_t step_launches = 0;
 };
 
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
@@ -336,6 +341,14 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
   T.box_mass = (float*)s->ptr[WBC_T_BOX_MASS]; T.box_timer = (float*)s->ptr[WBC_T_BOX_SLEEP_TIMER];
   T.feet_air_time = (float*)s->ptr[WBC_T_FEET_AIR_TIME]; T.last_contacts = (float*)s->ptr[WBC_T_LAST_CONTACTS];
   T.dropped = (float*)s->ptr[WBC_T_DROPPED_HITS];
+  {
+    const size_t fl = 2 * 8 * 2 * WBC_DEAL_WORDS * sizeof(uint64_t);
+    HIP_OK(hipMalloc((void**)&s->deal_mem, fl));
+    HIP_OK(hipMemset(s->deal_mem, 0, fl));
+    T.deal_flags = (uint64_t*)s->deal_mem;
+    const char* off = getenv("WBC_NO_DEAL");
+    s->deal_on = num_envs % 512 == 0 && num_envs / 512 <= WBC_DEAL_WORDS && !(off && off[0] == '1');
+  }
   // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
   {
     const int n = num_envs;
@@ -373,6 +386,7 @@ extern "C" int wbc_sim_destroy(wbc_sim* s) {
   DeviceGuard dg(s->device);
   if (s->own_arena && s->arena) (void)hipFree(s->arena);
   if (s->dc) (void)hipFree(s->dc);
+  if (s->deal_mem) (void)hipFree(s->deal_mem);
   if (s->dT) (void)hipFree(s->dT);
   if (s->hf_dev) (void)hipFree(s->hf_dev);
   delete s;
@@ -489,8 +503,10 @@ extern "C" int wbc_sim_step_rollout(wbc_sim* s, const float* actions_dev, float*
     return fail(-1, "wbc_sim_step_rollout: values, out_rewards and out_dones go together");
   s->step_counter += 1;
   const StepOut so{obs_out_dev, values_dev, out_rewards_dev, out_dones_dev, gamma};
-  hipLaunchKernelGGL(wbc_step_kernel, dim3(8 * ((s->n + 7) / 8)), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter, so);
+  const uint32_t deal = s->deal_on ? (2u | (uint32_t)(s->step_launches & 1)) : 0u;
+  hipLaunchKernelGGL(wbc_step_kernel, dim3(8 * ((s->n + 7) / 8)), dim3(64), 0, (hipStream_t)stream, s->dT, s->dc, actions_dev, s->n, s->seed, (uint64_t)s->step_counter, so, deal);
   HIP_OK(hipGetLastError());
+  s->step_launches += 1;
   return 0;
 }
 extern "C" int wbc_sim_step_to(wbc_sim* s, const float* actions_dev, float* obs_out_dev, void* stream) {

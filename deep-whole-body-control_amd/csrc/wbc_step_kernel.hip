@@ -158,6 +158,8 @@ struct __align__(16) Smem {
   uint32_t k_prk[WBC_NCP];       // DevConst::pr_pack: every lane's pair descriptor
   int dyn_dirty;                 // the per-body contact masks below carry bits of dynamic slots (restored before they are used again)
   int dropped;                   // broad-phase hits of this launch that found no free dynamic slot (WBC_T_DROPPED_HITS)
+  int deal_hint;                 // last substep: how heavy the next step of this env is expected to be, 0..2 (the next launch's deal)
+  int deal_word, deal_bit;       // where this env's hint bit goes (word index into DevTensors::deal_flags, -1: no dealing; bit 0..63)
   float goal[24], cmd[3], blv[3], bav[3];
   float act_last[WBC_NACT];      // newest (undelayed) action, sim order
   float ep_sums[WBC_NREW], met_sums[WBC_NMETRIC];
@@ -1036,12 +1038,21 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   // contacts that act on the tree (everything but the box's own corners): without one -- the robot in the air while the box lies
   // on the ground -- the tree's response is zero and its sweeps are skipped
   const bool any_tree = (abits & ~Cc->box_corner_mask) != 0ull;
+  if (want_outputs) {
+    // (wave-uniform) what the next launch's deal goes by. 1: in contact now, or a robot sphere that reaches the contact margin within
+    // a step at the base's rate of descent; 2: five or more contacts on the tree (lying on the ground), or limbs touching each other
+    // (the exact limb tests: the longest way a wave can go)
+    const float soon_gap = C->cfg.contact_margin + 0.02f + fmaxf(-s.root[9], 0.f) * (6.f * dt);      // (root[9]: the base's vertical velocity)
+    const uint64_t soon = __ballot(cpkind == WBC_CP_TERRAIN && !onbox && cgap < soon_gap);
+    const uint64_t tree = abits & ~Cc->box_corner_mask;
+    if (lane == 0) s.deal_hint = (__popcll(tree) >= 5 || (abits & Cc->dyn_self_mask) != 0ull) ? 2 : ((any_tree || soon != 0ull) ? 1 : 0);
+  }
   int dmax = 1;
 #pragma unroll
   for (int d = 2; d <= WBC_MAX_DEPTH; ++d) dmax = (abits & C->depth_cp_mask[d]) ? d : dmax;
   dmax = max(dmax, ddmax);
 #if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
-  if (lane == 0) s.dbg_ncon = __popcll(abits) | (dmax << 8) | (__popcll(abits & 0x3F800000ull) << 16);
+  if (lane == 0) s.dbg_ncon = __popcll(abits) | (dmax << 8) | (min((int)__popcll(abits & Cc->dyn_self_mask), 15) << 16);
 #endif
   // damped block-Jacobi: relaxation 1 / (number of active contacts acting on the busier of the contact's two bodies)
   float com = 1.f;
@@ -1966,7 +1977,7 @@ template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C
 // WidowGo1.step for one env per wave (oracle: env_step). `step` = common_step_counter after increment. so: optional
 // extra outputs (observation rows into the rollout storage slot of the next transition, this transition's reward / done slots).
 extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const DevTensors* __restrict__ Tp, const DevConst* __restrict__ Cg, const float* __restrict__ actions,
-                                                                    int num_envs, uint64_t seed, uint64_t step, StepOut so) {
+                                                                    int num_envs, uint64_t seed, uint64_t step, StepOut so, uint32_t deal) {
   CP C = (CP)Cg;
   __shared__ Smem s;
   // (the tensor table likewise: never written by a kernel -> constant address space, its pointers arrive by scalar loads on demand)
@@ -1974,12 +1985,63 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: XCD x takes the CONTIGUOUS env range
   // [x per, (x + 1) per), so the sub-64-B rows of neighbouring envs (13-float root rows, 3-float commands, ...) meet in one L2 and
   // leave it as whole lines instead of as byte-masked partial writes from two L2s (grid = 8 per workgroups, wbc_sim.hip).
-#ifndef WBC_NO_XCD_MAP
+  //
+  // WHICH env of its XCD's range a workgroup takes is dealt per launch (deal & 2; N a multiple of 512 up to 4096: every robot resident
+  // at once, 4 per SIMD). A launch ends with its busiest SIMD; left alone it waits for whichever SIMD happens to hold three or four
+  // robots in contact (+15..30 % cycles each) while the mean SIMD holds one or two. The dispatcher hands the workgroups of an XCD to
+  // its shader engines, their CUs and the CUs' SIMDs round-robin: any 64 consecutive workgroups of an XCD land on 64 different SIMDs,
+  // any 128 on >= 114, any 256 on all 128 (measured inside the training loop, where WHICH SIMD a given workgroup gets changes from
+  // launch to launch: tools/wave_bench_state.py). So the envs of the range are taken in the order "expected to lie on the ground or
+  // to touch itself", "expected in contact", the rest (a stable partition by the two hint bits the previous launch left in deal_flags:
+  // what its wave saw in its last substep, cleared by a reset): workgroup j of the XCD takes the j-th env of that order -- rank-select
+  // on the range's <= 8 flag words per bit plane. (Running every other window of 128 backwards, so that the SIMDs that got the
+  // heaviest robots get the lightest next: measured worse, 117-119 us against 114-116.) Any flag content
+  // gives a bijection (the flags of this launch's parity are not written during it); only the balance depends on the hints. Results
+  // do not depend on the deal: nothing but `env` is derived from blockIdx (tests/test_gpu_deal.py: bit for bit).
   const int per = (num_envs + 7) >> 3;
-  const int env = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-#else
-  const int env = blockIdx.x;
-#endif
+  const int xcd = blockIdx.x & 7;
+  int env = xcd * per + (blockIdx.x >> 3);
+  if (deal & 2u) {
+    const int nw = per >> 6;
+    const auto fw = G(T.deal_flags) + (((deal & 1u) * 8u + (uint32_t)xcd) * (2 * WBC_DEAL_WORDS));
+    uint32_t pos = blockIdx.x >> 3;
+    uint64_t wv = 0ull;
+    if ((int)threadIdx.x < 2 * WBC_DEAL_WORDS && (int)(threadIdx.x & (WBC_DEAL_WORDS - 1)) < nw) wv = fw[threadIdx.x];
+    uint64_t wv_[WBC_DEAL_WORDS], wh_[WBC_DEAL_WORDS], wl_[WBC_DEAL_WORDS];
+    int nV = 0, nH = 0;
+#pragma unroll
+    for (int i = 0; i < WBC_DEAL_WORDS; ++i) {
+      const uint64_t a = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wv >> 32), i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)wv, i);
+      const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wv >> 32), WBC_DEAL_WORDS + i) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)wv, WBC_DEAL_WORDS + i);
+      wv_[i] = b; wh_[i] = a & ~b; wl_[i] = i < nw ? ~(a | b) : 0ull;
+      nV += __popcll(b); nH += __popcll(a & ~b);
+    }
+    const int cls = (int)pos < nV ? 2 : ((int)pos < nV + nH ? 1 : 0);
+    int kk = (int)pos - (cls == 2 ? 0 : (cls == 1 ? nV : nV + nH)), idx = 0;
+    uint64_t W = 0ull;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < WBC_DEAL_WORDS; ++i) {
+      const uint64_t wi = cls == 2 ? wv_[i] : (cls == 1 ? wh_[i] : wl_[i]);
+      const int c = __popcll(wi);
+      if (!found) {
+        if (kk < c) { found = true; W = wi; idx = i; }
+        else kk -= c;
+      }
+    }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u));
+    const uint64_t hit = __ballot(((W >> threadIdx.x) & 1ull) != 0ull && (int)below == kk);
+    const int ein = idx * 64 + (int)__builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)hit) - 1);
+    env = xcd * per + ein;
+    // (raising the priority of the waves expected in contact from their first instruction on, instead of from their first active
+    // contact: measured, no gain -- 115.2 / 113.8 / 115.7 us without, 117.1 / 116.5 / 116.6 with, in the bench loop)
+    if (threadIdx.x == 0) {
+      // (kept in LDS, not in scalar registers across the kernel) the hints go to the OTHER parity's words
+      s.deal_word = (int)((((deal & 1u) ^ 1u) * 8u + (uint32_t)xcd) * (2 * WBC_DEAL_WORDS)) + (ein >> 6);
+      s.deal_bit = ein & 63;
+    }
+  } else if (threadIdx.x == 0) s.deal_word = -1;
   if (env >= num_envs) return;
   const int lane = threadIdx.x;
   const int chain = lane / CH_LANES, k = lane % CH_LANES;
@@ -2105,11 +2167,21 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
 #endif
   observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
   STAMP(17);
+  if (lane == 0 && s.deal_word >= 0) {
+    // the next launch's deal: this env's two hint bits (fire-and-forget atomics: 64 envs share a word)
+    auto fo = G(T2.deal_flags) + s.deal_word;
+    const uint64_t bit = 1ull << s.deal_bit;
+    const int hint = do_reset ? 0 : s.deal_hint;
+    if (hint >= 1) __hip_atomic_fetch_or(fo, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_and(fo, ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hint >= 2) __hip_atomic_fetch_or(fo + WBC_DEAL_WORDS, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_and(fo + WBC_DEAL_WORDS, ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   if (g_wave_dbg && lane == 0) {
     g_wave_dbg[6 * (size_t)env] = wave_t0; g_wave_dbg[6 * (size_t)env + 1] = clock64();
     g_wave_dbg[6 * (size_t)env + 3] = wave_t13; g_wave_dbg[6 * (size_t)env + 4] = wave_t15; g_wave_dbg[6 * (size_t)env + 5] = wave_t16;
-    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | ((long long)(s.dbg_ncon & 0xFFFF) << 8) | ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15) << 24) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) << 32);
+    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | (long long)(s.deal_hint != 0 ? 2 : 0) | (long long)(s.deal_hint == 2 ? 4 : 0) | ((long long)(s.dbg_ncon & 0xFFFF) << 8) | ((long long)((s.dbg_ncon >> 16) & 15) << 28) | ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15) << 24) | ((long long)((unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) & 0xFFFFu) << 32) | ((long long)(blockIdx.x & 0xFFFFu) << 48);
   }
 #endif
 }

@@ -1,4 +1,4 @@
-# XCD-aware env mapping of wbc_step_kernel against the identity mapping (tools/build_variant.py noxcd -DWBC_NO_XCD_MAP): time and HBM counters
+# XCD-aware env mapping of wbc_step_kernel against the identity mapping: time and HBM counters (round 4; the WBC_NO_XCD_MAP switch it built with was removed in round 6, when the per-launch deal inside each XCD range went in -- kept for the record)
 cd $GRAFT_REPO_ROOT
 bash tools/ab_flags.sh noxcd
 for v in "" noxcd; do

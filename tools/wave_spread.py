@@ -34,7 +34,7 @@ for rep in range(3):
     for k in sorted(set(ncon.tolist())):
         sel = ncon == k
         if sel.sum() >= 20: print(f"   active contacts {k:2d}: {sel.sum():5d} waves, substeps mean {sub[sel].mean():8.0f} (deepest level mean {dmax[sel].mean():.1f}, self-collision pairs {nself[sel].mean():.2f})")
-    hw = (fl >> 32) & 0xFFFFFFFF; xcc = (fl >> 24) & 15
+    hw = (fl >> 32) & 0xFFFF; xcc = (fl >> 24) & 15
     simd = ((hw >> 4) & 3) | (((hw >> 8) & 15) << 2) | (((hw >> 12) & 1) << 6) | (((hw >> 13) & 7) << 7) | (xcc << 10)     # simd, cu, sh, se, xcc
     heavy = (ncon > 0) | rst
     ids, inv = np.unique(simd, return_inverse=True)
