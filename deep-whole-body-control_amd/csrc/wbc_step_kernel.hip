@@ -41,12 +41,17 @@ static_assert(LANES == 64, "one wavefront per robot: cross-lane hand-overs rest 
 // every wave's own start / end / phase stamps (tools/wave_spread.py), without the phase stamps' pointer checks in the instruction stream
 __device__ long long* g_step_dbg = nullptr;
 __device__ long long* g_wave_dbg = nullptr;      // timing builds: per env {start, end, reset | HW_ID << 8} of the step kernel's wave
-#ifdef WBC_STEP_TIMING
+__device__ int g_phase_exit = -1;                // -DWBC_PHASE_EXIT builds: every wave ends at stamp g_phase_exit (tools/phase_counts.py)
+#if defined(WBC_PHASE_EXIT)
+// instruction counts per phase: a launch whose waves all end at stamp k, before any write-back (the state is left as it was), under
+// rocprofv3 --pmc SQ_INSTS_*; the difference between the launches for consecutive stamps is the phase between them
+#define STAMP(i) do { if (g_phase_exit == (i)) __builtin_amdgcn_endpgm(); } while (0)
+#elif defined(WBC_STEP_TIMING)
 #define STAMP(i) do { if (g_step_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_step_dbg[i] = clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
-#ifdef WBC_XSTAMPS
+#if defined(WBC_XSTAMPS) || defined(WBC_PHASE_EXIT)
 #define XSTAMP(i) STAMP(i)
 #else
 #define XSTAMP(i) do { } while (0)
@@ -2279,6 +2284,8 @@ extern "C" void wbc_debug_set_wave_timing(void* dev_buf) {
   long long* p = (long long*)dev_buf;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_dbg), &p, sizeof(p));
 }
+
+extern "C" void wbc_debug_set_phase_exit(int stamp) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_exit), &stamp, sizeof(stamp)); }
 
 extern "C" void wbc_debug_set_step_timing(void* dev_buf) {
   long long* p = (long long*)dev_buf;

@@ -41,7 +41,7 @@ for t in recs:
     first = np.full(len(ids), np.iinfo(np.int64).max); last = np.zeros(len(ids), dtype=np.int64)
     np.minimum.at(first, inv, t0); np.maximum.at(last, inv, t1)
     busy = (last - first).astype(float); nh = np.bincount(inv, weights=heavy.astype(float))
-    row = dict(busy_mean=busy.mean(), busy_max=busy.max(), span=float(t1.max() - t0.min()), heavy=heavy.mean(), rst=rst.mean(), ncon=ncon[ncon > 0].mean() if (ncon > 0).any() else 0,
+    row = dict(busy_mean=busy.mean(), busy_p90=np.percentile(busy, 90), busy_p99=np.percentile(busy, 99), busy_p999=np.percentile(busy, 99.9), busy_max=busy.max(), dur_p99=np.percentile((t1 - t0), 99), dur_p999=np.percentile((t1 - t0), 99.9), dur_max=float((t1 - t0).max()), span=float(t1.max() - t0.min()), heavy=heavy.mean(), rst=rst.mean(), ncon=ncon[ncon > 0].mean() if (ncon > 0).any() else 0,
                dl=dur[~heavy].mean(), dh=dur[heavy].mean(), nh4=(nh >= 3).sum())
     if prev is not None:
         ph = prev
