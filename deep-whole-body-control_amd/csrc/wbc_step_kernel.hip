@@ -424,43 +424,40 @@ __device__ __forceinline__ f3 closest_on_segment(f3 p, f3 b0, f3 b1) {
   const float t = e <= 1e-10f ? 0.f : clampf(dot(p - b0, d) * rcpf(e), 0.f, 1.f);
   return b0 + d * t;
 }
-__device__ void limb_pair(const Smem& s, uint32_t ck, const float (&rad)[6], float rest, LimbHit& out) {
-  const float ra = rad[0], rb = rad[3];
-  f3 bpa, bpb;
-  seg_seg_closest(ld3(s.sph[(ck >> 7) & 31]), ld3(s.sph[(ck >> 12) & 31]), ld3(s.sph[(ck >> 17) & 31]), ld3(s.sph[(ck >> 22) & 31]), &bpa, &bpb);
-  float best;
-  {
-    const f3 d = bpa - bpb;
-    best = __builtin_amdgcn_sqrtf(dot(d, d)) - ra - rb - rest;
+// The nine feature pairs of ONE limb pair on lanes 0..8 (feature f on lane f: 0 shaft-shaft, 1-2 an end sphere of A against B's shaft,
+// 3-4 A's shaft against an end sphere of B, 5-8 end sphere against end sphere), every lane of the wavefront taking part; the result
+// (the deepest pair; of equally deep ones the lowest f, as the oracle's ascending scan with a strict comparison finds it) on all lanes.
+// (Round 5 ran the pairs as a nine-trip loop on the promoted lane: the ~20 waves per launch that promote were the slowest of the
+// launch, 217-226 k cycles against 174 k.)
+__device__ __forceinline__ void limb_pair_wave(const Smem& s, uint32_t ck, float r0, float r1, float r2, float r3, float r4, float r5, float rest, int lane, LimbHit& out) {
+  const int f = lane;
+  const int ea = f == 0 ? -1 : (f <= 2 ? f - 1 : (f <= 4 ? -1 : (f - 5) >> 1));
+  const int eb = f <= 2 ? -1 : (f <= 4 ? f - 3 : (f - 5) & 1);
+  const float fra = ea < 0 ? r0 : (ea == 0 ? r1 : r2);
+  const float frb = eb < 0 ? r3 : (eb == 0 ? r4 : r5);
+  const f3 a0 = ld3(s.sph[(ck >> 7) & 31]), a1 = ld3(s.sph[(ck >> 12) & 31]), b0 = ld3(s.sph[(ck >> 17) & 31]), b1 = ld3(s.sph[(ck >> 22) & 31]);
+  f3 pa, pb;
+  if (f == 0) seg_seg_closest(a0, a1, b0, b1, &pa, &pb);
+  else if (ea >= 0) {
+    pa = ea == 0 ? a0 : a1;
+    pb = eb >= 0 ? (eb == 0 ? b0 : b1) : closest_on_segment(pa, b0, b1);
+  } else {
+    pb = eb == 0 ? b0 : b1;
+    pa = closest_on_segment(pb, a0, a1);
   }
-  out.fa = out.fb = 0; out.ra = ra; out.rb = rb;
-#pragma unroll 1
-  for (int f = 1; f < 9; ++f) {
-    const int ea = f <= 2 ? f - 1 : (f <= 4 ? -1 : (f - 5) >> 1);
-    const int eb = f <= 2 ? -1 : (f <= 4 ? f - 3 : (f - 5) & 1);
-    const float fra = ea < 0 ? ra : (ea == 0 ? rad[1] : rad[2]);
-    const float frb = eb < 0 ? rb : (eb == 0 ? rad[4] : rad[5]);
-    if (!(fra > 0.f) || !(frb > 0.f)) continue;     // (no such end sphere)
-    f3 pa, pb;
-    if (ea >= 0) {
-      pa = ld3(s.sph[(ck >> (ea == 0 ? 7 : 12)) & 31]);
-      pb = eb >= 0 ? ld3(s.sph[(ck >> (eb == 0 ? 17 : 22)) & 31]) : closest_on_segment(pa, ld3(s.sph[(ck >> 17) & 31]), ld3(s.sph[(ck >> 22) & 31]));
-    } else {
-      pb = ld3(s.sph[(ck >> (eb == 0 ? 17 : 22)) & 31]);
-      pa = closest_on_segment(pb, ld3(s.sph[(ck >> 7) & 31]), ld3(s.sph[(ck >> 12) & 31]));
-    }
-    const f3 d = pa - pb;
-    const float g = __builtin_amdgcn_sqrtf(dot(d, d)) - fra - frb - rest;
-    if (g < best) {
-      best = g; bpa = pa; bpb = pb;
-      out.fa = ea + 1; out.fb = eb + 1; out.ra = fra; out.rb = frb;
-    }
-  }
+  const f3 dd = pa - pb;
+  float g = __builtin_amdgcn_sqrtf(dot(dd, dd)) - fra - frb - rest;
+  if (f > 8 || (f != 0 && (!(fra > 0.f) || !(frb > 0.f)))) g = 3.0e38f;      // (no such feature / no such end sphere)
+  float m = g;
+  m = fminf(m, __shfl_xor(m, 1)); m = fminf(m, __shfl_xor(m, 2)); m = fminf(m, __shfl_xor(m, 4)); m = fminf(m, __shfl_xor(m, 8));
+  const int w = __ffsll((unsigned long long)(__ballot(g == m) & 0x1FFull)) - 1;          // (lanes 0..8 hold the minimum over lanes 0..15)
+  const f3 bpa = mk3(__shfl(pa.x, w), __shfl(pa.y, w), __shfl(pa.z, w)), bpb = mk3(__shfl(pb.x, w), __shfl(pb.y, w), __shfl(pb.z, w));
+  out.fa = __shfl(ea, w) + 1; out.fb = __shfl(eb, w) + 1; out.ra = __shfl(fra, w); out.rb = __shfl(frb, w);
   const f3 d = bpa - bpb;
   const float dist = __builtin_amdgcn_sqrtf(dot(d, d));
   out.n = dist > 1e-9f ? d * rcpf(dist) : mk3(1.f, 0.f, 0.f);
   out.q = bpb + out.n * out.rb;
-  out.gap = best;
+  out.gap = __shfl(g, w);
 }
 
 // One physics substep on the LDS-resident state (oracle: physics_substep).
@@ -859,6 +856,22 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   if (__ballot(do_static || cand >= 0) != 0ull) {
     bool sbox = do_static;
     int si = (prk >> 7) & 31;                                            // the sphere of a sphere-vs-box test
+    // promoted limb pairs (wave-uniform loop over the few of them): the pair's nine feature pairs on nine lanes, the result to its lane
+    LimbHit hit;
+    hit.gap = 0.f; hit.ra = hit.rb = 0.f; hit.n = hit.q = mk3(0.f, 0.f, 0.f); hit.fa = hit.fb = 0;
+    {
+      uint64_t lb = __ballot(cand >= 0 && (s.k_prk[cand < 0 ? 0 : cand] & 3) == WBC_PR_LIMBS);
+      while (lb != 0ull) {
+        const int L = __ffsll((unsigned long long)lb) - 1;
+        lb &= lb - 1;
+        const int cL = __builtin_amdgcn_readlane(cand, L);
+        const uint32_t ckL = s.k_prk[cL];
+        const float* rl = Cc->cand_rad[cL];
+        LimbHit h;
+        limb_pair_wave(s, ckL, rl[0], rl[1], rl[2], rl[3], rl[4], rl[5], Cc->model.pair_rest_offset, lane, h);
+        if (lane == L) hit = h;
+      }
+    }
     if (cand >= 0) {
       // everything the promoted pair needs in one round of independent loads: its descriptor (LDS), radii, rigid bodies, moving bodies
       const uint32_t ck = s.k_prk[cand], crb = Cc->cand_rbs[cand], cbd = Cc->cand_bodies[cand];
@@ -867,8 +880,6 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       for (int j = 0; j < 6; ++j) rad[j] = Cc->cand_rad[cand][j];
       cpb = cbd & 255; cpb2 = (cbd >> 8) & 255;
       if ((ck & 3) == WBC_PR_LIMBS) {
-        LimbHit hit;
-        limb_pair(s, ck, rad, Cc->model.pair_rest_offset, hit);
         cgap = hit.gap; cn = hit.n; cxcr = hit.q;
         cpkind = WBC_CP_LIMBS;
         cpr = hit.ra;

@@ -20,6 +20,10 @@ def gpu(wmodel, tcfg, n, seed=1):
 def test_box_sticks_below_the_friction_angle_on_the_kernel(robot, terrain_friction, tan_theta):
     r = pc.box_on_incline(robot, tan_theta, terrain_friction, make_sim=gpu)
     print(f"box sticks: terrain_friction {terrain_friction} tan {tan_theta}: acc {r['acc']:+.5f} v_end {r['v_end']:+.5f}")
+    # measured on the kernel, 4 solver sweeps (round 6; the fp64 oracle in brackets): |acc| 0.00006 [0.00015] / 0.00008 [0.00003] / 0.0169 [0.0169] m/s^2,
+    # v_end 0 / 0.025 / 0 m/s for the three cases. The third (mu = 0.4, tan 0.1) is the box still coming to rest inside the measuring window,
+    # identically on both sides -- that case is why the bound is 0.02 and not the 0.01 of the 2-sweep solver (0.008 there): a stuck box
+    # shows |acc| <= 0.0002.
     assert r["sticks_expected"] and abs(r["acc"]) < 0.02 and abs(r["v_end"]) < 0.05, r
 
 
@@ -35,6 +39,7 @@ def test_box_slides_at_the_coulomb_rate_on_the_kernel(robot, terrain_friction, t
 def test_robot_on_its_trunk_sticks_on_the_kernel(robot, mu_env, terrain_friction, tan_theta):
     r = pc.robot_on_incline(robot, tan_theta, mu_env, terrain_friction, t_settle=1.2, t_measure=0.4, make_sim=gpu)
     print(f"trunk sticks: mu_env {mu_env} terrain_friction {terrain_friction} tan {tan_theta}: acc {r['acc']:+.5f} v_end {r['v_end']:+.5f}")
+    # measured (round 6, kernel): |acc| 0.0003 / 0.00005 / 0.000001 m/s^2, |v_end| 0.0061 / 0.0049 / 0.00001 m/s
     assert r["sticks_expected"] and abs(r["acc"]) < 0.03 and abs(r["v_end"]) < 0.04, r
 
 
