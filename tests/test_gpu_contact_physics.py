@@ -22,7 +22,7 @@ def test_box_sticks_below_the_friction_angle_on_the_kernel(robot, terrain_fricti
     print(f"box sticks: terrain_friction {terrain_friction} tan {tan_theta}: acc {r['acc']:+.5f} v_end {r['v_end']:+.5f}")
     # measured on the kernel, 4 solver sweeps (round 6; the fp64 oracle in brackets): |acc| 0.00006 [0.00015] / 0.00008 [0.00003] / 0.0169 [0.0169] m/s^2,
     # v_end 0 / 0.025 / 0 m/s for the three cases. The third (mu = 0.4, tan 0.1) is the box still coming to rest inside the measuring window,
-    # identically on both sides -- that case is why the bound is 0.02 and not the 0.01 of the 2-sweep solver (0.008 there): a stuck box
+    # identically on both sides -- that case is why the bound is 0.02 and not 0.01: a stuck box
     # shows |acc| <= 0.0002.
     assert r["sticks_expected"] and abs(r["acc"]) < 0.02 and abs(r["v_end"]) < 0.05, r
 
