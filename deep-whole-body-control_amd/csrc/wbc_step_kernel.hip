@@ -474,14 +474,15 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   (void)chain_; (void)k_;
   const float dt = C->cfg.sim_dt;
   const float idt = 1.f / dt;
-  // constants of the one-body-per-lane phases: issued here, consumed after the kinematics (latency hidden)
+  // constants of the inertia phase (lane = 3 body + row): issued here, consumed after the kinematics (latency hidden)
+  const int ib = (int)((uint32_t)lane / 3u), ir = lane - 3 * ib;
   float bm = 0.f, bcom[3] = {0.f, 0.f, 0.f}, bI6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (lane < WBC_NB) {
-    bm = C->model.mass[lane];
+  if (ib < WBC_NB) {
+    bm = C->model.mass[ib];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) bcom[j] = C->model.com[lane][j];
+    for (int j = 0; j < 3; ++j) bcom[j] = C->model.com[ib][j];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bI6[j] = C->model.inertia[lane][j];
+    for (int j = 0; j < 6; ++j) bI6[j] = C->model.inertia[ib][j];
   }
   // root-frame quantities (lane 1, in the same instructions: the rotation of the free box actor)
   if (lane < 2) quat_to_mat(lane == 0 ? &s.root[3] : &s.box[3], lane == 0 ? s.R : s.bxRb);
@@ -517,9 +518,16 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
   WSYNC();
   STAMP(1);
   STAMP(2);
-  // spatial inertias in frame F and bias forces: one body per lane
-  if (lane < WBC_NB) {
-    const int i = lane;
+  // spatial inertias in frame F, bias forces and velocity-product terms: one ROW of one body per lane (lane = 3 body + row, 57 lanes;
+  // one body per lane -- 19 lanes -- cost 279 vector instructions per substep, a tenth of it). The lane works in the cyclically permuted
+  // component order (r, r+1, r+2): a cyclic permutation keeps cross products, so it computes "component 0" of every quantity with one
+  // instruction stream for all three rows; everything it reads from LDS it reads in that order (rows of E, components of pos, v, S), the
+  // body-frame quantities (com, the inertia tensor) are not permuted. What it needs of the other two rows (its third inertia entry --
+  // taken from the row that computes the mirrored one, so the matrix is exactly symmetric as before --, the other components of the
+  // two intermediate vectors of the bias force) comes through the LDS crossbar (ds_bpermute).
+  if (ib < WBC_NB) {
+    const int i = ib;
+    const int p0 = ir, p1 = ir == 2 ? 0 : ir + 1, p2 = ir == 0 ? 2 : ir - 1;
     float m = bm, com[3], I6[6];
 #pragma unroll
     for (int j = 0; j < 3; ++j) com[j] = bcom[j];
@@ -534,48 +542,45 @@ __device__ void physics_substep(Smem& s, CP C, const ChainRegs& cr, const int ch
       for (int j = 0; j < 6; ++j) I6[j] = bp[4 + j];
     }
     const float* E = s.E[i];
-    const f3 Cc = ld3(s.pos[i]) + mat_mul(E, mk3(com[0], com[1], com[2]));
+    const f3 E0 = ld3(&E[3 * p0]), E1 = ld3(&E[3 * p1]), E2 = ld3(&E[3 * p2]);       // rows r, r+1, r+2
+    const float* P = s.pos[i];
+    const float C0 = P[p0] + (E0.x * com[0] + E0.y * com[1] + E0.z * com[2]);
+    const float C1 = P[p1] + (E1.x * com[0] + E1.y * com[1] + E1.z * com[2]);
+    const float C2 = P[p2] + (E2.x * com[0] + E2.y * com[1] + E2.z * com[2]);
     const float Ib[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
-    float EI[9];
+    float EI[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) EI[r * 3 + cc] = E[r * 3] * Ib[cc] + E[r * 3 + 1] * Ib[3 + cc] + E[r * 3 + 2] * Ib[6 + cc];
-    // rotational block about F's origin (symmetric: upper triangle computed, mirrored on store):
-    // E Ib E^T + m (|C|^2 1 - C C^T); coupling blocks +-[h]x with h = m C; lower-right m 1
-    const float CC = dot(Cc, Cc);
-    const float Cv[3] = {Cc.x, Cc.y, Cc.z};
-    float Ir[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int cc = r; cc < 3; ++cc) {
-        const float v = (EI[r * 3] * E[cc * 3] + EI[r * 3 + 1] * E[cc * 3 + 1] + EI[r * 3 + 2] * E[cc * 3 + 2]) + m * ((r == cc ? CC : 0.f) - Cv[r] * Cv[cc]);
-        Ir[r * 3 + cc] = v; Ir[cc * 3 + r] = v;
-      }
-    const f3 h = Cc * m;
-    const float Hx[9] = {0.f, -h.z, h.y, h.z, 0.f, -h.x, -h.y, h.x, 0.f};
+    for (int cc = 0; cc < 3; ++cc) EI[cc] = E0.x * Ib[cc] + E0.y * Ib[3 + cc] + E0.z * Ib[6 + cc];
+    // rotational block about F's origin: E Ib E^T + m (|C|^2 1 - C C^T); coupling blocks +-[h]x with h = m C; lower-right m 1
+    const float CC = C0 * C0 + C1 * C1 + C2 * C2;
+    const float Ir00 = (EI[0] * E0.x + EI[1] * E0.y + EI[2] * E0.z) + m * (CC - C0 * C0);
+    const float Ir01 = (EI[0] * E1.x + EI[1] * E1.y + EI[2] * E1.z) + m * (0.f - C0 * C1);
+    const int lane1 = 3 * i + p1, lane2 = 3 * i + p2;
+    const float Ir02 = __shfl(Ir01, lane2);            // row r+2 computes (r+2, r): the mirror of (r, r+2)
+    const float h0 = C0 * m, h1 = C1 * m, h2 = C2 * m;
+    (void)h0;
     float* I = s.IA[i];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        I[r * 6 + cc] = Ir[r * 3 + cc];
-        I[r * 6 + 3 + cc] = Hx[r * 3 + cc];
-        I[(3 + r) * 6 + cc] = Hx[cc * 3 + r];
-        I[(3 + r) * 6 + 3 + cc] = (r == cc) ? m : 0.f;
-      }
+    float* Ra = &I[p0 * 6];
+    float* Rb = &I[(3 + p0) * 6];
+    Ra[p0] = Ir00; Ra[p1] = Ir01; Ra[p2] = Ir02;
+    Ra[3 + p0] = 0.f; Ra[3 + p1] = -h2; Ra[3 + p2] = h1;
+    Rb[p0] = 0.f; Rb[p1] = h2; Rb[p2] = -h1;
+    Rb[3 + p0] = m; Rb[3 + p1] = 0.f; Rb[3 + p2] = 0.f;
     // bias force v x* (I v) from the blocks: n = Irot w + h x vl, f = m vl - h x w
-    const f3 w = ld3(&s.v[i][0]), vl = ld3(&s.v[i][3]);
-    const f3 nn = mat_mul(Ir, w) + cross(h, vl), ff = vl * m - cross(h, w);
-    st3(&s.pA[i][0], cross(w, nn) + cross(vl, ff));
-    st3(&s.pA[i][3], cross(w, ff));
+    const float* V = s.v[i];
+    const float w0 = V[p0], w1 = V[p1], w2 = V[p2], vl0 = V[3 + p0], vl1 = V[3 + p1], vl2 = V[3 + p2];
+    const float nn0 = (Ir00 * w0 + Ir01 * w1 + Ir02 * w2) + (h1 * vl2 - h2 * vl1);
+    const float ff0 = vl0 * m - (h1 * w2 - h2 * w1);
+    const float nn1 = __shfl(nn0, lane1), nn2 = __shfl(nn0, lane2), ff1 = __shfl(ff0, lane1), ff2 = __shfl(ff0, lane2);
+    s.pA[i][p0] = (w1 * nn2 - w2 * nn1) + (vl1 * ff2 - vl2 * ff1);
+    s.pA[i][3 + p0] = w1 * ff2 - w2 * ff1;
     // velocity-product acceleration c = v x (S qd) = (w x ja; w x jl + vl x ja), (ja; jl) = S qd (the root's is zero: kin_walk)
     if (i > 0) {
       const float qd = s.qd[(s.k_body[i] >> 2) & 31];
-      const f3 ja = ld3(&s.S[i][0]) * qd, jl = ld3(&s.S[i][3]) * qd;
-      st3(&s.c[i][0], cross(w, ja));
-      st3(&s.c[i][3], cross(w, jl) + cross(vl, ja));
+      const float* Sb = s.S[i];
+      const float ja1 = Sb[p1] * qd, ja2 = Sb[p2] * qd, jl1 = Sb[3 + p1] * qd, jl2 = Sb[3 + p2] * qd;
+      s.c[i][p0] = w1 * ja2 - w2 * ja1;
+      s.c[i][3 + p0] = (w1 * jl2 - w2 * jl1) + (vl1 * ja2 - vl2 * ja1);
     }
   }
   WSYNC();
