@@ -1756,7 +1756,11 @@ __device__ __forceinline__ int policy_perm18(int j) { return j < 12 ? ((j / 3) ^
 // indices; only the LDS stores are masked.
 template <bool STEP, class TT>
 __device__ __forceinline__ void prologue(Smem& s, ChainRegs& cr, const TT& T, CP C, int env, int chain, const float* __restrict__ actions) {
-  const int lane = threadIdx.x;
+  // (a laundered lane index: the masks of this function's `lane < n` stores are otherwise kept for the identical conditions of the
+  // write-back at the other end of the kernel -- ten SGPR pairs spilled through v_writelane / v_readlane; a compare is one instruction)
+  int lane = threadIdx.x;
+  asm volatile("" : "+v"(lane));
+  lane &= LANES - 1;
   // ---- loads: constants
   const float c_jxyz = (&C->model.joint_xyz[0][0])[min(lane, WBC_NB * 3 - 1)];
   const int lb = min(lane, WBC_NB - 1);
@@ -2092,13 +2096,14 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // keeps alive across the loop exhaust the SGPR file and end up spilled to scratch memory through VGPRs.
   const DevTensorsK* Tq = (const DevTensorsK*)Tp;
   CP Cq = C;
-  asm volatile("" : "+s"(Tq), "+s"(Cq));
+  int envq = env;                                  // (likewise the env index: left alone, the byte offsets env * stride of a dozen tensor rows
+  asm volatile("" : "+s"(Tq), "+s"(Cq), "+s"(envq));   // computed for the prologue's loads are kept for the write-back -- 20 SGPRs spilled through v_writelane / v_readlane)
   const DevTensorsK& T2 = *Tq;
   // the observation's history block (obs_history_buf before this step's update, WG:992): 12 coalesced loads per lane, consumed by
   // observe_and_store at the very end
   float hist_in[12];
   {
-    auto hist = ROW(T2.obs_hist, env, (WBC_HIST * WBC_NPROP));
+    auto hist = ROW(T2.obs_hist, envq, (WBC_HIST * WBC_NPROP));
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
       const int idx = lane + r * LANES;
@@ -2121,7 +2126,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // the base class's reward terms (zero-scaled in the shipped config): their per-DoF sums, lane-parallel, only when one is on
   const bool base_on = ((Cq->cur.leg_active_mask | Cq->cur.arm_active_mask) >> WBC_NREW_WG) != 0ull;
   BaseSums bsums = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (base_on) bsums = base_reward_sums(s, T2, Cq, env);
+  if (base_on) bsums = base_reward_sums(s, T2, Cq, envq);
   // this step's random events (wave-uniform conditions, evaluated as lane 0 will find them below): their draws and the new EE goal
   // are prepared by all lanes, lane 0 applies them
   {
@@ -2130,7 +2135,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     const int need_cmd = __builtin_amdgcn_readfirstlane((int)(((s.ep_len + 1) % Cq->cfg.resample_interval) == 0));
     const int need_push = pi > 0 && (step % (uint64_t)pi) == 0;
     if (need_goal | need_cmd | need_push) {
-      draw_block(s, seed, env, step, SLOT_GOAL_ORN, SLOT_PUSH + 2);
+      draw_block(s, seed, envq, step, SLOT_GOAL_ORN, SLOT_PUSH + 2);
       if (need_goal) goal_pick(s, Cq, SLOT_GOAL_SPHERE);
     }
   }
@@ -2166,7 +2171,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     const int z_term = z < Cq->cfg.term_z_threshold;
     s.time_out = s.ep_len > Cq->cfg.max_episode_length;
     s.reset_flag = c_term | r_term | p_term | z_term | s.time_out;
-    compute_reward(s, T2, Cq, yq, ncol, base_on, bsums, env);
+    compute_reward(s, T2, Cq, yq, ncol, base_on, bsums, envq);
   }
   if (!base_on && lane >= WBC_NREW_WG && lane < WBC_NREW) s.term[lane] = 0.f;
   WSYNC();
@@ -2177,19 +2182,19 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   const long long wave_t15 = clock64();
 #endif
   const bool do_reset = s.reset_flag != 0;
-  if (do_reset) { __builtin_amdgcn_s_setprio(2); reset_env_call(s, T2, Cq, seed, env, step, s.base_yaw); }
+  if (do_reset) { __builtin_amdgcn_s_setprio(2); reset_env_call(s, T2, Cq, seed, envq, step, s.base_yaw); }
   if (do_reset && lane < WBC_ADELAY_LEN * WBC_NACT) {   // action_history_buf[env_ids] = 0 (WG:738)
-    ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane] = 0.f;
-    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) ROW(T2.act_hist, env, (WBC_ADELAY_LEN * WBC_NACT))[lane + LANES] = 0.f;
+    ROW(T2.act_hist, envq, (WBC_ADELAY_LEN * WBC_NACT))[lane] = 0.f;
+    if (lane + LANES < WBC_ADELAY_LEN * WBC_NACT) ROW(T2.act_hist, envq, (WBC_ADELAY_LEN * WBC_NACT))[lane + LANES] = 0.f;
   }
   STAMP(16);
 #if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   const long long wave_t16 = clock64();
 #endif
-  observe_and_store(s, T2, Cq, env, do_reset, so, hist_in);
+  observe_and_store(s, T2, Cq, envq, do_reset, so, hist_in);
   STAMP(17);
   if (lane == 0 && s.deal_word >= 0) {
-    // the next launch's deal: this env's two hint bits (fire-and-forget atomics: 64 envs share a word)
+    // the next launch's deal: this envq's two hint bits (fire-and-forget atomics: 64 envs share a word)
     auto fo = G(T2.deal_flags) + s.deal_word;
     const uint64_t bit = 1ull << s.deal_bit;
     const int hint = do_reset ? 0 : s.deal_hint;
@@ -2200,9 +2205,9 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   }
 #if defined(WBC_STEP_TIMING) || defined(WBC_WAVE_TIMING)
   if (g_wave_dbg && lane == 0) {
-    g_wave_dbg[6 * (size_t)env] = wave_t0; g_wave_dbg[6 * (size_t)env + 1] = clock64();
-    g_wave_dbg[6 * (size_t)env + 3] = wave_t13; g_wave_dbg[6 * (size_t)env + 4] = wave_t15; g_wave_dbg[6 * (size_t)env + 5] = wave_t16;
-    g_wave_dbg[6 * (size_t)env + 2] = (long long)(do_reset ? 1 : 0) | (long long)(s.deal_hint != 0 ? 2 : 0) | (long long)(s.deal_hint == 2 ? 4 : 0) | ((long long)(s.dbg_ncon & 0xFFFF) << 8) | ((long long)((s.dbg_ncon >> 16) & 15) << 28) | ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15) << 24) | ((long long)((unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) & 0xFFFFu) << 32) | ((long long)(blockIdx.x & 0xFFFFu) << 48);
+    g_wave_dbg[6 * (size_t)envq] = wave_t0; g_wave_dbg[6 * (size_t)envq + 1] = clock64();
+    g_wave_dbg[6 * (size_t)envq + 3] = wave_t13; g_wave_dbg[6 * (size_t)envq + 4] = wave_t15; g_wave_dbg[6 * (size_t)envq + 5] = wave_t16;
+    g_wave_dbg[6 * (size_t)envq + 2] = (long long)(do_reset ? 1 : 0) | (long long)(s.deal_hint != 0 ? 2 : 0) | (long long)(s.deal_hint == 2 ? 4 : 0) | ((long long)(s.dbg_ncon & 0xFFFF) << 8) | ((long long)((s.dbg_ncon >> 16) & 15) << 28) | ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) & 15) << 24) | ((long long)((unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) & 0xFFFFu) << 32) | ((long long)(blockIdx.x & 0xFFFFu) << 48);
   }
 #endif
 }
