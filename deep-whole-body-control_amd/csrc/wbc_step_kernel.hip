@@ -1424,6 +1424,9 @@ __device__ void rigid_body_pass(Smem& s, CP C, const ChainRegs& cr, const int ch
   kin_walk<true>(s, C, lane);
   // orientations: one lane per chain multiplies the joint quaternions down its chain (half-angle sin / cos: joint_pre_pass<true>),
   // every operand requested before the walk
+  // (the quaternions riding along the walk instead -- component `row` on the quad's four lanes, cos * own + (+-sin) * the partner one
+  // quad permutation away, 4 instructions per level -- was built and measured on one box: 83.2 against 82.2 us at 1024 envs, 100.8
+  // against 100.0 at 4096; not kept)
   if (k == 1) {
     float qp[4] = {s.root[3], s.root[4], s.root[5], s.root[6]};
     float sh[WBC_MAX_DEPTH], ch[WBC_MAX_DEPTH];
