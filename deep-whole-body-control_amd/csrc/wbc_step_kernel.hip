@@ -2023,7 +2023,8 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // to touch itself", "expected in contact", the rest (a stable partition by the two hint bits the previous launch left in deal_flags:
   // what its wave saw in its last substep, cleared by a reset): workgroup j of the XCD takes the j-th env of that order -- rank-select
   // on the range's <= 8 flag words per bit plane. (Running every other window of 128 backwards, so that the SIMDs that got the
-  // heaviest robots get the lightest next: measured worse, 117-119 us against 114-116.) Any flag content
+  // heaviest robots get the lightest next: measured worse, 117-119 us against 114-116; a column-aware order -- position p and p + 128 taken
+  // for the same SIMD, the heaviest class given the lightest mates -- likewise: 117.2 against 111.5 on one box. The plain order it is.) Any flag content
   // gives a bijection (the flags of this launch's parity are not written during it); only the balance depends on the hints. Results
   // do not depend on the deal: nothing but `env` is derived from blockIdx (tests/test_gpu_deal.py: bit for bit).
   const int per = (num_envs + 7) >> 3;
@@ -2060,7 +2061,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
     }
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u));
     const uint64_t hit = __ballot(((W >> threadIdx.x) & 1ull) != 0ull && (int)below == kk);
-    const int ein = idx * 64 + (int)__builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)hit) - 1);
+    const int ein = __builtin_amdgcn_readfirstlane(idx * 64 + (__ffsll((unsigned long long)hit) - 1));      // (wave-uniform by construction; said so)
     env = xcd * per + ein;
     // (raising the priority of the waves expected in contact from their first instruction on, instead of from their first active
     // contact: measured, no gain -- 115.2 / 113.8 / 115.7 us without, 117.1 / 116.5 / 116.6 with, in the bench loop)
