@@ -1938,7 +1938,7 @@ template <class TT> __device__ void observe_and_store(Smem& s, const TT& T, CP C
       const float* fs = s.out_sensor[(e - 63) ^ 1];
       val = dot6(fs, fs) > 2.25f ? 1.f : 0.f;
     } else if (e < 70) val = s.cmd[e - 67] * cf.commands_scale[e - 67];
-    else val = s.goal[(e < 73 ? G_CURR - 70 : G_DORN - 73) + e];
+    else val = s.goal[(e < 73 ? (cf.goal_command_cart ? G_CURR_CART : G_CURR) - 70 : G_DORN - 73) + e];      // (curr_ee_goal per command_mode, WG:589-593)
     s.post.o76[e] = val;
   }
   WSYNC();
@@ -2170,8 +2170,9 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
       s.root[7] = px * kk; s.root[8] = py * kk;
     }
     const float r = rpy.x, p = rpy.y, z = s.root[2], th = Cq->cfg.term_rp_threshold;
-    const int r_term = ((r > th) && (s.goal[G_CURR + 2] >= 0.f)) || ((r < -th) && (s.goal[G_CURR + 2] <= 0.f));
-    const int p_term = ((p > th) && (s.goal[G_CURR + 1] >= 0.f)) || ((p < -th) && (s.goal[G_CURR + 1] <= 0.f));
+    const int gc = Cq->cfg.goal_command_cart ? G_CURR_CART : G_CURR;                        // curr_ee_goal (WG:589-593)
+    const int r_term = ((r > th) && (s.goal[gc + 2] >= 0.f)) || ((r < -th) && (s.goal[gc + 2] <= 0.f));
+    const int p_term = ((p > th) && (s.goal[gc + 1] >= 0.f)) || ((p < -th) && (s.goal[gc + 1] <= 0.f));
     const int z_term = z < Cq->cfg.term_z_threshold;
     s.time_out = s.ep_len > Cq->cfg.max_episode_length;
     s.reset_flag = c_term | r_term | p_term | z_term | s.time_out;

@@ -74,7 +74,7 @@ class WbcTaskCfg(C.Structure):
         ("lin_vel_x_clip", f32), ("ang_vel_yaw_clip", f32),
         ("goal_collision_lower", f32 * 3), ("goal_collision_upper", f32 * 3), ("goal_underground_limit", f32),
         ("goal_collision_samples", i32), ("goal_delta_orn_range", (f32 * 2) * 3),
-        ("sphere_error_scale", f32 * 3), ("orn_error_scale", f32 * 3), ("z_invariant_offset", f32),
+        ("sphere_error_scale", f32 * 3), ("orn_error_scale", f32 * 3), ("z_invariant_offset", f32), ("goal_command_cart", i32),
         ("tracking_sigma", f32), ("tracking_ee_sigma", f32), ("only_positive_rewards", i32),
         ("soft_dof_lower", f32 * NDOF), ("soft_dof_upper", f32 * NDOF), ("soft_dof_vel_limit", f32 * NDOF), ("soft_torque_limit", f32 * NDOF),
         ("max_contact_force", f32), ("base_height_target", f32),
@@ -418,8 +418,6 @@ UNSUPPORTED_SWITCHES = [
     ("env.reorder_dofs", (True,), "the fused step hard-wires the policy <-> simulator joint order of WG:1003-1088"),
     ("domain_rand.observe_priv", (True,), "dead in the reference as well: obs_buf is only ever assigned inside `if observe_priv` (WG:986-992), so "
      "without it the policy sees the zero-initialised buffer forever (profiles/r04_reference_switches.txt)"),
-    ("goal_ee.command_mode", ("sphere",), "'cart' rebinds curr_ee_goal to the Cartesian goal (WG:589-593): observations [70:73] and the goal-sign tests of "
-     "check_termination (WG:945-946) would read Cartesian coordinates; the fused step implements the shipped spherical mode"),
     ("asset.fix_base_link", (False,), "the physics spec is a floating base (DESIGN.md section 3)"),
     ("asset.disable_gravity", (False,), "not modelled; set sim.gravity instead"),
     ("asset.collapse_fixed_joints", (True,), "the rigid-body list (27 bodies, quirk Q1) is the collapsed one"),
@@ -603,6 +601,10 @@ def fill_task_cfg(cfg, m: RobotModel, sim_dt: Optional[float] = None, check: boo
     _set(out.sphere_error_scale, g.sphere_error_scale)
     _set(out.orn_error_scale, g.orn_error_scale)
     out.z_invariant_offset = 0.53                                            # WG:597
+    mode = getattr(cfg.goal_ee, "command_mode", "sphere")
+    if mode not in ("cart", "sphere"):                                       # WG:589 asserts the same
+        raise ValueError(f"goal_ee.command_mode = {mode!r}: 'cart' or 'sphere'")
+    out.goal_command_cart = 1 if mode == "cart" else 0                       # which goal curr_ee_goal is bound to, WG:589-593
     out.tracking_sigma = float(cfg.rewards.tracking_sigma)
     out.tracking_ee_sigma = float(cfg.rewards.tracking_ee_sigma)
     out.only_positive_rewards = int(bool(cfg.rewards.only_positive_rewards))

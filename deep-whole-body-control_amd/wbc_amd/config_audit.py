@@ -27,7 +27,7 @@ commands.ranges.init_ang_vel_yaw commands.ranges.init_lin_vel_x commands.resampl
 control.action_scale control.damping control.decimation control.stiffness
 domain_rand.max_push_vel_xy domain_rand.push_interval_s domain_rand.push_robots
 env.action_delay env.episode_length_s
-goal_ee.collision_lower_limits goal_ee.collision_upper_limits goal_ee.l_schedule goal_ee.num_collision_check_samples
+goal_ee.collision_lower_limits goal_ee.collision_upper_limits goal_ee.command_mode goal_ee.l_schedule goal_ee.num_collision_check_samples
 goal_ee.orn_error_scale goal_ee.p_schedule goal_ee.ranges.final_delta_orn goal_ee.ranges.final_pos_l goal_ee.ranges.final_pos_p
 goal_ee.ranges.final_pos_y goal_ee.ranges.final_tracking_ee_reward goal_ee.ranges.init_pos_l goal_ee.ranges.init_pos_p
 goal_ee.ranges.init_pos_y goal_ee.sphere_error_scale goal_ee.tracking_ee_reward_schedule goal_ee.underground_limit goal_ee.y_schedule

@@ -214,6 +214,9 @@ typedef struct {
   float goal_delta_orn_range[3][2];
   float sphere_error_scale[3], orn_error_scale[3];
   float z_invariant_offset;           /* 0.53 (WG:597) */
+  int32_t goal_command_cart;          /* goal_ee.command_mode == 'cart' (WG:589-593): curr_ee_goal is the Cartesian goal -- observation
+                                         entries 70..72 (WG:980) and the sign tests of the roll / pitch termination (WG:945-946) read it
+                                         instead of the spherical one; 0 = 'sphere' (the shipped config) */
   /* rewards */
   float tracking_sigma, tracking_ee_sigma;
   int32_t only_positive_rewards;

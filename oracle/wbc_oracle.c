@@ -1252,7 +1252,7 @@ static void compute_observations(const ora_sim* s, ora_env* e) {
     o[63 + f] = nrm > (REAL)1.5 ? 1 : 0;
   }
   for (int k = 0; k < 3; ++k) o[67 + k] = e->commands[k] * (REAL)cf->commands_scale[k];   /* WG:979 */
-  for (int k = 0; k < 3; ++k) o[70 + k] = e->goal[G_CURR + k];                            /* WG:980 */
+  for (int k = 0; k < 3; ++k) o[70 + k] = e->goal[(cf->goal_command_cart ? G_CURR_CART : G_CURR) + k];   /* WG:980; curr_ee_goal per command_mode, WG:589-593 */
   for (int k = 0; k < 3; ++k) o[73 + k] = e->goal[G_DORN + k];                            /* WG:981 */
   REAL* ob = e->obs;
   for (int k = 0; k < WBC_NPROP; ++k) ob[k] = o[k];
@@ -1314,8 +1314,9 @@ static void env_step(const ora_sim* s, ora_env* e, int env, const REAL* actions_
   for (int rb = 0; rb < WBC_NRB; ++rb)
     if ((cf->term_contact_rb_mask >> rb) & 1u) c_term |= sqrt(dot3(e->contact_force[rb], e->contact_force[rb])) > (REAL)1.0;
   REAL r = rpy[0], p = rpy[1], z = e->root[0][2], th = (REAL)cf->term_rp_threshold;
-  int r_term = ((r > th) && (e->goal[G_CURR + 2] >= 0)) || ((r < -th) && (e->goal[G_CURR + 2] <= 0));
-  int p_term = ((p > th) && (e->goal[G_CURR + 1] >= 0)) || ((p < -th) && (e->goal[G_CURR + 1] <= 0));
+  const int gc = cf->goal_command_cart ? G_CURR_CART : G_CURR;                              /* curr_ee_goal (WG:589-593) */
+  int r_term = ((r > th) && (e->goal[gc + 2] >= 0)) || ((r < -th) && (e->goal[gc + 2] <= 0));
+  int p_term = ((p > th) && (e->goal[gc + 1] >= 0)) || ((p < -th) && (e->goal[gc + 1] <= 0));
   int z_term = z < (REAL)cf->term_z_threshold;
   e->time_out = e->episode_length > cf->max_episode_length;
   e->reset_buf = c_term | r_term | p_term | z_term | e->time_out;

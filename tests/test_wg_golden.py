@@ -36,7 +36,8 @@ CHECK_GPU = [("TORQUES", 3e-3, 1e-3), ("ROOT_STATES", 3e-4, 5e-4), ("DOF_STATE",
              ("LAST_DOF_VEL", 1.5e-3, 1e-3), ("LAST_ROOT_VEL", 5e-4, 1e-3), ("EPISODE_SUMS", 2e-4, 2e-3), ("METRIC_SUMS", 5e-3, 2e-3),
              ("FORCE_SENSOR", 0.05, 3e-3), ("NET_CONTACT_FORCE", 0.05, 3e-3), ("RIGID_BODY_STATE", 1e-3, 1e-3)]
 
-FIXTURES = ["wg_reference_counter0.npz", "wg_reference_default.npz", "wg_reference_allrewards.npz", "wg_reference_contacts.npz"]
+FIXTURES = ["wg_reference_counter0.npz", "wg_reference_default.npz", "wg_reference_allrewards.npz", "wg_reference_contacts.npz",
+            "wg_reference_cart.npz"]        # (cart: goal_ee.command_mode = 'cart', robots tilted past the roll / pitch threshold)
 
 
 def load(name):
@@ -67,6 +68,7 @@ def fixture_tcfg(robot, g):
     tc.term_z_threshold = float(g["tcfg/term_z_threshold"])
     tc.term_contact_rb_mask = int(g["tcfg/term_contact_rb_mask"])
     tc.penalize_contact_rb_mask = int(g["tcfg/penalize_contact_rb_mask"])
+    tc.goal_command_cart = int(g["tcfg/goal_command_cart"]) if "tcfg/goal_command_cart" in g else 0       # WG:589-593
     return tc
 
 

@@ -235,5 +235,50 @@ def main():
     save("wg_reference_contacts.npz", outC)
 
 
+def cart_fixture():
+    """D: goal_ee.command_mode = 'cart' (WG:589-593): curr_ee_goal is the Cartesian goal -- observation entries 70..72 and the sign
+    tests of the roll / pitch termination (WG:945-946). Robots tilted past the 0.2 rad threshold in both directions, with goals on both
+    sides, so that the two modes decide differently (checked below); goal resampling staged as in fixture A."""
+    rng = np.random.default_rng(20261001)
+    cfg = flat_cfg()
+    cfg.goal_ee.command_mode = "cart"
+    env = make_reference_env(24, seed=17, cfg=cfg)
+    env._backend.ora.set_heightfield(None, 0, 0, 0, 0, 0)
+    with torch.inference_mode():
+        env.reset()
+        env.update_command_curriculum()
+        stage_events(env, rng)
+        n = env.num_envs
+        tilt = torch.arange(n) < 16                               # roll / pitch of +-0.3 rad, standing height (no height termination)
+        ang = torch.tensor([[0.3, 0.0], [-0.3, 0.0], [0.0, 0.3], [0.0, -0.3]]).repeat(4, 1)
+        half = 0.5 * ang
+        qx = torch.stack([torch.sin(half[:, 0]), torch.zeros(16), torch.zeros(16), torch.cos(half[:, 0])], 1)
+        qy = torch.stack([torch.zeros(16), torch.sin(half[:, 1]), torch.zeros(16), torch.cos(half[:, 1])], 1)
+        env.root_states[tilt, 3:7] = torch.where(ang[:, :1] != 0, qx, qy)
+        env.root_states[tilt, 7:] = 0
+        outD = record_trajectory(env, 10, rng, "D command_mode = cart")
+    outD["tcfg/goal_command_cart"] = np.int64(1)
+    assert int(env._backend.tcfg.goal_command_cart) == 1
+    # the two bindings of curr_ee_goal must differ where it matters: observation entries and at least one termination decision
+    obs = np.stack([outD[f"s{k}/OBS_BUF"] for k in range(10)])
+    goal = np.stack([outD[f"s{k}/GOAL_STATE"] for k in range(10)])
+    assert np.abs(obs[:, :, 70:73] - goal[:, :, 12:15]).max() < 1e-6 and np.abs(obs[:, :, 70:73] - goal[:, :, 9:12]).max() > 0.1     # the Cartesian goal, not the spherical
+    roll, pitch = np.array([0.3, -0.3, 0, 0] * 4), np.array([0, 0, 0.3, -0.3] * 4)
+
+    def would_end(c, e):
+        return ((roll[e] > 0.2) and c[2] >= 0) or ((roll[e] < -0.2) and c[2] <= 0) or ((pitch[e] > 0.2) and c[1] >= 0) or ((pitch[e] < -0.2) and c[1] <= 0)
+    differ = sum(would_end(goal[0, e, 9:12], e) != would_end(goal[0, e, 12:15], e) for e in range(16))
+    print("   tilted envs whose first-step termination differs between the two bindings of curr_ee_goal:", differ)
+    assert differ >= 3
+    resets = np.stack([outD[f"s{k}/RESET_BUF"] for k in range(10)])
+    print("   resets per step:", resets.sum(1).tolist())
+    save("wg_reference_cart.npz", outD)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cart":
+        os.makedirs(GOLD, exist_ok=True)
+        cart_fixture()
+    else:
+        main()
+        cart_fixture()
