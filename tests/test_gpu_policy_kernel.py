@@ -12,7 +12,7 @@ from wbc_amd.rsl_rl.modules import ActorCritic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("rows", [1, 15, 16, 17, 33, 4096, 8224])
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 33, 1000, 2048, 4096, 8224])
 def test_fused_act_matches_torch_modules(rows):
     torch.manual_seed(3)
     ac = ActorCritic(76, 76, 18, **gp.POLICY_KW).cuda()
