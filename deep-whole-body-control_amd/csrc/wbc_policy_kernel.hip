@@ -35,6 +35,18 @@ static Tab16 make_tab16() {
   return t;
 }
 
+// Development aid (-DWBC_PPO_TIMING builds): when set to a device buffer of >= 128 int64, workgroup (0, 0) records clock64() at the four
+// stage boundaries of every layer (slots 32 + 4 layer + {0: start, 1: MFMA chain done, 2: epilogue done, 3: barrier passed}) and at the
+// kernel's own stages (slots 0..3: entry, inputs in LDS, layers done, outputs written). tools/time_act_layers.py prints them.
+#ifdef WBC_PPO_TIMING
+extern "C" void wbc_debug_set_policy_timing(void* dev_buf) {
+  long long* p = (long long*)dev_buf;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_dbg), &p, sizeof(p));
+}
+#define KSTAMP(i) do { if (g_mlp_dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mlp_dbg[i] = clock64(); } while (0)
+#else
+#define KSTAMP(i) do { } while (0)
+#endif
 #ifndef ACT16_OCC
 #define ACT16_OCC 2
 #endif
@@ -51,6 +63,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
   }
   __shared__ __attribute__((aligned(16))) float smem[T_END];
   const int tid = threadIdx.x;
+  KSTAMP(0);
   const int row0 = blockIdx.x * R16;
   const bool critic = blockIdx.y != 0;
   // x[16][128] <- obs[:, :100] (float4 loads); rows past the end and the columns 100..127 (k padding of the first layers) zero
@@ -74,6 +87,7 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
       }
     __syncthreads();
   }
+  KSTAMP(1);
   const int lbeg = critic ? L_CBB : (latent ? L_BB : 0), lend = critic ? NLAYERS : L_CBB;
   {
     float wa[66], wb[66];
@@ -82,13 +96,14 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
     for (int l = lbeg; l < lend; l += 2) {
       const bool two = l + 1 < lend;
       if (two) load16(wb, T.l[l + 1], wpack16, bias);
-      run16<1>(wa, T.l[l], smem, nullptr, row0, 0, T.l[l], false);
+      run16<1>(wa, T.l[l], smem, nullptr, row0, 0, T.l[l], false, NoHook(), l);
       if (two) {
         if (l + 2 < lend) load16(wa, T.l[l + 2], wpack16, bias);
-        run16<1>(wb, T.l[l + 1], smem, nullptr, row0, 0, T.l[l], false);
+        run16<1>(wb, T.l[l + 1], smem, nullptr, row0, 0, T.l[l], false, NoHook(), l + 1);
       }
     }
   }
+  KSTAMP(2);
   const float* outv = smem + T_OUTV;
   if (critic) {
     if (tid < R16 && row0 + tid < num_rows) {
@@ -124,7 +139,6 @@ extern "C" __global__ void __launch_bounds__(PT_THREADS, ACT16_OCC) wbc_policy_a
   }
 }
 
-// Development aid: when set to a device buffer of >= 32 int64, block 0 records clock64() at every stage boundary.
 
 static int fill_params(const void* const* params, PolicyParams* P) {
   const float** dst = reinterpret_cast<const float**>(P);
