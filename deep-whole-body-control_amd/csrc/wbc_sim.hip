@@ -72,7 +72,7 @@ struct wbc_sim {
   size_t arena_bytes = 0;
   int16_t* hf_dev = nullptr;
   // balanced dealing of the step kernel's workgroups (wbc_step_kernel): on when every robot is resident at once and an XCD's range is
-  // whole flag words (N a multiple of 512, at most 4096); WBC_NO_DEAL=1 in the environment switches it off (A/B runs)
+  // whole flag words (N a multiple of 512, 2048 to 4096); WBC_NO_DEAL=1 in the environment switches it off (A/B runs)
   char* deal_mem = nullptr;
   bool deal_on = false;
   int64_t step_launches = 0;
@@ -347,7 +347,9 @@ extern "C" int wbc_sim_create(const wbc_model* model, const wbc_task_cfg* cfg, i
     HIP_OK(hipMemset(s->deal_mem, 0, fl));
     T.deal_flags = (uint64_t*)s->deal_mem;
     const char* off = getenv("WBC_NO_DEAL");
-    s->deal_on = num_envs % 512 == 0 && num_envs / 512 <= WBC_DEAL_WORDS && !(off && off[0] == '1');
+    // (from 2048 envs on: with one robot per SIMD -- 1024 envs -- there is nothing to balance, and the rank-select at the head of every
+    // wave costs 0.7 us of the launch's dependent chain: 81.5 against 82.3 us, tools/r06_runs/r06_gpu32.sh)
+    s->deal_on = num_envs % 512 == 0 && num_envs >= 2048 && num_envs / 512 <= WBC_DEAL_WORDS && !(off && off[0] == '1');
   }
   // defaults: identity quaternions, unit friction/motor strength, nominal inertias, sane goal timers
   {

@@ -2014,7 +2014,7 @@ extern "C" __global__ void __launch_bounds__(LANES, 4) wbc_step_kernel(const Dev
   // [x per, (x + 1) per), so the sub-64-B rows of neighbouring envs (13-float root rows, 3-float commands, ...) meet in one L2 and
   // leave it as whole lines instead of as byte-masked partial writes from two L2s (grid = 8 per workgroups, wbc_sim.hip).
   //
-  // WHICH env of its XCD's range a workgroup takes is dealt per launch (deal & 2; N a multiple of 512 up to 4096: every robot resident
+  // WHICH env of its XCD's range a workgroup takes is dealt per launch (deal & 2; N a multiple of 512 from 2048 to 4096: every robot resident
   // at once, 4 per SIMD). A launch ends with its busiest SIMD; left alone it waits for whichever SIMD happens to hold three or four
   // robots in contact (+15..30 % cycles each) while the mean SIMD holds one or two. The dispatcher hands the workgroups of an XCD to
   // its shader engines, their CUs and the CUs' SIMDs round-robin: any 64 consecutive workgroups of an XCD land on 64 different SIMDs,
